@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz from the REAL reference.
+
+Run in the build container only (it needs /root/reference, which never travels to
+the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports the unmodified reference classes (``models.Encoder``, ``models.Regressor``,
+``models.Classifier``) and loss functions (``Train.*.get_MIL_loss`` etc.) on CPU with
+``cv2`` / ``h5py`` stubbed (both are dead imports for this path), feeds
+them inputs and weights from ``lstc_vad_amd.synthetic`` (portable counter-based
+generator), runs forward + loss + backward + two ``torch.optim.Adagrad`` steps exactly
+like the reference train loops do, and stores inputs and expected outputs.  All dropout
+rates are 0 (the reference's masks come from torch's generator and cannot be replayed
+elsewhere).  The fixtures are DATA: inputs + expected outputs; no reference source text.
+"""
+import os
+import sys
+import types
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+for name in ("cv2", "h5py"):
+    sys.modules.setdefault(name, types.ModuleType(name))
+sys.path.insert(0, REF)
+sys.path.insert(1, ROOT)
+sys.path.insert(2, HERE)
+
+from models.Encoder import Encoder as RefEncoder            # noqa: E402  (reference)
+from models.Regressor import Regressor as RefRegressor      # noqa: E402
+from models.Classifier import Classifier as RefClassifier   # noqa: E402
+import Train.temporal_transformer_shanghaitech as ref_ltn   # noqa: E402
+import Train.spatio_transformer_shanghaitech as ref_stn     # noqa: E402
+import Train.spatio_transformer_MIL_CE as ref_coteach       # noqa: E402
+from utils.eval_utils import eval as ref_eval               # noqa: E402
+
+from lstc_vad_amd import synthetic as syn                   # noqa: E402
+
+torch.set_num_threads(4)
+
+
+def fill_params(module: torch.nn.Module, seed: int):
+    """Overwrite every parameter with portable-generator values (stream = position)."""
+    with torch.no_grad():
+        for i, (k, p) in enumerate(module.named_parameters()):
+            if k.endswith("layer_norm.weight"):
+                v = 1.0 + syn.small_uniform(p.shape, seed, 100 + i, 0.2)
+            elif k.endswith("bias") and p.dim() == 1:
+                v = syn.small_uniform(p.shape, seed, 100 + i, 0.1)
+            elif k.endswith("relative_position_bias_table"):
+                v = syn.small_uniform(p.shape, seed, 100 + i, 0.5)
+            elif k in ("cls_token", "position_enc"):
+                v = syn.small_uniform(p.shape, seed, 100 + i, 0.3)
+            else:
+                v = syn.xavier_uniform(p.shape, seed, 100 + i)
+            p.copy_(torch.from_numpy(v))
+
+
+from cases import CASES   # noqa: E402
+
+
+def run_case(name, mode, enc_kw, st_kw, seed):
+    bs, pn, L, P = st_kw["batch_size"], st_kw["part_num"], st_kw["part_len"], st_kw["n_patch"]
+    d = enc_kw["d_model"]
+    args = Namespace(batch_size=bs, part_num=pn, part_len=L, n_patch=P, d_model=d, lambda_1=0.01,
+                     lambda_MIL=1.0, lambda_CE=0.8, lambda_BCE=1.0, lambda_normal=0.2, lambda_abnormal=2.0,
+                     temporal_only=st_kw.get("temporal_only", False), clip_grad=st_kw.get("clip_grad", False))
+    enc = RefEncoder(n_layers=3, MHA_attn_dropout=0.0, MHA_fc_dropout=0.0, FFN_dropout=0.0, position_dropout=0.0,
+                     weight_init=False, **enc_kw)
+    head = RefRegressor(d, 0.0, weight_init=False) if mode != "LTN" else RefClassifier(d, 0.0, weight_init=False)
+    fill_params(enc, seed)
+    fill_params(head, seed + 1)
+    enc.train(); head.train()
+    nf, nl, af, al = syn.training_batch(bs, pn, L, P, d, seed=seed, with_pseudo=True, threshold=0.6)
+    out = {"seed": np.int64(seed)}
+    for k, v in enc.state_dict().items():
+        out["enc_init." + k] = v.numpy().copy()
+    for k, v in head.state_dict().items():
+        out["head_init." + k] = v.numpy().copy()
+    out.update(norm_feats=nf, abnorm_feats=af, abnorm_labs=al)
+
+    # Adagrad exactly as Train/temporal_transformer_shanghaitech.py:83-85
+    opt = torch.optim.Adagrad([{"params": enc.parameters(), "lr": 1e-4},
+                               {"params": head.parameters(), "lr": 1e-2}], weight_decay=1e-3)
+    tnf, taf, tal = torch.from_numpy(nf), torch.from_numpy(af), torch.from_numpy(al)
+    for step in range(2):
+        if mode == "LTN":      # Train/temporal_transformer_shanghaitech.py:103-134
+            norm_labs = torch.zeros([bs, pn, 2]); norm_labs[:, :, 0] += 1
+            ab = tal.view([bs, pn, L]).mean(dim=-1).view([bs, pn, 1])
+            tmp = torch.zeros([bs, pn, 2]); tmp[:, :, 1] = ab[:, :, 0]; tmp[:, :, 0] = 1 - tmp[:, :, 1]
+            clip_labs = torch.cat([norm_labs, tmp], dim=0)
+            feats = torch.cat([tnf.float().view([bs * pn, L * P, d]), taf.float().view([bs * pn, L * P, d])], dim=0)
+            enc_out = enc(feats)
+            cls = enc_out[:, 0, :].float().view([bs * 2, pn, d])
+            outputs = head(cls).view([bs * 2 * pn, -1])
+            score = outputs[:, 1]
+            if not args.temporal_only:
+                aux = ref_ltn.get_CE_loss(args, outputs, clip_labs.view([bs * 2 * pn, -1]))
+            else:
+                aux = torch.zeros(())
+            mil, err, l1 = ref_ltn.get_MIL_loss(args, score)
+            loss = args.lambda_MIL * mil + args.lambda_CE * aux
+        elif mode == "STN":    # Train/spatio_transformer_shanghaitech.py:90-101
+            feats = torch.cat([tnf.float().view([bs * pn * L, P, d]), taf.float().view([bs * pn * L, P, d])], dim=0)
+            enc_out = enc(feats)
+            cls = enc_out[:, 0, :].float().view([bs * 2, pn * L, d])
+            outputs = head(cls).view([bs * 2, pn * L, -1])
+            loss, err, l1 = ref_stn.get_MIL_loss(args, outputs)
+            mil, aux, score = loss, torch.zeros(()), outputs.reshape(-1)
+        else:                  # Train/spatio_transformer_MIL_CE.py:156-181
+            norm_labs = torch.zeros([bs, pn, 2]); norm_labs[:, :, 0] += 1
+            ab = tal.view([bs, pn, L]).mean(dim=-1).view([bs, pn, 1])
+            tmp = torch.zeros([bs, pn, 2]); tmp[:, :, 1] = ab[:, :, 0]; tmp[:, :, 0] = 1 - tmp[:, :, 1]
+            clip_labs = torch.cat([norm_labs, tmp], dim=0)
+            feats = torch.cat([tnf.float().view([bs * pn * L, P, d]), taf.float().view([bs * pn * L, P, d])], dim=0)
+            enc_out = enc(feats)
+            outputs = head(enc_out[:, 0, :])
+            mil, err, l1 = ref_coteach.get_MIL_loss(args, outputs, L)
+            aux = ref_coteach.get_BCE_loss(args, torch.mean(outputs.view([bs * 2, pn, L]), dim=-1), clip_labs)
+            loss = args.lambda_BCE * aux + mil
+            score = outputs.reshape(-1)
+        opt.zero_grad()
+        loss.backward()
+        if args.clip_grad:
+            torch.nn.utils.clip_grad_norm_(enc.parameters(), 10)
+            torch.nn.utils.clip_grad_norm_(head.parameters(), 10)
+        if step == 0:
+            out["enc_out"] = enc_out.detach().numpy().copy()
+            out["outputs"] = outputs.detach().numpy().copy()
+            out["score"] = score.detach().numpy().copy()
+            out["scalars"] = np.array([loss.item(), mil.item(), err.item(), l1.item(), float(aux)], np.float64)
+            for k, p in enc.named_parameters():
+                if p.grad is not None:
+                    out["enc_grad." + k] = p.grad.numpy().copy()
+            for k, p in head.named_parameters():
+                if p.grad is not None:
+                    out["head_grad." + k] = p.grad.numpy().copy()
+        else:
+            out["scalars_step2"] = np.array([loss.item(), mil.item(), err.item(), l1.item(), float(aux)], np.float64)
+        opt.step()
+    for k, v in enc.state_dict().items():
+        out["enc_after2." + k] = v.numpy().copy()
+    for k, v in head.state_dict().items():
+        out["head_after2." + k] = v.numpy().copy()
+
+    # eval-mode forward and a short-tail sequence (S = 1 + 1*P) on the initial weights
+    enc2 = RefEncoder(n_layers=3, MHA_attn_dropout=0.3, MHA_fc_dropout=0.3, FFN_dropout=0.3, position_dropout=0.3,
+                      weight_init=False, **enc_kw)
+    fill_params(enc2, seed)
+    enc2.eval()
+    with torch.no_grad():
+        if mode == "LTN":
+            x = torch.from_numpy(nf).view([bs * pn, L * P, d])[:3]
+            out["eval_enc_out"] = enc2(x).numpy().copy()
+            if L > 1:   # tail part with fewer clips (Train/pseudo_labels_generator_temporal.py:110-137)
+                out["eval_tail_enc_out"] = enc2(x[:, : (L - 1) * P]).numpy().copy()
+                out["eval_tail1_enc_out"] = enc2(x[:, :P]).numpy().copy()
+        else:
+            x = torch.from_numpy(nf).view([bs * pn * L, P, d])[:3]
+            out["eval_enc_out"] = enc2(x).numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: loss {out['scalars'][0]:.6f} -> wrote {name}.npz "
+          f"({os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024:.0f} KiB)")
+
+
+def misc():
+    out = {}
+    from models.MultiHeadAttention import MultiHeadAttention as RefMHA
+    for (L, ws) in [(3, 4), (2, 4), (5, 4), (2, 3), (1, 4)]:
+        m = RefMHA(2, 8, 4, 4, relative_pe=True, window_size=ws, window_depth=L)
+        out[f"relidx3d_L{L}_ws{ws}"] = m.relative_position_index.numpy().copy()
+    for ws in (3, 4):
+        m = RefMHA(2, 8, 4, 4, relative_pe_2D=True, window_size=ws)
+        out[f"relidx2d_ws{ws}"] = m.relative_position_index.numpy().copy()
+    # AUC of fixed score / label vectors through utils/eval_utils.py:139-143 (incl. ties and [N,1] shape)
+    sc = syn.uniform((400,), 7, 1).astype(np.float64)
+    sc = np.round(sc * 20) / 20.0                      # many ties
+    lb = (syn.uniform((400,), 7, 2) + 0.3 * sc > 0.7).astype(np.float64)
+    out["auc_scores"], out["auc_labels"] = sc, lb
+    out["auc_value"] = np.float64(ref_eval(list(sc.reshape(-1, 1)), list(lb), None))
+    sc2 = syn.uniform((1000,), 8, 1).astype(np.float64)
+    lb2 = (syn.uniform((1000,), 8, 2) < 0.2).astype(np.float64)
+    out["auc2_scores"], out["auc2_labels"] = sc2, lb2
+    out["auc2_value"] = np.float64(ref_eval(list(sc2), list(lb2), None))
+    # parameter counts at full width
+    e = RefEncoder(3, 8, 256, 256, 2048, 4096, MHA_layerNorm=True, FFN_layerNorm=True, weight_init=False,
+                   relative_pe=True, window_size=4, window_depth=3)
+    out["ltn_param_count"] = np.int64(sum(p.numel() for p in e.parameters()))
+    out["ltn_state_keys"] = np.array(list(e.state_dict().keys()))
+    e = RefEncoder(3, 8, 256, 256, 2048, 3027, FFN_layerNorm=True, weight_init=False)
+    out["stn_param_count"] = np.int64(sum(p.numel() for p in e.parameters()))
+    out["stn_state_keys"] = np.array(list(e.state_dict().keys()))
+    out["classifier_param_count"] = np.int64(sum(p.numel() for p in RefClassifier(2048).parameters()))
+    out["regressor_param_count"] = np.int64(sum(p.numel() for p in RefRegressor(2048).parameters()))
+    out["classifier_state_keys"] = np.array(list(RefClassifier(8).state_dict().keys()))
+    out["regressor_state_keys"] = np.array(list(RefRegressor(8).state_dict().keys()))
+    np.savez_compressed(os.path.join(HERE, "misc.npz"), **out)
+    print("misc: auc", out["auc_value"], out["auc2_value"], "ltn params", out["ltn_param_count"],
+          "stn params", out["stn_param_count"])
+
+
+if __name__ == "__main__":
+    for i, (name, (mode, ekw, skw)) in enumerate(CASES.items()):
+        run_case(name, mode, ekw, skw, seed=11 + i)
+    misc()

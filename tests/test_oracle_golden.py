@@ -1,0 +1,107 @@
+"""The oracle (oracle/lstc_oracle.py) against the golden vectors captured from the real
+reference (tests/golden/make_golden.py).  CPU only.  Tolerances: the oracle and the reference
+run the same float32 torch-CPU ops in a slightly different association, so outputs agree to
+~1e-6; the bar written here is 2e-5 absolute on O(1) quantities and 1e-6 on the scalars."""
+import numpy as np
+import pytest
+import torch
+
+from cases import CASES
+from oracle import lstc_oracle as orc
+from lstc_vad_amd import synthetic as syn
+from util import load_case, sub, oracle_cfgs, max_abs_diff, GOLDEN
+
+torch.set_num_threads(4)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_generator_is_portable(name):
+    """The stored inputs must be regenerated bit-exactly from the seed (integer-only generator)."""
+    z, mode, ekw, skw = load_case(name)
+    nf, nl, af, al = syn.training_batch(skw["batch_size"], skw["part_num"], skw["part_len"], skw["n_patch"],
+                                        ekw["d_model"], seed=int(z["seed"]), with_pseudo=True, threshold=0.6)
+    assert np.array_equal(nf, z["norm_feats"]) and np.array_equal(af, z["abnorm_feats"])
+    assert np.array_equal(al, z["abnorm_labs"])
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_loss_backward_two_steps(name):
+    z, mode, ekw, skw = load_case(name)
+    ecfg, st = oracle_cfgs(mode, ekw, skw)
+    st.clip_grad = skw.get("clip_grad", False)
+    enc_P, head_P = sub(z, "enc_init."), sub(z, "head_init.")
+    nf, af, al = (torch.from_numpy(z[k]) for k in ("norm_feats", "abnorm_feats", "abnorm_labs"))
+    enc_S = {k: torch.zeros_like(v) for k, v in enc_P.items() if v.is_floating_point()}
+    head_S = {k: torch.zeros_like(v) for k, v in head_P.items()}
+    out, enc_P1, head_P1, enc_S, head_S, enc_g, head_g = orc.train_step(
+        enc_P, head_P, enc_S, head_S, ecfg, st, nf, af, al)
+    # forward
+    full = orc.encoder_forward(enc_P, torch.cat([
+        nf.reshape(-1, (skw["part_len"] if mode == "LTN" else 1) * skw["n_patch"], ekw["d_model"]),
+        af.reshape(-1, (skw["part_len"] if mode == "LTN" else 1) * skw["n_patch"], ekw["d_model"])], 0), ecfg, True)
+    assert max_abs_diff(full, z["enc_out"]) < 2e-5
+    assert max_abs_diff(out["outputs"].reshape(z["outputs"].shape), z["outputs"]) < 2e-6
+    sc = np.array([out["loss"].item(), out["mil"].item(), out["err"].item(), out["l1"].item(), float(out["aux"].detach())])
+    assert np.max(np.abs(sc - z["scalars"])) < 1e-6
+    # gradients: same set of parameters receives a gradient, values agree
+    ref_g = sub(z, "enc_grad.")
+    got = {k for k, g in enc_g.items() if g is not None}
+    assert got == set(ref_g), got ^ set(ref_g)
+    for k, g in ref_g.items():
+        scale = max(1e-6, float(g.abs().max()))
+        assert max_abs_diff(enc_g[k], g) / scale < 2e-4, k
+    for k, g in sub(z, "head_grad.").items():
+        scale = max(1e-6, float(g.abs().max()))
+        assert max_abs_diff(head_g[k], g) / scale < 2e-4, k
+    # second step, then weights after two Adagrad updates
+    out2, enc_P2, head_P2, *_ = orc.train_step(enc_P1, head_P1, enc_S, head_S, ecfg, st, nf, af, al)
+    sc2 = np.array([out2["loss"].item(), out2["mil"].item(), out2["err"].item(), out2["l1"].item(),
+                    float(out2["aux"].detach())])
+    assert np.max(np.abs(sc2 - z["scalars_step2"])) < 2e-5
+    for k, v in sub(z, "enc_after2.").items():
+        if v.is_floating_point():
+            assert max_abs_diff(enc_P2[k], v) < 2e-5, k
+    for k, v in sub(z, "head_after2.").items():
+        assert max_abs_diff(head_P2[k], v) < 2e-4, k
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_eval_mode_and_short_tail(name):
+    z, mode, ekw, skw = load_case(name)
+    ecfg, st = oracle_cfgs(mode, ekw, skw, dropout=0.3)       # eval mode: dropout must be inert
+    enc_P = sub(z, "enc_init.")
+    bs, pn, L, P, d = skw["batch_size"], skw["part_num"], skw["part_len"], skw["n_patch"], ekw["d_model"]
+    nf = torch.from_numpy(z["norm_feats"])
+    x = nf.reshape(bs * pn, L * P, d)[:3] if mode == "LTN" else nf.reshape(bs * pn * L, P, d)[:3]
+    assert max_abs_diff(orc.encoder_forward(enc_P, x, ecfg, False), z["eval_enc_out"]) < 2e-5
+    if "eval_tail_enc_out" in z.files:      # last part of a video may hold fewer clips (shorter sequence)
+        assert max_abs_diff(orc.encoder_forward(enc_P, x[:, :(L - 1) * P], ecfg, False), z["eval_tail_enc_out"]) < 2e-5
+        assert max_abs_diff(orc.encoder_forward(enc_P, x[:, :P], ecfg, False), z["eval_tail1_enc_out"]) < 2e-5
+
+
+def test_relative_position_index_closed_forms():
+    z = np.load(GOLDEN + "/misc.npz", allow_pickle=False)
+    for (L, ws) in [(3, 4), (2, 4), (5, 4), (2, 3), (1, 4)]:
+        assert np.array_equal(orc.relative_position_index_3d(L, ws).numpy(), z[f"relidx3d_L{L}_ws{ws}"])
+    for ws in (3, 4):
+        assert np.array_equal(orc.relative_position_index_2d(ws).numpy(), z[f"relidx2d_ws{ws}"])
+
+
+def test_auc_matches_reference_eval():
+    z = np.load(GOLDEN + "/misc.npz", allow_pickle=False)
+    assert abs(orc.roc_auc(z["auc_scores"], z["auc_labels"]) - float(z["auc_value"])) < 1e-12
+    assert abs(orc.roc_auc(z["auc2_scores"], z["auc2_labels"]) - float(z["auc2_value"])) < 1e-12
+
+
+def test_param_shapes_match_reference_counts_and_keys():
+    z = np.load(GOLDEN + "/misc.npz", allow_pickle=False)
+    ltn = orc.EncoderCfg(d_inner=4096, MHA_layerNorm=True, relative_pe=True, window_size=4, window_depth=3)
+    stn = orc.EncoderCfg(d_inner=3027)
+    n = lambda sh: sum(int(np.prod(s)) for s in sh.values())
+    assert n(orc.encoder_param_shapes(ltn)) == int(z["ltn_param_count"]) == 100716280
+    assert n(orc.encoder_param_shapes(stn)) == int(z["stn_param_count"]) == 87571321
+    assert n(orc.head_param_shapes(2048, "classifier")) == int(z["classifier_param_count"])
+    assert n(orc.head_param_shapes(2048, "regressor")) == int(z["regressor_param_count"])
+    keys = [k for k in z["ltn_state_keys"].tolist() if not k.endswith("relative_position_index")]
+    assert sorted(keys) == sorted(orc.encoder_param_shapes(ltn))
+    assert sorted(z["stn_state_keys"].tolist()) == sorted(orc.encoder_param_shapes(stn))
