@@ -1,0 +1,25 @@
+# Builds liblstc_hip.so (gfx950 only) and the oracle-side helpers.  `python -c "import __graft_entry__ as g; g.build()"`
+# drives the same commands.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := lstc_vad_amd/csrc
+SRCS  := $(wildcard $(CSRC)/*.hip)
+OBJS  := $(SRCS:.hip=.o)
+LIB   := lstc_vad_amd/liblstc_hip.so
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -ffp-contract=off
+
+all: $(LIB)
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/lstc_common.h include/lstc_hip.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS)
+
+tools/gemm_check: tools/gemm_check.cpp $(LIB)
+	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude $< -o $@ -Llstc_vad_amd -llstc_hip -Wl,-rpath,'$$ORIGIN/../lstc_vad_amd'
+
+clean:
+	rm -f $(OBJS) $(LIB) tools/gemm_check
+
+.PHONY: all clean

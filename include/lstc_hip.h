@@ -1,0 +1,206 @@
+/*
+ * lstc_hip.h — C ABI of liblstc_hip.so, the MI355X (gfx950) native kernels behind the
+ * LSTC_VAD training hot path.
+ *
+ * The reference (shengyangsun/LSTC_VAD) has no FFI / plugin layer: its hot path is the
+ * Python class surface models.Encoder / MultiHeadAttention / FFN / Regressor / Classifier
+ * plus the loss functions and torch.optim.Adagrad inside Train/*.py, all of it implicit
+ * ATen kernels.  Each entry point below replaces the ATen work of the reference lines it
+ * cites (paths relative to the reference root).  lstc_vad_amd/_lib.py binds them with
+ * ctypes; INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch types.
+ *  - Every buffer is owned by the caller (PyTorch allocates); the library never allocates
+ *    or frees device memory and keeps no pointer after return.
+ *  - Asynchronous on the given HIP stream (hipStream_t passed as void*); no internal sync.
+ *  - Return 0 on success; <0 = argument/shape error detected on the host before launch
+ *    (LSTC_E_*); >0 = hipError_t from the launch.  lstc_strerror() names either.
+ *  - All matrices are row-major; "ld" = leading dimension in elements.
+ */
+#ifndef LSTC_HIP_H
+#define LSTC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSTC_VERSION 100            /* 0.1.0 */
+
+enum {
+    LSTC_OK = 0,
+    LSTC_E_NULL = -1,               /* required pointer is NULL */
+    LSTC_E_SHAPE = -2,              /* non-positive / inconsistent dimension */
+    LSTC_E_ALIGN = -3,              /* pointer / leading dimension breaks a documented alignment rule */
+    LSTC_E_UNSUPPORTED = -4,        /* combination not implemented */
+    LSTC_E_RANGE = -5               /* size exceeds a documented limit (e.g. sequence length, 32-bit indexing) */
+};
+
+enum { LSTC_F32 = 0, LSTC_BF16 = 1 };
+
+/* ----------------------------------------------------------------------------- GEMM
+ * C[M,N] = epilogue( alpha * op(A)[M,K] * op(B)[K,N] )
+ *   transA = 0: A stored [M,K] (K contiguous)      transA = 1: A stored [K,M] (M contiguous)
+ *   transB = 0: B stored [K,N] (N contiguous)      transB = 1: B stored [N,K] (K contiguous)
+ * Replaces every nn.Linear / torch.matmul-with-weights on the path:
+ *   forward  X*W^T  (transA=0, transB=1): models/MultiHeadAttention.py:97-99,123; models/FFN.py:17;
+ *                                         models/Regressor.py:19-20; models/Classifier.py:21-22
+ *   backward dX = dY*W (0,0) and dW = dY^T*X (1,0): autograd of the above,
+ *                                         Train/temporal_transformer_shanghaitech.py:138
+ * Epilogue order (each stage optional, selected by `flags`):
+ *   v = alpha*acc; v += bias[n]; v = relu(v); v = dropout(v); v += residual[m,n];
+ *   v *= (relu_src[m,n] > 0); C = v   (or C += v with LSTC_EPI_ACCUM)
+ * fusing  relu(W1 x + b1)            models/FFN.py:17
+ *         dropout(W2 h + b2) + x     models/FFN.py:17-19
+ *         dropout(fc(o)) + residual  models/MultiHeadAttention.py:123-124
+ * Dropout keeps element i = m*N+n iff hash(seed, i) >= p*2^32 and scales kept values by
+ * 1/(1-p); lstc_dropout_mask() / lstc_dropout_apply() regenerate the same mask.
+ * dtype LSTC_F32: exact f32 MFMA (v_mfma_f32_32x32x2_f32) — bitwise a k-ordered fmaf chain.
+ * dtype LSTC_BF16: A/B bf16, f32 accumulate; C bf16 unless LSTC_EPI_OUT_F32.
+ */
+enum {
+    LSTC_EPI_BIAS = 1, LSTC_EPI_RELU = 2, LSTC_EPI_DROPOUT = 4, LSTC_EPI_RESIDUAL = 8,
+    LSTC_EPI_RELU_MASK = 16, LSTC_EPI_ACCUM = 32, LSTC_EPI_OUT_F32 = 64
+};
+
+typedef struct LstcGemmDesc {
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc;
+    int32_t transA, transB;
+    int32_t dtype;                  /* LSTC_F32 | LSTC_BF16 */
+    int32_t flags;                  /* LSTC_EPI_* */
+    float   alpha;
+    float   dropout_p;
+    uint64_t dropout_seed;
+    int32_t ldr;                    /* residual leading dimension */
+    int32_t ld_relu;                /* relu_src leading dimension */
+    int32_t split_k;                /* 0/1 = none; >1: K split over workgroups, partial sums added with f32 atomics
+                                       into C, which the caller must have zeroed (only alpha epilogue allowed) */
+    int32_t variant;                /* 0 = library default tile; >0 selects a tile variant (tuning / tests) */
+    const void* A;
+    const void* B;
+    void*       C;
+    const float* bias;              /* [N] */
+    const void*  residual;          /* [M,ldr], same dtype as C */
+    const void*  relu_src;          /* [M,ld_relu], same dtype as C */
+} LstcGemmDesc;
+
+int lstc_gemm(const LstcGemmDesc* d, void* stream);
+
+/* ------------------------------------------------------------------------ attention
+ * Fused core of models/MultiHeadAttention.py:103-122 for one layer, all sequences, heads:
+ *   A = (Q/sqrt(d_k)) K^T ; A[:, :, 1:, 1:] += table[index[i-1, j-1], h] ; P = softmax(A, -1) ;
+ *   Pd = dropout(P) ; O = Pd V, written head-merged ([N, S, H*dv]).
+ * Q, K, V are the projection outputs as the GEMM leaves them: [N, S, H*dk] (token-major, heads
+ * interleaved) — the reference's transpose(1,2)/contiguous copies (:101,:122) disappear.
+ * `probs` [N, H, S, S] receives P (pre-dropout) for the backward pass / return_attn.
+ * rel-bias: `table` [n_rows, H] float, `index` int64 [index_ld-wide rows]; entry used for
+ * (i, j), 1 <= i,j < S is table[index[(i-1)*index_ld + (j-1)], h] — the top-left (S-1)x(S-1)
+ * block, exactly the reference's `relative_position_index[:len_q-1, :len_q-1]` slice (:108).
+ */
+typedef struct LstcAttnDesc {
+    int32_t N, S, H, dk, dv;        /* dk, dv multiples of 32; S <= 128 */
+    int32_t ldq, ldk, ldv, ldo;     /* token strides in elements (normally H*dk / H*dv) */
+    int32_t dtype;
+    int32_t index_ld;               /* 0 = no relative bias */
+    float   scale;                  /* 1/sqrt(d_k): multiplies Q (reference divides by temperature :49,:103) */
+    float   dropout_p;
+    uint64_t dropout_seed;
+    const void* Q; const void* K; const void* V;
+    void*  O;
+    float* probs;                   /* [N,H,S,S] f32 */
+    const float*   table;           /* [rows, H] or NULL */
+    const int64_t* index;           /* or NULL */
+    /* backward only */
+    const void* dO;                 /* [N,S,H*dv] */
+    void* dQ; void* dK; void* dV;   /* [N,S,H*dk|dv], written (not accumulated) */
+    float* dtable;                  /* [rows,H] accumulated with atomics; caller zeroes; NULL = skip */
+} LstcAttnDesc;
+
+int lstc_attn_fwd(const LstcAttnDesc* d, void* stream);
+/* autograd of the above (dV = Pd^T dO; dPd = dO V^T; dA = P*(dP - rowsum(dP*P)); dQ = dA K*scale;
+ * dK = dA^T Q*scale; dtable[index] += dA[1:,1:] summed over sequences). */
+int lstc_attn_bwd(const LstcAttnDesc* d, void* stream);
+
+/* ------------------------------------------------------------------- row-wise kernels */
+/* y = LayerNorm(x) * gamma + beta over the last dim (eps inside the sqrt, biased variance) —
+ * nn.LayerNorm(d_model, eps=1e-6): models/MultiHeadAttention.py:47,125-126; models/FFN.py:10,20-21;
+ * models/Encoder.py:31,48-49.  Saves mean / rstd per row for the backward. */
+int lstc_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                       float* mean, float* rstd, int64_t rows, int32_t d, float eps, void* stream);
+/* dx, and per-workgroup partial dgamma/dbeta in `partial` [2, n_partial, d] (reduce with lstc_colsum). */
+int lstc_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                       float* dx, float* partial, int32_t n_partial, int64_t rows, int32_t d, void* stream);
+
+/* CLS = mean over tokens (or `cls_token` if not NULL), prepended; optional `pos` [S, d] added to every
+ * sequence — models/Encoder.py:51-58.  x [N, S-1, d] -> y [N, S, d]. */
+int lstc_cls_concat_fwd(const float* x, const float* cls_token, const float* pos, float* y,
+                        int64_t N, int32_t S, int32_t d, void* stream);
+
+/* out[c] = sum_r x[r, c] for x [rows, ld] (first `cols` columns); deterministic two-pass reduction.
+ * `partial` is caller workspace of n_partial*cols floats.  Bias / LayerNorm / pos-enc gradients. */
+int lstc_colsum(const float* x, int64_t rows, int32_t cols, int32_t ld, float* partial, int32_t n_partial,
+                float* out, int32_t accumulate, void* stream);
+
+/* y[i] = x[i] * keep(i)/(1-p) with the GEMM epilogue's mask (dropout backward / standalone dropout). */
+int lstc_dropout_apply(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* mask[i] = keep(i) ? 1 : 0 — exported so tests can replay a HIP dropout run through the oracle. */
+int lstc_dropout_mask(uint8_t* mask, int64_t n, float p, uint64_t seed, void* stream);
+
+/* Last head layer fused with its activation: out = sigmoid(x W^T + b) (c=1, models/Regressor.py:9) or
+ * softmax(x W^T + b) (c=2, models/Classifier.py:10).  x [rows, 32]. */
+int lstc_head_out_fwd(const float* x, const float* W, const float* b, float* out, int64_t rows, int32_t c,
+                      void* stream);
+/* dx [rows,32], dW [c,32], db [c] from d(out); dW/db are accumulated with atomics (caller zeroes). */
+int lstc_head_out_bwd(const float* x, const float* W, const float* out, const float* dout,
+                      float* dx, float* dW, float* db, int64_t rows, int32_t c, void* stream);
+
+/* ----------------------------------------------------------------------------- loss
+ * MIL ranking loss + sparsity (+ CE on softmax outputs | + weighted BCE) and its gradient w.r.t. the
+ * head output, one launch:
+ *   mode 0 (STN):  Train/spatio_transformer_shanghaitech.py:21-32
+ *   mode 1 (LTN):  Train/temporal_transformer_shanghaitech.py:21-36,125-134  (out [2bs*pn, 2]; score = out[:,1])
+ *   mode 2 (STN + BCE): Train/spatio_transformer_MIL_CE.py:23-26,32-44,176-181
+ * bag[v] = max_p mean_l score[v,p,l]; err = sum_ij relu(1 - abn_j + nor_i)/bs^2;
+ * l1 = mean(score[l1_skip:]) (flat slice quirk: l1_skip = bs*pn*L for STN, bs for LTN / co-teach).
+ * Data-parallel: `bag_global` (length 2*bs_global) holds every rank's bag maxima (all-reduced by the
+ * caller); this rank owns videos [vid0, vid0+n_local_videos) of each half.  Single GPU: pass NULL.
+ * scalars[0..4] = loss, mil, err, l1, aux(CE|BCE) — the rank-local *contributions* (sum over ranks
+ * gives the global value; identical to the reference on one GPU).
+ */
+typedef struct LstcLossDesc {
+    int32_t mode;
+    int32_t bs_global, bs_local, rank_off;  /* pairs per global batch / on this rank / first pair index */
+    int32_t part_num, part_len;
+    int32_t l1_skip_global;         /* number of leading flat score entries (global numbering) excluded from l1 */
+    float lambda_1, lambda_MIL, lambda_aux, lambda_normal, lambda_abnormal;
+    const float* out;               /* head output: [rows_local, 1] or [rows_local, 2] */
+    const float* targets;           /* [rows_local(/L), 2] soft targets (mode 1: per row; mode 2: per part) or NULL */
+    const float* bag_global;        /* optional [2*bs_global] */
+    float* bag_local;               /* [2*bs_local] out: this rank's bag maxima (normal half then abnormal half) */
+    float* dout;                    /* gradient of the rank's loss contribution w.r.t. `out` */
+    float* scalars;                 /* [5] */
+    int32_t phase;                  /* 0 = compute bag_local only; 1 = loss + gradient (bag_global or bag_local) */
+} LstcLossDesc;
+
+int lstc_vad_loss(const LstcLossDesc* d, void* stream);
+
+/* ------------------------------------------------------------------------ optimizer
+ * torch.optim.Adagrad step as configured at Train/temporal_transformer_shanghaitech.py:83-85,142
+ * (lr_decay=0, eps=1e-10, initial accumulator 0): g = grad*gscale + wd*w; s += g*g; w -= lr*g/(sqrt(s)+eps).
+ * `gscale` carries the clip_grad_norm_ coefficient (:139-141) or 1. */
+int lstc_adagrad_step(float* w, const float* grad, float* state, int64_t n, float lr, float weight_decay,
+                      float eps, float gscale, void* stream);
+/* out[0] += sum(x^2) (f32 atomics over workgroup partials; caller zeroes) — for clip_grad_norm_. */
+int lstc_sqnorm_accum(const float* x, int64_t n, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------ misc */
+int lstc_version(void);
+const char* lstc_strerror(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSTC_HIP_H */

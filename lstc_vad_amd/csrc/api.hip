@@ -1,0 +1,33 @@
+// C-ABI front door: dtype dispatch, version, error strings.
+#include "lstc_common.h"
+
+int lstc_gemm_f32_impl(const LstcGemmDesc* d, hipStream_t st);
+int lstc_gemm_bf16_impl(const LstcGemmDesc* d, hipStream_t st) __attribute__((weak));
+
+extern "C" {
+
+int lstc_gemm(const LstcGemmDesc* d, void* stream) {
+    if (!d) return LSTC_E_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == LSTC_F32) return lstc_gemm_f32_impl(d, st);
+    if (d->dtype == LSTC_BF16 && lstc_gemm_bf16_impl) return lstc_gemm_bf16_impl(d, st);
+    return LSTC_E_UNSUPPORTED;
+}
+
+int lstc_version(void) { return LSTC_VERSION; }
+
+const char* lstc_strerror(int code) {
+    switch (code) {
+        case LSTC_OK: return "ok";
+        case LSTC_E_NULL: return "lstc: required pointer is NULL";
+        case LSTC_E_SHAPE: return "lstc: bad or inconsistent dimension";
+        case LSTC_E_ALIGN: return "lstc: pointer or leading dimension not aligned as required";
+        case LSTC_E_UNSUPPORTED: return "lstc: unsupported combination";
+        case LSTC_E_RANGE: return "lstc: size exceeds a documented limit";
+        default: break;
+    }
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "lstc: unknown error";
+}
+
+}  // extern "C"

@@ -1,0 +1,330 @@
+// Exact-f32 MFMA GEMM with fused epilogues for gfx950 (MI355X).
+//
+// C[M,N] = epi(alpha * op(A) * op(B)), all three operand layouts the training step needs:
+//   NT  X * W^T      forward of every nn.Linear             (A K-contig, B K-contig)
+//   NN  dY * W       input gradient                         (A K-contig, B N-contig)
+//   TN  dY^T * X     weight gradient, K = tokens (~1e5)     (A M-contig, B N-contig)
+//
+// Design (MI355X_MICROARCH / cdna_hip_programming 3, 5):
+//  * v_mfma_f32_32x32x2_f32: the only exact-f32 matrix instruction; 64 cycles per issue per SIMD,
+//    so one wave per SIMD with >=4 independent accumulators already saturates the pipe and every
+//    other instruction (LDS reads, global prefetch, epilogue of the co-resident workgroup) hides
+//    behind it.  Each wave owns a (BM/WGM)x(BN/WGN) tile = TMxTN accumulators of 32x32.
+//  * K order is free inside a dot product, so lane half h (lane>>5) takes k = 16h..16h+15 of each
+//    32-deep K tile instead of the interleaved {h, h+2, ...}: a K-contiguous operand row is then
+//    read from LDS with 4 ds_read_b128 per 32x32x32 block instead of 16 ds_read_b32.
+//  * LDS images: K-contiguous operands as [rows][36] floats (144-B rows: 16-B aligned for
+//    ds_write_b128 / ds_read_b128, 36 = 4*9 with 9 odd -> every 16-lane b128 group hits 16 distinct
+//    16-B slots: conflict-free); M/N-contiguous operands as [32][rows] read with ds_read_b32
+//    (32 consecutive floats per half-wave: conflict-free).
+//  * Register-staged double buffering: global loads of K tile t+1 are issued before the MFMAs of
+//    tile t and written to the other LDS buffer after them; one barrier per K tile.
+//  * XCD-aware tile order: consecutive workgroup ids go round-robin to the 8 XCDs, so ids are remapped
+//    (bijectively) to give each XCD a contiguous run of tiles with the N index fastest: an XCD's L2
+//    then holds the A panel its tiles share.
+//  * Epilogue in the accumulator layout (col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5)): every
+//    wave-level load/store is two 128-B row segments.
+#include "lstc_common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = 36;   // padded K stride of K-contiguous LDS images
+
+struct GemmParams {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    const float* res;
+    const float* relu_src;
+    int M, N, K, lda, ldb, ldc, ldr, ld_relu;
+    int flags;
+    float alpha;
+    DropKey dk;
+    int tilesM, tilesN;
+    int ktiles, ktiles_per_split;
+};
+
+// Stages one operand tile (R rows/cols x 32 k) global -> registers -> LDS.
+//  KC = true : operand stored [R_total][K] (K contiguous); LDS image [R][LDK].
+//  KC = false: operand stored [K][R_total] (R contiguous); LDS image [32][R].
+template <int R, int NT, bool KC, bool VEC>
+struct Stager {
+    static constexpr int NV = R * 8 / NT;
+    static_assert(NV >= 1 && (R * 8) % NT == 0, "tile/threads mismatch");
+    float4 v[NV];
+
+    __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int r0, int r_total, int k0, int K) {
+        const int t = threadIdx.x;
+        if (KC) {
+            const int c = (t & 7) * 4;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int r = r0 + (t >> 3) + i * (NT / 8);
+                const int k = k0 + c;
+                const float* p = base + (size_t)r * ld + k;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < r_total) {
+                    if (VEC) {
+                        if (k < K) x = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (k + 0 < K) x.x = p[0];
+                        if (k + 1 < K) x.y = p[1];
+                        if (k + 2 < K) x.z = p[2];
+                        if (k + 3 < K) x.w = p[3];
+                    }
+                }
+                v[i] = x;
+            }
+        } else {
+            constexpr int CPR = R / 4;          // float4 columns per k row
+            const int c = (t % CPR) * 4;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int k = k0 + t / CPR + i * (NT / CPR);
+                const int r = r0 + c;
+                const float* p = base + (size_t)k * ld + r;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < K) {
+                    if (VEC) {
+                        if (r < r_total) x = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (r + 0 < r_total) x.x = p[0];
+                        if (r + 1 < r_total) x.y = p[1];
+                        if (r + 2 < r_total) x.z = p[2];
+                        if (r + 3 < r_total) x.w = p[3];
+                    }
+                }
+                v[i] = x;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(float* __restrict__ lds) const {
+        const int t = threadIdx.x;
+        if (KC) {
+            const int c = (t & 7) * 4;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int r = (t >> 3) + i * (NT / 8);
+                *reinterpret_cast<float4*>(lds + r * LDK + c) = v[i];
+            }
+        } else {
+            constexpr int CPR = R / 4;
+            const int c = (t % CPR) * 4;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int k = t / CPR + i * (NT / CPR);
+                *reinterpret_cast<float4*>(lds + k * R + c) = v[i];
+            }
+        }
+    }
+};
+
+template <int R, bool KC>
+constexpr int stage_floats() { return KC ? R * LDK : BK * R; }
+
+// Reads this lane's 8 k-values (k = 16*h + 8*half + j) of operand row `row` from the LDS image.
+template <int R, bool KC>
+__device__ __forceinline__ void read_frag(const float* __restrict__ lds, int row, int h, int half, float (&f)[8]) {
+    if (KC) {
+        const float4* p = reinterpret_cast<const float4*>(lds + row * LDK + 16 * h + 8 * half);
+        const float4 a = p[0], b = p[1];
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
+        f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    } else {
+        const float* p = lds + (16 * h + 8 * half) * R + row;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = p[j * R];
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC, bool VA, bool VB>
+__global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParams p) {
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int A_ST = stage_floats<BM, A_KC>();
+    constexpr int B_ST = stage_floats<BN, B_KC>();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As = smem;                  // 2 stages
+    float* const Bs = smem + 2 * A_ST;       // 2 stages
+
+    // ---- XCD-aware, bijective workgroup -> tile map
+    const int nwg = p.tilesM * p.tilesN;
+    int pid = blockIdx.x;
+    {
+        const int xcd = pid & 7, idx = pid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mt = pid / p.tilesN, nt = pid % p.tilesN;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int kt0 = blockIdx.y * p.ktiles_per_split;
+    const int kt1 = min(p.ktiles, kt0 + p.ktiles_per_split);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    Stager<BM, NT, A_KC, VA> sa;
+    Stager<BN, NT, B_KC, VB> sb;
+
+    if (kt0 < kt1) {
+        sa.load(p.A, p.lda, m0, p.M, kt0 * BK, p.K);
+        sb.load(p.B, p.ldb, n0, p.N, kt0 * BK, p.K);
+        sa.store(As);
+        sb.store(Bs);
+    }
+    __syncthreads();
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        const bool more = kt + 1 < kt1;
+        if (more) {
+            sa.load(p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K);
+            sb.load(p.B, p.ldb, n0, p.N, (kt + 1) * BK, p.K);
+        }
+        const float* a_lds = As + cur * A_ST;
+        const float* b_lds = Bs + cur * B_ST;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float af[TM][8], bf[TN][8];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) read_frag<BM, A_KC>(a_lds, wm * WTM + i * 32 + l31, h, half, af[i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) read_frag<BN, B_KC>(b_lds, wn * WTN + j * 32 + l31, h, half, bf[j]);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            sa.store(As + (cur ^ 1) * A_ST);
+            sb.store(Bs + (cur ^ 1) * B_ST);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    const int flags = p.flags;
+    const bool atomic = gridDim.y > 1;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * WTN + j * 32 + l31;
+        if (col >= p.N) continue;
+        const float bv = (flags & LSTC_EPI_BIAS) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rbase = m0 + wm * WTM + i * 32 + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] * p.alpha;
+                float* cp = p.C + (size_t)row * p.ldc + col;
+                if (atomic) {
+                    atomicAdd(cp, v);
+                    continue;
+                }
+                v += bv;
+                if (flags & LSTC_EPI_RELU) v = fmaxf(v, 0.f);
+                if (flags & LSTC_EPI_DROPOUT) {
+                    const uint32_t idx = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+                    v = drop_keep(idx, p.dk) ? v * p.dk.scale : 0.f;
+                }
+                if (flags & LSTC_EPI_RESIDUAL) v += p.res[(size_t)row * p.ldr + col];
+                if (flags & LSTC_EPI_RELU_MASK) v = p.relu_src[(size_t)row * p.ld_relu + col] > 0.f ? v : 0.f;
+                if (flags & LSTC_EPI_ACCUM) v += *cp;
+                *cp = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC>
+int launch_cfg(const GemmParams& p, bool va, bool vb, int splits, hipStream_t st) {
+    constexpr int NT = WGM * WGN * 64;
+    constexpr size_t lds = (size_t)(2 * stage_floats<BM, A_KC>() + 2 * stage_floats<BN, B_KC>()) * sizeof(float);
+    dim3 grid(p.tilesM * p.tilesN, splits), block(NT);
+#define LSTC_GO(VA, VB)                                                                                     \
+    do {                                                                                                    \
+        auto kern = gemm_f32_kernel<BM, BN, WGM, WGN, A_KC, B_KC, VA, VB>;                                  \
+        static bool attr_done = false;                                                                      \
+        if (!attr_done) {                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                  \
+            attr_done = true;                                                                               \
+        }                                                                                                   \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, p);                                                  \
+    } while (0)
+    if (va && vb) LSTC_GO(true, true);
+    else if (va) LSTC_GO(true, false);
+    else if (vb) LSTC_GO(false, true);
+    else LSTC_GO(false, false);
+#undef LSTC_GO
+    return lstc_launch_status();
+}
+
+template <bool A_KC, bool B_KC>
+int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipStream_t st) {
+    int BM, BN;
+    switch (variant) {
+        case 2: BM = 256; BN = 128; break;
+        case 3: BM = 128; BN = 256; break;
+        case 4: BM = 256; BN = 256; break;
+        default: BM = 128; BN = 128; break;
+    }
+    p.tilesM = (p.M + BM - 1) / BM;
+    p.tilesN = (p.N + BN - 1) / BN;
+    switch (variant) {
+        case 2: return launch_cfg<256, 128, 4, 2, A_KC, B_KC>(p, va, vb, splits, st);
+        case 3: return launch_cfg<128, 256, 2, 4, A_KC, B_KC>(p, va, vb, splits, st);
+        case 4: return launch_cfg<256, 256, 2, 4, A_KC, B_KC>(p, va, vb, splits, st);
+        default: return launch_cfg<128, 128, 2, 2, A_KC, B_KC>(p, va, vb, splits, st);
+    }
+}
+
+}  // namespace
+
+int lstc_gemm_f32_impl(const LstcGemmDesc* d, hipStream_t st) {
+    if (!d->A || !d->B || !d->C) return LSTC_E_NULL;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0) return LSTC_E_SHAPE;
+    const int a_min = d->transA ? d->M : d->K, b_min = d->transB ? d->K : d->N;
+    if (d->lda < a_min || d->ldb < b_min || d->ldc < d->N) return LSTC_E_SHAPE;
+    if ((d->flags & LSTC_EPI_BIAS) && !d->bias) return LSTC_E_NULL;
+    if ((d->flags & LSTC_EPI_RESIDUAL) && (!d->residual || d->ldr < d->N)) return LSTC_E_NULL;
+    if ((d->flags & LSTC_EPI_RELU_MASK) && (!d->relu_src || d->ld_relu < d->N)) return LSTC_E_NULL;
+    if ((d->flags & LSTC_EPI_DROPOUT) && (uint64_t)d->M * (uint64_t)d->N > 0xffffffffull) return LSTC_E_RANGE;
+    if (d->transA && d->transB) return LSTC_E_UNSUPPORTED;
+    const int splits = d->split_k > 1 ? d->split_k : 1;
+    if (splits > 1 && d->flags != 0) return LSTC_E_UNSUPPORTED;
+    GemmParams p;
+    p.A = (const float*)d->A; p.B = (const float*)d->B; p.C = (float*)d->C;
+    p.bias = d->bias; p.res = (const float*)d->residual; p.relu_src = (const float*)d->relu_src;
+    p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+    p.ldr = d->ldr; p.ld_relu = d->ld_relu; p.flags = d->flags; p.alpha = d->alpha;
+    p.dk = make_drop_key(d->dropout_p, d->dropout_seed);
+    p.ktiles = (d->K + BK - 1) / BK;
+    p.ktiles_per_split = (p.ktiles + splits - 1) / splits;
+    const int eff_splits = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
+    // float4 global loads need 16-B aligned rows; the contiguous extent must be a multiple of 4 so a
+    // float4 is entirely inside or outside the matrix.
+    const bool va = aligned16(d->A) && (d->lda % 4 == 0) && ((d->transA ? d->M : d->K) % 4 == 0);
+    const bool vb = aligned16(d->B) && (d->ldb % 4 == 0) && ((d->transB ? d->K : d->N) % 4 == 0);
+    if (!d->transA && d->transB) return launch_layout<true, true>(p, va, vb, eff_splits, d->variant, st);
+    if (!d->transA && !d->transB) return launch_layout<true, false>(p, va, vb, eff_splits, d->variant, st);
+    return launch_layout<false, false>(p, va, vb, eff_splits, d->variant, st);
+}

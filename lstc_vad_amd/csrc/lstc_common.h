@@ -1,0 +1,75 @@
+// Shared device/host helpers for liblstc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lstc_hip.h"
+
+#define LSTC_WAVE 64
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------- dropout RNG
+// Counter-based keep/drop decision for flat element index i under a 64-bit seed.  Two-multiply
+// avalanche hash (cheap enough to sit in a GEMM epilogue); keep iff hash >= p * 2^32.
+struct DropKey {
+    uint32_t k0, k1, thr;
+    float scale;
+};
+
+__host__ __device__ inline DropKey make_drop_key(float p, uint64_t seed) {
+    DropKey k;
+    k.k0 = (uint32_t)(seed & 0xffffffffu) * 0x9E3779B1u + 0x7F4A7C15u;
+    k.k1 = (uint32_t)(seed >> 32) * 0x85EBCA77u + 0x165667B1u;
+    double t = (double)p * 4294967296.0;
+    k.thr = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+    k.scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
+    return k;
+}
+
+__host__ __device__ inline uint32_t drop_hash(uint32_t i, const DropKey& k) {
+    uint32_t h = i ^ k.k0;
+    h *= 0x9E3779B1u;
+    h ^= h >> 15;
+    h += k.k1;
+    h *= 0x85EBCA77u;
+    h ^= h >> 13;
+    h *= 0xC2B2AE3Du;
+    h ^= h >> 16;
+    return h;
+}
+
+__host__ __device__ inline bool drop_keep(uint32_t i, const DropKey& k) { return drop_hash(i, k) >= k.thr; }
+
+// ---------------------------------------------------------------------------------- reductions
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum for blockDim.x == NT (multiple of 64); `red` is NT/64 floats of LDS.
+template <int NT>
+__device__ inline float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) t += red[i];
+    return t;
+}
+
+static inline int lstc_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

@@ -1,0 +1,542 @@
+// HBM-bound row-wise kernels of the training step (gfx950): LayerNorm fwd/bwd, CLS-mean + concat,
+// column sums, dropout replay, the fused last head layer, Adagrad, squared-norm.
+// All of them stream their operands once with 16-B-per-lane accesses where the layout allows
+// (cdna_hip_programming Guideline 13) and reduce with wave shuffles.
+#include "lstc_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ------------------------------------------------------------------------------- LayerNorm
+// One wave per row; the row lives in registers (NV float4 per lane, d <= 256*NV) so x is read once.
+// Two-pass statistics (mean, then centred variance) like ATen's CPU kernel for parity.
+template <int NV>
+__global__ void __launch_bounds__(NT) ln_fwd_vec(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, float* __restrict__ y,
+                                                  float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
+                                                  int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (NT / 64);
+    const int nv4 = d >> 2;
+    float4 g[NV], b[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv4) {
+            g[i] = reinterpret_cast<const float4*>(gamma)[c];
+            b[i] = reinterpret_cast<const float4*>(beta)[c];
+        }
+    }
+    for (int64_t r = wave0; r < rows; r += nwaves) {
+        const float4* xr = reinterpret_cast<const float4*>(x + r * d);
+        float4 v[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < nv4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        const float mu = wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv4) {
+                const float a0 = v[i].x - mu, a1 = v[i].y - mu, a2 = v[i].z - mu, a3 = v[i].w - mu;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        }
+        const float rs = 1.f / sqrtf(wave_sum(q) / (float)d + eps);
+        float4* yr = reinterpret_cast<float4*>(y + r * d);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv4) {
+                float4 o;
+                o.x = (v[i].x - mu) * rs * g[i].x + b[i].x;
+                o.y = (v[i].y - mu) * rs * g[i].y + b[i].y;
+                o.z = (v[i].z - mu) * rs * g[i].z + b[i].z;
+                o.w = (v[i].w - mu) * rs * g[i].w + b[i].w;
+                yr[c] = o;
+            }
+        }
+        if (lane == 0) {
+            mean[r] = mu;
+            rstd[r] = rs;
+        }
+    }
+}
+
+// Any d (odd widths, > 2048): scalar, three passes over the row (re-reads hit L1/L2).
+__global__ void __launch_bounds__(NT) ln_fwd_generic(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ y,
+                                                      float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
+                                                      int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (NT / 64);
+    for (int64_t r = wave0; r < rows; r += nwaves) {
+        const float* xr = x + r * d;
+        float s = 0.f;
+        for (int c = lane; c < d; c += 64) s += xr[c];
+        const float mu = wave_sum(s) / (float)d;
+        float q = 0.f;
+        for (int c = lane; c < d; c += 64) {
+            const float a = xr[c] - mu;
+            q += a * a;
+        }
+        const float rs = 1.f / sqrtf(wave_sum(q) / (float)d + eps);
+        for (int c = lane; c < d; c += 64) y[r * d + c] = (xr[c] - mu) * rs * gamma[c] + beta[c];
+        if (lane == 0) {
+            mean[r] = mu;
+            rstd[r] = rs;
+        }
+    }
+}
+
+// dx = rstd * (g*dy - mean_d(g*dy) - xhat * mean_d(g*dy*xhat)); per-workgroup partial dgamma = sum dy*xhat,
+// dbeta = sum dy written to partial[0][blockIdx.x][:] / partial[1][blockIdx.x][:].
+template <int NV>
+__global__ void __launch_bounds__(NT) ln_bwd_vec(const float* __restrict__ dy, const float* __restrict__ x,
+                                                  const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                  const float* __restrict__ rstd, float* __restrict__ dx,
+                                                  float* __restrict__ partial, int64_t rows, int d) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [NT/64][2][d]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave0 = (int64_t)blockIdx.x * (NT / 64) + wv;
+    const int64_t nwaves = (int64_t)gridDim.x * (NT / 64);
+    const int nv4 = d >> 2;
+    float4 g[NV], ag[NV], ab[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        g[i] = c < nv4 ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int64_t r = wave0; r < rows; r += nwaves) {
+        const float4* xr = reinterpret_cast<const float4*>(x + r * d);
+        const float4* dr = reinterpret_cast<const float4*>(dy + r * d);
+        const float mu = mean[r], rs = rstd[r];
+        float4 xh[NV], gd[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv4) {
+                const float4 xv = xr[c], dv = dr[c];
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                gd[i] = make_float4(dv.x * g[i].x, dv.y * g[i].y, dv.z * g[i].z, dv.w * g[i].w);
+                s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
+                s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
+                ag[i].x += dv.x * xh[i].x; ag[i].y += dv.y * xh[i].y; ag[i].z += dv.z * xh[i].z; ag[i].w += dv.w * xh[i].w;
+                ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
+            } else {
+                xh[i] = gd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d;
+        float4* o = reinterpret_cast<float4*>(dx + r * d);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv4)
+                o[c] = make_float4(rs * (gd[i].x - m1 - xh[i].x * m2), rs * (gd[i].y - m1 - xh[i].y * m2),
+                                   rs * (gd[i].z - m1 - xh[i].z * m2), rs * (gd[i].w - m1 - xh[i].w * m2));
+        }
+    }
+    // combine the workgroup's 4 waves through LDS, one partial row per workgroup
+    float4* s4 = reinterpret_cast<float4*>(sm);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv4) {
+            s4[(wv * 2 + 0) * nv4 + c] = ag[i];
+            s4[(wv * 2 + 1) * nv4 + c] = ab[i];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * nv4; c += NT) {
+        const int which = c / nv4, cc = c % nv4;
+        float4 t = s4[(0 * 2 + which) * nv4 + cc];
+#pragma unroll
+        for (int w = 1; w < NT / 64; ++w) {
+            const float4 u = s4[(w * 2 + which) * nv4 + cc];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        reinterpret_cast<float4*>(partial + ((size_t)which * gridDim.x + blockIdx.x) * d)[cc] = t;
+    }
+}
+
+__global__ void __launch_bounds__(NT) ln_bwd_generic(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, float* __restrict__ dx,
+                                                      float* __restrict__ partial, int64_t rows, int d) {
+    // one workgroup = one partial row; each wave walks rows, threads accumulate columns in LDS-free fashion
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][d] accumulated with LDS atomics
+    for (int c = threadIdx.x; c < 2 * d; c += NT) sm[c] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (NT / 64);
+    for (int64_t r = wave0; r < rows; r += nwaves) {
+        const float mu = mean[r], rs = rstd[r];
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < d; c += 64) {
+            const float xh = (x[r * d + c] - mu) * rs, gd = dy[r * d + c] * gamma[c];
+            s1 += gd;
+            s2 += gd * xh;
+        }
+        const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d;
+        for (int c = lane; c < d; c += 64) {
+            const float xh = (x[r * d + c] - mu) * rs, dv = dy[r * d + c];
+            dx[r * d + c] = rs * (dv * gamma[c] - m1 - xh * m2);
+            atomicAdd(&sm[c], dv * xh);
+            atomicAdd(&sm[d + c], dv);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * d; c += NT) {
+        const int which = c / d, cc = c % d;
+        partial[((size_t)which * gridDim.x + blockIdx.x) * d + cc] = sm[c];
+    }
+}
+
+// ------------------------------------------------------------------------------ CLS concat
+// grid (N, ceil(d/NT)); thread owns one column (coalesced across the workgroup), walks the tokens.
+__global__ void __launch_bounds__(NT) cls_concat_fwd_kernel(const float* __restrict__ x, const float* __restrict__ cls,
+                                                             const float* __restrict__ pos, float* __restrict__ y, int S,
+                                                             int d) {
+    const int64_t n = blockIdx.x;
+    const int c = blockIdx.y * NT + threadIdx.x;
+    if (c >= d) return;
+    const float* xr = x + n * (int64_t)(S - 1) * d + c;
+    float* yr = y + n * (int64_t)S * d + c;
+    float s = 0.f;
+    for (int t = 0; t < S - 1; ++t) {
+        const float v = xr[(int64_t)t * d];
+        s += v;
+        yr[(int64_t)(t + 1) * d] = pos ? v + pos[(int64_t)(t + 1) * d + c] : v;
+    }
+    float cv = cls ? cls[c] : s / (float)(S - 1);
+    if (pos) cv += pos[c];
+    yr[0] = cv;
+}
+
+// dx[n,t,:] = dy[n,t+1,:] + (mean_cls ? dy[n,0,:]/(S-1) : 0)
+__global__ void __launch_bounds__(NT) cls_concat_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int S,
+                                                             int d, int mean_cls) {
+    const int64_t n = blockIdx.x;
+    const int c = blockIdx.y * NT + threadIdx.x;
+    if (c >= d) return;
+    const float* dr = dy + n * (int64_t)S * d + c;
+    float* xr = dx + n * (int64_t)(S - 1) * d + c;
+    const float g0 = mean_cls ? dr[0] / (float)(S - 1) : 0.f;
+    for (int t = 0; t < S - 1; ++t) xr[(int64_t)t * d] = dr[(int64_t)(t + 1) * d] + g0;
+}
+
+// ---------------------------------------------------------------------------------- colsum
+// pass 1: grid (ceil(cols/NT), n_partial): workgroup y sums rows y, y+n_partial, ... of NT columns.
+__global__ void __launch_bounds__(NT) colsum_pass1(const float* __restrict__ x, int64_t rows, int cols, int ld,
+                                                    float* __restrict__ partial) {
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if (c >= cols) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int64_t step = gridDim.y;
+    int64_t r = blockIdx.y;
+    for (; r + 3 * step < rows; r += 4 * step) {
+        s0 += x[r * ld + c];
+        s1 += x[(r + step) * ld + c];
+        s2 += x[(r + 2 * step) * ld + c];
+        s3 += x[(r + 3 * step) * ld + c];
+    }
+    for (; r < rows; r += step) s0 += x[r * ld + c];
+    partial[(size_t)blockIdx.y * cols + c] = (s0 + s1) + (s2 + s3);
+}
+__global__ void __launch_bounds__(NT) colsum_pass2(const float* __restrict__ partial, int n_partial, int cols,
+                                                    float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int p = 0; p < n_partial; ++p) s += partial[(size_t)p * cols + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// --------------------------------------------------------------------------------- dropout
+__global__ void __launch_bounds__(NT) dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            int64_t n, DropKey k) {
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride)
+        y[i] = drop_keep((uint32_t)i, k) ? x[i] * k.scale : 0.f;
+}
+__global__ void __launch_bounds__(NT) dropout_mask_kernel(uint8_t* __restrict__ m, int64_t n, DropKey k) {
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) m[i] = drop_keep((uint32_t)i, k) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------ head output
+// x [rows,32] -> c logits -> sigmoid (c=1) or softmax (c=2); thread per row.
+__global__ void __launch_bounds__(NT) head_out_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                           const float* __restrict__ b, float* __restrict__ out,
+                                                           int64_t rows, int c) {
+    __shared__ float w[2 * 32 + 2];
+    if (threadIdx.x < c * 32) w[threadIdx.x] = W[threadIdx.x];
+    if (threadIdx.x < c) w[64 + threadIdx.x] = b[threadIdx.x];
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (r >= rows) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + r * 32);
+    float z0 = 0.f, z1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float4 v = xr[i];
+        z0 += v.x * w[4 * i] + v.y * w[4 * i + 1] + v.z * w[4 * i + 2] + v.w * w[4 * i + 3];
+        if (c == 2) z1 += v.x * w[32 + 4 * i] + v.y * w[32 + 4 * i + 1] + v.z * w[32 + 4 * i + 2] + v.w * w[32 + 4 * i + 3];
+    }
+    z0 += w[64];
+    if (c == 1) {
+        out[r] = 1.f / (1.f + expf(-z0));
+    } else {
+        z1 += w[65];
+        const float m = fmaxf(z0, z1);
+        const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+        const float inv = 1.f / (e0 + e1);
+        out[2 * r] = e0 * inv;
+        out[2 * r + 1] = e1 * inv;
+    }
+}
+
+__global__ void __launch_bounds__(NT) head_out_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                           const float* __restrict__ out, const float* __restrict__ dout,
+                                                           float* __restrict__ dx, float* __restrict__ dW,
+                                                           float* __restrict__ db, int64_t rows, int c) {
+    __shared__ float w[64];
+    __shared__ float acc[2 * 32 + 2];
+    if (threadIdx.x < c * 32) w[threadIdx.x] = W[threadIdx.x];
+    if (threadIdx.x < 66) acc[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x;
+    float dz0 = 0.f, dz1 = 0.f;
+    float xv[32];
+    const bool live = r < rows;
+    if (live) {
+        if (c == 1) {
+            const float o = out[r];
+            dz0 = dout[r] * o * (1.f - o);
+        } else {
+            const float o0 = out[2 * r], o1 = out[2 * r + 1], g0 = dout[2 * r], g1 = dout[2 * r + 1];
+            const float dot = g0 * o0 + g1 * o1;
+            dz0 = o0 * (g0 - dot);
+            dz1 = o1 * (g1 - dot);
+        }
+        const float4* xr = reinterpret_cast<const float4*>(x + r * 32);
+        float4* dr = reinterpret_cast<float4*>(dx + r * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 v = xr[i];
+            xv[4 * i] = v.x; xv[4 * i + 1] = v.y; xv[4 * i + 2] = v.z; xv[4 * i + 3] = v.w;
+            float4 d4;
+            d4.x = dz0 * w[4 * i] + (c == 2 ? dz1 * w[32 + 4 * i] : 0.f);
+            d4.y = dz0 * w[4 * i + 1] + (c == 2 ? dz1 * w[32 + 4 * i + 1] : 0.f);
+            d4.z = dz0 * w[4 * i + 2] + (c == 2 ? dz1 * w[32 + 4 * i + 2] : 0.f);
+            d4.w = dz0 * w[4 * i + 3] + (c == 2 ? dz1 * w[32 + 4 * i + 3] : 0.f);
+            dr[i] = d4;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) xv[i] = 0.f;
+    }
+    // workgroup reduction of dW / db: wave shuffles, then LDS atomics, then one global atomic per entry
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const float a = wave_sum(dz0 * xv[i]);
+        if (lane == 0) atomicAdd(&acc[i], a);
+        if (c == 2) {
+            const float bb = wave_sum(dz1 * xv[i]);
+            if (lane == 0) atomicAdd(&acc[32 + i], bb);
+        }
+    }
+    {
+        const float a = wave_sum(dz0), bb = wave_sum(dz1);
+        if (lane == 0) {
+            atomicAdd(&acc[64], a);
+            atomicAdd(&acc[65], bb);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < c * 32) atomicAdd(&dW[threadIdx.x], acc[threadIdx.x]);
+    if (threadIdx.x < c) atomicAdd(&db[threadIdx.x], acc[64 + threadIdx.x]);
+}
+
+// --------------------------------------------------------------------------------- Adagrad
+__global__ void __launch_bounds__(NT) adagrad_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                      float* __restrict__ s, int64_t n, float lr, float wd, float eps,
+                                                      float gscale) {
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    const int64_t n4 = n >> 2;
+    const bool vec = aligned16(w) && aligned16(g) && aligned16(s);
+    int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (vec) {
+        for (; i < n4; i += stride) {
+            float4 wv = reinterpret_cast<float4*>(w)[i], sv = reinterpret_cast<float4*>(s)[i];
+            const float4 gv = reinterpret_cast<const float4*>(g)[i];
+            float gg;
+            gg = gv.x * gscale + wd * wv.x; sv.x += gg * gg; wv.x -= lr * gg / (sqrtf(sv.x) + eps);
+            gg = gv.y * gscale + wd * wv.y; sv.y += gg * gg; wv.y -= lr * gg / (sqrtf(sv.y) + eps);
+            gg = gv.z * gscale + wd * wv.z; sv.z += gg * gg; wv.z -= lr * gg / (sqrtf(sv.z) + eps);
+            gg = gv.w * gscale + wd * wv.w; sv.w += gg * gg; wv.w -= lr * gg / (sqrtf(sv.w) + eps);
+            reinterpret_cast<float4*>(w)[i] = wv;
+            reinterpret_cast<float4*>(s)[i] = sv;
+        }
+        i = n4 * 4 + (int64_t)blockIdx.x * NT + threadIdx.x;
+    }
+    for (; i < n; i += stride) {
+        const float gg = g[i] * gscale + wd * w[i];
+        const float sv = s[i] + gg * gg;
+        s[i] = sv;
+        w[i] -= lr * gg / (sqrtf(sv) + eps);
+    }
+}
+
+__global__ void __launch_bounds__(NT) sqnorm_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+    __shared__ float red[NT / 64];
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) s += x[i] * x[i];
+    s = block_sum<NT>(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+inline int grid_for(int64_t work_items, int per_block, int cap = 2048) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lstc_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                       int64_t rows, int32_t d, float eps, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd) return LSTC_E_NULL;
+    if (rows <= 0 || d <= 0) return LSTC_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(rows, NT / 64, 4096);
+    const bool vec = d % 4 == 0 && d <= 2048 && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta);
+    if (vec) {
+        if (d <= 256) hipLaunchKernelGGL(ln_fwd_vec<1>, grid, NT, 0, st, x, gamma, beta, y, mean, rstd, rows, d, eps);
+        else if (d <= 512) hipLaunchKernelGGL(ln_fwd_vec<2>, grid, NT, 0, st, x, gamma, beta, y, mean, rstd, rows, d, eps);
+        else if (d <= 1024) hipLaunchKernelGGL(ln_fwd_vec<4>, grid, NT, 0, st, x, gamma, beta, y, mean, rstd, rows, d, eps);
+        else hipLaunchKernelGGL(ln_fwd_vec<8>, grid, NT, 0, st, x, gamma, beta, y, mean, rstd, rows, d, eps);
+    } else {
+        hipLaunchKernelGGL(ln_fwd_generic, grid, NT, 0, st, x, gamma, beta, y, mean, rstd, rows, d, eps);
+    }
+    return lstc_launch_status();
+}
+
+int lstc_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                       float* dx, float* partial, int32_t n_partial, int64_t rows, int32_t d, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !partial) return LSTC_E_NULL;
+    if (rows <= 0 || d <= 0 || n_partial <= 0) return LSTC_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = d % 4 == 0 && d <= 2048 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) &&
+                     aligned16(partial);
+    if (vec) {
+        const size_t lds = (size_t)(NT / 64) * 2 * d * sizeof(float);
+        if (d <= 256) hipLaunchKernelGGL(ln_bwd_vec<1>, n_partial, NT, lds, st, dy, x, gamma, mean, rstd, dx, partial, rows, d);
+        else if (d <= 512) hipLaunchKernelGGL(ln_bwd_vec<2>, n_partial, NT, lds, st, dy, x, gamma, mean, rstd, dx, partial, rows, d);
+        else if (d <= 1024) hipLaunchKernelGGL(ln_bwd_vec<4>, n_partial, NT, lds, st, dy, x, gamma, mean, rstd, dx, partial, rows, d);
+        else hipLaunchKernelGGL(ln_bwd_vec<8>, n_partial, NT, lds, st, dy, x, gamma, mean, rstd, dx, partial, rows, d);
+    } else {
+        if ((size_t)2 * d * sizeof(float) > 64 * 1024) return LSTC_E_RANGE;
+        hipLaunchKernelGGL(ln_bwd_generic, n_partial, NT, (size_t)2 * d * sizeof(float), st, dy, x, gamma, mean, rstd, dx,
+                           partial, rows, d);
+    }
+    return lstc_launch_status();
+}
+
+int lstc_cls_concat_fwd(const float* x, const float* cls_token, const float* pos, float* y, int64_t N, int32_t S,
+                        int32_t d, void* stream) {
+    if (!x || !y) return LSTC_E_NULL;
+    if (N <= 0 || S < 2 || d <= 0) return LSTC_E_SHAPE;
+    hipLaunchKernelGGL(cls_concat_fwd_kernel, dim3((unsigned)N, (d + NT - 1) / NT), NT, 0, (hipStream_t)stream, x,
+                       cls_token, pos, y, S, d);
+    return lstc_launch_status();
+}
+
+int lstc_cls_concat_bwd(const float* dy, float* dx, int64_t N, int32_t S, int32_t d, int32_t mean_cls, void* stream) {
+    if (!dy || !dx) return LSTC_E_NULL;
+    if (N <= 0 || S < 2 || d <= 0) return LSTC_E_SHAPE;
+    hipLaunchKernelGGL(cls_concat_bwd_kernel, dim3((unsigned)N, (d + NT - 1) / NT), NT, 0, (hipStream_t)stream, dy, dx,
+                       S, d, mean_cls);
+    return lstc_launch_status();
+}
+
+int lstc_colsum(const float* x, int64_t rows, int32_t cols, int32_t ld, float* partial, int32_t n_partial, float* out,
+                int32_t accumulate, void* stream) {
+    if (!x || !partial || !out) return LSTC_E_NULL;
+    if (rows <= 0 || cols <= 0 || ld < cols || n_partial <= 0) return LSTC_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int np = (int)(rows < n_partial ? rows : n_partial);
+    hipLaunchKernelGGL(colsum_pass1, dim3((cols + NT - 1) / NT, np), NT, 0, st, x, rows, cols, ld, partial);
+    hipLaunchKernelGGL(colsum_pass2, dim3((cols + NT - 1) / NT), NT, 0, st, partial, np, cols, out, accumulate);
+    return lstc_launch_status();
+}
+
+int lstc_dropout_apply(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+    if (!x || !y) return LSTC_E_NULL;
+    if (n <= 0) return LSTC_E_SHAPE;
+    if ((uint64_t)n > 0xffffffffull) return LSTC_E_RANGE;
+    hipLaunchKernelGGL(dropout_apply_kernel, grid_for(n, NT * 4), NT, 0, (hipStream_t)stream, x, y, n, make_drop_key(p, seed));
+    return lstc_launch_status();
+}
+
+int lstc_dropout_mask(uint8_t* mask, int64_t n, float p, uint64_t seed, void* stream) {
+    if (!mask) return LSTC_E_NULL;
+    if (n <= 0) return LSTC_E_SHAPE;
+    if ((uint64_t)n > 0xffffffffull) return LSTC_E_RANGE;
+    hipLaunchKernelGGL(dropout_mask_kernel, grid_for(n, NT * 4), NT, 0, (hipStream_t)stream, mask, n, make_drop_key(p, seed));
+    return lstc_launch_status();
+}
+
+int lstc_head_out_fwd(const float* x, const float* W, const float* b, float* out, int64_t rows, int32_t c, void* stream) {
+    if (!x || !W || !b || !out) return LSTC_E_NULL;
+    if (rows <= 0 || (c != 1 && c != 2)) return LSTC_E_SHAPE;
+    if (!aligned16(x)) return LSTC_E_ALIGN;
+    hipLaunchKernelGGL(head_out_fwd_kernel, (unsigned)((rows + NT - 1) / NT), NT, 0, (hipStream_t)stream, x, W, b, out, rows, c);
+    return lstc_launch_status();
+}
+
+int lstc_head_out_bwd(const float* x, const float* W, const float* out, const float* dout, float* dx, float* dW,
+                      float* db, int64_t rows, int32_t c, void* stream) {
+    if (!x || !W || !out || !dout || !dx || !dW || !db) return LSTC_E_NULL;
+    if (rows <= 0 || (c != 1 && c != 2)) return LSTC_E_SHAPE;
+    if (!aligned16(x) || !aligned16(dx)) return LSTC_E_ALIGN;
+    hipLaunchKernelGGL(head_out_bwd_kernel, (unsigned)((rows + NT - 1) / NT), NT, 0, (hipStream_t)stream, x, W, out, dout,
+                       dx, dW, db, rows, c);
+    return lstc_launch_status();
+}
+
+int lstc_adagrad_step(float* w, const float* grad, float* state, int64_t n, float lr, float weight_decay, float eps,
+                      float gscale, void* stream) {
+    if (!w || !grad || !state) return LSTC_E_NULL;
+    if (n <= 0) return LSTC_E_SHAPE;
+    hipLaunchKernelGGL(adagrad_kernel, grid_for(n, NT * 4), NT, 0, (hipStream_t)stream, w, grad, state, n, lr,
+                       weight_decay, eps, gscale);
+    return lstc_launch_status();
+}
+
+int lstc_sqnorm_accum(const float* x, int64_t n, float* out, void* stream) {
+    if (!x || !out) return LSTC_E_NULL;
+    if (n <= 0) return LSTC_E_SHAPE;
+    hipLaunchKernelGGL(sqnorm_kernel, grid_for(n, NT * 8, 1024), NT, 0, (hipStream_t)stream, x, n, out);
+    return lstc_launch_status();
+}
+
+}  // extern "C"
