@@ -105,6 +105,7 @@ typedef struct LstcAttnDesc {
     int32_t ldq, ldk, ldv, ldo;     /* token strides in elements (normally H*dk / H*dv) */
     int32_t dtype;
     int32_t index_ld;               /* 0 = no relative bias */
+    int32_t table_rows;             /* rows of `table` / `dtable` (backward: size of the per-workgroup LDS accumulator) */
     float   scale;                  /* 1/sqrt(d_k): multiplies Q (reference divides by temperature :49,:103) */
     float   dropout_p;
     uint64_t dropout_seed;
@@ -139,6 +140,10 @@ int lstc_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
 int lstc_cls_concat_fwd(const float* x, const float* cls_token, const float* pos, float* y,
                         int64_t N, int32_t S, int32_t d, void* stream);
 
+/* Gradient w.r.t. the Encoder input, needed only when something upstream is trainable (input_layerNorm,
+ * models/Encoder.py:48-49): dx[n,t,:] = dy[n,t+1,:] + (mean_cls ? dy[n,0,:]/(S-1) : 0). */
+int lstc_cls_concat_bwd(const float* dy, float* dx, int64_t N, int32_t S, int32_t d, int32_t mean_cls, void* stream);
+
 /* out[c] = sum_r x[r, c] for x [rows, ld] (first `cols` columns); deterministic two-pass reduction.
  * `partial` is caller workspace of n_partial*cols floats.  Bias / LayerNorm / pos-enc gradients. */
 int lstc_colsum(const float* x, int64_t rows, int32_t cols, int32_t ld, float* partial, int32_t n_partial,
@@ -165,24 +170,33 @@ int lstc_head_out_bwd(const float* x, const float* W, const float* out, const fl
  *   mode 2 (STN + BCE): Train/spatio_transformer_MIL_CE.py:23-26,32-44,176-181
  * bag[v] = max_p mean_l score[v,p,l]; err = sum_ij relu(1 - abn_j + nor_i)/bs^2;
  * l1 = mean(score[l1_skip:]) (flat slice quirk: l1_skip = bs*pn*L for STN, bs for LTN / co-teach).
- * Data-parallel: `bag_global` (length 2*bs_global) holds every rank's bag maxima (all-reduced by the
- * caller); this rank owns videos [vid0, vid0+n_local_videos) of each half.  Single GPU: pass NULL.
- * scalars[0..4] = loss, mil, err, l1, aux(CE|BCE) — the rank-local *contributions* (sum over ranks
- * gives the global value; identical to the reference on one GPU).
+ * Soft targets are built in-kernel (Train/temporal_transformer_shanghaitech.py:103-112): normal parts
+ * [1,0]; abnormal parts t1 = mean over label_len pseudo labels, t0 = 1-t1.
+ * Data-parallel: the hinge couples all bs_global x bs_global pairs, so ranks exchange bag maxima
+ * (2*bs_global floats, one sum-all-reduce) between phase 0 and phase 1; every other term is a local sum
+ * divided by a global count.  scalars = rank-local contributions (their sum over ranks is the reference
+ * value; on one GPU they are the reference values).
  */
 typedef struct LstcLossDesc {
-    int32_t mode;
-    int32_t bs_global, bs_local, rank_off;  /* pairs per global batch / on this rank / first pair index */
-    int32_t part_num, part_len;
-    int32_t l1_skip_global;         /* number of leading flat score entries (global numbering) excluded from l1 */
+    int32_t mode;                   /* 0 STN, 1 LTN (MIL + CE), 2 STN co-teaching (MIL + BCE) */
+    int32_t bs_global, bs_local, rank_off;  /* pairs per global batch / on this rank / first pair index of this rank */
+    int32_t part_num;
+    int32_t score_len;              /* scores per part in `out`: part_len for modes 0/2, 1 for mode 1 */
+    int32_t label_len;              /* pseudo labels per part in `abn_labels` (= --part_len) */
+    int32_t l1_skip;                /* leading entries of the GLOBAL flat score vector excluded from the l1 mean */
     float lambda_1, lambda_MIL, lambda_aux, lambda_normal, lambda_abnormal;
-    const float* out;               /* head output: [rows_local, 1] or [rows_local, 2] */
-    const float* targets;           /* [rows_local(/L), 2] soft targets (mode 1: per row; mode 2: per part) or NULL */
-    const float* bag_global;        /* optional [2*bs_global] */
-    float* bag_local;               /* [2*bs_local] out: this rank's bag maxima (normal half then abnormal half) */
-    float* dout;                    /* gradient of the rank's loss contribution w.r.t. `out` */
-    float* scalars;                 /* [5] */
-    int32_t phase;                  /* 0 = compute bag_local only; 1 = loss + gradient (bag_global or bag_local) */
+    const float* out;               /* head output of this rank: [2*bs_local*part_num*score_len, c], c = 2 (mode 1) or 1;
+                                       normal videos first, abnormal second (the reference's cat order) */
+    const float* abn_labels;        /* [bs_local, part_num*label_len] pseudo labels of this rank's abnormal videos;
+                                       NULL = no CE/BCE term (--temporal_only / mode 0) */
+    const float* targets;           /* optional explicit soft targets [parts_local, 2] (parts = rows for mode 1,
+                                       [2*bs_local*part_num] for mode 2); overrides abn_labels — used by the
+                                       reference-named get_CE_loss / get_BCE_loss wrappers */
+    float* bag;                     /* [2*bs_global] bag maxima, normal half then abnormal half.  phase 0 writes this
+                                       rank's entries (caller zeroes first, then sum-all-reduces); phase 1 reads all */
+    float* dout;                    /* same shape as `out`: d(rank's loss contribution)/d(out) */
+    float* scalars;                 /* [5] loss, mil, err, l1, aux — this rank's contributions */
+    int32_t phase;                  /* 0 = bags only; 1 = loss + gradient from `bag`; 2 = both (single rank) */
 } LstcLossDesc;
 
 int lstc_vad_loss(const LstcLossDesc* d, void* stream);
@@ -195,6 +209,9 @@ int lstc_adagrad_step(float* w, const float* grad, float* state, int64_t n, floa
                       float eps, float gscale, void* stream);
 /* out[0] += sum(x^2) (f32 atomics over workgroup partials; caller zeroes) — for clip_grad_norm_. */
 int lstc_sqnorm_accum(const float* x, int64_t n, float* out, void* stream);
+
+/* x *= alpha in place: applies the clip_grad_norm_ coefficient to a gradient tensor. */
+int lstc_scale(float* x, int64_t n, float alpha, void* stream);
 
 /* ------------------------------------------------------------------------------ misc */
 int lstc_version(void);

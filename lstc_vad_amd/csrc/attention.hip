@@ -1,0 +1,357 @@
+// Fused multi-head attention core with relative-position bias for short sequences (S <= 128), gfx950.
+//
+// One workgroup (4 waves) owns one (sequence, head): the whole S x S logit tile lives in LDS
+// (S in {17,19,33,49,81} on this path, padded to 32*T), so there is no online softmax and no K/V
+// tiling.  Both contractions run on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32):
+//   scores = (Q*scale) K^T : operands straight from global in the MFMA lane layout (lane = row,
+//            lane-half = a 16-float run of the 32-deep K chunk -> each lane pair reads one 128-B line);
+//   O      = P V           : A operand = P from LDS (row stride 32T+1: conflict-free for lane = row and
+//            for lane = column), B operand = V rows from global, 128 B per half-wave.
+// Softmax / bias gather / dropout run on the LDS tile with one wave per row and wave-shuffle
+// reductions.  Q, K, V, O stay in the token-major [N, S, H*d] layout the projection GEMMs produce.
+// Backward recomputes nothing but the dropout mask: P is saved by the forward ([N,H,S,S], 0.6 % of
+// the layer's activations), dP = dO V^T, dA = P (dP - rowsum(dP P)), dV = Pd^T dO, dQ = dA K scale,
+// dK = dA^T Q scale, and the bias-table gradient is accumulated per workgroup in LDS over a chunk of
+// sequences before one atomic flush.
+#include "lstc_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+struct AttnParams {
+    const float *Q, *K, *V;
+    float* O;
+    float* probs;
+    const float* table;
+    const int64_t* index;
+    const float* dO;
+    float *dQ, *dK, *dV;
+    float* dtable;
+    int N, S, H, dk, dv, ldq, ldk, ldv, ldo, index_ld, table_rows;
+    float scale;
+    DropKey dkey;
+    int has_drop;
+    int vec_qk, vec_v;     // float4 operand loads allowed for the dk / dv contractions
+    int n_per_wg;
+};
+
+__device__ __forceinline__ void load16(const float* __restrict__ p, int k0, int kdim, bool vec, float (&f)[16]) {
+    if (vec && k0 + 16 <= kdim) {
+        const float4* q = reinterpret_cast<const float4*>(p + k0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 v = q[i];
+            f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) f[e] = (k0 + e < kdim) ? p[k0 + e] : 0.f;
+    }
+}
+
+// 32x32 tile of  A[rowA0.., :] * B[rowB0.., :]^T  contracted over kdim; rows beyond S-1 are clamped
+// (their results are discarded by the caller).  A is scaled by a_scale before the product.
+__device__ __forceinline__ floatx16 tile_abt(const float* __restrict__ A, int lda, int rowA0, const float* __restrict__ B,
+                                             int ldb, int rowB0, int S, int kdim, float a_scale, bool vec) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h2 = lane >> 5;
+    const float* pa = A + (size_t)min(rowA0 + r, S - 1) * lda;
+    const float* pb = B + (size_t)min(rowB0 + r, S - 1) * ldb;
+    floatx16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int kb = 0; kb < kdim; kb += 32) {
+        float a[16], b[16];
+        load16(pa, kb + 16 * h2, kdim, vec, a);
+        load16(pb, kb + 16 * h2, kdim, vec, b);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s] * a_scale, b[s], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+template <int LD>
+__device__ __forceinline__ void store_tile_lds(float* __restrict__ sm, int ti, int tj, const floatx16& acc) {
+    const int lane = threadIdx.x & 63, c = lane & 31, h2 = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sm[(32 * ti + (r & 3) + 8 * (r >> 2) + 4 * h2) * LD + 32 * tj + c] = acc[r];
+}
+
+// Out[S, ncols] = scale * op(Alds) * B[S, ncols]   (op = transpose when TRANS).  Alds is SP x SP with
+// stride LD and MUST be zero wherever its contraction index is >= S.  Wave w owns column tiles w, w+4, ...
+template <int T, bool TRANS>
+__device__ __forceinline__ void lds_times_rows(const float* __restrict__ Alds, const float* __restrict__ B, int ldb, int S,
+                                               int ncols, float scale, float* __restrict__ Out, int ldo) {
+    constexpr int SP = 32 * T, LD = SP + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c31 = lane & 31, h2 = lane >> 5;
+    const int ctiles = (ncols + 31) >> 5;
+    for (int ct = wave; ct < ctiles; ct += NT / 64) {
+        const int c = 32 * ct + c31;
+        const bool cvalid = c < ncols;
+        floatx16 acc[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        for (int jb = 0; jb < SP; jb += 16) {
+            float bv[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int j = min(jb + 8 * h2 + s, S - 1);
+                bv[s] = cvalid ? B[(size_t)j * ldb + c] : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                float av[8];
+                const int i = 32 * t + c31;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const int k = jb + 8 * h2 + s;
+                    av[s] = TRANS ? Alds[k * LD + i] : Alds[i * LD + k];
+                }
+#pragma unroll
+                for (int s = 0; s < 8; ++s) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc[t], 0, 0, 0);
+            }
+        }
+        if (cvalid) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                    if (row < S) Out[(size_t)row * ldo + c] = acc[t][r] * scale;
+                }
+        }
+    }
+}
+
+template <int T>
+__global__ void __launch_bounds__(NT) attn_fwd_kernel(const AttnParams p) {
+    constexpr int SP = 32 * T, LD = SP + 1, NJ = (SP + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int n = blockIdx.x, h = blockIdx.y, S = p.S;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* Qb = p.Q + (size_t)n * S * p.ldq + (size_t)h * p.dk;
+    const float* Kb = p.K + (size_t)n * S * p.ldk + (size_t)h * p.dk;
+    const float* Vb = p.V + (size_t)n * S * p.ldv + (size_t)h * p.dv;
+    float* Ob = p.O + (size_t)n * S * p.ldo + (size_t)h * p.dv;
+
+    for (int t = wave; t < T * T; t += NT / 64) {
+        const int ti = t / T, tj = t % T;
+        if (32 * ti >= S || 32 * tj >= S) continue;   // fully padded tile: rows/cols are rewritten below
+        const floatx16 acc = tile_abt(Qb, p.ldq, 32 * ti, Kb, p.ldk, 32 * tj, S, p.dk, p.scale, p.vec_qk);
+        store_tile_lds<LD>(sm, ti, tj, acc);
+    }
+    __syncthreads();
+
+    float* pr_base = p.probs + ((size_t)n * p.H + h) * S * S;
+    const uint32_t flat0 = ((uint32_t)n * p.H + h) * (uint32_t)(S * S);
+    for (int i = wave; i < SP; i += NT / 64) {
+        float* row = sm + i * LD;
+        if (i >= S) {
+            for (int j = lane; j < SP; j += 64) row[j] = 0.f;
+            continue;
+        }
+        float v[NJ];
+        float m = -INFINITY;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int j = lane + 64 * jj;
+            float x = -INFINITY;
+            if (j < S) {
+                x = row[j];
+                if (p.index_ld > 0 && i >= 1 && j >= 1)
+                    x += p.table[(size_t)p.index[(size_t)(i - 1) * p.index_ld + (j - 1)] * p.H + h];
+            }
+            v[jj] = x;
+            m = fmaxf(m, x);
+        }
+        m = wave_max(m);
+        float s = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            v[jj] = (lane + 64 * jj < S) ? expf(v[jj] - m) : 0.f;
+            s += v[jj];
+        }
+        s = wave_sum(s);
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int j = lane + 64 * jj;
+            if (j < SP) {
+                float pv = 0.f;
+                if (j < S) {
+                    pv = v[jj] / s;
+                    pr_base[(size_t)i * S + j] = pv;
+                    if (p.has_drop) pv = drop_keep(flat0 + (uint32_t)(i * S + j), p.dkey) ? pv * p.dkey.scale : 0.f;
+                }
+                row[j] = pv;
+            }
+        }
+    }
+    __syncthreads();
+    lds_times_rows<T, false>(sm, Vb, p.ldv, S, p.dv, 1.f, Ob, p.ldo);
+}
+
+template <int T>
+__global__ void __launch_bounds__(NT) attn_bwd_kernel(const AttnParams p) {
+    constexpr int SP = 32 * T, LD = SP + 1, NJ = (SP + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Dm = sm;                 // dP~ then dA
+    float* Pm = sm + SP * LD;       // dropped probabilities
+    float* tacc = sm + 2 * SP * LD; // [table_rows] bias-table gradient of this head
+    const int h = blockIdx.y, S = p.S;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool has_bias = p.index_ld > 0 && p.dtable != nullptr;
+    if (has_bias)
+        for (int i = threadIdx.x; i < p.table_rows; i += NT) tacc[i] = 0.f;
+    const int n_begin = blockIdx.x * p.n_per_wg;
+    const int n_end = min(p.N, n_begin + p.n_per_wg);
+    for (int n = n_begin; n < n_end; ++n) {
+        const float* Qb = p.Q + (size_t)n * S * p.ldq + (size_t)h * p.dk;
+        const float* Kb = p.K + (size_t)n * S * p.ldk + (size_t)h * p.dk;
+        const float* Vb = p.V + (size_t)n * S * p.ldv + (size_t)h * p.dv;
+        const float* dOb = p.dO + (size_t)n * S * p.ldo + (size_t)h * p.dv;
+        __syncthreads();   // previous sequence's LDS readers are done
+        for (int t = wave; t < T * T; t += NT / 64) {
+            const int ti = t / T, tj = t % T;
+            if (32 * ti >= S || 32 * tj >= S) continue;
+            const floatx16 acc = tile_abt(dOb, p.ldo, 32 * ti, Vb, p.ldv, 32 * tj, S, p.dv, 1.f, p.vec_v);
+            store_tile_lds<LD>(Dm, ti, tj, acc);
+        }
+        __syncthreads();
+        const float* pr_base = p.probs + ((size_t)n * p.H + h) * S * S;
+        const uint32_t flat0 = ((uint32_t)n * p.H + h) * (uint32_t)(S * S);
+        for (int i = wave; i < SP; i += NT / 64) {
+            float* drow = Dm + i * LD;
+            float* prow = Pm + i * LD;
+            if (i >= S) {
+                for (int j = lane; j < SP; j += 64) drow[j] = prow[j] = 0.f;
+                continue;
+            }
+            float pv[NJ], dp[NJ], keep[NJ];
+            float s = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int j = lane + 64 * jj;
+                pv[jj] = dp[jj] = keep[jj] = 0.f;
+                if (j < S) {
+                    pv[jj] = pr_base[(size_t)i * S + j];
+                    keep[jj] = p.has_drop ? (drop_keep(flat0 + (uint32_t)(i * S + j), p.dkey) ? p.dkey.scale : 0.f) : 1.f;
+                    dp[jj] = drow[j] * keep[jj];
+                    s += dp[jj] * pv[jj];
+                }
+            }
+            s = wave_sum(s);
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int j = lane + 64 * jj;
+                if (j < SP) {
+                    const float da = pv[jj] * (dp[jj] - s);      // zero for j >= S
+                    drow[j] = da;
+                    prow[j] = pv[jj] * keep[jj];
+                    if (has_bias && i >= 1 && j >= 1 && j < S)
+                        atomicAdd(&tacc[p.index[(size_t)(i - 1) * p.index_ld + (j - 1)]], da);
+                }
+            }
+        }
+        __syncthreads();
+        lds_times_rows<T, true>(Pm, dOb, p.ldo, S, p.dv, 1.f, p.dV + (size_t)n * S * p.ldv + (size_t)h * p.dv, p.ldv);
+        lds_times_rows<T, false>(Dm, Kb, p.ldk, S, p.dk, p.scale, p.dQ + (size_t)n * S * p.ldq + (size_t)h * p.dk, p.ldq);
+        lds_times_rows<T, true>(Dm, Qb, p.ldq, S, p.dk, p.scale, p.dK + (size_t)n * S * p.ldk + (size_t)h * p.dk, p.ldk);
+    }
+    if (has_bias) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < p.table_rows; i += NT) atomicAdd(&p.dtable[(size_t)i * p.H + h], tacc[i]);
+    }
+}
+
+int fill_params(const LstcAttnDesc* d, AttnParams& p, bool bwd) {
+    if (!d) return LSTC_E_NULL;
+    if (d->dtype != LSTC_F32) return LSTC_E_UNSUPPORTED;
+    if (!d->Q || !d->K || !d->V || !d->probs) return LSTC_E_NULL;
+    if (!bwd && !d->O) return LSTC_E_NULL;
+    if (bwd && (!d->dO || !d->dQ || !d->dK || !d->dV)) return LSTC_E_NULL;
+    if (d->N <= 0 || d->S < 1 || d->H <= 0 || d->dk <= 0 || d->dv <= 0) return LSTC_E_SHAPE;
+    if (d->S > 128) return LSTC_E_RANGE;
+    if (d->ldq < d->H * d->dk || d->ldk < d->H * d->dk || d->ldv < d->H * d->dv || d->ldo < d->H * d->dv) return LSTC_E_SHAPE;
+    if ((uint64_t)d->N * d->H * d->S * d->S > 0xffffffffull) return LSTC_E_RANGE;
+    if (d->index_ld > 0 && (!d->table || !d->index || d->index_ld < d->S - 1)) return LSTC_E_NULL;
+    p.Q = (const float*)d->Q; p.K = (const float*)d->K; p.V = (const float*)d->V; p.O = (float*)d->O;
+    p.probs = d->probs; p.table = d->table; p.index = d->index;
+    p.dO = (const float*)d->dO; p.dQ = (float*)d->dQ; p.dK = (float*)d->dK; p.dV = (float*)d->dV; p.dtable = d->dtable;
+    p.N = d->N; p.S = d->S; p.H = d->H; p.dk = d->dk; p.dv = d->dv;
+    p.ldq = d->ldq; p.ldk = d->ldk; p.ldv = d->ldv; p.ldo = d->ldo; p.index_ld = d->index_ld;
+    p.table_rows = 0;
+    p.scale = d->scale;
+    p.has_drop = d->dropout_p > 0.f;
+    p.dkey = make_drop_key(d->dropout_p, d->dropout_seed);
+    p.vec_qk = d->dk % 4 == 0 && d->ldq % 4 == 0 && d->ldk % 4 == 0 && aligned16(d->Q) && aligned16(d->K);
+    p.vec_v = d->dv % 4 == 0 && d->ldv % 4 == 0 && d->ldo % 4 == 0 && aligned16(d->V) && (!bwd || aligned16(d->dO));
+    p.n_per_wg = 1;
+    return 0;
+}
+
+template <typename Kern>
+void set_lds(Kern k, size_t lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+}  // namespace
+
+extern "C" {
+
+int lstc_attn_fwd(const LstcAttnDesc* d, void* stream) {
+    AttnParams p;
+    int rc = fill_params(d, p, false);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int T = (p.S + 31) / 32;
+    const size_t lds = (size_t)(32 * T) * (32 * T + 1) * sizeof(float);
+    dim3 grid(p.N, p.H);
+    switch (T) {
+        case 1: hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, NT, lds, st, p); break;
+        case 2: hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, NT, lds, st, p); break;
+        case 3: hipLaunchKernelGGL(attn_fwd_kernel<3>, grid, NT, lds, st, p); break;
+        default: {
+            static bool once = false;
+            if (!once) { set_lds(attn_fwd_kernel<4>, lds); once = true; }
+            hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, NT, lds, st, p);
+        }
+    }
+    return lstc_launch_status();
+}
+
+// d->dtable rows: the caller passes the table row count through `index_ld`'s companion below.
+int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
+    AttnParams p;
+    int rc = fill_params(d, p, true);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int T = (p.S + 31) / 32;
+    p.table_rows = (d->index_ld > 0 && d->dtable) ? d->table_rows : 0;
+    if (d->index_ld > 0 && d->dtable && d->table_rows <= 0) return LSTC_E_SHAPE;
+    const size_t lds = ((size_t)2 * (32 * T) * (32 * T + 1) + p.table_rows) * sizeof(float);
+    if (lds > 160 * 1024) return LSTC_E_RANGE;
+    // enough workgroups to fill the chip (>= ~2048) while amortising the bias-table flush over a few sequences
+    int npw = (int)(((int64_t)p.N * p.H + 4095) / 4096);
+    if (npw < 1) npw = 1;
+    if (npw > 8) npw = 8;
+    p.n_per_wg = npw;
+    dim3 grid((p.N + npw - 1) / npw, p.H);
+#define LSTC_BWD(TT)                                                         \
+    do {                                                                     \
+        static bool once = false;                                            \
+        if (!once) { set_lds(attn_bwd_kernel<TT>, 160 * 1024); once = true; } \
+        hipLaunchKernelGGL(attn_bwd_kernel<TT>, grid, NT, lds, st, p);       \
+    } while (0)
+    switch (T) {
+        case 1: LSTC_BWD(1); break;
+        case 2: LSTC_BWD(2); break;
+        case 3: LSTC_BWD(3); break;
+        default: LSTC_BWD(4); break;
+    }
+#undef LSTC_BWD
+    return lstc_launch_status();
+}
+
+}  // extern "C"

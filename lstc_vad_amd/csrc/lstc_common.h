@@ -72,4 +72,4 @@ static inline int lstc_launch_status() {
     return e == hipSuccess ? 0 : (int)e;
 }
 
-static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+__host__ __device__ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

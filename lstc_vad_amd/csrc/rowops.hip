@@ -411,6 +411,11 @@ __global__ void __launch_bounds__(NT) sqnorm_kernel(const float* __restrict__ x,
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
 
+__global__ void __launch_bounds__(NT) scale_kernel(float* __restrict__ x, int64_t n, float alpha) {
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) x[i] *= alpha;
+}
+
 inline int grid_for(int64_t work_items, int per_block, int cap = 2048) {
     int64_t g = (work_items + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -529,6 +534,13 @@ int lstc_adagrad_step(float* w, const float* grad, float* state, int64_t n, floa
     if (n <= 0) return LSTC_E_SHAPE;
     hipLaunchKernelGGL(adagrad_kernel, grid_for(n, NT * 4), NT, 0, (hipStream_t)stream, w, grad, state, n, lr,
                        weight_decay, eps, gscale);
+    return lstc_launch_status();
+}
+
+int lstc_scale(float* x, int64_t n, float alpha, void* stream) {
+    if (!x) return LSTC_E_NULL;
+    if (n <= 0) return LSTC_E_SHAPE;
+    hipLaunchKernelGGL(scale_kernel, grid_for(n, NT * 4), NT, 0, (hipStream_t)stream, x, n, alpha);
     return lstc_launch_status();
 }
 

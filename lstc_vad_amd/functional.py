@@ -1,0 +1,478 @@
+"""Thin op layer over the C ABI plus the autograd Functions the model classes use.
+
+Every function here launches hand-written HIP kernels from liblstc_hip.so on the current stream;
+nothing falls back to ATen compute.  torch supplies allocation (``torch.empty``), views and the
+autograd graph.  Shapes follow the reference: tokens are kept as ``[M = N*S, d]``
+row-major matrices from the CLS concat to the head, so no transposes or copies appear between ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from contextlib import contextmanager
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_ACCUM, EPI_BIAS, EPI_DROPOUT, EPI_RELU, EPI_RELU_MASK, EPI_RESIDUAL, F32, AttnDesc, GemmDesc,
+                   LossDesc, check, dev_ptr, stream_ptr)
+
+# ------------------------------------------------------------------------------------------ RNG
+_MASK64 = (1 << 64) - 1
+_counter = 0
+_recorder = None          # list collecting (site, p, seed, shape) while record_dropout() is active
+
+
+def next_seed() -> int:
+    """64-bit seed for one dropout site invocation: a hash of torch's seed and a call counter, so a run
+    is reproducible under ``torch.manual_seed`` without touching torch's generators."""
+    global _counter
+    _counter += 1
+    x = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _counter * 0xD1342543DE82EF95) & _MASK64
+    x ^= x >> 32
+    x = (x * 0xD6E8FEB86659FD93) & _MASK64
+    x ^= x >> 32
+    return x
+
+
+def reset_rng(counter: int = 0):
+    global _counter
+    _counter = counter
+
+
+@contextmanager
+def record_dropout():
+    """Collect every dropout site fired inside the block as ``(site, p, seed, shape)`` so a test can
+    regenerate the masks (``dropout_mask``) and replay the step through the oracle."""
+    global _recorder
+    prev, _recorder = _recorder, []
+    try:
+        yield _recorder
+    finally:
+        _recorder = prev
+
+
+def _note(site, p, seed, shape):
+    if _recorder is not None:
+        _recorder.append((site, float(p), int(seed), tuple(shape)))
+
+
+# --------------------------------------------------------------------------------------- helpers
+def _mat(t: torch.Tensor):
+    """(ptr, rows, cols, ld) of a 2-D f32 tensor whose rows are contiguous."""
+    assert t.dim() == 2 and t.dtype == torch.float32, (t.shape, t.dtype)
+    if t.stride(1) != 1 and t.shape[1] != 1:
+        raise RuntimeError("lstc gemm operands need unit stride along the last dim")
+    return dev_ptr(t), t.shape[0], t.shape[1], (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out: Optional[torch.Tensor] = None,
+         bias=None, relu=False, dropout=None, residual=None, relu_mask=None, accumulate=False, alpha=1.0,
+         split_k=1, variant=0) -> torch.Tensor:
+    """``out = epi(alpha * op(a) @ op(b))`` through ``lstc_gemm`` (include/lstc_hip.h)."""
+    pa, ar, ac, lda = _mat(a)
+    pb, br, bc, ldb = _mat(b)
+    M, K = (ac, ar) if trans_a else (ar, ac)
+    Kb, N = (bc, br) if trans_b else (br, bc)
+    if K != Kb:
+        raise RuntimeError(f"gemm inner dims differ: {K} vs {Kb}")
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+        if split_k > 1:
+            out.zero_()
+    pc, cr, cc, ldc = _mat(out)
+    assert (cr, cc) == (M, N)
+    d = GemmDesc()
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, lda, ldb, ldc
+    d.transA, d.transB, d.dtype = int(trans_a), int(trans_b), F32
+    flags = 0
+    if bias is not None:
+        flags |= EPI_BIAS
+        d.bias = dev_ptr(bias)
+    if relu:
+        flags |= EPI_RELU
+    if dropout is not None and dropout[0] > 0.0:
+        flags |= EPI_DROPOUT
+        d.dropout_p, d.dropout_seed = float(dropout[0]), int(dropout[1])
+    if residual is not None:
+        flags |= EPI_RESIDUAL
+        pr, rr, rc_, ldr = _mat(residual)
+        assert (rr, rc_) == (M, N)
+        d.residual, d.ldr = pr, ldr
+    if relu_mask is not None:
+        flags |= EPI_RELU_MASK
+        pm, mr, mc, ldm = _mat(relu_mask)
+        assert (mr, mc) == (M, N)
+        d.relu_src, d.ld_relu = pm, ldm
+    if accumulate:
+        flags |= EPI_ACCUM
+    d.flags, d.alpha, d.split_k, d.variant = flags, float(alpha), int(split_k), int(variant)
+    d.A, d.B, d.C = pa, pb, pc
+    check(_lib.load().lstc_gemm(C.byref(d), stream_ptr()), "lstc_gemm")
+    return out
+
+
+def _wgrad_split(m_out: int, n_out: int) -> int:
+    """Split-K factor for weight gradients: K = token count is huge and the output small, so the K range is
+    split until the grid has >= ~2 workgroups per CU (256 CUs, 128x128 tiles)."""
+    tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
+    s = 1
+    while tiles * s < 512 and s < 16:
+        s *= 2
+    return s
+
+
+def wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dW[out, in] = dy[M, out]^T @ x[M, in]  (autograd of nn.Linear's weight)."""
+    s = _wgrad_split(dy.shape[1], x.shape[1]) if dy.shape[0] >= 4096 else 1
+    return gemm(dy, x, trans_a=True, trans_b=False, split_k=s)
+
+
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate=False) -> torch.Tensor:
+    px, rows, cols, ld = _mat(x)
+    n_partial = int(min(rows, 256))
+    partial = torch.empty((n_partial, cols), device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((cols,), device=x.device, dtype=torch.float32)
+    check(_lib.load().lstc_colsum(px, rows, cols, ld, dev_ptr(partial), n_partial, dev_ptr(out), int(accumulate),
+                                  stream_ptr()), "lstc_colsum")
+    return out
+
+
+def dropout_apply(x: torch.Tensor, p: float, seed: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().lstc_dropout_apply(dev_ptr(x), dev_ptr(out), x.numel(), float(p), int(seed), stream_ptr()),
+          "lstc_dropout_apply")
+    return out
+
+
+def dropout_mask(shape, p: float, seed: int, device) -> torch.Tensor:
+    m = torch.empty(shape, device=device, dtype=torch.uint8)
+    check(_lib.load().lstc_dropout_mask(dev_ptr(m), m.numel(), float(p), int(seed), stream_ptr()), "lstc_dropout_mask")
+    return m
+
+
+def layernorm_fwd(x2: torch.Tensor, gamma, beta, eps=1e-6):
+    rows, d = x2.shape
+    y = torch.empty_like(x2)
+    mean = torch.empty((rows,), device=x2.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    check(_lib.load().lstc_layernorm_fwd(dev_ptr(x2), dev_ptr(gamma), dev_ptr(beta), dev_ptr(y), dev_ptr(mean),
+                                         dev_ptr(rstd), rows, d, float(eps), stream_ptr()), "lstc_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy2, x2, gamma, mean, rstd):
+    rows, d = x2.shape
+    dy2 = dy2.contiguous()
+    dx = torch.empty_like(x2)
+    n_partial = int(min(max(rows // 4, 1), 512))
+    partial = torch.empty((2, n_partial, d), device=x2.device, dtype=torch.float32)
+    check(_lib.load().lstc_layernorm_bwd(dev_ptr(dy2), dev_ptr(x2), dev_ptr(gamma), dev_ptr(mean), dev_ptr(rstd),
+                                         dev_ptr(dx), dev_ptr(partial), n_partial, rows, d, stream_ptr()),
+          "lstc_layernorm_bwd")
+    dgamma = colsum(partial[0])
+    dbeta = colsum(partial[1])
+    return dx, dgamma, dbeta
+
+
+def attn_fwd(q, k, v, N, S, H, dk, dv, table, index, p_drop, seed):
+    M = N * S
+    o = torch.empty((M, H * dv), device=q.device, dtype=torch.float32)
+    probs = torch.empty((N, H, S, S), device=q.device, dtype=torch.float32)
+    d = AttnDesc()
+    d.N, d.S, d.H, d.dk, d.dv = N, S, H, dk, dv
+    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
+    d.dtype = F32
+    if table is not None:
+        d.index_ld, d.table_rows = index.shape[1], table.shape[0]
+        d.table, d.index = dev_ptr(table), dev_ptr(index)
+    d.scale = 1.0 / (dk ** 0.5)
+    d.dropout_p, d.dropout_seed = float(p_drop), int(seed)
+    d.Q, d.K, d.V, d.O, d.probs = dev_ptr(q), dev_ptr(k), dev_ptr(v), dev_ptr(o), dev_ptr(probs)
+    check(_lib.load().lstc_attn_fwd(C.byref(d), stream_ptr()), "lstc_attn_fwd")
+    return o, probs
+
+
+def attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, p_drop, seed):
+    dq, dk_, dv_ = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    d = AttnDesc()
+    d.N, d.S, d.H, d.dk, d.dv = N, S, H, dk, dv
+    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), do.stride(0)
+    assert dq.stride(0) == q.stride(0) and dk_.stride(0) == k.stride(0) and dv_.stride(0) == v.stride(0)
+    d.dtype = F32
+    dtable = None
+    if table is not None:
+        dtable = torch.zeros_like(table)
+        d.index_ld, d.table_rows = index.shape[1], table.shape[0]
+        d.table, d.index, d.dtable = dev_ptr(table), dev_ptr(index), dev_ptr(dtable)
+    d.scale = 1.0 / (dk ** 0.5)
+    d.dropout_p, d.dropout_seed = float(p_drop), int(seed)
+    d.Q, d.K, d.V, d.probs = dev_ptr(q), dev_ptr(k), dev_ptr(v), dev_ptr(probs)
+    d.dO, d.dQ, d.dK, d.dV = dev_ptr(do), dev_ptr(dq), dev_ptr(dk_), dev_ptr(dv_)
+    check(_lib.load().lstc_attn_bwd(C.byref(d), stream_ptr()), "lstc_attn_bwd")
+    return dq, dk_, dv_, dtable
+
+
+# ------------------------------------------------------------------------------ autograd Functions
+class MHAFunction(torch.autograd.Function):
+    """models/MultiHeadAttention.py:93-132 (self-attention) as one autograd node.
+
+    forward:  Q,K,V = X Wq^T, X Wk^T, X Wv^T -> fused attention core -> dropout(O Wfc^T) + X -> [LayerNorm]
+    backward: hand-derived; every contraction is an lstc_gemm / lstc_attn_bwd launch."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, wfc, ln_w, ln_b, table, index, cfg):
+        N, S, dm = x.shape
+        H, dk, dv = cfg["n_head"], cfg["d_k"], cfg["d_v"]
+        training = cfg["training"]
+        p_attn = cfg["attn_dropout"] if training else 0.0
+        p_fc = cfg["fc_dropout"] if training else 0.0
+        x2 = x.contiguous().view(N * S, dm)
+        q = gemm(x2, wq, trans_b=True)
+        k = gemm(x2, wk, trans_b=True)
+        v = gemm(x2, wv, trans_b=True)
+        seed_a = next_seed() if p_attn > 0 else 0
+        seed_f = next_seed() if p_fc > 0 else 0
+        if p_attn > 0:
+            _note(cfg["site"] + "attn_dropout", p_attn, seed_a, (N, H, S, S))
+        if p_fc > 0:
+            _note(cfg["site"] + "dropout", p_fc, seed_f, (N, S, dm))
+        o, probs = attn_fwd(q, k, v, N, S, H, dk, dv, table, index, p_attn, seed_a)
+        y = gemm(o, wfc, trans_b=True, dropout=(p_fc, seed_f), residual=x2)
+        if cfg["layer_norm"]:
+            z, mean, rstd = layernorm_fwd(y, ln_w, ln_b, 1e-6)
+        else:
+            z, mean, rstd = y, None, None
+        ctx.cfg = dict(cfg, N=N, S=S, p_attn=p_attn, p_fc=p_fc, seed_a=seed_a, seed_f=seed_f)
+        ctx.save_for_backward(x2, wq, wk, wv, wfc, ln_w, table, index, q, k, v, o, probs,
+                              y if cfg["layer_norm"] else None, mean, rstd)
+        ctx.mark_non_differentiable(probs)
+        return z.view(N, S, dm), probs
+
+    @staticmethod
+    def backward(ctx, dz, _dprobs):
+        x2, wq, wk, wv, wfc, ln_w, table, index, q, k, v, o, probs, y, mean, rstd = ctx.saved_tensors
+        c = ctx.cfg
+        N, S, H, dk, dv = c["N"], c["S"], c["n_head"], c["d_k"], c["d_v"]
+        dz2 = dz.contiguous().view(N * S, -1)
+        dln_w = dln_b = None
+        if c["layer_norm"]:
+            dy, dln_w, dln_b = layernorm_bwd(dz2, y, ln_w, mean, rstd)
+        else:
+            dy = dz2
+        df = dropout_apply(dy, c["p_fc"], c["seed_f"]) if c["p_fc"] > 0 else dy
+        dwfc = wgrad(df, o)
+        do = gemm(df, wfc)                                   # [M, H*dv]
+        dq, dk_, dv_, dtable = attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, c["p_attn"], c["seed_a"])
+        dwq, dwk, dwv = wgrad(dq, x2), wgrad(dk_, x2), wgrad(dv_, x2)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm(dq, wq, residual=dy)
+            gemm(dk_, wk, out=dx, accumulate=True)
+            gemm(dv_, wv, out=dx, accumulate=True)
+            dx = dx.view(N, S, -1)
+        return dx, dwq, dwk, dwv, dwfc, dln_w, dln_b, dtable, None, None
+
+
+class FFNFunction(torch.autograd.Function):
+    """models/FFN.py:14-22: LN?( dropout(W2 relu(W1 x + b1) + b2) + x )."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, ln_w, ln_b, cfg):
+        shape = x.shape
+        dm = shape[-1]
+        x2 = x.contiguous().view(-1, dm)
+        p = cfg["dropout"] if cfg["training"] else 0.0
+        seed = next_seed() if p > 0 else 0
+        if p > 0:
+            _note(cfg["site"] + "dropout", p, seed, shape)
+        h1 = gemm(x2, w1, trans_b=True, bias=b1, relu=True)
+        y = gemm(h1, w2, trans_b=True, bias=b2, dropout=(p, seed), residual=x2)
+        if cfg["layer_norm"]:
+            z, mean, rstd = layernorm_fwd(y, ln_w, ln_b, 1e-6)
+        else:
+            z, mean, rstd = y, None, None
+        ctx.cfg = dict(cfg, p=p, seed=seed, shape=tuple(shape))
+        ctx.save_for_backward(x2, w1, w2, ln_w, h1, y if cfg["layer_norm"] else None, mean, rstd)
+        return z.view(shape)
+
+    @staticmethod
+    def backward(ctx, dz):
+        x2, w1, w2, ln_w, h1, y, mean, rstd = ctx.saved_tensors
+        c = ctx.cfg
+        dz2 = dz.contiguous().view(-1, dz.shape[-1])
+        dln_w = dln_b = None
+        if c["layer_norm"]:
+            dy, dln_w, dln_b = layernorm_bwd(dz2, y, ln_w, mean, rstd)
+        else:
+            dy = dz2
+        df = dropout_apply(dy, c["p"], c["seed"]) if c["p"] > 0 else dy
+        db2 = colsum(df)
+        dw2 = wgrad(df, h1)
+        dh1 = gemm(df, w2, relu_mask=h1)                     # [M, F], relu' fused
+        db1 = colsum(dh1)
+        dw1 = wgrad(dh1, x2)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm(dh1, w1, residual=dy).view(c["shape"])
+        return dx, dw1, db1, dw2, db2, dln_w, dln_b, None
+
+
+class LayerNormFunction(torch.autograd.Function):
+    """nn.LayerNorm(d_model, eps=1e-6) on the Encoder input (models/Encoder.py:48-49)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x2 = x.contiguous().view(-1, x.shape[-1])
+        y, mean, rstd = layernorm_fwd(x2, w, b, 1e-6)
+        ctx.save_for_backward(x2, w, mean, rstd)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, mean, rstd = ctx.saved_tensors
+        dx, dw, db = layernorm_bwd(dy.contiguous().view(x2.shape), x2, w, mean, rstd)
+        return (dx.view(dy.shape) if ctx.needs_input_grad[0] else None), dw, db
+
+
+class ClsConcatFunction(torch.autograd.Function):
+    """models/Encoder.py:51-58: CLS (token mean or learned) prepended, optional learned position table added."""
+
+    @staticmethod
+    def forward(ctx, x, cls_token, pos):
+        N, Sm1, dm = x.shape
+        S = Sm1 + 1
+        x = x.contiguous()
+        y = torch.empty((N, S, dm), device=x.device, dtype=torch.float32)
+        pos_s = pos[0, :S].contiguous() if pos is not None else None
+        cls_v = cls_token.reshape(-1) if cls_token is not None else None
+        check(_lib.load().lstc_cls_concat_fwd(dev_ptr(x), dev_ptr(cls_v), dev_ptr(pos_s), dev_ptr(y), N, S, dm,
+                                              stream_ptr()), "lstc_cls_concat_fwd")
+        ctx.meta = (N, S, dm, cls_token is not None, pos.shape if pos is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, S, dm, learned, pos_shape = ctx.meta
+        dy = dy.contiguous()
+        dx = dcls = dpos = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((N, S - 1, dm), device=dy.device, dtype=torch.float32)
+            check(_lib.load().lstc_cls_concat_bwd(dev_ptr(dy), dev_ptr(dx), N, S, dm, int(not learned), stream_ptr()),
+                  "lstc_cls_concat_bwd")
+        if learned or pos_shape is not None:
+            tok = colsum(dy.view(N, S * dm))                 # sum over sequences of every (token, channel)
+            if learned:
+                dcls = tok[:dm].clone().view(1, 1, dm)
+            if pos_shape is not None:
+                dpos = torch.zeros(pos_shape, device=dy.device, dtype=torch.float32)
+                dpos[0, :S] = tok.view(S, dm)
+        return dx, dcls, dpos
+
+
+class DropoutFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, site):
+        seed = next_seed()
+        _note(site, p, seed, x.shape)
+        ctx.ps = (p, seed)
+        return dropout_apply(x, p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dropout_apply(dy, *ctx.ps), None, None
+
+
+class HeadFunction(torch.autograd.Function):
+    """Regressor (models/Regressor.py:7-21) / Classifier (models/Classifier.py:8-23):
+    view(-1,d) -> Linear(d,512)+ReLU+Drop -> Linear(512,32)+Drop -> Linear(32,c) -> Sigmoid | Softmax."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w3, b3, w5, b5, cfg):
+        x2 = x.contiguous().view(-1, x.shape[-1])
+        p = cfg["dropout"] if cfg["training"] else 0.0
+        c = w5.shape[0]
+        s1 = next_seed() if p > 0 else 0
+        s2 = next_seed() if p > 0 else 0
+        rows = x2.shape[0]
+        if p > 0:
+            _note(cfg["site"] + ".2", p, s1, (rows, w0.shape[0]))
+            _note(cfg["site"] + ".4", p, s2, (rows, 32))
+        h1 = gemm(x2, w0, trans_b=True, bias=b0, relu=True, dropout=(p, s1))        # relu then dropout
+        h2 = gemm(h1, w3, trans_b=True, bias=b3, dropout=(p, s2))
+        out = torch.empty((rows, c), device=x.device, dtype=torch.float32)
+        check(_lib.load().lstc_head_out_fwd(dev_ptr(h2), dev_ptr(w5), dev_ptr(b5), dev_ptr(out), rows, c, stream_ptr()),
+              "lstc_head_out_fwd")
+        ctx.cfg = dict(cfg, p=p, s1=s1, s2=s2, c=c, in_shape=tuple(x.shape))
+        ctx.save_for_backward(x2, w0, w3, w5, h1, h2, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, w0, w3, w5, h1, h2, out = ctx.saved_tensors
+        cf = ctx.cfg
+        rows, c, p = x2.shape[0], cf["c"], cf["p"]
+        dout = dout.contiguous()
+        dh2 = torch.empty_like(h2)
+        dw5 = torch.zeros_like(w5)
+        db5 = torch.zeros((c,), device=x2.device, dtype=torch.float32)
+        check(_lib.load().lstc_head_out_bwd(dev_ptr(h2), dev_ptr(w5), dev_ptr(out), dev_ptr(dout), dev_ptr(dh2),
+                                            dev_ptr(dw5), dev_ptr(db5), rows, c, stream_ptr()), "lstc_head_out_bwd")
+        da2 = dropout_apply(dh2, p, cf["s2"]) if p > 0 else dh2          # grad of Linear(512,32) output
+        db3 = colsum(da2)
+        dw3 = wgrad(da2, h1)
+        # h1 = dropout(relu(.)) was saved: (h1 > 0) <=> relu passed AND the unit was kept, and dropped units get a
+        # zero gradient from dropout_apply anyway, so masking with h1 > 0 (fused in the GEMM epilogue) is exact.
+        da1 = gemm(da2, w3, relu_mask=h1)                                # [rows, 512]
+        if p > 0:
+            da1 = dropout_apply(da1, p, cf["s1"])
+        db0 = colsum(da1)
+        dw0 = wgrad(da1, x2)
+        dx = gemm(da1, w0).view(cf["in_shape"]) if ctx.needs_input_grad[0] else None
+        return dx, dw0, db0, dw3, db3, dw5, db5, None
+
+
+class VadLossFunction(torch.autograd.Function):
+    """MIL (+CE | +BCE) loss: one lstc_vad_loss launch produces the scalars and d(loss)/d(head output)."""
+
+    @staticmethod
+    def forward(ctx, out, abn_labels, targets, cfg):
+        out = out.contiguous()
+        dev = out.device
+        d = LossDesc()
+        d.mode = cfg["mode"]
+        d.bs_global, d.bs_local, d.rank_off = cfg["bs_global"], cfg["bs_local"], cfg["rank_off"]
+        d.part_num, d.score_len, d.label_len, d.l1_skip = cfg["part_num"], cfg["score_len"], cfg["label_len"], cfg["l1_skip"]
+        d.lambda_1, d.lambda_MIL, d.lambda_aux = cfg["lambda_1"], cfg["lambda_MIL"], cfg["lambda_aux"]
+        d.lambda_normal, d.lambda_abnormal = cfg.get("lambda_normal", 0.0), cfg.get("lambda_abnormal", 0.0)
+        dout = torch.empty_like(out)
+        scalars = torch.empty((5,), device=dev, dtype=torch.float32)
+        bag = torch.zeros((2 * cfg["bs_global"],), device=dev, dtype=torch.float32)
+        labs = abn_labels.contiguous().float() if abn_labels is not None else None
+        tg = targets.contiguous().float() if targets is not None else None
+        d.out, d.abn_labels, d.targets, d.bag = dev_ptr(out), dev_ptr(labs), dev_ptr(tg), dev_ptr(bag)
+        d.dout, d.scalars = dev_ptr(dout), dev_ptr(scalars)
+        lib = _lib.load()
+        group = cfg.get("group")
+        if cfg["bs_local"] == cfg["bs_global"]:
+            d.phase = 2
+            check(lib.lstc_vad_loss(C.byref(d), stream_ptr()), "lstc_vad_loss")
+        else:
+            import torch.distributed as dist
+            d.phase = 0
+            check(lib.lstc_vad_loss(C.byref(d), stream_ptr()), "lstc_vad_loss")
+            dist.all_reduce(bag, group=group)                # 2*bs floats: the only coupling between ranks
+            d.phase = 1
+            check(lib.lstc_vad_loss(C.byref(d), stream_ptr()), "lstc_vad_loss")
+        ctx.save_for_backward(dout)
+        ctx.mark_non_differentiable(scalars)
+        return scalars[0], scalars
+
+    @staticmethod
+    def backward(ctx, gloss, _gs):
+        (dout,) = ctx.saved_tensors
+        return dout * gloss, None, None, None

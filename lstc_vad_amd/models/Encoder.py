@@ -1,0 +1,80 @@
+"""Drop-in for the reference ``models/Encoder.py`` (:4-74)."""
+import torch
+from torch import nn
+
+from ..functional import ClsConcatFunction, DropoutFunction, LayerNormFunction
+from .EncoderLayer import EncoderLayer
+
+
+class Encoder(nn.Module):
+    def __init__(self, n_layers, n_head, d_k, d_v, d_model, d_inner,
+                 MHA_attn_dropout=0.1, MHA_fc_dropout=0.1, MHA_layerNorm=False,
+                 FFN_dropout=0.1, FFN_layerNorm=True,
+                 weight_init=True, CLS_learned=False, position_dropout=0.1, position_encoding=False,
+                 max_position_tokens=100, relative_pe=False, window_size=4, window_depth=3, conv_patch=False,
+                 input_layerNorm=False, relative_pe_2D=False, FFN_need=True):
+        super().__init__()
+        self.CLS_learned = CLS_learned
+        if CLS_learned:
+            self.cls_token = nn.Parameter(torch.randn(1, 1, d_model))
+        self.position_encoding = position_encoding
+        if position_encoding:
+            self.position_dropout = nn.Dropout(position_dropout)
+            self.position_enc = nn.Parameter(torch.randn(1, max_position_tokens, d_model))
+        self.layer_stack = nn.ModuleList([
+            EncoderLayer(d_model, d_inner, n_head, d_k, d_v, MHA_attn_dropout=MHA_attn_dropout,
+                         MHA_fc_dropout=MHA_fc_dropout, MHA_layerNorm=MHA_layerNorm, FFN_dropout=FFN_dropout,
+                         FFN_layerNorm=FFN_layerNorm, relative_pe=relative_pe, window_size=window_size,
+                         window_depth=window_depth, conv_patch=conv_patch, relative_pe_2D=relative_pe_2D,
+                         FFN_need=FFN_need)
+            for _ in range(n_layers)])
+        self.layer_norm = nn.LayerNorm(d_model, eps=1e-6)
+        self.input_layerNorm = input_layerNorm
+        for i, layer in enumerate(self.layer_stack):      # dropout-site names = reference module paths
+            layer.slf_attn._site = f"layer_stack.{i}.slf_attn."
+            layer.pos_ffn._site = f"layer_stack.{i}.pos_ffn."
+        if weight_init:
+            self._reset_parameters()
+
+    def _reset_parameters(self):
+        # xavier-uniform on every parameter with dim > 1, bias table / cls / pos-enc included (reference :38-41)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def used_parameters(self):
+        """Parameters that receive a gradient for this configuration.  The reference creates LayerNorms it
+        never calls (``layer_norm`` unless input_layerNorm, ``slf_attn.layer_norm`` unless MHA_layerNorm, ...);
+        Adagrad skips them (grad is None) and so must the gradient all-reduce (SURVEY 7 'Unused parameters')."""
+        skip = set()
+        if not self.input_layerNorm:
+            skip.update(id(p) for p in self.layer_norm.parameters())
+        for layer in self.layer_stack:
+            if not layer.slf_attn.layerNorm_flag:
+                skip.update(id(p) for p in layer.slf_attn.layer_norm.parameters())
+            if not layer.FFN_need:
+                skip.update(id(p) for p in layer.pos_ffn.parameters())
+            elif not layer.pos_ffn.layerNorm_flag:
+                skip.update(id(p) for p in layer.pos_ffn.layer_norm.parameters())
+        return [p for p in self.parameters() if id(p) not in skip]
+
+    def forward(self, enc_output, src_mask=None, return_attn=False, return_attn_v=False):
+        attn_list, v_list = [], []
+        if self.input_layerNorm:
+            enc_output = LayerNormFunction.apply(enc_output, self.layer_norm.weight, self.layer_norm.bias)
+        enc_output = ClsConcatFunction.apply(enc_output, self.cls_token if self.CLS_learned else None,
+                                             self.position_enc if self.position_encoding else None)
+        if self.position_encoding and self.training and self.position_dropout.p > 0:
+            enc_output = DropoutFunction.apply(enc_output, self.position_dropout.p, "position_dropout")
+        for layer in self.layer_stack:
+            res = layer(enc_output, slf_attn_mask=src_mask, return_attn=return_attn, return_attn_v=return_attn_v)
+            enc_output = res[0]
+            if return_attn or return_attn_v:
+                attn_list.append(res[1])
+            if return_attn_v:
+                v_list.append(res[2])
+        if return_attn_v:
+            return enc_output, attn_list, v_list
+        if return_attn:
+            return enc_output, attn_list
+        return enc_output

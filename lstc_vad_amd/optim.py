@@ -1,0 +1,68 @@
+"""Adagrad with the reference's settings, stepped by the fused HIP kernel.
+
+The reference builds ``torch.optim.Adagrad([{params: encoder, lr: lr_encoder}, {params: head, lr: lr_head}],
+weight_decay=wd)`` (Train/temporal_transformer_shanghaitech.py:83-85) and calls ``zero_grad / backward /
+[clip_grad_norm_] / step`` (:137-142).  This class keeps that surface (param groups, ``zero_grad``, ``step``,
+``state_dict``) and the exact update ``g += wd*w; s += g*g; w -= lr*g/(sqrt(s)+1e-10)``; parameters whose
+``grad`` is None are skipped exactly like upstream (unused LayerNorms never get a gradient).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import check, dev_ptr, stream_ptr
+
+
+class Adagrad(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-2, lr_decay=0, weight_decay=0, initial_accumulator_value=0, eps=1e-10):
+        if lr_decay != 0:
+            raise NotImplementedError("lr_decay is 0 everywhere on the LSTC_VAD path")
+        defaults = dict(lr=lr, weight_decay=weight_decay, eps=eps, initial_accumulator_value=initial_accumulator_value)
+        super().__init__(params, defaults)
+        for group in self.param_groups:
+            for p in group["params"]:
+                self.state[p]["sum"] = torch.full_like(p, float(group["initial_accumulator_value"]),
+                                                       memory_format=torch.preserve_format)
+                self.state[p]["step"] = 0
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scales=None):
+        """``grad_scales``: optional {group index: device-or-host scale} from ``clip_grad_norm_`` below."""
+        lib = _lib.load()
+        st = stream_ptr()
+        for gi, group in enumerate(self.param_groups):
+            gs = 1.0 if not grad_scales else float(grad_scales.get(gi, 1.0))
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                state = self.state[p]
+                state["step"] += 1
+                check(lib.lstc_adagrad_step(dev_ptr(p.data), dev_ptr(g), dev_ptr(state["sum"]), p.numel(),
+                                            float(group["lr"]), float(group["weight_decay"]), float(group["eps"]),
+                                            gs, st), "lstc_adagrad_step")
+        return None
+
+
+def clip_grad_norm_(parameters, max_norm: float, norm_type: float = 2.0) -> torch.Tensor:
+    """``torch.nn.utils.clip_grad_norm_(params, 10)`` (Train/temporal_transformer_shanghaitech.py:139-141):
+    total L2 norm over the given parameters' grads via ``lstc_sqnorm_accum``; grads are scaled in place by
+    ``max_norm / (total + 1e-6)`` clamped to 1 (torch semantics).  Returns the total norm (device scalar)."""
+    if norm_type != 2.0:
+        raise NotImplementedError
+    params = [p for p in parameters if p.grad is not None]
+    if not params:
+        return torch.zeros(())
+    lib = _lib.load()
+    acc = torch.zeros((1,), device=params[0].grad.device, dtype=torch.float32)
+    for p in params:
+        assert p.grad.is_contiguous()
+        check(lib.lstc_sqnorm_accum(dev_ptr(p.grad), p.grad.numel(), dev_ptr(acc), stream_ptr()),
+              "lstc_sqnorm_accum")
+    total = float(acc.sqrt().item())            # the reference syncs here too (python float compare inside torch)
+    coef = min(1.0, max_norm / (total + 1e-6))
+    if coef < 1.0:
+        for p in params:
+            check(lib.lstc_scale(dev_ptr(p.grad), p.grad.numel(), coef, stream_ptr()), "lstc_scale")
+    return torch.tensor(total)
