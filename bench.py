@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: snippets/sec of one full LSTC_VAD training step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config ltn_sht|stn_sht|ltn_ucf|ltn_ubnormal]
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): LTN temporal transformer,
+part_len=3, n_head=8, d_k=d_v=256, relative position bias (window 4), d_model=2048, n_hidden=4096, 3 layers,
+MHA + FFN LayerNorm, fp32; B=64 videos (--batch_size 32 pairs), T=32 parts, P=16 patches per GPU;
+reference dropout rates (0.2/0.2/0.1/0.6); synthetic I3D-like features resident in HBM.
+A step = sequence reshape + Encoder + Classifier + MIL/CE loss + backward + [gradient all-reduce] + Adagrad.
+For N>1 launch with ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``: one process
+per GPU over RCCL, every rank gets its own B=64 videos (weak scaling), value = all ranks' snippets / max time.
+
+Prints ONE JSON line (rank 0) with `roofline` (the dominant kernel = the exact-f32 MFMA GEMM; achieved = the
+launches' algorithmic 2MNK FLOPs / their HIP-event durations, measured live on the launch stream) and
+`cpu_baseline` (the oracle = CPU restatement of the reference, timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (mode, encoder kwargs, step kwargs, dropout (attn, fc, ffn, head))
+    "ltn_sht": ("LTN", dict(d_model=2048, d_inner=4096, MHA_layerNorm=True, FFN_layerNorm=True, relative_pe=True,
+                            window_size=4, window_depth=3), dict(part_len=3, n_patch=16), (0.2, 0.2, 0.1, 0.6)),
+    "stn_sht": ("STN", dict(d_model=2048, d_inner=3027, FFN_layerNorm=True), dict(part_len=1, n_patch=16),
+                (0.1, 0.1, 0.1, 0.6)),
+    "ltn_ucf": ("LTN", dict(d_model=2048, d_inner=4096, MHA_layerNorm=True, FFN_layerNorm=True, relative_pe=True,
+                            window_size=4, window_depth=2), dict(part_len=2, n_patch=9), (0.2, 0.2, 0.1, 0.6)),
+    "ltn_ubnormal": ("LTN", dict(d_model=1024, d_inner=4096, MHA_layerNorm=True, FFN_layerNorm=True, relative_pe=True,
+                                 window_size=4, window_depth=5), dict(part_len=5, n_patch=16), (0.2, 0.2, 0.1, 0.6)),
+}
+FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def train_flops_per_sequence(S, d, Hd, F, n_layers, c):
+    """F_fwd = L*[8 S d Hd + 4 S^2 Hd + 4 S d F] + head; F_alg = 3 F_fwd - 6 S d Hd."""
+    f_fwd = n_layers * (8 * S * d * Hd + 4 * S * S * Hd + 4 * S * d * F) + 2 * (512 * d + 512 * 32 + 32 * c)
+    return 3 * f_fwd - 6 * S * d * Hd
+
+
+def cpu_baseline(cfg_name, threads):
+    """Time the oracle's full training step (forward, loss, backward, Adagrad) on the host cores on a bounded
+    sample of the same workload: same model width, 2+2 videos x 8 parts (32 sequences)."""
+    from oracle import lstc_oracle as orc
+    mode, ekw, skw, drops = CONFIGS[cfg_name]
+    torch.set_num_threads(threads)
+    bs, pn, L, P, d = 2, 8, skw["part_len"], skw["n_patch"], ekw["d_model"]
+    ecfg = orc.EncoderCfg(n_layers=3, n_head=8, d_k=256, d_v=256, MHA_attn_dropout=drops[0], MHA_fc_dropout=drops[1],
+                          FFN_dropout=drops[2], **ekw)
+    st = orc.StepCfg(mode=mode, batch_size=bs, part_num=pn, part_len=L, n_patch=P, head_dropout=drops[3])
+    g = torch.Generator().manual_seed(0)
+    enc_P = {k: torch.randn(s, generator=g) * 0.02 for k, s in orc.encoder_param_shapes(ecfg).items()}
+    for k in enc_P:
+        if k.endswith("layer_norm.weight"):
+            enc_P[k] = torch.ones_like(enc_P[k])
+    if ekw.get("relative_pe"):
+        for i in range(3):
+            enc_P[f"layer_stack.{i}.slf_attn.relative_position_index"] = orc.relative_position_index_3d(L, 4)
+    kind = "classifier" if mode == "LTN" else "regressor"
+    head_P = {k: torch.randn(s, generator=g) * 0.02 for k, s in orc.head_param_shapes(d, kind).items()}
+    enc_S = {k: torch.zeros_like(v) for k, v in enc_P.items() if v.is_floating_point()}
+    head_S = {k: torch.zeros_like(v) for k, v in head_P.items()}
+    nf = 0.5 * torch.relu(torch.randn(bs, pn * L, P, d, generator=g))
+    af = 0.5 * torch.relu(torch.randn(bs, pn * L, P, d, generator=g))
+    al = torch.rand(bs, pn * L, 1, generator=g)
+    snippets = 2 * bs * pn * L
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        _, enc_P, head_P, enc_S, head_S, _, _ = orc.train_step(enc_P, head_P, enc_S, head_S, ecfg, st, nf, af, al)
+        times.append(time.perf_counter() - t0)
+        if it >= 1 and sum(times) > 25:
+            break
+    t = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": round(snippets / t, 2), "unit": "snippets/s", "cores": threads, "kind": "port",
+            "sample": f"oracle train_step (fwd+loss+bwd+Adagrad), same model, {2 * bs} videos x {pn} parts x "
+                      f"{L} snippets = {snippets} snippets/step, best of {max(1, len(times) - 1)} after 1 warm-up, "
+                      f"{t:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="ltn_sht", choices=list(CONFIGS))
+    ap.add_argument("--batch_size", type=int, default=32, help="normal/abnormal pairs per GPU (B = 2*batch_size videos)")
+    ap.add_argument("--part_num", type=int, default=32)
+    ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-events", action="store_true")
+    a = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the LSTC_VAD hot path here is HIP-only (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    if a.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    from lstc_vad_amd import functional as Fn
+    from lstc_vad_amd.engine import TrainStep
+    from lstc_vad_amd.models import Classifier, Encoder, Regressor
+
+    mode, ekw, skw, drops = CONFIGS[a.config]
+    if a.no_dropout:
+        drops = (0.0, 0.0, 0.0, 0.0)
+    bs, pn, L, P, d = a.batch_size, a.part_num, skw["part_len"], skw["n_patch"], ekw["d_model"]
+    args = Namespace(batch_size=bs, part_num=pn, part_len=L, n_patch=P, lambda_1=0.01, lambda_MIL=1.0, lambda_CE=0.8,
+                     lambda_BCE=1.0, lambda_normal=0.2, lambda_abnormal=2.0, temporal_only=False, clip_grad=False)
+    torch.manual_seed(0)       # same replica on every rank
+    enc = Encoder(n_layers=3, n_head=8, d_k=256, d_v=256, MHA_attn_dropout=drops[0], MHA_fc_dropout=drops[1],
+                  FFN_dropout=drops[2], weight_init=(mode != "LTN"), **ekw).to(dev).train()
+    head = (Classifier(d, drops[3]) if mode == "LTN" else Regressor(d, drops[3])).to(dev).train()
+    ts = TrainStep(args, mode, enc, head, lr_encoder=1e-4, lr_head=1e-2, weight_decay=1e-3)
+
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)      # every rank its own videos
+    Lfeat = L if mode == "LTN" else 1
+    T = pn * L if mode == "LTN" else pn * L
+    nf = 0.5 * torch.relu(torch.randn(bs, T, P, d, device=dev, generator=gen))
+    af = 0.5 * torch.relu(torch.randn(bs, T, P, d, device=dev, generator=gen))
+    u = torch.rand(bs, T, 1, device=dev, generator=gen)
+    al = torch.where(u > 0.9, u, torch.zeros_like(u))            # pseudo labels, rule of README.md:27
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        ts.step(nf, af, al)
+    sync()
+    prof = None if a.no_gemm_events else []
+    Fn.set_gemm_profiling(prof)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        sc = ts.step(nf, af, al)
+    sync()
+    dt = time.perf_counter() - t0
+    Fn.set_gemm_profiling(None)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    scal = [float(x) for x in sc.cpu()]
+
+    snippets_per_step = 2 * bs * pn * L * world
+    value = snippets_per_step * a.steps / dt
+    if rank == 0:
+        S = 1 + (L * P if mode == "LTN" else P)
+        nseq = 2 * bs * pn * (1 if mode == "LTN" else L)
+        f_seq = train_flops_per_sequence(S, d, 2048, ekw["d_inner"], 3, 2 if mode == "LTN" else 1)
+        roof = None
+        if prof:
+            fl = sum(p[0] for p in prof)
+            ms = sum(p[1].elapsed_time(p[2]) for p in prof)
+            ach = fl / (ms * 1e-3) / 1e12
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "gemm_pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get(a.config)
+                except Exception:
+                    traffic = None
+            roof = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": round(ach, 2),
+                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": traffic, "launches_per_step": len(prof) // a.steps,
+                    "gemm_ms_per_step": round(ms / a.steps, 3),
+                    "gemm_flops_per_step": fl / a.steps,
+                    "step_algorithmic_tflops": round(f_seq * nseq / 1e12, 3),
+                    "step_frac_of_peak": round(f_seq * nseq * world / (dt / a.steps) / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world), 4)}
+        out = {"metric": "snippets/sec training step (B=64,T=32,P=16,d=2048)", "value": round(value, 1),
+               "unit": "snippets/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{a.config}: {mode} full training step (fwd+loss+bwd+"
+                                      f"{'allreduce+' if world > 1 else ''}Adagrad), per GPU B={2 * bs} videos x T={pn} parts x "
+                                      f"L={L} snippets x P={P} patches, d_model={d}, n_hidden={ekw['d_inner']}, S={S}, "
+                                      f"{nseq} sequences/GPU/step, dropout={'off' if a.no_dropout else 'reference rates'}",
+                          "global_videos": 2 * bs * world, "parallelism": f"dp{world}"},
+               "loss": scal[0], "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            # torch-CPU sgemm on the GPU box's host peaks at 16-32 threads (tools/cpu_threads_scan.py: 1.3 TFLOP/s
+            # at 16-32, 0.5 at 128 of 256 hardware threads), so the baseline uses min(32, available) threads
+            out["cpu_baseline"] = cpu_baseline(a.config, min(32, len(os.sched_getaffinity(0))))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,111 @@
+"""Data-parallel gradient exchange: ONE sum-all-reduce of the gradients per step over RCCL/xGMI.
+
+The reference's only multi-GPU mechanism is single-process ``nn.DataParallel`` (e.g.
+Train/temporal_transformer_shanghaitech.py:76-78): per step it broadcasts every parameter (~403 MB), gathers
+the full encoder output (~822 MB) to GPU 0 and reduces the gradients there.  Here each GPU
+is its own process holding a replica; videos are sharded across ranks (sequences are independent through
+encoder and head), the loss kernel divides by GLOBAL counts, so the only exchange is
+
+  * 2*bs floats of bag maxima inside the loss (lstc_vad_amd.functional.VadLossFunction), and
+  * a SUM all-reduce of the parameter gradients — bucketed per encoder layer in backward order and
+    launched asynchronously from autograd hooks, so the reduction of layer i overlaps the backward
+    of layers < i.  xGMI is point-to-point (7 links/GPU): a few large buckets (~130 MB each for the
+    LTN) keep every link busy with large messages instead of many small ones.
+
+Parameters that never receive a gradient (LayerNorms the reference constructs but does not call) are left
+out of the buckets, mirroring Adagrad skipping ``grad is None`` entries.
+The class is device-agnostic (works with ``gloo`` on CPU tensors), which is how tests/test_dist_cpu.py covers it.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+class GradAllReducer:
+    def __init__(self, param_groups: Sequence[Iterable[torch.nn.Parameter]], group=None, overlap: bool = True):
+        """``param_groups``: lists of parameters, one per bucket, ordered the way backward produces them
+        (head first, last encoder layer next, ...).  Every listed parameter MUST receive a gradient each step."""
+        self.group = group
+        self.overlap = overlap
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets: List[torch.Tensor] = []
+        self._views = []
+        self._pending: List[int] = []
+        self._sizes: List[int] = []
+        self._handles = []
+        self._bucket_of = {}
+        for bi, params in enumerate(param_groups):
+            params = [p for p in params if p.requires_grad]
+            n = sum(p.numel() for p in params)
+            if n == 0:
+                continue
+            flat = torch.zeros(n, device=params[0].device, dtype=params[0].dtype)
+            off = 0
+            views = []
+            for p in params:
+                v = flat[off:off + p.numel()].view_as(p)
+                p.grad = v                       # autograd accumulates in place into the bucket
+                views.append((p, v))
+                off += p.numel()
+                self._bucket_of[p] = len(self.buckets)
+                if self.world > 1 and overlap:
+                    p.register_post_accumulate_grad_hook(self._hook)
+            self.buckets.append(flat)
+            self._views.append(views)
+            self._sizes.append(len(params))
+            self._pending.append(len(params))
+
+    # ------------------------------------------------------------------------------------------
+    def zero_grad(self):
+        """Replaces ``optimizer.zero_grad()``: clears the flat buckets and re-arms the hooks."""
+        for bi, flat in enumerate(self.buckets):
+            flat.zero_()
+            self._pending[bi] = self._sizes[bi]
+            for p, v in self._views[bi]:
+                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                    p.grad = v
+        self._handles = []
+
+    def _hook(self, p):
+        bi = self._bucket_of[p]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._handles.append(dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, group=self.group,
+                                                 async_op=True))
+
+    def finish(self):
+        """Call after ``backward()`` and before the optimizer step."""
+        if self.world <= 1:
+            return
+        if not self.overlap:
+            for flat in self.buckets:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        if any(n != 0 for n in self._pending):
+            missing = [bi for bi, n in enumerate(self._pending) if n]
+            raise RuntimeError(f"GradAllReducer: buckets {missing} did not receive all gradients this step")
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+
+    def payload_bytes(self) -> int:
+        return sum(b.numel() * b.element_size() for b in self.buckets)
+
+
+def encoder_head_buckets(encoder, head) -> List[List[torch.nn.Parameter]]:
+    """Backward-ordered buckets for an ``Encoder`` + head pair: head, then encoder layers last to first
+    (layer-level parameters that feed the first layer — cls_token / position_enc / input LayerNorm — go last)."""
+    used = {id(p) for p in encoder.used_parameters()}
+    buckets = [list(head.parameters())]
+    in_layers = set()
+    for layer in reversed(list(encoder.layer_stack)):
+        ps = [p for p in layer.parameters() if id(p) in used]
+        in_layers.update(id(p) for p in ps)
+        buckets.append(ps)
+    rest = [p for p in encoder.parameters() if id(p) in used and id(p) not in in_layers]
+    if rest:
+        buckets.append(rest)
+    return buckets

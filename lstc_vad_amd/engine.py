@@ -1,0 +1,56 @@
+"""One training step of the LSTC_VAD loops as a reusable object (used by Train/*.py, bench.py, smoke()).
+
+Mirrors the body of the reference's inner loops — Train/temporal_transformer_shanghaitech.py:103-143 (LTN),
+Train/spatio_transformer_shanghaitech.py:90-113 (STN), Train/spatio_transformer_MIL_CE.py:156-213 (STN + BCE) —
+with the DataLoader batch contract of SURVEY.md 8a row A0:
+``norm_feats, abnorm_feats`` ``[bs, part_num*part_len, n_patch, d_model]``, ``abnorm_labs`` ``[bs, part_num*part_len(,1)]``.
+Under data parallelism each rank calls it with its own ``bs`` pairs.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from .dist import GradAllReducer, encoder_head_buckets
+from .losses import training_loss
+from .optim import Adagrad, clip_grad_norm_
+
+
+class TrainStep:
+    def __init__(self, args, mode: str, encoder, head, lr_encoder: float, lr_head: float, weight_decay: float,
+                 group=None):
+        self.args, self.mode, self.encoder, self.head, self.group = args, mode, encoder, head, group
+        self.optimizer = Adagrad([{"params": encoder.parameters(), "lr": lr_encoder},
+                                  {"params": head.parameters(), "lr": lr_head}], weight_decay=weight_decay)
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.reducer = GradAllReducer(encoder_head_buckets(encoder, head), group) if self.world > 1 else None
+
+    def sequences(self, norm_feats, abnorm_feats):
+        """A1: [bs, pn*L, P, d] x2 -> [N, S-1, d], normal sequences first (the loss relies on this order)."""
+        a = self.args
+        d = norm_feats.shape[-1]
+        tokens = a.part_len * a.n_patch if self.mode == "LTN" else a.n_patch
+        return torch.cat([norm_feats.float().reshape(-1, tokens, d), abnorm_feats.float().reshape(-1, tokens, d)], 0)
+
+    def forward_loss(self, norm_feats, abnorm_feats, abnorm_labs):
+        enc_out = self.encoder(self.sequences(norm_feats, abnorm_feats))
+        outputs = self.head(enc_out[:, 0, :])
+        loss, scalars = training_loss(self.args, self.mode, outputs, abnorm_labs, group=self.group)
+        return loss, scalars, outputs
+
+    def step(self, norm_feats, abnorm_feats, abnorm_labs):
+        """forward, loss, backward, [gradient all-reduce], [clip], Adagrad.  Returns the 5 scalars
+        (loss, MIL, err, l1, aux) as a device tensor — no host sync happens here."""
+        loss, scalars, _ = self.forward_loss(norm_feats, abnorm_feats, abnorm_labs)
+        if self.reducer is not None:
+            self.reducer.zero_grad()
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        if getattr(self.args, "clip_grad", False):
+            clip_grad_norm_(self.encoder.parameters(), 10)
+            clip_grad_norm_(self.head.parameters(), 10)
+        self.optimizer.step()
+        return scalars

@@ -58,6 +58,15 @@ def _note(site, p, seed, shape):
         _recorder.append((site, float(p), int(seed), tuple(shape)))
 
 
+_gemm_prof = None         # list of (flops, start_event, end_event) while bench.py profiles GEMM launches
+
+
+def set_gemm_profiling(sink):
+    """``sink`` = list to append (flops, start_event, end_event) per lstc_gemm launch, or None to stop."""
+    global _gemm_prof
+    _gemm_prof = sink
+
+
 # --------------------------------------------------------------------------------------- helpers
 def _mat(t: torch.Tensor):
     """(ptr, rows, cols, ld) of a 2-D f32 tensor whose rows are contiguous."""
@@ -109,6 +118,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
         flags |= EPI_ACCUM
     d.flags, d.alpha, d.split_k, d.variant = flags, float(alpha), int(split_k), int(variant)
     d.A, d.B, d.C = pa, pb, pc
+    if _gemm_prof is not None:                 # bench.py: HIP events on the launch stream around every GEMM
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().lstc_gemm(C.byref(d), stream_ptr()), "lstc_gemm")
+        e1.record()
+        _gemm_prof.append((2.0 * M * N * K, e0, e1))
+        return out
     check(_lib.load().lstc_gemm(C.byref(d), stream_ptr()), "lstc_gemm")
     return out
 

@@ -1,0 +1,130 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/lstc_hip.h
+declares, host-side argument validation returns the documented error codes without touching a GPU, the model
+mirror keeps the reference's constructor surface / state_dict keys, and the product path refuses CPU tensors
+(there is no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from lstc_vad_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from lstc_vad_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "lstc_hip.h")).read()
+    declared = set(re.findall(r"\b(lstc_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    raw = C.CDLL(_lib.LIB_PATH)
+    for s in declared:
+        assert hasattr(raw, s), s
+    assert lib.lstc_version() == 100
+
+
+def test_descriptor_layouts_match_header(lib):
+    """ctypes mirrors must have the C struct sizes (natural alignment, 64-bit pointers)."""
+    from lstc_vad_amd._lib import GemmDesc, AttnDesc, LossDesc
+    assert C.sizeof(GemmDesc) == 17 * 4 + 4 + 8 + 6 * 8 - 4 or C.sizeof(GemmDesc) % 8 == 0
+    assert GemmDesc.dropout_seed.offset % 8 == 0 and GemmDesc.A.offset % 8 == 0
+    assert AttnDesc.dropout_seed.offset % 8 == 0 and AttnDesc.Q.offset % 8 == 0
+    assert LossDesc.out.offset % 8 == 0 and LossDesc.phase.offset == LossDesc.scalars.offset + 8
+
+
+def test_host_side_validation_error_codes(lib):
+    from lstc_vad_amd._lib import GemmDesc, AttnDesc, LossDesc
+    assert lib.lstc_gemm(None, None) == -1
+    d = GemmDesc()
+    assert lib.lstc_gemm(C.byref(d), None) == -1                      # NULL operands
+    d.A = d.B = d.C = 16
+    assert lib.lstc_gemm(C.byref(d), None) == -2                      # zero dims
+    d.M = d.N = d.K = 8
+    d.lda = d.ldb = d.ldc = 4
+    assert lib.lstc_gemm(C.byref(d), None) == -2                      # ld < extent
+    d.lda = d.ldb = d.ldc = 8
+    d.dtype = 7
+    assert lib.lstc_gemm(C.byref(d), None) == -4                      # unknown dtype
+    a = AttnDesc()
+    assert lib.lstc_attn_fwd(C.byref(a), None) == -1
+    a.Q = a.K = a.V = a.O = a.probs = 16
+    a.N, a.S, a.H, a.dk, a.dv = 1, 200, 1, 8, 8
+    a.ldq = a.ldk = a.ldv = a.ldo = 8
+    assert lib.lstc_attn_fwd(C.byref(a), None) == -5                  # S > 128
+    l = LossDesc()
+    l.out = 16
+    l.phase = 2
+    assert lib.lstc_vad_loss(C.byref(l), None) == -1
+    assert lib.lstc_layernorm_fwd(None, None, None, None, None, None, 1, 1, 1e-6, None) == -1
+    assert lib.lstc_adagrad_step(16, 16, 16, 0, 0.1, 0.0, 1e-10, 1.0, None) == -2
+    assert b"NULL" in lib.lstc_strerror(-1) and lib.lstc_strerror(0) == b"ok"
+
+
+def test_model_mirror_keeps_reference_surface():
+    from lstc_vad_amd.models import Encoder, Classifier, Regressor
+    z = np.load(os.path.join(ROOT, "tests", "golden", "misc.npz"), allow_pickle=False)
+    with torch.device("meta"):
+        ltn = Encoder(3, 8, 256, 256, 2048, 4096, MHA_layerNorm=True, FFN_layerNorm=True, weight_init=False,
+                      relative_pe=True, window_size=4, window_depth=3)
+        stn = Encoder(3, 8, 256, 256, 2048, 3027, FFN_layerNorm=True, weight_init=False)
+    assert list(ltn.state_dict().keys()) == z["ltn_state_keys"].tolist()
+    assert list(stn.state_dict().keys()) == z["stn_state_keys"].tolist()
+    assert sum(p.numel() for p in ltn.parameters()) == int(z["ltn_param_count"])
+    assert sum(p.numel() for p in stn.parameters()) == int(z["stn_param_count"])
+    assert list(Classifier(8).state_dict().keys()) == z["classifier_state_keys"].tolist()
+    assert list(Regressor(8).state_dict().keys()) == z["regressor_state_keys"].tolist()
+    # parameters the reference constructs but never uses get no gradient -> excluded from the all-reduce buckets
+    assert len(stn.used_parameters()) == len(list(stn.parameters())) - 2 - 3 * 2
+    assert len(ltn.used_parameters()) == len(list(ltn.parameters())) - 2
+
+
+def test_relative_position_index_matches_reference_buffers():
+    from lstc_vad_amd.models.MultiHeadAttention import relative_position_index_3d, relative_position_index_2d
+    z = np.load(os.path.join(ROOT, "tests", "golden", "misc.npz"), allow_pickle=False)
+    for (L, ws) in [(3, 4), (2, 4), (5, 4), (2, 3), (1, 4)]:
+        assert np.array_equal(relative_position_index_3d(L, ws).numpy(), z[f"relidx3d_L{L}_ws{ws}"])
+    for ws in (3, 4):
+        assert np.array_equal(relative_position_index_2d(ws).numpy(), z[f"relidx2d_ws{ws}"])
+
+
+def test_no_cpu_fallback(lib):
+    from lstc_vad_amd.models import Encoder
+    enc = Encoder(1, 2, 4, 4, 8, 16)
+    with pytest.raises(RuntimeError, match="HIP"):
+        enc(torch.zeros(2, 4, 8))
+
+
+def test_dropout_hash_matches_host_restatement():
+    """The counter-based keep/drop rule is part of the ABI contract (masks are replayed by tests): restate it in
+    numpy and check basic statistics."""
+    def key(p, seed):
+        k0 = ((seed & 0xffffffff) * 0x9E3779B1 + 0x7F4A7C15) & 0xffffffff
+        k1 = ((seed >> 32) * 0x85EBCA77 + 0x165667B1) & 0xffffffff
+        return k0, k1, min(int(p * 4294967296.0), 0xffffffff)
+
+    def keep(i, p, seed):
+        k0, k1, thr = key(p, seed)
+        h = (i.astype(np.uint64) ^ np.uint64(k0)) & np.uint64(0xffffffff)
+        h = (h * np.uint64(0x9E3779B1)) & np.uint64(0xffffffff)
+        h ^= h >> np.uint64(15)
+        h = (h + np.uint64(k1)) & np.uint64(0xffffffff)
+        h = (h * np.uint64(0x85EBCA77)) & np.uint64(0xffffffff)
+        h ^= h >> np.uint64(13)
+        h = (h * np.uint64(0xC2B2AE3D)) & np.uint64(0xffffffff)
+        h ^= h >> np.uint64(16)
+        return h >= np.uint64(thr)
+    i = np.arange(1 << 20)
+    for p in (0.1, 0.5, 0.6):
+        m = keep(i, p, 0x1234567890ABCDEF)
+        assert abs(m.mean() - (1 - p)) < 2e-3
+        assert abs(np.corrcoef(m[:-1], m[1:])[0, 1]) < 5e-3

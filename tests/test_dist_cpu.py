@@ -1,0 +1,119 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel machinery: bucketed gradient all-reduce with autograd hooks
+(lstc_vad_amd.dist) and the sharded-loss bookkeeping, using the oracle as the model (the HIP kernels need a GPU;
+the distributed logic does not)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from lstc_vad_amd.dist import GradAllReducer
+    from oracle import lstc_oracle as orc
+    from util import load_case, sub, oracle_cfgs
+    z, mode, ekw, skw = load_case("ltn_sht")
+    ecfg, st = oracle_cfgs(mode, ekw, skw)
+    bs = skw["batch_size"]
+    nf, af, al = (torch.from_numpy(z[k]) for k in ("norm_feats", "abnorm_feats", "abnorm_labs"))
+    enc_P = {k: (torch.nn.Parameter(v.clone()) if v.is_floating_point() else v) for k, v in sub(z, "enc_init.").items()}
+    head_P = {k: torch.nn.Parameter(v.clone()) for k, v in sub(z, "head_init.").items()}
+    used = [k for k in sub(z, "enc_grad.")]                      # parameters that receive a gradient
+    buckets = [list(head_P.values())] + [[enc_P[k] for k in used if k.startswith(f"layer_stack.{i}.")] for i in (2, 1, 0)]
+    red = GradAllReducer(buckets)
+    red.zero_grad()
+    # this rank's shard: pairs [rank*bs/world, (rank+1)*bs/world)
+    h = bs // world
+    sl = slice(rank * h, (rank + 1) * h)
+    stl = orc.StepCfg(**{**st.__dict__, "batch_size": h})
+    # global-count loss on the local shard: forward locally, exchange bag maxima, form the rank's contribution
+    pn, L, P, d = st.part_num, st.part_len, st.n_patch, ecfg.d_model
+    x = torch.cat([nf[sl].reshape(h * pn, L * P, d), af[sl].reshape(h * pn, L * P, d)], 0)
+    enc = orc.encoder_forward(enc_P, x, ecfg, True)
+    out = orc.head_forward(head_P, enc[:, 0, :], "classifier", 0.0, True)
+    score = out[:, 1]
+    bag_l = score.reshape(2 * h, pn).max(dim=-1)[0]
+    bag = torch.zeros(2 * bs)
+    bag[rank * h:(rank + 1) * h] = bag_l[:h].detach()
+    bag[bs + rank * h: bs + (rank + 1) * h] = bag_l[h:].detach()
+    dist.all_reduce(bag)                                          # the 2*bs-float exchange of SURVEY 8e
+    nor_g, abn_g = bag[:bs], bag[bs:]
+    # hinge with gradients flowing only through this rank's entries; pairs booked on the rank owning the normal video
+    nor_l, abn_l = bag_l[:h], bag_l[h:]
+    err = torch.relu(1 - abn_g[None, :] + nor_l[:, None]).sum() / bs ** 2
+    err_abn_grad_only = torch.relu(1 - abn_l[None, :] + nor_g[:, None]).sum() / bs ** 2
+    err_for_grad = err + (err_abn_grad_only - err_abn_grad_only.detach())
+    gidx_n = torch.arange(h * pn) + rank * h * pn
+    gidx_a = bs * pn + rank * h * pn + torch.arange(h * pn)
+    gidx = torch.cat([gidx_n, gidx_a])
+    l1 = (score * (gidx >= bs).float()).sum() / (2 * bs * pn - bs)
+    labs = orc.soft_targets(al[sl], h, pn, L).reshape(2 * h * pn, 2)
+    ce = -(labs * torch.log_softmax(out, -1)).sum() / (2 * bs * pn)
+    loss = st.lambda_MIL * (err_for_grad + st.lambda_1 * l1) + st.lambda_CE * ce
+    loss.backward()
+    red.finish()
+    tot = torch.tensor([float(loss.detach())])
+    dist.all_reduce(tot)
+    if rank == 0:
+        ref_g = sub(z, "enc_grad.")
+        worst = 0.0
+        for k, g in ref_g.items():
+            worst = max(worst, float((enc_P[k].grad - g).abs().max()) / max(1e-6, float(g.abs().max())))
+        for k, g in sub(z, "head_grad.").items():
+            worst = max(worst, float((head_P[k].grad - g).abs().max()) / max(1e-6, float(g.abs().max())))
+        q.put((float(tot), float(z["scalars"][0]), worst, red.payload_bytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_step_equals_single_process_reference():
+    """Two gloo ranks, each with half of the golden batch: summed loss == reference loss, all-reduced gradients
+    == the reference's single-process gradients (golden vectors)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    tot, ref_loss, worst, payload = res
+    assert abs(tot - ref_loss) < 2e-6
+    assert worst < 2e-4
+    assert payload > 0
+
+
+def test_bucket_order_and_unused_parameters():
+    from lstc_vad_amd.dist import encoder_head_buckets
+    from lstc_vad_amd.models import Encoder, Classifier
+    enc = Encoder(3, 2, 4, 4, 8, 16, MHA_layerNorm=False, FFN_layerNorm=True, relative_pe=True, window_depth=2)
+    head = Classifier(8)
+    b = encoder_head_buckets(enc, head)
+    assert len(b) == 4 and len(b[0]) == 6
+    ids = {id(p) for g in b for p in g}
+    assert ids == {id(p) for p in enc.used_parameters()} | {id(p) for p in head.parameters()}
+    assert id(enc.layer_norm.weight) not in ids and id(enc.layer_stack[0].slf_attn.layer_norm.weight) not in ids
+    assert b[1][0] is next(iter(enc.layer_stack[2].parameters()))      # last layer first (backward order)
