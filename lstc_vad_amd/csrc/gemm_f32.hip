@@ -25,6 +25,7 @@
 //  * Epilogue in the accumulator layout (col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5)): every
 //    wave-level load/store is two 128-B row segments.
 #include "lstc_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -44,6 +45,7 @@ struct GemmParams {
     DropKey dk;
     int tilesM, tilesN;
     int ktiles, ktiles_per_split;
+    int debug;     // timing-only ablations (tools/gemm_check): 1 = no global loads in the loop, 2 = no LDS writes, 4 = no barrier
 };
 
 // Stages one operand tile (R rows/cols x 32 k) global -> registers -> LDS.
@@ -55,47 +57,47 @@ struct Stager {
     static_assert(NV >= 1 && (R * 8) % NT == 0, "tile/threads mismatch");
     float4 v[NV];
 
+    // Rows/cols outside the matrix are CLAMPED to the last valid one instead of predicated: the accumulators they
+    // feed belong to output rows/cols that the epilogue never stores, and the main loop stays branch-free.
+    // Only the K tail needs zero fill (CHECK_K = true, used for the last K tile when K % 32 != 0).
+    template <bool CHECK_K>
     __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int r0, int r_total, int k0, int K) {
         const int t = threadIdx.x;
         if (KC) {
             const int c = (t & 7) * 4;
+            const int k = k0 + c;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                const int r = r0 + (t >> 3) + i * (NT / 8);
-                const int k = k0 + c;
+                const int r = min(r0 + (t >> 3) + i * (NT / 8), r_total - 1);
                 const float* p = base + (size_t)r * ld + k;
                 float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r < r_total) {
-                    if (VEC) {
-                        if (k < K) x = *reinterpret_cast<const float4*>(p);
-                    } else {
-                        if (k + 0 < K) x.x = p[0];
-                        if (k + 1 < K) x.y = p[1];
-                        if (k + 2 < K) x.z = p[2];
-                        if (k + 3 < K) x.w = p[3];
-                    }
+                if (VEC) {
+                    if (!CHECK_K || k < K) x = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (!CHECK_K || k + 0 < K) x.x = p[0];
+                    if (!CHECK_K || k + 1 < K) x.y = p[1];
+                    if (!CHECK_K || k + 2 < K) x.z = p[2];
+                    if (!CHECK_K || k + 3 < K) x.w = p[3];
                 }
                 v[i] = x;
             }
         } else {
             constexpr int CPR = R / 4;          // float4 columns per k row
-            const int c = (t % CPR) * 4;
+            const int c = r0 + (t % CPR) * 4;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int k = k0 + t / CPR + i * (NT / CPR);
-                const int r = r0 + c;
-                const float* p = base + (size_t)k * ld + r;
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < K) {
-                    if (VEC) {
-                        if (r < r_total) x = *reinterpret_cast<const float4*>(p);
-                    } else {
-                        if (r + 0 < r_total) x.x = p[0];
-                        if (r + 1 < r_total) x.y = p[1];
-                        if (r + 2 < r_total) x.z = p[2];
-                        if (r + 3 < r_total) x.w = p[3];
-                    }
+                const float* p = base + (size_t)(CHECK_K ? min(k, K - 1) : k) * ld;
+                float4 x;
+                if (VEC) {
+                    x = *reinterpret_cast<const float4*>(p + min(c, r_total - 4));
+                } else {
+                    x.x = p[min(c + 0, r_total - 1)];
+                    x.y = p[min(c + 1, r_total - 1)];
+                    x.z = p[min(c + 2, r_total - 1)];
+                    x.w = p[min(c + 3, r_total - 1)];
                 }
+                if (CHECK_K && k >= K) x = make_float4(0.f, 0.f, 0.f, 0.f);
                 v[i] = x;
             }
         }
@@ -140,7 +142,7 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int row
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC, bool VA, bool VB>
+template <int BM, int BN, int WGM, int WGN, int PIPE, bool A_KC, bool B_KC, bool VA, bool VB>
 __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParams p) {
     constexpr int NT = WGM * WGN * 64;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -178,44 +180,148 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParam
 
     Stager<BM, NT, A_KC, VA> sa;
     Stager<BN, NT, B_KC, VB> sb;
+    const int nkt = kt1 - kt0;
+    const bool k_tail = (p.K % BK) != 0;          // only the globally last K tile can be partial
 
-    if (kt0 < kt1) {
-        sa.load(p.A, p.lda, m0, p.M, kt0 * BK, p.K);
-        sb.load(p.B, p.ldb, n0, p.N, kt0 * BK, p.K);
+    auto gload = [&](int kt) {
+        if (k_tail && kt == p.ktiles - 1) {
+            sa.template load<true>(p.A, p.lda, m0, p.M, kt * BK, p.K);
+            sb.template load<true>(p.B, p.ldb, n0, p.N, kt * BK, p.K);
+        } else {
+            sa.template load<false>(p.A, p.lda, m0, p.M, kt * BK, p.K);
+            sb.template load<false>(p.B, p.ldb, n0, p.N, kt * BK, p.K);
+        }
+    };
+
+    // Software pipeline with ONE barrier per K tile, placed in the middle of the tile's MFMAs:
+    //   phase 1: LDS-write tile t+1 (registers, loaded one iteration ago) | issue global loads of tile t+2 |
+    //            LDS-read the 2nd-half fragments of tile t      -> all hidden behind the 1st-half MFMAs of tile t
+    //   barrier: publishes tile t+1 and retires every read of tile t's stage
+    //   phase 2: LDS-read the 1st-half fragments of tile t+1   -> hidden behind the 2nd-half MFMAs of tile t
+    // so a wave reaches each MFMA block with its operands already in registers; only barrier skew is exposed.
+    if constexpr (PIPE == 0) {
+        // Plain double buffering: global loads of tile t+1 issued before the MFMAs of tile t, LDS write after them,
+        // one barrier at the end of the tile (fragment reads of the next tile are exposed after the barrier).
+        if (nkt > 0) {
+            gload(kt0);
+            sa.store(As);
+            sb.store(Bs);
+        }
+        __syncthreads();
+        for (int it = 0; it < nkt; ++it) {
+            const int cur = it & 1;
+            const bool more = it + 1 < nkt;
+            if (more && !(p.debug & 1)) gload(kt0 + it + 1);
+            const float* a_lds = As + cur * A_ST;
+            const float* b_lds = Bs + cur * B_ST;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float af[TM][8], bf[TN][8];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) read_frag<BM, A_KC>(a_lds, wm * WTM + i * 32 + l31, h, half, af[i]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) read_frag<BN, B_KC>(b_lds, wn * WTN + j * 32 + l31, h, half, bf[j]);
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+            }
+            if (more && !(p.debug & 2)) {
+                sa.store(As + (cur ^ 1) * A_ST);
+                sb.store(Bs + (cur ^ 1) * B_ST);
+            }
+            if (!(p.debug & 4)) __syncthreads();
+        }
+    } else {
+    float fa0[TM][8], fb0[TN][8], fa1[TM][8], fb1[TN][8];
+    if (nkt > 0) {
+        gload(kt0);
         sa.store(As);
         sb.store(Bs);
+        if (nkt > 1) gload(kt0 + 1);
     }
     __syncthreads();
-
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        const bool more = kt + 1 < kt1;
-        if (more) {
-            sa.load(p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K);
-            sb.load(p.B, p.ldb, n0, p.N, (kt + 1) * BK, p.K);
-        }
+    if (nkt > 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) read_frag<BM, A_KC>(As, wm * WTM + i * 32 + l31, h, 0, fa0[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) read_frag<BN, B_KC>(Bs, wn * WTN + j * 32 + l31, h, 0, fb0[j]);
+    }
+    // One K tile.  STEADY (compile-time): tiles it+1 and it+2 exist and are full -> branch-free body whose memory
+    // instructions are interleaved with the MFMAs by sched_group_barrier (PIPE == 2): a wave-level global load that
+    // touches 8 separate 128-B lines holds the issue port for tens of cycles; clustered at the top of the tile they
+    // delayed the MFMA stream of BOTH waves of the SIMD (measured: -11 % on the NT layout), spread two MFMAs apart
+    // they disappear in the 64-cycle shadow of each MFMA.
+    auto tile_step = [&](int it, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const int cur = it & 1;
         const float* a_lds = As + cur * A_ST;
         const float* b_lds = Bs + cur * B_ST;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float af[TM][8], bf[TN][8];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) read_frag<BM, A_KC>(a_lds, wm * WTM + i * 32 + l31, h, half, af[i]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) read_frag<BN, B_KC>(b_lds, wn * WTN + j * 32 + l31, h, half, bf[j]);
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
-        }
-        if (more) {
+        if (STEADY || it + 1 < nkt) {
             sa.store(As + (cur ^ 1) * A_ST);
             sb.store(Bs + (cur ^ 1) * B_ST);
         }
+        if (STEADY) {
+            sa.template load<false>(p.A, p.lda, m0, p.M, (kt0 + it + 2) * BK, p.K);
+            sb.template load<false>(p.B, p.ldb, n0, p.N, (kt0 + it + 2) * BK, p.K);
+        } else if (it + 2 < nkt) {
+            gload(kt0 + it + 2);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) read_frag<BM, A_KC>(a_lds, wm * WTM + i * 32 + l31, h, 1, fa1[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) read_frag<BN, B_KC>(b_lds, wn * WTN + j * 32 + l31, h, 1, fb1[j]);
+        if (!(STEADY && PIPE == 2)) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][kk], fb0[j][kk], acc[i][j], 0, 0, 0);
+        if constexpr (STEADY && PIPE == 2 && VA && VB) {
+            constexpr int NRD = (A_KC ? 2 * TM : 8 * TM) + (B_KC ? 2 * TN : 8 * TN);     // fragment reads
+            constexpr int NWR = Stager<BM, NT, A_KC, VA>::NV + Stager<BN, NT, B_KC, VB>::NV;   // ds_write_b128 == global loads
+            constexpr int NMF = TM * TN * 8;
+            constexpr int PER = NMF / (2 * NWR) > 0 ? NMF / (2 * NWR) : 1;
+            __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);              // fragment reads first (needed after the barrier)
+#pragma unroll
+            for (int q = 0; q < NWR; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);            // ds_write  (tile it+1)
+                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);          // MFMA
+            }
+#pragma unroll
+            for (int q = 0; q < NWR; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            // global load (tile it+2)
+                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+        if (STEADY || it + 1 < nkt) {
+            const float* a_nx = As + (cur ^ 1) * A_ST;
+            const float* b_nx = Bs + (cur ^ 1) * B_ST;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) read_frag<BM, A_KC>(a_nx, wm * WTM + i * 32 + l31, h, 0, fa0[i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) read_frag<BN, B_KC>(b_nx, wn * WTN + j * 32 + l31, h, 0, fb0[j]);
+        }
+        if (!(STEADY && PIPE == 2)) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[i][kk], fb1[j][kk], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int it = 0;
+    for (; it + 3 < nkt; ++it) tile_step(it, std::true_type{});
+    for (; it < nkt; ++it) tile_step(it, std::false_type{});
     }
 
     // ---- epilogue
@@ -254,14 +360,14 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParam
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC>
+template <int BM, int BN, int WGM, int WGN, int PIPE, bool A_KC, bool B_KC>
 int launch_cfg(const GemmParams& p, bool va, bool vb, int splits, hipStream_t st) {
     constexpr int NT = WGM * WGN * 64;
     constexpr size_t lds = (size_t)(2 * stage_floats<BM, A_KC>() + 2 * stage_floats<BN, B_KC>()) * sizeof(float);
     dim3 grid(p.tilesM * p.tilesN, splits), block(NT);
 #define LSTC_GO(VA, VB)                                                                                     \
     do {                                                                                                    \
-        auto kern = gemm_f32_kernel<BM, BN, WGM, WGN, A_KC, B_KC, VA, VB>;                                  \
+        auto kern = gemm_f32_kernel<BM, BN, WGM, WGN, PIPE, A_KC, B_KC, VA, VB>;                                  \
         static bool attr_done = false;                                                                      \
         if (!attr_done) {                                                                                   \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -280,20 +386,24 @@ int launch_cfg(const GemmParams& p, bool va, bool vb, int splits, hipStream_t st
 
 template <bool A_KC, bool B_KC>
 int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipStream_t st) {
-    int BM, BN;
-    switch (variant) {
-        case 2: BM = 256; BN = 128; break;
-        case 3: BM = 128; BN = 256; break;
-        case 4: BM = 256; BN = 256; break;
-        default: BM = 128; BN = 128; break;
-    }
+    variant &= 15;
+    // variant: 0 = library default for the layout (measured on MI355X, LTN shapes, TFLOP/s NT / NN / TN(split-K 4)):
+    //            1 = 128x128, plain double buffering                      117 / 129 / 133
+    //            7 = 128x128, mid-barrier software pipeline               126 / 127 / 128
+    //            3 = 128x128, pipeline + MFMA-interleaved memory ops      135 / 130 / 128   <- default NT, NN
+    //            2, 6, 5 = 256x128 (8 waves) pipelined / interleaved / plain  (115-126, never the best)
+    if (variant == 0) variant = (!A_KC && !B_KC) ? 1 : 3;
+    const int BM = (variant == 2 || variant == 5 || variant == 6) ? 256 : 128, BN = 128;
     p.tilesM = (p.M + BM - 1) / BM;
     p.tilesN = (p.N + BN - 1) / BN;
     switch (variant) {
-        case 2: return launch_cfg<256, 128, 4, 2, A_KC, B_KC>(p, va, vb, splits, st);
-        case 3: return launch_cfg<128, 256, 2, 4, A_KC, B_KC>(p, va, vb, splits, st);
-        case 4: return launch_cfg<256, 256, 2, 4, A_KC, B_KC>(p, va, vb, splits, st);
-        default: return launch_cfg<128, 128, 2, 2, A_KC, B_KC>(p, va, vb, splits, st);
+        case 1: return launch_cfg<128, 128, 2, 2, 0, A_KC, B_KC>(p, va, vb, splits, st);
+        case 3: return launch_cfg<128, 128, 2, 2, 2, A_KC, B_KC>(p, va, vb, splits, st);
+        case 6: return launch_cfg<256, 128, 4, 2, 2, A_KC, B_KC>(p, va, vb, splits, st);
+        case 2: return launch_cfg<256, 128, 4, 2, 1, A_KC, B_KC>(p, va, vb, splits, st);
+        case 5: return launch_cfg<256, 128, 4, 2, 0, A_KC, B_KC>(p, va, vb, splits, st);
+        case 7: return launch_cfg<128, 128, 2, 2, 1, A_KC, B_KC>(p, va, vb, splits, st);
+        default: return launch_cfg<128, 128, 2, 2, 2, A_KC, B_KC>(p, va, vb, splits, st);
     }
 }
 
@@ -319,6 +429,7 @@ int lstc_gemm_f32_impl(const LstcGemmDesc* d, hipStream_t st) {
     p.dk = make_drop_key(d->dropout_p, d->dropout_seed);
     p.ktiles = (d->K + BK - 1) / BK;
     p.ktiles_per_split = (p.ktiles + splits - 1) / splits;
+    p.debug = d->variant >> 4;
     const int eff_splits = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
     // float4 global loads need 16-B aligned rows; the contiguous extent must be a multiple of 4 so a
     // float4 is entirely inside or outside the matrix.
