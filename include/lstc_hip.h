@@ -125,6 +125,14 @@ int lstc_attn_fwd(const LstcAttnDesc* d, void* stream);
  * dK = dA^T Q*scale; dtable[index] += dA[1:,1:] summed over sequences). */
 int lstc_attn_bwd(const LstcAttnDesc* d, void* stream);
 
+/* CLS-query attention for the LAST encoder layer: only enc_output[:, 0, :] is consumed downstream
+ * (Train/temporal_transformer_shanghaitech.py:123; Train/spatio_transformer_shanghaitech.py:97), so its queries are
+ * needed for token 0 only while keys/values still span all S tokens (row 0 carries no relative bias:
+ * models/MultiHeadAttention.py:111 adds it to attn[:, :, 1:, 1:]).  Same descriptor; Q/dQ/O/dO hold ONE row per
+ * sequence ([N, ldq] / [N, ldo]) and probs is [N, H, S]. */
+int lstc_attn_cls_fwd(const LstcAttnDesc* d, void* stream);
+int lstc_attn_cls_bwd(const LstcAttnDesc* d, void* stream);
+
 /* ------------------------------------------------------------------- row-wise kernels */
 /* y = LayerNorm(x) * gamma + beta over the last dim (eps inside the sqrt, biased variance) —
  * nn.LayerNorm(d_model, eps=1e-6): models/MultiHeadAttention.py:47,125-126; models/FFN.py:10,20-21;

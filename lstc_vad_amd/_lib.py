@@ -18,7 +18,7 @@ F32, BF16 = 0, 1
 EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_RESIDUAL, EPI_RELU_MASK, EPI_ACCUM, EPI_OUT_F32 = 1, 2, 4, 8, 16, 32, 64
 
 EXPORTS = (
-    "lstc_gemm", "lstc_attn_fwd", "lstc_attn_bwd", "lstc_layernorm_fwd", "lstc_layernorm_bwd",
+    "lstc_gemm", "lstc_attn_fwd", "lstc_attn_bwd", "lstc_attn_cls_fwd", "lstc_attn_cls_bwd", "lstc_layernorm_fwd", "lstc_layernorm_bwd",
     "lstc_cls_concat_fwd", "lstc_cls_concat_bwd", "lstc_colsum", "lstc_dropout_apply", "lstc_dropout_mask",
     "lstc_head_out_fwd", "lstc_head_out_bwd", "lstc_vad_loss", "lstc_adagrad_step", "lstc_sqnorm_accum", "lstc_scale",
     "lstc_version", "lstc_strerror",
@@ -74,6 +74,8 @@ def load():
         "lstc_gemm": [C.POINTER(GemmDesc), vp],
         "lstc_attn_fwd": [C.POINTER(AttnDesc), vp],
         "lstc_attn_bwd": [C.POINTER(AttnDesc), vp],
+        "lstc_attn_cls_fwd": [C.POINTER(AttnDesc), vp],
+        "lstc_attn_cls_bwd": [C.POINTER(AttnDesc), vp],
         "lstc_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
         "lstc_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp],
         "lstc_cls_concat_fwd": [vp, vp, vp, vp, i64, i32, i32, vp],

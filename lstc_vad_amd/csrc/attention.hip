@@ -355,3 +355,187 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
 }
 
 }  // extern "C"
+
+// =====================================================================================================
+// CLS-query attention for the LAST encoder layer.  Only enc_output[:, 0, :] is consumed downstream
+// (Train/temporal_transformer_shanghaitech.py:123), so the last layer needs queries for token 0 only while its
+// keys/values still span every token.  Row 0 carries no relative bias (the reference adds the
+// bias to attn[:, :, 1:, 1:] only).  One wave per (sequence, head); lanes own features (coalesced 1-KB K/V rows),
+// the S scores live in LDS.  HBM-bound: K and V are streamed once forward, K, V, dK, dV once backward.
+// Dropout indices are those of row 0 of the full [N,H,S,S] tensor, so this path reproduces the full kernel's
+// CLS output bit for bit, dropout included.
+// =====================================================================================================
+namespace {
+
+struct ClsParams {
+    const float *Q, *K, *V;      // Q [N, ldq] (one row per sequence), K/V [N*S, ld]
+    float* O;                    // [N, ldo]
+    float* probs;                // [N, H, S]
+    const float* dO;
+    float *dQ, *dK, *dV;
+    int N, S, H, dk, dv, ldq, ldk, ldv, ldo;
+    float scale;
+    DropKey dkey;
+    int has_drop;
+};
+
+constexpr int CLS_MAXS = 128;
+
+__global__ void __launch_bounds__(NT) attn_cls_fwd_kernel(const ClsParams p) {
+    __shared__ float sc[NT / 64][CLS_MAXS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * (NT / 64) + wave;
+    if (pair >= p.N * p.H) return;
+    const int n = pair / p.H, h = pair % p.H, S = p.S;
+    const float* q = p.Q + (size_t)n * p.ldq + (size_t)h * p.dk;
+    const float* Kb = p.K + (size_t)n * S * p.ldk + (size_t)h * p.dk;
+    const float* Vb = p.V + (size_t)n * S * p.ldv + (size_t)h * p.dv;
+    float* s = sc[wave];
+    for (int j = 0; j < S; ++j) {
+        float a = 0.f;
+        for (int c = lane; c < p.dk; c += 64) a += (q[c] * p.scale) * Kb[(size_t)j * p.ldk + c];
+        a = wave_sum(a);
+        if (lane == 0) s[j] = a;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float v[2], m = -INFINITY;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int j = lane + 64 * jj;
+        v[jj] = j < S ? s[j] : -INFINITY;
+        m = fmaxf(m, v[jj]);
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        v[jj] = (lane + 64 * jj < S) ? expf(v[jj] - m) : 0.f;
+        sum += v[jj];
+    }
+    sum = wave_sum(sum);
+    const uint32_t flat0 = ((uint32_t)n * p.H + h) * (uint32_t)(S * S);       // row 0 of the full tensor
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int j = lane + 64 * jj;
+        if (j < S) {
+            float pv = v[jj] / sum;
+            p.probs[((size_t)n * p.H + h) * S + j] = pv;
+            if (p.has_drop) pv = drop_keep(flat0 + (uint32_t)j, p.dkey) ? pv * p.dkey.scale : 0.f;
+            s[j] = pv;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float* o = p.O + (size_t)n * p.ldo + (size_t)h * p.dv;
+    for (int c = lane; c < p.dv; c += 64) {
+        float a = 0.f;
+        for (int j = 0; j < S; ++j) a += s[j] * Vb[(size_t)j * p.ldv + c];
+        o[c] = a;
+    }
+}
+
+__global__ void __launch_bounds__(NT) attn_cls_bwd_kernel(const ClsParams p) {
+    __shared__ float sp[NT / 64][CLS_MAXS];      // dropped probabilities
+    __shared__ float sd[NT / 64][CLS_MAXS];      // d(logit)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * (NT / 64) + wave;
+    if (pair >= p.N * p.H) return;
+    const int n = pair / p.H, h = pair % p.H, S = p.S;
+    const float* q = p.Q + (size_t)n * p.ldq + (size_t)h * p.dk;
+    const float* Kb = p.K + (size_t)n * S * p.ldk + (size_t)h * p.dk;
+    const float* Vb = p.V + (size_t)n * S * p.ldv + (size_t)h * p.dv;
+    const float* dO = p.dO + (size_t)n * p.ldo + (size_t)h * p.dv;
+    float* dKb = p.dK + (size_t)n * S * p.ldk + (size_t)h * p.dk;
+    float* dVb = p.dV + (size_t)n * S * p.ldv + (size_t)h * p.dv;
+    float* pd = sp[wave];
+    float* ds = sd[wave];
+    // dP~_j = dO . V_j
+    for (int j = 0; j < S; ++j) {
+        float a = 0.f;
+        for (int c = lane; c < p.dv; c += 64) a += dO[c] * Vb[(size_t)j * p.ldv + c];
+        a = wave_sum(a);
+        if (lane == 0) ds[j] = a;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t flat0 = ((uint32_t)n * p.H + h) * (uint32_t)(S * S);
+    float pv[2], dp[2], keep[2], rs = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int j = lane + 64 * jj;
+        pv[jj] = dp[jj] = keep[jj] = 0.f;
+        if (j < S) {
+            pv[jj] = p.probs[((size_t)n * p.H + h) * S + j];
+            keep[jj] = p.has_drop ? (drop_keep(flat0 + (uint32_t)j, p.dkey) ? p.dkey.scale : 0.f) : 1.f;
+            dp[jj] = ds[j] * keep[jj];
+            rs += dp[jj] * pv[jj];
+        }
+    }
+    rs = wave_sum(rs);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int j = lane + 64 * jj;
+        if (j < S) {
+            ds[j] = pv[jj] * (dp[jj] - rs);
+            pd[j] = pv[jj] * keep[jj];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // dV_j = Pd_j dO ; dK_j = scale dA_j q ; dq = scale sum_j dA_j K_j
+    for (int c = lane; c < p.dv; c += 64) {
+        const float g = dO[c];
+        for (int j = 0; j < S; ++j) dVb[(size_t)j * p.ldv + c] = pd[j] * g;
+    }
+    float* dq = p.dQ + (size_t)n * p.ldq + (size_t)h * p.dk;
+    for (int c = lane; c < p.dk; c += 64) {
+        const float qs = q[c] * p.scale;
+        float a = 0.f;
+        for (int j = 0; j < S; ++j) {
+            a += ds[j] * Kb[(size_t)j * p.ldk + c];
+            dKb[(size_t)j * p.ldk + c] = ds[j] * qs;
+        }
+        dq[c] = a * p.scale;
+    }
+}
+
+int fill_cls(const LstcAttnDesc* d, ClsParams& p, bool bwd) {
+    if (!d) return LSTC_E_NULL;
+    if (d->dtype != LSTC_F32) return LSTC_E_UNSUPPORTED;
+    if (!d->Q || !d->K || !d->V || !d->probs) return LSTC_E_NULL;
+    if (!bwd && !d->O) return LSTC_E_NULL;
+    if (bwd && (!d->dO || !d->dQ || !d->dK || !d->dV)) return LSTC_E_NULL;
+    if (d->N <= 0 || d->S < 1 || d->H <= 0 || d->dk <= 0 || d->dv <= 0) return LSTC_E_SHAPE;
+    if (d->S > CLS_MAXS) return LSTC_E_RANGE;
+    if (d->ldq < d->H * d->dk || d->ldk < d->H * d->dk || d->ldv < d->H * d->dv || d->ldo < d->H * d->dv) return LSTC_E_SHAPE;
+    if ((uint64_t)d->N * d->H * d->S * d->S > 0xffffffffull) return LSTC_E_RANGE;
+    p.Q = (const float*)d->Q; p.K = (const float*)d->K; p.V = (const float*)d->V; p.O = (float*)d->O; p.probs = d->probs;
+    p.dO = (const float*)d->dO; p.dQ = (float*)d->dQ; p.dK = (float*)d->dK; p.dV = (float*)d->dV;
+    p.N = d->N; p.S = d->S; p.H = d->H; p.dk = d->dk; p.dv = d->dv;
+    p.ldq = d->ldq; p.ldk = d->ldk; p.ldv = d->ldv; p.ldo = d->ldo;
+    p.scale = d->scale;
+    p.has_drop = d->dropout_p > 0.f;
+    p.dkey = make_drop_key(d->dropout_p, d->dropout_seed);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lstc_attn_cls_fwd(const LstcAttnDesc* d, void* stream) {
+    ClsParams p;
+    int rc = fill_cls(d, p, false);
+    if (rc) return rc;
+    const int pairs = p.N * p.H;
+    hipLaunchKernelGGL(attn_cls_fwd_kernel, (pairs + NT / 64 - 1) / (NT / 64), NT, 0, (hipStream_t)stream, p);
+    return lstc_launch_status();
+}
+
+int lstc_attn_cls_bwd(const LstcAttnDesc* d, void* stream) {
+    ClsParams p;
+    int rc = fill_cls(d, p, true);
+    if (rc) return rc;
+    const int pairs = p.N * p.H;
+    hipLaunchKernelGGL(attn_cls_bwd_kernel, (pairs + NT / 64 - 1) / (NT / 64), NT, 0, (hipStream_t)stream, p);
+    return lstc_launch_status();
+}
+
+}  // extern "C"

@@ -33,8 +33,8 @@ class TrainStep:
         return torch.cat([norm_feats.float().reshape(-1, tokens, d), abnorm_feats.float().reshape(-1, tokens, d)], 0)
 
     def forward_loss(self, norm_feats, abnorm_feats, abnorm_labs):
-        enc_out = self.encoder(self.sequences(norm_feats, abnorm_feats))
-        outputs = self.head(enc_out[:, 0, :])
+        cls = self.encoder.forward_cls(self.sequences(norm_feats, abnorm_feats))      # == encoder(x)[:, 0, :]
+        outputs = self.head(cls)
         loss, scalars = training_loss(self.args, self.mode, outputs, abnorm_labs, group=self.group)
         return loss, scalars, outputs
 

@@ -294,6 +294,100 @@ class MHAFunction(torch.autograd.Function):
         return dx, dwq, dwk, dwv, dwfc, dln_w, dln_b, dtable, None, None
 
 
+def attn_cls_fwd(qc, k, v, N, S, H, dk, dv, p_drop, seed):
+    oc = torch.empty((N, H * dv), device=qc.device, dtype=torch.float32)
+    probs = torch.empty((N, H, S), device=qc.device, dtype=torch.float32)
+    d = AttnDesc()
+    d.N, d.S, d.H, d.dk, d.dv = N, S, H, dk, dv
+    d.ldq, d.ldk, d.ldv, d.ldo = qc.stride(0), k.stride(0), v.stride(0), oc.stride(0)
+    d.dtype, d.scale = F32, 1.0 / (dk ** 0.5)
+    d.dropout_p, d.dropout_seed = float(p_drop), int(seed)
+    d.Q, d.K, d.V, d.O, d.probs = dev_ptr(qc), dev_ptr(k), dev_ptr(v), dev_ptr(oc), dev_ptr(probs)
+    check(_lib.load().lstc_attn_cls_fwd(C.byref(d), stream_ptr()), "lstc_attn_cls_fwd")
+    return oc, probs
+
+
+def attn_cls_bwd(doc, qc, k, v, probs, N, S, H, dk, dv, p_drop, seed):
+    dqc, dk_, dv_ = torch.empty_like(qc), torch.empty_like(k), torch.empty_like(v)
+    d = AttnDesc()
+    d.N, d.S, d.H, d.dk, d.dv = N, S, H, dk, dv
+    d.ldq, d.ldk, d.ldv, d.ldo = qc.stride(0), k.stride(0), v.stride(0), doc.stride(0)
+    d.dtype, d.scale = F32, 1.0 / (dk ** 0.5)
+    d.dropout_p, d.dropout_seed = float(p_drop), int(seed)
+    d.Q, d.K, d.V, d.probs = dev_ptr(qc), dev_ptr(k), dev_ptr(v), dev_ptr(probs)
+    d.dO, d.dQ, d.dK, d.dV = dev_ptr(doc), dev_ptr(dqc), dev_ptr(dk_), dev_ptr(dv_)
+    check(_lib.load().lstc_attn_cls_bwd(C.byref(d), stream_ptr()), "lstc_attn_cls_bwd")
+    return dqc, dk_, dv_
+
+
+class MHAClsFunction(torch.autograd.Function):
+    """Self-attention of the LAST encoder layer restricted to the CLS query: the train loops read
+    only ``enc_output[:, 0, :]`` (Train/temporal_transformer_shanghaitech.py:123), so Q, the output projection,
+    dropout, residual and LayerNorm are evaluated for token 0 only; K and V still cover every token.
+    x [N, S, d] -> [N, d].  Same math as MHAFunction row 0 (models/MultiHeadAttention.py:93-126)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, wfc, ln_w, ln_b, table, cfg):
+        # `table`: the layer's relative-position bias table.  Row 0 never sees the bias, so its gradient is exactly
+        # zero — but the reference still hands Adagrad that zero tensor, and Adagrad applies weight decay to it
+        # (grad != None).  backward() therefore returns zeros for it instead of None to keep the update identical.
+        N, S, dm = x.shape
+        H, dk, dv = cfg["n_head"], cfg["d_k"], cfg["d_v"]
+        training = cfg["training"]
+        p_attn = cfg["attn_dropout"] if training else 0.0
+        p_fc = cfg["fc_dropout"] if training else 0.0
+        ctx.table_shape = None if table is None else tuple(table.shape)
+        x = x.contiguous()
+        x2 = x.view(N * S, dm)
+        xc = x[:, 0, :]                                     # [N, d] view, row stride S*d
+        k = gemm(x2, wk, trans_b=True)
+        v = gemm(x2, wv, trans_b=True)
+        qc = gemm(xc, wq, trans_b=True)
+        seed_a = next_seed() if p_attn > 0 else 0
+        seed_f = next_seed() if p_fc > 0 else 0
+        if p_attn > 0:
+            _note(cfg["site"] + "attn_dropout#cls", p_attn, seed_a, (N, H, S, S))     # row 0 of the full mask
+        if p_fc > 0:
+            _note(cfg["site"] + "dropout#cls", p_fc, seed_f, (N, dm))
+        oc, probs = attn_cls_fwd(qc, k, v, N, S, H, dk, dv, p_attn, seed_a)
+        y = gemm(oc, wfc, trans_b=True, dropout=(p_fc, seed_f), residual=xc)
+        if cfg["layer_norm"]:
+            z, mean, rstd = layernorm_fwd(y, ln_w, ln_b, 1e-6)
+        else:
+            z, mean, rstd = y, None, None
+        ctx.cfg = dict(cfg, N=N, S=S, p_attn=p_attn, p_fc=p_fc, seed_a=seed_a, seed_f=seed_f)
+        ctx.save_for_backward(x, wq, wk, wv, wfc, ln_w, qc, k, v, oc, probs, y if cfg["layer_norm"] else None, mean, rstd)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, wq, wk, wv, wfc, ln_w, qc, k, v, oc, probs, y, mean, rstd = ctx.saved_tensors
+        c = ctx.cfg
+        N, S, H, dk, dv = c["N"], c["S"], c["n_head"], c["d_k"], c["d_v"]
+        dm = x.shape[-1]
+        x2, xc = x.view(N * S, dm), x[:, 0, :]
+        dz = dz.contiguous()
+        dln_w = dln_b = None
+        if c["layer_norm"]:
+            dy, dln_w, dln_b = layernorm_bwd(dz, y, ln_w, mean, rstd)
+        else:
+            dy = dz
+        df = dropout_apply(dy, c["p_fc"], c["seed_f"]) if c["p_fc"] > 0 else dy
+        dwfc = wgrad(df, oc)
+        doc = gemm(df, wfc)
+        dqc, dk_, dv_ = attn_cls_bwd(doc, qc, k, v, probs, N, S, H, dk, dv, c["p_attn"], c["seed_a"])
+        dwq = wgrad(dqc, xc)
+        dwk, dwv = wgrad(dk_, x2), wgrad(dv_, x2)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm(dk_, wk)
+            gemm(dv_, wv, out=dx, accumulate=True)
+            gemm(dqc, wq, out=dx.view(N, S, dm)[:, 0, :], accumulate=True, residual=dy)   # CLS rows: + dQ Wq + residual
+            dx = dx.view(N, S, dm)
+        dtable = None if ctx.table_shape is None else torch.zeros(ctx.table_shape, device=x.device, dtype=torch.float32)
+        return dx, dwq, dwk, dwv, dwfc, dln_w, dln_b, dtable, None
+
+
 class FFNFunction(torch.autograd.Function):
     """models/FFN.py:14-22: LN?( dropout(W2 relu(W1 x + b1) + b2) + x )."""
 

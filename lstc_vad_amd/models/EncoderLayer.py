@@ -24,3 +24,9 @@ class EncoderLayer(nn.Module):
                             return_attn_v=return_attn_v)
         enc_output = self.pos_ffn(res[0]) if self.FFN_need else res[0]
         return (enc_output,) + tuple(res[1:])
+
+    def forward_cls(self, enc_input):
+        """Last-layer shortcut: returns only the CLS row [N, d]; attention output projection and FFN run on N rows
+        instead of N*S (the rest of the layer's output is never read by the train loops)."""
+        out = self.slf_attn.forward_cls(enc_input)
+        return self.pos_ffn(out) if self.FFN_need else out

@@ -36,23 +36,29 @@ def _args(mode, skw):
                      clip_grad=skw.get("clip_grad", False))
 
 
-def _step(enc, head, mode, args, nf, af, al, d):
-    """One forward + loss (+ backward by the caller), mirroring the reference loops' reshapes."""
+def _step(enc, head, mode, args, nf, af, al, d, cls_only=False):
+    """One forward + loss (+ backward by the caller), mirroring the reference loops' reshapes.  ``cls_only`` uses
+    Encoder.forward_cls (last layer evaluated for the CLS token only), which is what lstc_vad_amd.engine runs."""
     from lstc_vad_amd.losses import training_loss
     bs, pn, L, P = args.batch_size, args.part_num, args.part_len, args.n_patch
     if mode == "LTN":
         feats = torch.cat([nf.view(bs * pn, L * P, d), af.view(bs * pn, L * P, d)], 0)
     else:
         feats = torch.cat([nf.view(bs * pn * L, P, d), af.view(bs * pn * L, P, d)], 0)
-    enc_out = enc(feats)
-    cls = enc_out[:, 0, :]
+    if cls_only:
+        cls = enc.forward_cls(feats)
+        enc_out = cls.unsqueeze(1)
+    else:
+        enc_out = enc(feats)
+        cls = enc_out[:, 0, :]
     outputs = head(cls)
     loss, scalars = training_loss(args, mode, outputs, al)
     return enc_out, outputs, loss, scalars
 
 
+@pytest.mark.parametrize("cls_only", [False, True])
 @pytest.mark.parametrize("name", list(CASES))
-def test_training_step_matches_reference_golden(name):
+def test_training_step_matches_reference_golden(name, cls_only):
     from lstc_vad_amd.optim import Adagrad, clip_grad_norm_
     z, mode, ekw, skw = load_case(name)
     d = ekw["d_model"]
@@ -65,14 +71,15 @@ def test_training_step_matches_reference_golden(name):
     opt = Adagrad([{"params": enc.parameters(), "lr": 1e-4}, {"params": head.parameters(), "lr": 1e-2}],
                   weight_decay=1e-3)
     for step in range(2):
-        enc_out, outputs, loss, sc = _step(enc, head, mode, args, nf, af, al, d)
+        enc_out, outputs, loss, sc = _step(enc, head, mode, args, nf, af, al, d, cls_only)
         opt.zero_grad()
         loss.backward()
         if args.clip_grad:
             clip_grad_norm_(enc.parameters(), 10)
             clip_grad_norm_(head.parameters(), 10)
         if step == 0:
-            assert max_abs_diff(enc_out, z["enc_out"]) < 1e-4                       # north_star tolerance
+            ref_enc = z["enc_out"][:, :1, :] if cls_only else z["enc_out"]
+            assert max_abs_diff(enc_out, ref_enc) < 1e-4                            # north_star tolerance
             assert max_abs_diff(outputs.reshape(z["outputs"].shape), z["outputs"]) < 1e-4
             assert np.max(np.abs(sc.cpu().double().numpy() - z["scalars"])) < 2e-5
             ref_g = sub(z, "enc_grad.")
@@ -115,8 +122,9 @@ def test_eval_mode_and_short_tail(name):
             assert max_abs_diff(enc(x[:, :P].contiguous()), z["eval_tail1_enc_out"]) < 1e-4
 
 
+@pytest.mark.parametrize("cls_only", [False, True])
 @pytest.mark.parametrize("name", ["ltn_sht", "stn_mil_ce", "stn_relpe2d_extras"])
-def test_dropout_run_replays_through_oracle(name):
+def test_dropout_run_replays_through_oracle(name, cls_only):
     """Training with every dropout ON: the masks of the HIP run are exported (lstc_dropout_mask) and injected
     into the oracle, which must then reproduce loss and gradients."""
     from lstc_vad_amd import functional as Fn
@@ -132,12 +140,22 @@ def test_dropout_run_replays_through_oracle(name):
     torch.manual_seed(1234)
     Fn.reset_rng()
     with Fn.record_dropout() as sites:
-        enc_out, outputs, loss, sc = _step(enc, head, mode, args, nf, af, al, d)
+        enc_out, outputs, loss, sc = _step(enc, head, mode, args, nf, af, al, d, cls_only)
     loss.backward()
-    masks = {site: Fn.dropout_mask(shape, pp, seed, DEV).cpu() for site, pp, seed, shape in sites}
+    masks, keeps = {}, []
+    for site, pp, seed, shape in sites:
+        m = Fn.dropout_mask(shape, pp, seed, DEV).cpu()
+        if "classifier" not in site and "regressor" not in site:
+            keeps.append(float(m.float().mean()))
+        if cls_only and (site.endswith("dropout#cls") and len(shape) == 2 or (site.startswith("layer_stack.2.pos_ffn") and len(shape) == 2)):
+            # CLS-only last layer: the HIP mask covers token 0; the other tokens of that layer are never read
+            S_full = 1 + (args.part_len * args.n_patch if mode == "LTN" else args.n_patch)
+            full = torch.ones(shape[0], S_full, shape[1], dtype=torch.uint8)
+            full[:, 0, :] = m
+            m = full
+        masks[site.replace("#cls", "")] = m
     assert len(masks) == len(sites) and len(sites) >= 3 * 3 + 2
-    keep = np.mean([float(m.float().mean()) for k, m in masks.items() if "classifier" not in k and "regressor" not in k])
-    assert abs(keep - (1 - p)) < 0.02                                   # keep-rate of the counter-based RNG
+    assert abs(np.mean(keeps) - (1 - p)) < 0.02                                   # keep-rate of the counter-based RNG
     ecfg, st = oracle_cfgs(mode, ekw, skw, dropout=p)
     st.head_dropout = ph
     enc_P = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sub(z, "enc_init.").items()}
@@ -273,3 +291,21 @@ def test_full_width_scores_match_oracle():
         big = torch.cat([x.to(DEV), 0.5 * torch.relu(torch.randn(250, 48, 2048, device=DEV))], 0)
         got_big = enc(big)
         assert torch.equal(got_big[:6], got_enc)                    # bit-exact batch invariance
+
+
+@pytest.mark.parametrize("name", ["ltn_sht", "stn_sht", "ltn_ucf", "stn_relpe2d_extras"])
+def test_forward_cls_equals_full_forward_row0(name):
+    """Encoder.forward_cls (last layer on the CLS query only) == Encoder.forward(...)[:, 0, :] to rounding."""
+    z, mode, ekw, skw = load_case(name)
+    d = ekw["d_model"]
+    enc, _ = _models(mode, ekw, d)
+    enc.load_state_dict(sub(z, "enc_init."), strict=True)
+    enc = enc.to(DEV).eval()
+    bs, pn, L, P = skw["batch_size"], skw["part_num"], skw["part_len"], skw["n_patch"]
+    nf = torch.from_numpy(z["norm_feats"]).to(DEV)
+    x = nf.view(bs * pn, L * P, d) if mode == "LTN" else nf.view(bs * pn * L, P, d)
+    with torch.no_grad():
+        full = enc(x)
+        cls = enc.forward_cls(x)
+    assert cls.shape == (x.shape[0], d)
+    assert max_abs_diff(cls, full[:, 0, :]) < 5e-6
