@@ -1,0 +1,12 @@
+#!/usr/bin/env python3
+"""MI355X drop-in for the reference's Train/pseudo_labels_generator_temporal.py: same flags (lstc_vad_amd/cli_flags.json), same loop,
+HIP kernels underneath.  See lstc_vad_amd/cli.py."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from lstc_vad_amd.cli import main  # noqa: E402
+
+if __name__ == "__main__":
+    main("pseudo_labels_generator_temporal")

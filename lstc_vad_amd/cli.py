@@ -1,0 +1,220 @@
+"""Command-line surface of the reference's Train/*.py scripts on top of the HIP training step.
+
+Flag names, types and defaults come from ``cli_flags.json`` — the surface extracted from the reference's own
+``parser_arg()`` functions (author-machine absolute path defaults blanked) — so every reference
+command line parses unchanged.  Additions: ``--synthetic`` (default on when no ``--dataset_path`` is given: the feature
+files are external downloads and ``h5py`` is not available here), ``--synthetic_pairs``, ``--steps`` (stop after N
+optimisation steps), ``--log_dir`` (the reference hard-codes ``/data/ssy/...`` and crashes elsewhere,
+utils/utils.py:152-173).  ``--gpu`` selects the device through ``HIP_VISIBLE_DEVICES`` (reference:
+``CUDA_VISIBLE_DEVICES``, e.g. Train/temporal_transformer_shanghaitech.py:328).
+
+Loop structure follows the reference: epochs over a pair loader, one step per batch, the same log line formats, an
+evaluation every ``--inter_epoch`` epochs, best-AUC checkpoints named like upstream
+(Train/temporal_transformer_shanghaitech.py:240-248).  Under ``torchrun`` every process takes its own shard of pairs.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import logging
+import os
+import random
+import sys
+from argparse import Namespace
+
+_FLAGS = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "cli_flags.json")))
+_TYPES = {"int": int, "float": float, "str": str}
+
+SCRIPTS = {
+    # script name -> (mode, head kind, prefix used for the model flags)
+    "spatio_transformer_shanghaitech": ("STN", "regressor", ""),
+    "spatio_transformer_UCF": ("STN", "regressor", ""),
+    "spatio_transformer_UBnormal": ("STN", "regressor", ""),
+    "temporal_transformer_shanghaitech": ("LTN", "classifier", ""),
+    "temporal_transformer_UCF": ("LTN", "classifier", ""),
+    "temporal_transformer_UBnormal": ("LTN", "classifier", ""),
+    "spatio_transformer_MIL_CE": ("STN_MIL_CE", "regressor", "spatio_"),
+}
+
+
+def build_parser(script: str) -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(prog=script + ".py", description=f"MI355X drop-in for the reference Train/{script}.py")
+    for flag, kind, default in _FLAGS[script]:
+        if kind == "flag":
+            p.add_argument(flag, action="store_true", default=bool(default))
+        else:
+            p.add_argument(flag, type=_TYPES.get(kind, str), default=default)
+    if not any(f[0] == "--encoder_weight_init" for f in _FLAGS[script]):
+        # the reference's generators read this flag without defining it (AttributeError upstream)
+        p.add_argument("--encoder_weight_init", action="store_true")
+    p.add_argument("--synthetic", action="store_true", help="train on lstc_vad_amd.data.SyntheticVideos")
+    p.add_argument("--synthetic_pairs", type=int, default=0, help="normal/abnormal pairs in the synthetic set (default 2*batch_size)")
+    p.add_argument("--steps", type=int, default=0, help="stop after this many optimisation steps (0 = run all epochs)")
+    p.add_argument("--log_dir", type=str, default="", help="log / checkpoint directory (default: ./log/<dataset>)")
+    return p
+
+
+def _get(args, name, prefix="", default=None):
+    return getattr(args, prefix + name, getattr(args, name, default))
+
+
+def _logger(args, script):
+    log_dir = args.log_dir or os.path.join("log", str(getattr(args, "dataset", "run")))
+    os.makedirs(log_dir, exist_ok=True)
+    lg = logging.getLogger(script)
+    lg.setLevel(logging.INFO)
+    lg.handlers.clear()
+    fmt = logging.Formatter("%(asctime)s: %(message)s")
+    for h in (logging.StreamHandler(sys.stderr), logging.FileHandler(os.path.join(log_dir, script + ".log"))):
+        h.setFormatter(fmt)
+        lg.addHandler(h)
+    return lg, log_dir
+
+
+def train(script: str, argv=None):
+    mode, head_kind, pre = SCRIPTS[script]
+    args = build_parser(script).parse_args(argv)
+    if "LOCAL_RANK" not in os.environ:                      # single process: honour --gpu like the reference does
+        os.environ.setdefault("HIP_VISIBLE_DEVICES", str(getattr(args, "gpu", 0)))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from .data import SyntheticVideos
+    from .engine import TrainStep
+    from .metrics import roc_auc
+    from .models import Classifier, Encoder, Regressor
+
+    seed = int(getattr(args, "seed", 0))                    # utils/utils.py:107-116
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    if not torch.cuda.is_available():
+        raise SystemExit("no HIP device visible: the LSTC_VAD training path here is MI355X-only (no CPU fallback)")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    logger, log_dir = _logger(args, script) if rank == 0 else (logging.getLogger("null"), "")
+    if getattr(args, "data_parallel", False) and world == 1 and rank == 0:
+        logger.info("--data_parallel: nn.DataParallel is replaced by one process per GPU; launch with "
+                    "`python -m torch.distributed.run --nproc-per-node N` to use N GPUs")
+
+    part_len = _get(args, "part_len", pre)
+    d_model = args.d_model
+    enc = Encoder(n_layers=_get(args, "n_layers", pre), n_head=_get(args, "n_head", pre), d_k=_get(args, "d_k", pre),
+                  d_v=_get(args, "d_v", pre), d_model=d_model, d_inner=_get(args, "n_hidden", pre),
+                  MHA_attn_dropout=_get(args, "MHA_attn_dropout", pre), MHA_fc_dropout=_get(args, "MHA_fc_dropout", pre),
+                  MHA_layerNorm=_get(args, "MHA_layerNorm", pre), FFN_dropout=_get(args, "FFN_dropout", pre),
+                  FFN_layerNorm=_get(args, "FFN_layerNorm", pre), position_dropout=_get(args, "position_dropout", pre, 0.1),
+                  weight_init=_get(args, "encoder_weight_init", pre, False),
+                  position_encoding=_get(args, "position_encoding", pre, False),
+                  CLS_learned=_get(args, "CLS_learned", pre, False),
+                  max_position_tokens=_get(args, "max_position_tokens", pre, 100),
+                  relative_pe=bool(getattr(args, "relative_position_encoding", False)) and mode == "LTN",
+                  window_size=getattr(args, "window_size", 4), window_depth=part_len if mode == "LTN" else 3,
+                  conv_patch=getattr(args, "conv_patch", False),
+                  relative_pe_2D=bool(getattr(args, "relative_pe_2D", False)) and mode != "LTN",
+                  input_layerNorm=bool(getattr(args, "input_layerNorm", False)))
+    if head_kind == "classifier":
+        head = Classifier(d_model, args.classifier_dropout, weight_init=args.classifier_weight_init)
+        lr_head = args.lr_classifier
+    else:
+        head = Regressor(d_model, _get(args, "regressor_dropout", "", 0.6),
+                         weight_init=_get(args, "regressor_weight_init", "", False))
+        lr_head = _get(args, "lr_regressor", "", 1e-2)
+    if getattr(args, "load_model", False):          # state_dict files with the reference's key names (non-strict)
+        strip = lambda sd: {k[7:] if k.startswith("module.") else k: v for k, v in sd.items()}
+        enc_path = getattr(args, "load_temporal_model_path", None) or getattr(args, "load_spatio_model_path", "")
+        enc.load_state_dict(strip(torch.load(enc_path, map_location="cpu")), False)
+        head.load_state_dict(strip(torch.load(args.load_classifier_model_path, map_location="cpu")), False)
+    enc, head = enc.to(dev).train(), head.to(dev).train()
+
+    step_args = Namespace(batch_size=args.batch_size, part_num=args.part_num, part_len=part_len, n_patch=args.n_patch,
+                          lambda_1=args.lambda_1, lambda_MIL=getattr(args, "lambda_MIL", 1.0),
+                          lambda_CE=getattr(args, "lambda_CE", 0.0), lambda_BCE=getattr(args, "lambda_BCE", 1.0),
+                          lambda_normal=getattr(args, "lambda_normal", 0.2), lambda_abnormal=getattr(args, "lambda_abnormal", 2.0),
+                          temporal_only=getattr(args, "temporal_only", False), clip_grad=getattr(args, "clip_grad", False))
+    ts = TrainStep(step_args, mode, enc, head, _get(args, "lr_encoder", pre, 1e-4), lr_head, args.weight_decay)
+
+    if not args.synthetic and getattr(args, "dataset_path", ""):
+        raise SystemExit("HDF5 feature loading is not built yet (h5py is unavailable in this image; SURVEY.md 8f-3). "
+                         "Run with --synthetic.")
+    n_pairs = args.synthetic_pairs or 2 * args.batch_size
+    thr = None if mode == "STN" else 0.65
+    data = SyntheticVideos(n_pairs, args.batch_size, args.part_num, part_len, args.n_patch, d_model, dev,
+                           seed=seed + 1000 * rank, sample=args.sample, pseudo_threshold=thr)
+    epochs = int(_get(args, "epochs", pre, 1))
+    inter = int(getattr(args, "inter_epoch", 10))
+    best_auc, it = 0.0, 0
+    for epoch in range(epochs):
+        for norm_feats, norm_labs, abnorm_feats, abnorm_labs in data:
+            sc = ts.step(norm_feats, abnorm_feats, abnorm_labs)
+            if rank == 0:
+                loss, mil, err, l1, aux = (float(x) for x in sc.cpu())          # one D2H copy per step
+                if mode == "LTN":
+                    logger.info('[{}/{}]: loss {:.4f}, MIL_loss {:.4f}, CE_loss {:.4f} MIL_l1 {:.4f}'.format(it, epoch, loss, mil, aux, l1))
+                elif mode == "STN":
+                    logger.info('[{}/{}]: loss {:.4f}, err {:.4f}, l1 {:.4f}'.format(it, epoch, loss, err, l1))
+                else:
+                    logger.info('Round 0 [{}/{}]: spatio_loss {:.4f}, CE_loss {:.4f}, MIL_loss {:.4f}, err {:.4f}, l1 {:.4f}'.format(
+                        it, epoch, loss, aux, mil, err, l1))
+            it += 1
+            if args.steps and it >= args.steps:
+                break
+        data.shuffle_keys()
+        if rank == 0 and epoch % inter == 0:
+            auc = evaluate(enc, head, mode, data, part_len, roc_auc)
+            logger.info('epoch {} test AUC {:.4f} (best {:.4f})'.format(epoch, auc, best_auc))
+            if auc > best_auc:
+                best_auc = auc
+                tag = "temporal" if mode == "LTN" else "spatio"
+                prefix = getattr(args, "saved_prefix", None) or ""
+                save_dir = getattr(args, "model_save_dir", "") or log_dir
+                os.makedirs(save_dir, exist_ok=True)
+                name = "{}{}_model_{}_{}_{:.4f}".format(prefix, tag, args.data_crop, args.type, auc)
+                torch.save(enc.state_dict(), os.path.join(save_dir, name))
+                torch.save(head.state_dict(), os.path.join(save_dir, name.replace(tag + "_model", head_kind + "_model")))
+        if args.steps and it >= args.steps:
+            break
+    if world > 1:
+        dist.destroy_process_group()
+    return best_auc
+
+
+def evaluate(enc, head, mode, data, part_len, roc_auc, segment_len=16):
+    """Frame-level AUC as the reference's in-loop evaluation (Train/temporal_transformer_shanghaitech.py:151-229):
+    LTN scores every part of ``part_len`` clips (the last part may be shorter: shorter sequence, same model),
+    STN scores every clip; scores are repeated to frame level (x segment_len)."""
+    import numpy as np
+    import torch
+    enc.eval(); head.eval()
+    scores, labels = [], []
+    with torch.no_grad():
+        for feats, labs in data.test_videos():
+            n, P, d = feats.shape
+            if mode == "LTN":
+                full = n // part_len
+                s = []
+                if full:
+                    cls = enc.forward_cls(feats[: full * part_len].reshape(full, part_len * P, d))
+                    s.append(head(cls)[:, 1].repeat_interleave(part_len))
+                if n > full * part_len:
+                    tail = feats[full * part_len:].reshape(1, -1, d)
+                    s.append(head(enc.forward_cls(tail))[:, 1].repeat_interleave(n - full * part_len))
+                sc = torch.cat(s)
+            else:
+                sc = head(enc.forward_cls(feats)).reshape(-1)
+            scores.append(np.repeat(sc.cpu().numpy(), segment_len))
+            labels.append(np.repeat(labs.reshape(-1).cpu().numpy(), segment_len))
+    enc.train(); head.train()
+    return roc_auc(np.concatenate(scores), np.concatenate(labels))
+
+
+def main(script: str):
+    if script not in SCRIPTS:
+        raise SystemExit(f"{script}: inference-side script; its loop is the 'next' row of SURVEY.md 8f "
+                         "(flags parse via lstc_vad_amd.cli.build_parser)")
+    train(script)

@@ -1,0 +1,90 @@
+"""Batch source with the reference DataLoader's tensor contract and window-sampling rule.
+
+The reference reads I3D features from HDF5 (utils/load_dataset.py:29-48) and samples ``part_num`` windows of
+``part_len`` clips per video (``sample_feat`` :56-88).  No feature files ship with the reference and ``h5py`` is not
+installed here, so this module provides (i) ``sample_windows`` — the reference's uniform / random rule restated, and
+(ii) ``SyntheticVideos`` — seeded synthetic videos (lstc_vad_amd.synthetic) served through that rule, normal/abnormal
+pairs, ``drop_last`` batching, ``shuffle_keys`` per epoch.  An HDF5-backed source with the same interface is the "next"
+row.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import synthetic as syn
+
+
+def sample_windows(n_clips: int, part_num: int, part_len: int, sample: str = "uniform", rng=np.random) -> np.ndarray:
+    """Clip indices [part_num*part_len] (utils/load_dataset.py:69-88).  uniform: one random shift ``move`` for all
+    windows, starts = linspace(0, n-L, pn+1, dtype=int)[:pn] + move; random: an independent shift per window."""
+    L = part_len
+    starts = np.linspace(0, n_clips - L, part_num + 1, dtype=int)
+    if sample == "uniform":
+        span = (n_clips - L) // (part_num + 1)
+        move = rng.randint(span) if span >= 1 else 0
+        begins = starts[:part_num] + move
+    else:
+        gap = max(int(starts[1] - starts[0]), 1)
+        begins = np.array([s + rng.randint(0, gap) for s in starts[:part_num]])
+    return (begins[:, None] + np.arange(L)[None, :]).reshape(-1)
+
+
+class SyntheticVideos:
+    """``n_pairs`` normal + abnormal synthetic videos; iterating yields (norm_feats, norm_labs, abnorm_feats,
+    abnorm_labs) exactly shaped like the reference loader's batches, already on ``device``."""
+
+    def __init__(self, n_pairs, batch_size, part_num, part_len, n_patch, d_model, device, seed=0, sample="uniform",
+                 pseudo_threshold=None, min_clips=24, max_clips=160):
+        self.bs, self.pn, self.L, self.P, self.d = batch_size, part_num, part_len, n_patch, d_model
+        self.device, self.seed, self.sample, self.thr = device, seed, sample, pseudo_threshold
+        rs = np.random.RandomState(seed)
+        need = part_len + 1
+        self.lengths = rs.randint(max(min_clips, need), max(max_clips, need + 1) + 1, size=(2, n_pairs))
+        self.order = np.arange(n_pairs)
+        self.rng = np.random.RandomState(seed + 1)
+
+    def shuffle_keys(self):                      # reference: dataset.shuffle_keys() after every epoch
+        self.rng.shuffle(self.order)
+
+    def __len__(self):
+        return len(self.order) // self.bs        # drop_last=True
+
+    def _video(self, kind, vid, n=None):
+        n = int(self.lengths[kind, vid]) if n is None else int(n)
+        g = torch.Generator(device=self.device).manual_seed(self.seed * 100003 + kind * 50021 + vid)
+        feats = 0.5 * torch.relu(torch.randn(n, self.P, self.d, device=self.device, generator=g))
+        if kind == 1:    # abnormal videos carry a brighter anomalous stretch so a model can learn something
+            a, b = n // 3, n // 3 + max(n // 4, 1)
+            feats[a:b] += 0.25
+            labs = torch.zeros(n, 1, device=self.device)
+            labs[a:b] = 1.0
+        else:
+            labs = torch.zeros(n, 1, device=self.device)
+        return feats, labs
+
+    def __iter__(self):
+        for b in range(len(self)):
+            ids = self.order[b * self.bs:(b + 1) * self.bs]
+            out = [[], [], [], []]
+            for vid in ids:
+                for kind in (0, 1):
+                    feats, labs = self._video(kind, int(vid))
+                    idx = torch.from_numpy(sample_windows(feats.shape[0], self.pn, self.L, self.sample, self.rng)).to(self.device)
+                    f = feats[idx]
+                    if kind == 0:
+                        l = torch.zeros(idx.numel(), 1, device=self.device)
+                    elif self.thr is None:
+                        l = torch.ones(idx.numel(), 1, device=self.device)      # no pseudo labels: ones (:59-63)
+                    else:
+                        u = labs[idx] * 0.9 + 0.05
+                        l = torch.where(u > self.thr, u, torch.zeros_like(u))   # thresholded pseudo scores
+                    out[2 * kind].append(f)
+                    out[2 * kind + 1].append(l)
+            yield tuple(torch.stack(x) for x in out)
+
+    def test_videos(self, n_videos=8):
+        """(features [n_clips, P, d], per-clip 0/1 labels) for evaluation."""
+        rs = np.random.RandomState(self.seed + 7)
+        for v in range(n_videos):
+            yield self._video(v % 2, 10_000 + v, rs.randint(self.L + 1, 64))

@@ -1,0 +1,70 @@
+"""CPU checks of the Train/*.py command-line surface and the window sampler."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from lstc_vad_amd import cli
+from lstc_vad_amd.data import sample_windows
+from lstc_vad_amd.metrics import roc_auc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_flag_surface_counts_match_survey():
+    # SURVEY.md Appendix A, extracted from the reference's parser_arg() functions
+    want = {"spatio_transformer_shanghaitech": 55, "spatio_transformer_UCF": 57, "spatio_transformer_UBnormal": 49,
+            "temporal_transformer_shanghaitech": 57, "temporal_transformer_UCF": 51, "temporal_transformer_UBnormal": 56,
+            "spatio_transformer_MIL_CE": 84, "pseudo_labels_generator_spatio": 29, "pseudo_labels_generator_temporal": 37,
+            "evaluation_shanghaitech_ubnormal": 35, "evaluation_UCF": 32}
+    flags = json.load(open(os.path.join(ROOT, "lstc_vad_amd", "cli_flags.json")))
+    assert {k: len(v) for k, v in flags.items()} == want
+
+
+def test_reference_command_lines_parse():
+    p = cli.build_parser("temporal_transformer_shanghaitech")      # README.md:31
+    a = p.parse_args("--part_len 3 --MHA_layerNorm --FFN_layerNorm --relative_position_encoding "
+                     "--pseudo_labels_path STN_pseudo_labels.npy --dataset_path SHT_I3D_16PATCH.h5 --gpu 0".split())
+    assert a.part_len == 3 and a.MHA_layerNorm and a.n_hidden == 4096 and a.batch_size == 40 and a.lambda_CE == 0.8
+    assert a.MHA_attn_dropout == 0.2 and a.lr_encoder == 1e-4 and a.weight_decay == 1e-3 and a.window_size == 4
+    p = cli.build_parser("spatio_transformer_shanghaitech")        # README.md:23 minus the flag upstream rejects too
+    a = p.parse_args("--encoder_weight_init --regressor_weight_init --FFN_layerNorm --FFN_dropout 0.3 --gpu 0".split())
+    assert a.n_hidden == 3027 and a.part_len == 7 and a.FFN_dropout == 0.3 and a.lr_regressor == 1e-2
+    with pytest.raises(SystemExit):                                 # README's --MHA_dropout is rejected upstream as well
+        p.parse_args(["--MHA_dropout", "0.3"])
+    a = cli.build_parser("spatio_transformer_MIL_CE").parse_args([])
+    assert a.spatio_part_len == 7 and a.lambda_normal == 0.2 and a.lambda_abnormal == 2.0 and a.lambda_BCE == 1.0
+    a = cli.build_parser("temporal_transformer_UCF").parse_args([])
+    assert a.n_patch == 9 and not hasattr(a, "data_parallel")
+    a = cli.build_parser("pseudo_labels_generator_temporal").parse_args([])
+    assert a.threshold == 0.9 and a.encoder_weight_init is False     # flag the reference forgets to define
+
+
+def test_every_train_script_exists():
+    for s in list(cli.SCRIPTS) + ["pseudo_labels_generator_spatio", "pseudo_labels_generator_temporal"]:
+        assert os.path.exists(os.path.join(ROOT, "Train", s + ".py")), s
+
+
+def test_window_sampler_matches_reference_example():
+    # SURVEY.md Appendix B (verified by executing the reference): n=40, pn=4, L=3, np seed 0
+    np.random.seed(0)
+    assert sample_windows(40, 4, 3, "uniform").tolist() == [4, 5, 6, 13, 14, 15, 22, 23, 24, 31, 32, 33]
+    idx = sample_windows(10, 4, 3, "uniform")          # (n-L)//(pn+1) = 1 -> move = randint(1) = 0
+    assert idx.tolist() == [0, 1, 2, 1, 2, 3, 3, 4, 5, 5, 6, 7]
+    idx = sample_windows(200, 32, 2, "random", np.random.RandomState(1))
+    assert idx.shape == (64,) and idx.max() < 200 and (np.diff(idx.reshape(32, 2), axis=1) == 1).all()
+
+
+def test_auc_matches_reference_eval():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "misc.npz"), allow_pickle=False)
+    assert abs(roc_auc(z["auc_scores"], z["auc_labels"]) - float(z["auc_value"])) < 1e-12
+    assert abs(roc_auc(z["auc2_scores"], z["auc2_labels"]) - float(z["auc2_value"])) < 1e-12
+
+
+def test_models_import_shim():
+    from models.Encoder import Encoder
+    from models.FFN import PositionwiseFeedForward
+    from models.Classifier import Classifier
+    from lstc_vad_amd.models import Encoder as E2
+    assert Encoder is E2 and PositionwiseFeedForward.__name__ == "PositionwiseFeedForward" and Classifier
