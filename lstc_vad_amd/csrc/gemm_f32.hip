@@ -103,6 +103,33 @@ struct Stager {
         }
     }
 
+    // Single-element forms for the hand-interleaved pipeline (PIPE 3): one global load / one LDS write per call.
+    __device__ __forceinline__ void load_one(int i, const float* __restrict__ base, int ld, int r0, int r_total, int k0) {
+        const int t = threadIdx.x;
+        if (KC) {
+            const int r = min(r0 + (t >> 3) + i * (NT / 8), r_total - 1);
+            const float* p = base + (size_t)r * ld + k0 + (t & 7) * 4;
+            if (VEC) v[i] = *reinterpret_cast<const float4*>(p);
+            else v[i] = make_float4(p[0], p[1], p[2], p[3]);
+        } else {
+            constexpr int CPR = R / 4;
+            const int c = r0 + (t % CPR) * 4;
+            const float* p = base + (size_t)(k0 + t / CPR + i * (NT / CPR)) * ld;
+            if (VEC) v[i] = *reinterpret_cast<const float4*>(p + min(c, r_total - 4));
+            else v[i] = make_float4(p[min(c, r_total - 1)], p[min(c + 1, r_total - 1)], p[min(c + 2, r_total - 1)],
+                                    p[min(c + 3, r_total - 1)]);
+        }
+    }
+    __device__ __forceinline__ void store_one(int i, float* __restrict__ lds) const {
+        const int t = threadIdx.x;
+        if (KC) {
+            *reinterpret_cast<float4*>(lds + ((t >> 3) + i * (NT / 8)) * LDK + (t & 7) * 4) = v[i];
+        } else {
+            constexpr int CPR = R / 4;
+            *reinterpret_cast<float4*>(lds + (t / CPR + i * (NT / CPR)) * R + (t % CPR) * 4) = v[i];
+        }
+    }
+
     __device__ __forceinline__ void store(float* __restrict__ lds) const {
         const int t = threadIdx.x;
         if (KC) {
@@ -260,6 +287,56 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParam
         const int cur = it & 1;
         const float* a_lds = As + cur * A_ST;
         const float* b_lds = Bs + cur * B_ST;
+        if constexpr (STEADY && PIPE == 3) {
+            // Hand-interleaved steady state: each group of TM*TN independent MFMAs (one k step, all accumulators)
+            // carries at most one LDS write, one global load and one fragment read, pinned by sched_barrier so the
+            // compiler neither clusters the memory instructions nor chains MFMAs on one accumulator.
+            constexpr int NVA = Stager<BM, NT, A_KC, VA>::NV, NVB = Stager<BN, NT, B_KC, VB>::NV;
+            constexpr int MPK = (NVA + NVB + 7) / 8;          // staged float4 per k step (1 for 128x128, 2 for 256x256)
+            static_assert(TM + TN <= 8, "one fragment read per k step");
+            float* a_st = As + (cur ^ 1) * A_ST;
+            float* b_st = Bs + (cur ^ 1) * B_ST;
+            const int k_next = (kt0 + it + 2) * BK;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                // k steps 0-3: LDS-write the staged tile t+1 (loaded one iteration ago); k steps 4-7: issue the global
+                // loads of tile t+2 into the same registers.  Keeping every write ahead of every new load matters:
+                // vmcnt retires in order, and with the two interleaved the compiler's wait before a write also
+                // forced the newest loads of THIS iteration to land (s_waitcnt vmcnt(5): ~10 % stall).
+#pragma unroll
+                for (int q = 0; q < 2 * MPK; ++q) {
+                    const int e = (kk & 3) * 2 * MPK + q;
+                    if (kk < 4) {
+                        if (e < NVA) sa.store_one(e, a_st);
+                        else if (e - NVA < NVB) sb.store_one(e - NVA, b_st);
+                    } else {
+                        if (e < NVA) sa.load_one(e, p.A, p.lda, m0, p.M, k_next);
+                        else if (e - NVA < NVB) sb.load_one(e - NVA, p.B, p.ldb, n0, p.N, k_next);
+                    }
+                }
+                if (kk < TM) read_frag<BM, A_KC>(a_lds, wm * WTM + kk * 32 + l31, h, 1, fa1[kk < TM ? kk : 0]);
+                else if (kk - TM < TN) read_frag<BN, B_KC>(b_lds, wn * WTN + (kk - TM) * 32 + l31, h, 1, fb1[kk - TM < TN ? kk - TM : 0]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][kk], fb0[j][kk], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                if (kk < TM) read_frag<BM, A_KC>(a_st, wm * WTM + kk * 32 + l31, h, 0, fa0[kk < TM ? kk : 0]);
+                else if (kk - TM < TN) read_frag<BN, B_KC>(b_st, wn * WTN + (kk - TM) * 32 + l31, h, 0, fb0[kk - TM < TN ? kk - TM : 0]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[i][kk], fb1[j][kk], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
         if (STEADY || it + 1 < nkt) {
             sa.store(As + (cur ^ 1) * A_ST);
             sb.store(Bs + (cur ^ 1) * B_ST);
@@ -387,13 +464,16 @@ int launch_cfg(const GemmParams& p, bool va, bool vb, int splits, hipStream_t st
 template <bool A_KC, bool B_KC>
 int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipStream_t st) {
     variant &= 15;
-    // variant: 0 = library default for the layout (measured on MI355X, LTN shapes, TFLOP/s NT / NN / TN(split-K 4)):
-    //            1 = 128x128, plain double buffering                      117 / 129 / 133
-    //            7 = 128x128, mid-barrier software pipeline               126 / 127 / 128
-    //            3 = 128x128, pipeline + MFMA-interleaved memory ops      135 / 130 / 128   <- default NT, NN
-    //            2, 6, 5 = 256x128 (8 waves) pipelined / interleaved / plain  (115-126, never the best)
-    if (variant == 0) variant = (!A_KC && !B_KC) ? 1 : 3;
-    const int BM = (variant == 2 || variant == 5 || variant == 6) ? 256 : 128, BN = 128;
+    // variant: 0 = library default.  Measured on MI355X, LTN shapes, TFLOP/s NT / NN / TN(split-K 4)
+    // (profiles/r01_gemm_variants.log, tools/gemm_check):
+    //   1 = 128x128, plain double buffering (PIPE 0)                              117 / 129 / 134
+    //   7 = 128x128, mid-barrier software pipeline (PIPE 1)                       126 / 127 / 128
+    //   3 = 128x128, pipeline + sched_group_barrier interleave (PIPE 2)           136 / 131 / 129
+    //   8 = 128x128, pipeline + hand-interleaved k-step groups (PIPE 3)           138 / 136 / 138   <- default
+    //   9 = 256x128, 4 waves x (128x64), one wave per SIMD, PIPE 3                125 / 124 / 134
+    //   2, 6, 5 = 256x128 with 8 waves (PIPE 1 / 2 / 0)                           115-126, never the best
+    if (variant == 0) variant = 8;
+    const int BM = (variant == 2 || variant == 5 || variant == 6 || variant == 9) ? 256 : 128, BN = 128;
     p.tilesM = (p.M + BM - 1) / BM;
     p.tilesN = (p.N + BN - 1) / BN;
     switch (variant) {
@@ -403,6 +483,8 @@ int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipS
         case 2: return launch_cfg<256, 128, 4, 2, 1, A_KC, B_KC>(p, va, vb, splits, st);
         case 5: return launch_cfg<256, 128, 4, 2, 0, A_KC, B_KC>(p, va, vb, splits, st);
         case 7: return launch_cfg<128, 128, 2, 2, 1, A_KC, B_KC>(p, va, vb, splits, st);
+        case 8: return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);
+        case 9: return launch_cfg<256, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // 4 waves x (128x64): 1 wave/SIMD
         default: return launch_cfg<128, 128, 2, 2, 2, A_KC, B_KC>(p, va, vb, splits, st);
     }
 }
