@@ -108,9 +108,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the LSTC_VAD hot path here is HIP-only (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("LSTC_FORCE_DIST", "0") == "1"      # exercise the RCCL code path on a single GPU
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
     if a.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -203,7 +205,7 @@ def main():
             # at 16-32, 0.5 at 128 of 256 hardware threads), so the baseline uses min(32, available) threads
             out["cpu_baseline"] = cpu_baseline(a.config, min(32, len(os.sched_getaffinity(0))))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -25,12 +25,14 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, param_groups: Sequence[Iterable[torch.nn.Parameter]], group=None, overlap: bool = True):
+    def __init__(self, param_groups: Sequence[Iterable[torch.nn.Parameter]], group=None, overlap: bool = True,
+                 force: bool = False):
         """``param_groups``: lists of parameters, one per bucket, ordered the way backward produces them
         (head first, last encoder layer next, ...).  Every listed parameter MUST receive a gradient each step."""
         self.group = group
         self.overlap = overlap
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())     # force: exercise the RCCL path on one GPU
         self.buckets: List[torch.Tensor] = []
         self._views = []
         self._pending: List[int] = []
@@ -51,7 +53,7 @@ class GradAllReducer:
                 views.append((p, v))
                 off += p.numel()
                 self._bucket_of[p] = len(self.buckets)
-                if self.world > 1 and overlap:
+                if self.active and overlap:
                     p.register_post_accumulate_grad_hook(self._hook)
             self.buckets.append(flat)
             self._views.append(views)
@@ -78,7 +80,7 @@ class GradAllReducer:
 
     def finish(self):
         """Call after ``backward()`` and before the optimizer step."""
-        if self.world <= 1:
+        if not self.active:
             return
         if not self.overlap:
             for flat in self.buckets:

@@ -8,6 +8,8 @@ Under data parallelism each rank calls it with its own ``bs`` pairs.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -23,7 +25,9 @@ class TrainStep:
         self.optimizer = Adagrad([{"params": encoder.parameters(), "lr": lr_encoder},
                                   {"params": head.parameters(), "lr": lr_head}], weight_decay=weight_decay)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.reducer = GradAllReducer(encoder_head_buckets(encoder, head), group) if self.world > 1 else None
+        force = os.environ.get("LSTC_FORCE_DIST", "0") == "1" and dist.is_available() and dist.is_initialized()
+        self.reducer = (GradAllReducer(encoder_head_buckets(encoder, head), group, force=force)
+                        if (self.world > 1 or force) else None)
 
     def sequences(self, norm_feats, abnorm_feats):
         """A1: [bs, pn*L, P, d] x2 -> [N, S-1, d], normal sequences first (the loss relies on this order)."""

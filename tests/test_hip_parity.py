@@ -309,3 +309,42 @@ def test_forward_cls_equals_full_forward_row0(name):
         cls = enc.forward_cls(x)
     assert cls.shape == (x.shape[0], d)
     assert max_abs_diff(cls, full[:, 0, :]) < 5e-6
+
+
+def test_rccl_gradient_bucket_path_single_rank():
+    """The data-parallel machinery (RCCL process group, flat gradient buckets as .grad views, async all-reduce from
+    autograd hooks, Adagrad stepping from the bucket views) on ONE GPU must reproduce the plain path bit for bit."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from lstc_vad_amd.engine import TrainStep
+    z, mode, ekw, skw = load_case("ltn_sht")
+    d = ekw["d_model"]
+    args = _args(mode, skw)
+    nf, af, al = (torch.from_numpy(z[k]).to(DEV) for k in ("norm_feats", "abnorm_feats", "abnorm_labs"))
+
+    def run(forced):
+        enc, head = _models(mode, ekw, d)
+        enc.load_state_dict(sub(z, "enc_init."), strict=True)
+        head.load_state_dict(sub(z, "head_init."), strict=True)
+        enc, head = enc.to(DEV).train(), head.to(DEV).train()
+        os.environ["LSTC_FORCE_DIST"] = "1" if forced else "0"
+        ts = TrainStep(args, mode, enc, head, 1e-4, 1e-2, 1e-3)
+        assert (ts.reducer is not None) == forced
+        for _ in range(2):
+            sc = ts.step(nf, af, al)
+        return sc.cpu(), {k: v.detach().cpu().clone() for k, v in enc.state_dict().items()}
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sc1, w1 = run(True)
+    finally:
+        dist.destroy_process_group()
+        os.environ["LSTC_FORCE_DIST"] = "0"
+    sc0, w0 = run(False)
+    assert torch.equal(sc0, sc1)
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), k
+    assert abs(float(sc0[0]) - float(z["scalars_step2"][0])) < 1e-4
