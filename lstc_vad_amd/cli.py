@@ -144,8 +144,12 @@ def train(script: str, argv=None):
                          "Run with --synthetic.")
     n_pairs = args.synthetic_pairs or 2 * args.batch_size
     thr = None if mode == "STN" else 0.65
+    pseudo = None
+    ppath = getattr(args, "pseudo_labels_path", None) or getattr(args, "temporal_pseudo_path", None)
+    if ppath and ppath != "None" and os.path.exists(ppath if ppath.endswith(".npy") else ppath + ".npy"):
+        pseudo = np.load(ppath if ppath.endswith(".npy") else ppath + ".npy", allow_pickle=True).tolist()
     data = SyntheticVideos(n_pairs, args.batch_size, args.part_num, part_len, args.n_patch, d_model, dev,
-                           seed=seed + 1000 * rank, sample=args.sample, pseudo_threshold=thr)
+                           seed=seed + 1000 * rank, sample=args.sample, pseudo_threshold=thr, pseudo_labels=pseudo)
     epochs = int(_get(args, "epochs", pre, 1))
     inter = int(getattr(args, "inter_epoch", 10))
     best_auc, it = 0.0, 0
@@ -194,27 +198,82 @@ def evaluate(enc, head, mode, data, part_len, roc_auc, segment_len=16):
     scores, labels = [], []
     with torch.no_grad():
         for feats, labs in data.test_videos():
-            n, P, d = feats.shape
-            if mode == "LTN":
-                full = n // part_len
-                s = []
-                if full:
-                    cls = enc.forward_cls(feats[: full * part_len].reshape(full, part_len * P, d))
-                    s.append(head(cls)[:, 1].repeat_interleave(part_len))
-                if n > full * part_len:
-                    tail = feats[full * part_len:].reshape(1, -1, d)
-                    s.append(head(enc.forward_cls(tail))[:, 1].repeat_interleave(n - full * part_len))
-                sc = torch.cat(s)
-            else:
-                sc = head(enc.forward_cls(feats)).reshape(-1)
+            sc = score_video(enc, head, mode, feats, part_len)
             scores.append(np.repeat(sc.cpu().numpy(), segment_len))
             labels.append(np.repeat(labs.reshape(-1).cpu().numpy(), segment_len))
     enc.train(); head.train()
     return roc_auc(np.concatenate(scores), np.concatenate(labels))
 
 
+def score_video(enc, head, mode, feats, part_len):
+    """Clip-level scores [n_clips] of one video.  STN: one score per clip.  LTN: one score per part of ``part_len``
+    clips, repeated for the part's clips; a shorter tail part is a shorter sequence through the same model
+    (Train/pseudo_labels_generator_temporal.py:120-141).  All full parts of the video go through ONE launch sequence
+    instead of the reference's batch-1 loop."""
+    import torch
+    n, P, d = feats.shape
+    if mode != "LTN":
+        return head(enc.forward_cls(feats)).reshape(-1)
+    full = n // part_len
+    out = []
+    if full:
+        cls = enc.forward_cls(feats[: full * part_len].reshape(full, part_len * P, d))
+        out.append(head(cls)[:, 1].repeat_interleave(part_len))
+    if n > full * part_len:
+        out.append(head(enc.forward_cls(feats[full * part_len:].reshape(1, -1, d)))[:, 1].repeat_interleave(n - full * part_len))
+    return torch.cat(out)
+
+
+def generate_pseudo_labels(script: str, argv=None):
+    """Train/pseudo_labels_generator_{spatio,temporal}.py: score every training video, keep ``score > threshold``
+    (else 0), save ``{key: [n_clips, 1]}`` with ``np.save`` (the pickled-dict format utils/load_dataset.py:20 reads)."""
+    mode = "LTN" if script.endswith("temporal") else "STN"
+    args = build_parser(script).parse_args(argv)
+    os.environ.setdefault("HIP_VISIBLE_DEVICES", str(getattr(args, "gpu", 0)))
+    import numpy as np
+    import torch
+    from .data import SyntheticVideos
+    from .models import Classifier, Encoder, Regressor
+    if not torch.cuda.is_available():
+        raise SystemExit("no HIP device visible: MI355X-only path")
+    dev = torch.device("cuda", 0)
+    part_len = getattr(args, "part_len", 1)
+    enc = Encoder(n_layers=args.n_layers, n_head=args.n_head, d_k=args.d_k, d_v=args.d_v, d_model=args.d_model,
+                  d_inner=args.n_hidden, MHA_layerNorm=args.MHA_layerNorm, FFN_layerNorm=args.FFN_layerNorm,
+                  position_dropout=args.position_dropout, weight_init=args.encoder_weight_init,
+                  position_encoding=args.position_encoding, CLS_learned=args.CLS_learned,
+                  max_position_tokens=args.max_position_tokens, relative_pe=args.relative_position_encoding,
+                  window_size=args.window_size, window_depth=part_len if mode == "LTN" else 3,
+                  conv_patch=args.conv_patch)
+    head = Classifier(args.d_model) if mode == "LTN" else Regressor(args.d_model)
+    strip = lambda sd: {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+    enc_path = getattr(args, "temporal_model_path", "") if mode == "LTN" else getattr(args, "spatio_model_path", "")
+    head_path = getattr(args, "classifier_model_path", "") if mode == "LTN" else getattr(args, "regression_model_path", "")
+    for m, path in ((enc, enc_path), (head, head_path)):
+        if path and os.path.exists(path):
+            m.load_state_dict(strip(torch.load(path, map_location="cpu")), False)
+        else:
+            print(f"[{script}] checkpoint {path!r} not found: scoring with the current initialisation", file=sys.stderr)
+    enc, head = enc.to(dev).eval(), head.to(dev).eval()
+    # same seed -> same synthetic training videos (keys, lengths) as the Train/*.py loops on rank 0
+    data = SyntheticVideos(args.synthetic_pairs or 8, 1, 1, part_len, args.n_patch, args.d_model, dev,
+                           seed=int(getattr(args, "seed", 0)))
+    out = {}
+    with torch.no_grad():
+        for key, feats in data.train_videos():
+            s = score_video(enc, head, mode, feats, part_len)
+            s = torch.where(s > args.threshold, s, torch.zeros_like(s))
+            out[key] = s.reshape(-1, 1).cpu().numpy()
+    np.save(args.pseudo_labels_path, out)
+    print(f"{'temporal' if mode == 'LTN' else 'spatio'} pseudo label generation finished.")
+    return out
+
+
 def main(script: str):
-    if script not in SCRIPTS:
-        raise SystemExit(f"{script}: inference-side script; its loop is the 'next' row of SURVEY.md 8f "
-                         "(flags parse via lstc_vad_amd.cli.build_parser)")
-    train(script)
+    if script.startswith("pseudo_labels_generator"):
+        generate_pseudo_labels(script)
+    elif script in SCRIPTS:
+        train(script)
+    else:
+        raise SystemExit(f"{script}: evaluation CLI is the 'next' row of SURVEY.md 8f-2 "
+                         "(flags parse via lstc_vad_amd.cli.build_parser; the loop is lstc_vad_amd.cli.evaluate)")

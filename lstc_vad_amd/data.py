@@ -35,12 +35,14 @@ class SyntheticVideos:
     abnorm_labs) exactly shaped like the reference loader's batches, already on ``device``."""
 
     def __init__(self, n_pairs, batch_size, part_num, part_len, n_patch, d_model, device, seed=0, sample="uniform",
-                 pseudo_threshold=None, min_clips=24, max_clips=160):
+                 pseudo_threshold=None, min_clips=24, max_clips=160, pseudo_labels=None):
         self.bs, self.pn, self.L, self.P, self.d = batch_size, part_num, part_len, n_patch, d_model
         self.device, self.seed, self.sample, self.thr = device, seed, sample, pseudo_threshold
         rs = np.random.RandomState(seed)
         need = part_len + 1
         self.lengths = rs.randint(max(min_clips, need), max(max_clips, need + 1) + 1, size=(2, n_pairs))
+        self.pseudo = pseudo_labels          # {"syn_abnormal_<i>.npy": [n_clips, 1]} as written by the generators
+        self.n_pairs = n_pairs
         self.order = np.arange(n_pairs)
         self.rng = np.random.RandomState(seed + 1)
 
@@ -74,6 +76,12 @@ class SyntheticVideos:
                     f = feats[idx]
                     if kind == 0:
                         l = torch.zeros(idx.numel(), 1, device=self.device)
+                    elif self.pseudo is not None:                               # labels from a generator file (:64-67)
+                        pl = np.asarray(self.pseudo[self.key(1, int(vid))], np.float32).reshape(-1, 1)
+                        if pl.shape[0] != feats.shape[0]:
+                            raise ValueError(f"pseudo labels for {self.key(1, int(vid))} cover {pl.shape[0]} clips, video has "
+                                             f"{feats.shape[0]} (generated from a different --seed / --synthetic_pairs?)")
+                        l = torch.from_numpy(pl).to(self.device)[idx]
                     elif self.thr is None:
                         l = torch.ones(idx.numel(), 1, device=self.device)      # no pseudo labels: ones (:59-63)
                     else:
@@ -82,6 +90,16 @@ class SyntheticVideos:
                     out[2 * kind].append(f)
                     out[2 * kind + 1].append(l)
             yield tuple(torch.stack(x) for x in out)
+
+    @staticmethod
+    def key(kind, vid):
+        return f"syn_{'abnormal' if kind else 'normal'}_{vid}.npy"
+
+    def train_videos(self):
+        """(key, features [n_clips, P, d]) of every training video — what the pseudo-label generators iterate."""
+        for vid in range(self.n_pairs):
+            for kind in (0, 1):
+                yield self.key(kind, vid), self._video(kind, vid)[0]
 
     def test_videos(self, n_videos=8):
         """(features [n_clips, P, d], per-clip 0/1 labels) for evaluation."""
