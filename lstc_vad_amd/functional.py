@@ -59,6 +59,23 @@ def _note(site, p, seed, shape):
 
 
 _gemm_prof = None         # list of (flops, start_event, end_event) while bench.py profiles GEMM launches
+_compute_dtype = F32      # LstcGemmDesc.dtype used by every GEMM: F32 = exact f32 MFMA, BF16 = bf16 MFMA on f32 storage
+
+
+def set_compute_dtype(name: str):
+    """"fp32" (default; exact-f32 MFMA, the parity mode) or "bf16" (operands rounded to bf16 inside the GEMM, f32
+    accumulate and f32 storage everywhere: BASELINE.json configs 3 / 5).  Attention, LayerNorm, loss and Adagrad stay f32."""
+    global _compute_dtype
+    if name in ("fp32", "f32", "float32"):
+        _compute_dtype = F32
+    elif name in ("bf16", "bfloat16"):
+        _compute_dtype = _lib.BF16
+    else:
+        raise ValueError(name)
+
+
+def get_compute_dtype() -> str:
+    return "bf16" if _compute_dtype == _lib.BF16 else "fp32"
 
 
 def set_gemm_profiling(sink):
@@ -94,7 +111,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
     assert (cr, cc) == (M, N)
     d = GemmDesc()
     d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, lda, ldb, ldc
-    d.transA, d.transB, d.dtype = int(trans_a), int(trans_b), F32
+    d.transA, d.transB, d.dtype = int(trans_a), int(trans_b), _compute_dtype
     flags = 0
     if bias is not None:
         flags |= EPI_BIAS

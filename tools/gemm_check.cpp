@@ -20,7 +20,13 @@ static std::vector<float> rnd(size_t n, unsigned seed) {
     return v;
 }
 
-struct Case { int M, N, K, tA, tB, flags, variant, split; };
+struct Case { int M, N, K, tA, tB, flags, variant, split, dtype = 0; };
+
+static float bf16_round(float x) {   // RNE to bfloat16, back to float (host model of the kernel's operand rounding)
+    uint32_t u; memcpy(&u, &x, 4);
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+    float y; memcpy(&y, &u, 4); return y;
+}
 
 static int check(const Case& c) {
     const int M = c.M, N = c.N, K = c.K;
@@ -41,7 +47,7 @@ static int check(const Case& c) {
     CK(hipMemcpy(dC, hC.data(), hC.size() * 4, hipMemcpyHostToDevice));
     LstcGemmDesc d; memset(&d, 0, sizeof(d));
     d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc; d.transA = c.tA; d.transB = c.tB;
-    d.dtype = LSTC_F32; d.flags = c.flags; d.alpha = 0.75f; d.dropout_p = 0.f; d.ldr = ldr; d.ld_relu = ldm;
+    d.dtype = c.dtype; d.flags = c.flags; d.alpha = 0.75f; d.dropout_p = 0.f; d.ldr = ldr; d.ld_relu = ldm;
     d.split_k = c.split; d.variant = c.variant; d.A = dA; d.B = dB; d.C = dC; d.bias = dbias; d.residual = dres; d.relu_src = dmask;
     int rc = lstc_gemm(&d, nullptr);
     if (rc) { printf("lstc_gemm rc=%d (%s)\n", rc, lstc_strerror(rc)); return 1; }
@@ -53,9 +59,10 @@ static int check(const Case& c) {
         for (int n = 0; n < N; ++n) {
             double s = 0;
             for (int k = 0; k < K; ++k) {
-                const double a = c.tA ? hA[(size_t)k * lda + m] : hA[(size_t)m * lda + k];
-                const double b = c.tB ? hB[(size_t)n * ldb + k] : hB[(size_t)k * ldb + n];
-                s += a * b;
+                float af = c.tA ? hA[(size_t)k * lda + m] : hA[(size_t)m * lda + k];
+                float bf = c.tB ? hB[(size_t)n * ldb + k] : hB[(size_t)k * ldb + n];
+                if (c.dtype == LSTC_BF16) { af = bf16_round(af); bf = bf16_round(bf); }
+                s += (double)af * (double)bf;
             }
             double v = s * 0.75;
             if (c.split <= 1) {
@@ -72,13 +79,13 @@ static int check(const Case& c) {
     for (int m = 0; m < M; ++m)
         for (int n = N; n < ldc; ++n) pad_ok &= out[(size_t)m * ldc + n] == (c.split > 1 ? 0.f : 0.5f);
     const bool ok = maxerr < 2e-4 * std::sqrt((double)K) && pad_ok;
-    printf("%s M=%d N=%d K=%d tA=%d tB=%d flags=%d var=%d split=%d maxerr=%.3g pad_ok=%d\n", ok ? "PASS" : "FAIL", M, N, K,
-           c.tA, c.tB, c.flags, c.variant, c.split, maxerr, (int)pad_ok);
+    printf("%s %s M=%d N=%d K=%d tA=%d tB=%d flags=%d var=%d split=%d maxerr=%.3g pad_ok=%d\n", ok ? "PASS" : "FAIL",
+           c.dtype ? "bf16c" : "f32", M, N, K, c.tA, c.tB, c.flags, c.variant, c.split, maxerr, (int)pad_ok);
     hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dbias); hipFree(dres); hipFree(dmask);
     return ok ? 0 : 1;
 }
 
-static void timeit(int M, int N, int K, int tA, int tB, int variant, int split, int flags, int iters, int pad_a = 0, int pad_b = 0) {
+static void timeit(int M, int N, int K, int tA, int tB, int variant, int split, int flags, int iters, int pad_a = 0, int pad_b = 0, int dtype = 0) {
     const int lda = (tA ? M : K) + pad_a, ldb = (tB ? K : N) + pad_b;
     const size_t na = (size_t)(tA ? K : M) * lda, nb = (size_t)(tB ? N : K) * ldb, nc = (size_t)M * N;
     float *dA, *dB, *dC, *dbias;
@@ -91,7 +98,7 @@ static void timeit(int M, int N, int K, int tA, int tB, int variant, int split, 
         CK(hipMemset(dC, 0, nc * 4));
     }
     LstcGemmDesc d; memset(&d, 0, sizeof(d));
-    d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = N; d.transA = tA; d.transB = tB; d.dtype = LSTC_F32;
+    d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = N; d.transA = tA; d.transB = tB; d.dtype = dtype;
     d.flags = flags; d.alpha = 1.f; d.split_k = split; d.variant = variant; d.A = dA; d.B = dB; d.C = dC; d.bias = dbias;
     d.residual = dC; d.ldr = N; d.dropout_p = 0.1f; d.dropout_seed = 5;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -102,7 +109,7 @@ static void timeit(int M, int N, int K, int tA, int tB, int variant, int split, 
     CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
     const double tf = 2.0 * M * N * (double)K / (ms * 1e-3) / 1e12;
-    printf("TIME M=%6d N=%5d K=%6d tA=%d tB=%d var=%d split=%d flags=%2d pad=%d,%d : %8.3f ms  %7.2f TFLOP/s (%.1f%% of 157.3)\n", M, N, K, tA, tB,
+    printf("TIME %s M=%6d N=%5d K=%6d tA=%d tB=%d var=%d split=%d flags=%2d pad=%d,%d : %8.3f ms  %7.2f TFLOP/s (%.1f%% of 157.3)\n", dtype ? "bf16c" : "f32", M, N, K, tA, tB,
            variant, split, flags, pad_a, pad_b, ms, tf, 100.0 * tf / 157.3);
     fflush(stdout);
     hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dbias);
@@ -111,7 +118,7 @@ static void timeit(int M, int N, int K, int tA, int tB, int variant, int split, 
 int main(int argc, char** argv) {
     if (argc >= 10 && !strcmp(argv[1], "one")) {   // one M N K tA tB variant split flags iters
         timeit(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]),
-               atoi(argv[9]), argc > 10 ? atoi(argv[10]) : 3, argc > 11 ? atoi(argv[11]) : 0, argc > 12 ? atoi(argv[12]) : 0);
+               atoi(argv[9]), argc > 10 ? atoi(argv[10]) : 3, argc > 11 ? atoi(argv[11]) : 0, argc > 12 ? atoi(argv[12]) : 0, argc > 13 ? atoi(argv[13]) : 0);
         return 0;
     }
     const bool time_only = argc > 1 && !strcmp(argv[1], "time");
@@ -131,6 +138,15 @@ int main(int argc, char** argv) {
         fails += check({256, 256, 128, 0, 0, 0, 1, 1});
         fails += check({256, 256, 128, 1, 0, 0, 1, 1});
         fails += check({384, 132, 260, 1, 0, 0, 1, 2});
+        const int ALLB = LSTC_EPI_BIAS | LSTC_EPI_RELU | LSTC_EPI_RESIDUAL | LSTC_EPI_RELU_MASK | LSTC_EPI_ACCUM;
+        for (int variant : {0, 1, 2}) {        // bf16-compute kernel; odd variant id -> aligned (vector) loads
+            fails += check({300, 200, 100, 0, 1, 0, variant, 1, LSTC_BF16});
+            fails += check({257, 131, 67, 0, 1, ALLB, variant, 1, LSTC_BF16});
+            fails += check({300, 200, 132, 0, 0, LSTC_EPI_RELU_MASK, variant, 1, LSTC_BF16});
+            fails += check({130, 260, 515, 1, 0, 0, variant, 1, LSTC_BF16});
+            fails += check({132, 260, 512, 1, 0, 0, variant, 3, LSTC_BF16});
+            fails += check({64, 1, 32, 0, 1, LSTC_EPI_BIAS, variant, 1, LSTC_BF16});
+        }
         printf("%s: %d failing cases\n", fails ? "FAILED" : "ALL PASS", fails);
     }
     // LTN headline shapes: tokens M = 2048*49 = 100352, d = 2048, Hd = 2048, F = 4096.  A smaller M (25088)
