@@ -60,7 +60,8 @@ __device__ __forceinline__ floatx16 tile_abt(const float* __restrict__ A, int ld
     floatx16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (int kb = 0; kb < kdim; kb += 32) {
+#pragma unroll 1
+    for (int kb = 0; kb < kdim; kb += 32) {      // not unrolled: occupancy (registers) hides the load latency, not ILP
         float a[16], b[16];
         load16(pa, kb + 16 * h2, kdim, vec, a);
         load16(pb, kb + 16 * h2, kdim, vec, b);
@@ -85,6 +86,7 @@ __device__ __forceinline__ void lds_times_rows(const float* __restrict__ Alds, c
     constexpr int SP = 32 * T, LD = SP + 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c31 = lane & 31, h2 = lane >> 5;
     const int ctiles = (ncols + 31) >> 5;
+#pragma unroll 1
     for (int ct = wave; ct < ctiles; ct += NT / 64) {
         const int c = 32 * ct + c31;
         const bool cvalid = c < ncols;
@@ -93,6 +95,7 @@ __device__ __forceinline__ void lds_times_rows(const float* __restrict__ Alds, c
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll 1
         for (int jb = 0; jb < SP; jb += 16) {
             float bv[8];
 #pragma unroll
@@ -126,7 +129,7 @@ __device__ __forceinline__ void lds_times_rows(const float* __restrict__ Alds, c
 }
 
 template <int T>
-__global__ void __launch_bounds__(NT) attn_fwd_kernel(const AttnParams p) {
+__global__ void __launch_bounds__(NT, T <= 2 ? 4 : 2) attn_fwd_kernel(const AttnParams p) {
     constexpr int SP = 32 * T, LD = SP + 1, NJ = (SP + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int n = blockIdx.x, h = blockIdx.y, S = p.S;
@@ -136,6 +139,7 @@ __global__ void __launch_bounds__(NT) attn_fwd_kernel(const AttnParams p) {
     const float* Vb = p.V + (size_t)n * S * p.ldv + (size_t)h * p.dv;
     float* Ob = p.O + (size_t)n * S * p.ldo + (size_t)h * p.dv;
 
+#pragma unroll 1
     for (int t = wave; t < T * T; t += NT / 64) {
         const int ti = t / T, tj = t % T;
         if (32 * ti >= S || 32 * tj >= S) continue;   // fully padded tile: rows/cols are rewritten below
@@ -146,6 +150,7 @@ __global__ void __launch_bounds__(NT) attn_fwd_kernel(const AttnParams p) {
 
     float* pr_base = p.probs + ((size_t)n * p.H + h) * S * S;
     const uint32_t flat0 = ((uint32_t)n * p.H + h) * (uint32_t)(S * S);
+#pragma unroll 1
     for (int i = wave; i < SP; i += NT / 64) {
         float* row = sm + i * LD;
         if (i >= S) {
@@ -193,7 +198,7 @@ __global__ void __launch_bounds__(NT) attn_fwd_kernel(const AttnParams p) {
 }
 
 template <int T>
-__global__ void __launch_bounds__(NT) attn_bwd_kernel(const AttnParams p) {
+__global__ void __launch_bounds__(NT, T <= 3 ? 2 : 1) attn_bwd_kernel(const AttnParams p) {
     constexpr int SP = 32 * T, LD = SP + 1, NJ = (SP + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Dm = sm;                 // dP~ then dA
@@ -206,12 +211,14 @@ __global__ void __launch_bounds__(NT) attn_bwd_kernel(const AttnParams p) {
         for (int i = threadIdx.x; i < p.table_rows; i += NT) tacc[i] = 0.f;
     const int n_begin = blockIdx.x * p.n_per_wg;
     const int n_end = min(p.N, n_begin + p.n_per_wg);
+#pragma unroll 1
     for (int n = n_begin; n < n_end; ++n) {
         const float* Qb = p.Q + (size_t)n * S * p.ldq + (size_t)h * p.dk;
         const float* Kb = p.K + (size_t)n * S * p.ldk + (size_t)h * p.dk;
         const float* Vb = p.V + (size_t)n * S * p.ldv + (size_t)h * p.dv;
         const float* dOb = p.dO + (size_t)n * S * p.ldo + (size_t)h * p.dv;
         __syncthreads();   // previous sequence's LDS readers are done
+#pragma unroll 1
         for (int t = wave; t < T * T; t += NT / 64) {
             const int ti = t / T, tj = t % T;
             if (32 * ti >= S || 32 * tj >= S) continue;
@@ -221,6 +228,7 @@ __global__ void __launch_bounds__(NT) attn_bwd_kernel(const AttnParams p) {
         __syncthreads();
         const float* pr_base = p.probs + ((size_t)n * p.H + h) * S * S;
         const uint32_t flat0 = ((uint32_t)n * p.H + h) * (uint32_t)(S * S);
+#pragma unroll 1
         for (int i = wave; i < SP; i += NT / 64) {
             float* drow = Dm + i * LD;
             float* prow = Pm + i * LD;

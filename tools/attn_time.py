@@ -1,0 +1,25 @@
+"""Times the fused attention kernels at the LTN-SHT layer shape (N=2048, S=49, H=8, dk=dv=256) with torch events."""
+import sys, os, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lstc_vad_amd import functional as Fn
+from lstc_vad_amd.models.MultiHeadAttention import relative_position_index_3d
+dev = "cuda"
+for (N, S, L) in ((2048, 49, 3), (2048, 17, 1), (2048, 81, 5)):
+    H, dk = 8, 256
+    M = N * S
+    q, k, v = (torch.randn(M, H * dk, device=dev) for _ in range(3))
+    do = torch.randn(M, H * dk, device=dev)
+    idx = relative_position_index_3d(L, 4).to(dev)
+    tab = torch.randn((2 * L - 1) * 49, H, device=dev) * 0.1
+    def t(fn, n=5):
+        for _ in range(2): fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n): r = fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n, r
+    tf, (o, p) = t(lambda: Fn.attn_fwd(q, k, v, N, S, H, dk, dk, tab, idx, 0.2, 7))
+    tb, _ = t(lambda: Fn.attn_bwd(do, q, k, v, p, N, S, H, dk, dk, tab, idx, 0.2, 7))
+    gb = 4 * M * H * dk * 4 / 1e9
+    print(f"ATTN N={N} S={S}: fwd {tf:.3f} ms ({gb / tf:.2f} TB/s alg), bwd {tb:.3f} ms ({2 * gb / tb:.2f} TB/s alg)", flush=True)
