@@ -144,9 +144,11 @@ int lstc_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
                        float* dx, float* partial, int32_t n_partial, int64_t rows, int32_t d, void* stream);
 
 /* CLS = mean over tokens (or `cls_token` if not NULL), prepended; optional `pos` [S, d] added to every
- * sequence — models/Encoder.py:51-58.  x [N, S-1, d] -> y [N, S, d]. */
-int lstc_cls_concat_fwd(const float* x, const float* cls_token, const float* pos, float* y,
-                        int64_t N, int32_t S, int32_t d, void* stream);
+ * sequence — models/Encoder.py:51-58.  x [N, S-1, d] -> y [N, S, d].  When `x_hi` is not NULL, sequences
+ * [0, n_lo) are read from `x` and [n_lo, N) from `x_hi`: the reference's torch.cat([norm_feats, abnorm_feats])
+ * (Train/temporal_transformer_shanghaitech.py:120) is fused into this pass instead of costing its own copy. */
+int lstc_cls_concat_fwd(const float* x, const float* x_hi, int64_t n_lo, const float* cls_token, const float* pos,
+                        float* y, int64_t N, int32_t S, int32_t d, void* stream);
 
 /* Gradient w.r.t. the Encoder input, needed only when something upstream is trainable (input_layerNorm,
  * models/Encoder.py:48-49): dx[n,t,:] = dy[n,t+1,:] + (mean_cls ? dy[n,0,:]/(S-1) : 0). */

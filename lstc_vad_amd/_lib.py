@@ -78,7 +78,7 @@ def load():
         "lstc_attn_cls_bwd": [C.POINTER(AttnDesc), vp],
         "lstc_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
         "lstc_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp],
-        "lstc_cls_concat_fwd": [vp, vp, vp, vp, i64, i32, i32, vp],
+        "lstc_cls_concat_fwd": [vp, vp, i64, vp, vp, vp, i64, i32, i32, vp],
         "lstc_cls_concat_bwd": [vp, vp, i64, i32, i32, i32, vp],
         "lstc_colsum": [vp, i64, i32, i32, vp, i32, vp, i32, vp],
         "lstc_dropout_apply": [vp, vp, i64, f32, u64, vp],

@@ -207,13 +207,15 @@ __global__ void __launch_bounds__(NT) ln_bwd_generic(const float* __restrict__ d
 
 // ------------------------------------------------------------------------------ CLS concat
 // grid (N, ceil(d/NT)); thread owns one column (coalesced across the workgroup), walks the tokens.
-__global__ void __launch_bounds__(NT) cls_concat_fwd_kernel(const float* __restrict__ x, const float* __restrict__ cls,
+__global__ void __launch_bounds__(NT) cls_concat_fwd_kernel(const float* __restrict__ x, const float* __restrict__ x_hi,
+                                                             int64_t n_lo, const float* __restrict__ cls,
                                                              const float* __restrict__ pos, float* __restrict__ y, int S,
                                                              int d) {
     const int64_t n = blockIdx.x;
     const int c = blockIdx.y * NT + threadIdx.x;
     if (c >= d) return;
-    const float* xr = x + n * (int64_t)(S - 1) * d + c;
+    // sequences [0, n_lo) come from x, [n_lo, N) from x_hi: the reference's cat([normal, abnormal]) fused away
+    const float* xr = (x_hi && n >= n_lo ? x_hi + (n - n_lo) * (int64_t)(S - 1) * d : x + n * (int64_t)(S - 1) * d) + c;
     float* yr = y + n * (int64_t)S * d + c;
     float s = 0.f;
     for (int t = 0; t < S - 1; ++t) {
@@ -256,13 +258,30 @@ __global__ void __launch_bounds__(NT) colsum_pass1(const float* __restrict__ x, 
     for (; r < rows; r += step) s0 += x[r * ld + c];
     partial[(size_t)blockIdx.y * cols + c] = (s0 + s1) + (s2 + s3);
 }
+// pass 2: 64 threads per column group of 64 columns x 4 partial-row lanes; each thread sums every 4th partial row with
+// 4 independent accumulators (the loop is latency-bound, not bandwidth-bound), then the 4 lanes combine through LDS.
 __global__ void __launch_bounds__(NT) colsum_pass2(const float* __restrict__ partial, int n_partial, int cols,
                                                     float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * NT + threadIdx.x;
-    if (c >= cols) return;
-    float s = 0.f;
-    for (int p = 0; p < n_partial; ++p) s += partial[(size_t)p * cols + c];
-    out[c] = accumulate ? out[c] + s : s;
+    __shared__ float red[NT];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int lane_p = threadIdx.x >> 6;                 // 0..3
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < cols) {
+        int p = lane_p;
+        for (; p + 12 < n_partial; p += 16) {
+            s0 += partial[(size_t)p * cols + c];
+            s1 += partial[(size_t)(p + 4) * cols + c];
+            s2 += partial[(size_t)(p + 8) * cols + c];
+            s3 += partial[(size_t)(p + 12) * cols + c];
+        }
+        for (; p < n_partial; p += 4) s0 += partial[(size_t)p * cols + c];
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (lane_p == 0 && c < cols) {
+        const float s = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+        out[c] = accumulate ? out[c] + s : s;
+    }
 }
 
 // --------------------------------------------------------------------------------- dropout
@@ -466,12 +485,12 @@ int lstc_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
     return lstc_launch_status();
 }
 
-int lstc_cls_concat_fwd(const float* x, const float* cls_token, const float* pos, float* y, int64_t N, int32_t S,
-                        int32_t d, void* stream) {
+int lstc_cls_concat_fwd(const float* x, const float* x_hi, int64_t n_lo, const float* cls_token, const float* pos,
+                        float* y, int64_t N, int32_t S, int32_t d, void* stream) {
     if (!x || !y) return LSTC_E_NULL;
-    if (N <= 0 || S < 2 || d <= 0) return LSTC_E_SHAPE;
-    hipLaunchKernelGGL(cls_concat_fwd_kernel, dim3((unsigned)N, (d + NT - 1) / NT), NT, 0, (hipStream_t)stream, x,
-                       cls_token, pos, y, S, d);
+    if (N <= 0 || S < 2 || d <= 0 || (x_hi && (n_lo < 0 || n_lo > N))) return LSTC_E_SHAPE;
+    hipLaunchKernelGGL(cls_concat_fwd_kernel, dim3((unsigned)N, (d + NT - 1) / NT), NT, 0, (hipStream_t)stream, x, x_hi,
+                       n_lo, cls_token, pos, y, S, d);
     return lstc_launch_status();
 }
 
@@ -490,7 +509,7 @@ int lstc_colsum(const float* x, int64_t rows, int32_t cols, int32_t ld, float* p
     hipStream_t st = (hipStream_t)stream;
     const int np = (int)(rows < n_partial ? rows : n_partial);
     hipLaunchKernelGGL(colsum_pass1, dim3((cols + NT - 1) / NT, np), NT, 0, st, x, rows, cols, ld, partial);
-    hipLaunchKernelGGL(colsum_pass2, dim3((cols + NT - 1) / NT), NT, 0, st, partial, np, cols, out, accumulate);
+    hipLaunchKernelGGL(colsum_pass2, dim3((cols + 63) / 64), NT, 0, st, partial, np, cols, out, accumulate);
     return lstc_launch_status();
 }
 

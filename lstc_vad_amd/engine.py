@@ -37,7 +37,10 @@ class TrainStep:
         return torch.cat([norm_feats.float().reshape(-1, tokens, d), abnorm_feats.float().reshape(-1, tokens, d)], 0)
 
     def forward_loss(self, norm_feats, abnorm_feats, abnorm_labs):
-        cls = self.encoder.forward_cls(self.sequences(norm_feats, abnorm_feats))      # == encoder(x)[:, 0, :]
+        a, d = self.args, norm_feats.shape[-1]
+        tokens = a.part_len * a.n_patch if self.mode == "LTN" else a.n_patch
+        # normal sequences first, abnormal second (A1); the cat itself is fused into the CLS-concat kernel
+        cls = self.encoder.forward_cls(norm_feats.float().reshape(-1, tokens, d), abnorm_feats.float().reshape(-1, tokens, d))
         outputs = self.head(cls)
         loss, scalars = training_loss(self.args, self.mode, outputs, abnorm_labs, group=self.group)
         return loss, scalars, outputs

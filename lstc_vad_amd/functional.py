@@ -164,7 +164,7 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
 
 def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate=False) -> torch.Tensor:
     px, rows, cols, ld = _mat(x)
-    n_partial = int(min(rows, 256))
+    n_partial = int(min(rows, 128))
     partial = torch.empty((n_partial, cols), device=x.device, dtype=torch.float32)
     if out is None:
         out = torch.empty((cols,), device=x.device, dtype=torch.float32)
@@ -470,15 +470,19 @@ class ClsConcatFunction(torch.autograd.Function):
     """models/Encoder.py:51-58: CLS (token mean or learned) prepended, optional learned position table added."""
 
     @staticmethod
-    def forward(ctx, x, cls_token, pos):
-        N, Sm1, dm = x.shape
+    def forward(ctx, x, cls_token, pos, x_hi=None):
+        # x_hi: optional second half of the batch (abnormal sequences); the cat is fused into the kernel
+        N_lo, Sm1, dm = x.shape
+        N = N_lo + (x_hi.shape[0] if x_hi is not None else 0)
         S = Sm1 + 1
         x = x.contiguous()
+        x_hi = x_hi.contiguous() if x_hi is not None else None
         y = torch.empty((N, S, dm), device=x.device, dtype=torch.float32)
         pos_s = pos[0, :S].contiguous() if pos is not None else None
         cls_v = cls_token.reshape(-1) if cls_token is not None else None
-        check(_lib.load().lstc_cls_concat_fwd(dev_ptr(x), dev_ptr(cls_v), dev_ptr(pos_s), dev_ptr(y), N, S, dm,
-                                              stream_ptr()), "lstc_cls_concat_fwd")
+        check(_lib.load().lstc_cls_concat_fwd(dev_ptr(x), dev_ptr(x_hi), N_lo, dev_ptr(cls_v), dev_ptr(pos_s), dev_ptr(y),
+                                              N, S, dm, stream_ptr()), "lstc_cls_concat_fwd")
+        ctx.two = x_hi is not None
         ctx.meta = (N, S, dm, cls_token is not None, pos.shape if pos is not None else None)
         return y
 
@@ -488,6 +492,8 @@ class ClsConcatFunction(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dcls = dpos = None
         if ctx.needs_input_grad[0]:
+            if ctx.two:
+                raise RuntimeError("input gradients with a split batch are not supported: concatenate first")
             dx = torch.empty((N, S - 1, dm), device=dy.device, dtype=torch.float32)
             check(_lib.load().lstc_cls_concat_bwd(dev_ptr(dy), dev_ptr(dx), N, S, dm, int(not learned), stream_ptr()),
                   "lstc_cls_concat_bwd")
@@ -498,7 +504,7 @@ class ClsConcatFunction(torch.autograd.Function):
             if pos_shape is not None:
                 dpos = torch.zeros(pos_shape, device=dy.device, dtype=torch.float32)
                 dpos[0, :S] = tok.view(S, dm)
-        return dx, dcls, dpos
+        return dx, dcls, dpos, None
 
 
 class DropoutFunction(torch.autograd.Function):

@@ -58,21 +58,24 @@ class Encoder(nn.Module):
                 skip.update(id(p) for p in layer.pos_ffn.layer_norm.parameters())
         return [p for p in self.parameters() if id(p) not in skip]
 
-    def _embed(self, enc_output):
+    def _embed(self, enc_output, enc_output_hi=None):
         if self.input_layerNorm:
+            if enc_output_hi is not None:
+                enc_output, enc_output_hi = torch.cat([enc_output, enc_output_hi], 0), None
             enc_output = LayerNormFunction.apply(enc_output, self.layer_norm.weight, self.layer_norm.bias)
         enc_output = ClsConcatFunction.apply(enc_output, self.cls_token if self.CLS_learned else None,
-                                             self.position_enc if self.position_encoding else None)
+                                             self.position_enc if self.position_encoding else None, enc_output_hi)
         if self.position_encoding and self.training and self.position_dropout.p > 0:
             enc_output = DropoutFunction.apply(enc_output, self.position_dropout.p, "position_dropout")
         return enc_output
 
-    def forward_cls(self, enc_output):
+    def forward_cls(self, enc_output, enc_output_hi=None):
         """``forward(x)[:, 0, :]`` without computing the rows nobody reads: the train / eval loops consume only the
         CLS token of the last layer (Train/temporal_transformer_shanghaitech.py:123,
         Train/spatio_transformer_shanghaitech.py:97), so the last layer evaluates its query, output projection and
         FFN for that token alone (K/V still use every token).  Saves ~25 % of the step's FLOPs at 3 layers."""
-        enc_output = self._embed(enc_output)
+        # enc_output_hi: optional second half of the batch (the abnormal sequences) so the caller need not cat
+        enc_output = self._embed(enc_output, enc_output_hi)
         for layer in self.layer_stack[:-1]:
             enc_output = layer(enc_output)[0]
         return self.layer_stack[-1].forward_cls(enc_output)
