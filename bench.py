@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--part_num", type=int, default=32)
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="GEMM compute type: fp32 = exact-f32 MFMA (headline, parity mode); bf16 = bf16 MFMA on f32 storage")
+    ap.add_argument("--h2d", action="store_true", help="also time the step with the batch arriving from pinned host memory "
+                    "every step through lstc_vad_amd.feed.PinnedFeeder (reported as pcie_inclusive, never as value)")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
@@ -164,6 +166,21 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     scal = [float(x) for x in sc.cpu()]
+    pcie = None
+    if a.h2d and world == 1:
+        from lstc_vad_amd.feed import PinnedFeeder
+        host = tuple(t.cpu() for t in (nf, torch.zeros_like(al), af, al))
+        feeder = PinnedFeeder((host for _ in range(a.steps + 2)), dev)
+        t1 = None
+        for i, (hnf, _, haf, hal) in enumerate(feeder):
+            if i == 2:
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+            ts.step(hnf, haf, hal)
+        torch.cuda.synchronize()
+        dth = (time.perf_counter() - t1) / a.steps
+        pcie = {"value": round(2 * bs * pn * L / dth, 1), "unit": "snippets/s", "ms_per_step": round(1e3 * dth, 3),
+                "batch_MB": round(sum(t.numel() * 4 for t in host) / 1e6, 1),
+                "note": "batch copied pageable->pinned->HBM every step on a side stream, overlapped with the previous step"}
 
     snippets_per_step = 2 * bs * pn * L * world
     value = snippets_per_step * a.steps / dt
@@ -205,6 +222,8 @@ def main():
                                       f"{nseq} sequences/GPU/step, dropout={'off' if a.no_dropout else 'reference rates'}",
                           "global_videos": 2 * bs * world, "parallelism": f"dp{world}"},
                "loss": scal[0], "roofline": roof}
+        if pcie:
+            out["pcie_inclusive"] = pcie
         if world == 1 and not a.no_cpu_baseline:
             # torch-CPU sgemm on the GPU box's host peaks at 16-32 threads (tools/cpu_threads_scan.py: 1.3 TFLOP/s
             # at 16-32, 0.5 at 128 of 256 hardware threads), so the baseline uses min(32, available) threads

@@ -269,8 +269,78 @@ def generate_pseudo_labels(script: str, argv=None):
     return out
 
 
+def evaluate_cli(script: str, argv=None):
+    """Test/evaluation_shanghaitech_ubnormal.py (:69-96) and Test/evaluation_UCF.py (:47-88): frame-level AUC of a
+    trained LTN.  SHT/UBnormal: consecutive parts of ``part_len`` clips, a short tail is RE-WINDOWED to the video's last
+    ``part_len`` clips (:83-84; unlike the pseudo-label generators, which feed the short tail as a shorter sequence).
+    UCF: every video is averaged into 32 bins (linspace :54), parts of part_len = 2 bins (:42), features L2-normalised
+    (:77).  All full parts of a video are scored in one launch sequence instead of one part per launch."""
+    args = build_parser(script).parse_args(argv)
+    os.environ.setdefault("HIP_VISIBLE_DEVICES", str(getattr(args, "gpu", 0)))
+    import numpy as np
+    import torch
+    from .data import SyntheticVideos
+    from .metrics import roc_auc
+    from .models import Classifier, Encoder
+    if not torch.cuda.is_available():
+        raise SystemExit("no HIP device visible: MI355X-only path")
+    dev = torch.device("cuda", 0)
+    ucf = script.endswith("UCF")
+    part_len = 2 if ucf else args.part_len
+    rel = getattr(args, "temporal_relative_position_encoding", False) or getattr(args, "relative_position_encoding", False)
+    enc = Encoder(n_layers=args.temporal_n_layers, n_head=args.temporal_n_head, d_k=args.temporal_d_k, d_v=args.temporal_d_v,
+                  d_model=args.d_model, d_inner=args.temporal_n_hidden, MHA_layerNorm=args.temporal_MHA_layerNorm,
+                  FFN_layerNorm=args.temporal_FFN_layerNorm, relative_pe=rel, window_size=args.window_size,
+                  window_depth=args.part_len, weight_init=False)
+    head = Classifier(args.d_model)
+    strip = lambda sd: {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+    for m, path in ((enc, args.temporal_model_path), (head, args.classifier_model_path)):
+        if path and os.path.exists(path):
+            m.load_state_dict(strip(torch.load(path, map_location="cpu")), False)
+        else:
+            print(f"[{script}] checkpoint {path!r} not found: evaluating the current initialisation", file=sys.stderr)
+    enc, head = enc.to(dev).eval(), head.to(dev).eval()
+    seg = getattr(args, "segment_len", 16)
+    data = SyntheticVideos(2, 1, 1, part_len, args.n_patch, args.d_model, dev, seed=0)
+    scores, labels = [], []
+    with torch.no_grad():
+        for feats, labs in data.test_videos(getattr(args, "synthetic_pairs", 0) or 8):
+            n, P, d = feats.shape
+            lab = labs.reshape(-1)
+            if ucf:
+                r = np.linspace(0, n, 33, dtype=np.int32)
+                bins = torch.stack([feats[r[i]] if r[i] == r[i + 1] else feats[r[i]:r[i + 1]].mean(dim=0) for i in range(32)])
+                bins = torch.nn.functional.normalize(bins, p=2, dim=-1)
+                nparts = (32 + part_len - 1) // part_len
+                begs = [min(i * part_len, 32 - part_len) for i in range(nparts)]
+                ends = [min((i + 1) * part_len, 32) for i in range(nparts)]
+                x = torch.stack([bins[b:b + part_len].reshape(part_len * P, d) for b in begs])
+                sc = head(enc.forward_cls(x))[:, 1].cpu().numpy()
+                for s_, b, e in zip(sc, begs, ends):
+                    scores.append(np.full((r[e] - r[b]) * seg, s_))
+                    labels.append(np.repeat(lab[r[b]:r[e]].cpu().numpy(), seg))
+            else:
+                nparts = (n + part_len - 1) // part_len
+                begs = [i * part_len for i in range(nparts)]
+                ends = [min((i + 1) * part_len, n) for i in range(nparts)]
+                win = [max(e - part_len, 0) if e - b < part_len else b for b, e in zip(begs, ends)]
+                if n >= part_len:
+                    x = torch.stack([feats[w:w + part_len].reshape(part_len * P, d) for w in win])
+                    sc = head(enc.forward_cls(x))[:, 1].cpu().numpy()
+                else:           # video shorter than one part: a single shorter sequence
+                    sc = head(enc.forward_cls(feats.reshape(1, n * P, d)))[:, 1].cpu().numpy()
+                for s_, b, e in zip(sc, begs, ends):
+                    scores.append(np.full((e - b) * seg, s_))
+                    labels.append(np.repeat(lab[b:e].cpu().numpy(), seg))
+    auc = roc_auc(np.concatenate(scores), np.concatenate(labels))
+    print("auc = ", auc)
+    return auc
+
+
 def main(script: str):
-    if script.startswith("pseudo_labels_generator"):
+    if script.startswith("evaluation"):
+        evaluate_cli(script)
+    elif script.startswith("pseudo_labels_generator"):
         generate_pseudo_labels(script)
     elif script in SCRIPTS:
         train(script)

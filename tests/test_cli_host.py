@@ -44,6 +44,11 @@ def test_reference_command_lines_parse():
 def test_every_train_script_exists():
     for s in list(cli.SCRIPTS) + ["pseudo_labels_generator_spatio", "pseudo_labels_generator_temporal"]:
         assert os.path.exists(os.path.join(ROOT, "Train", s + ".py")), s
+    for s in ("evaluation_shanghaitech_ubnormal", "evaluation_UCF"):
+        assert os.path.exists(os.path.join(ROOT, "Test", s + ".py")), s
+    a = cli.build_parser("evaluation_UCF").parse_args("--n_patch 9 --part_num 32 --part_len 2 --temporal_MHA_layerNorm "
+                                                      "--temporal_FFN_layerNorm --relative_position_encoding --gpu 0".split())
+    assert a.n_patch == 9 and a.temporal_n_hidden == 4096 and a.window_size == 4       # README.md:59
 
 
 def test_window_sampler_matches_reference_example():

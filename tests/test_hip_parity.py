@@ -402,3 +402,17 @@ def test_bf16_compute_training_step_close_to_golden():
             # more where the hinge / bag-max selections sit close to a tie on this tiny d_model=32 case)
             cos = float((p.grad.cpu() * g).sum() / (p.grad.cpu().norm() * g.norm() + 1e-20))
             assert cos > 0.95, (k, cos)
+
+
+def test_pinned_feeder_delivers_batches_in_order():
+    from lstc_vad_amd.feed import PinnedFeeder
+    torch.manual_seed(0)
+    batches = [(torch.randn(4, 6, 3, 8), torch.zeros(4, 6, 1), torch.randn(4, 6, 3, 8), torch.rand(4, 6, 1)) for _ in range(5)]
+    got = []
+    for b in PinnedFeeder(iter(batches), DEV):
+        got.append(tuple(t.clone() for t in b))        # clone: the feeder reuses its device slots
+        torch.cuda._sleep(200000)                      # make "compute" outlast the next copy
+    assert len(got) == 5
+    for g, b in zip(got, batches):
+        for x, y in zip(g, b):
+            assert torch.equal(x.cpu(), y)
