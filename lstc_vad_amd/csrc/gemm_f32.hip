@@ -169,8 +169,10 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int row
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int PIPE, bool A_KC, bool B_KC, bool VA, bool VB>
+template <int BM, int BN, int WGM, int WGN, int PIPE_ABL, bool A_KC, bool B_KC, bool VA, bool VB>
 __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParams p) {
+    constexpr int PIPE = PIPE_ABL & 15;
+    constexpr int ABL = PIPE_ABL >> 4;     // timing-only ablation of the PIPE 3 body: 1 no global loads, 2 no LDS writes, 4 no barrier
     constexpr int NT = WGM * WGN * 64;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -307,11 +309,15 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParam
                 for (int q = 0; q < 2 * MPK; ++q) {
                     const int e = (kk & 3) * 2 * MPK + q;
                     if (kk < 4) {
-                        if (e < NVA) sa.store_one(e, a_st);
-                        else if (e - NVA < NVB) sb.store_one(e - NVA, b_st);
+                        if constexpr (!(ABL & 2)) {
+                            if (e < NVA) sa.store_one(e, a_st);
+                            else if (e - NVA < NVB) sb.store_one(e - NVA, b_st);
+                        }
                     } else {
-                        if (e < NVA) sa.load_one(e, p.A, p.lda, m0, p.M, k_next);
-                        else if (e - NVA < NVB) sb.load_one(e - NVA, p.B, p.ldb, n0, p.N, k_next);
+                        if constexpr (!(ABL & 1)) {
+                            if (e < NVA) sa.load_one(e, p.A, p.lda, m0, p.M, k_next);
+                            else if (e - NVA < NVB) sb.load_one(e - NVA, p.B, p.ldb, n0, p.N, k_next);
+                        }
                     }
                 }
                 if (kk < TM) read_frag<BM, A_KC>(a_lds, wm * WTM + kk * 32 + l31, h, 1, fa1[kk < TM ? kk : 0]);
@@ -323,7 +329,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParam
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][kk], fb0[j][kk], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();
+            if constexpr (!(ABL & 4)) __syncthreads();
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 if (kk < TM) read_frag<BM, A_KC>(a_st, wm * WTM + kk * 32 + l31, h, 0, fa0[kk < TM ? kk : 0]);
@@ -485,6 +491,10 @@ int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipS
         case 7: return launch_cfg<128, 128, 2, 2, 1, A_KC, B_KC>(p, va, vb, splits, st);
         case 8: return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);
         case 9: return launch_cfg<256, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // 4 waves x (128x64): 1 wave/SIMD
+        case 12: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 1, A_KC, B_KC>(p, va, vb, splits, st); break;
+        case 13: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 3, A_KC, B_KC>(p, va, vb, splits, st); break;
+        case 14: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 7, A_KC, B_KC>(p, va, vb, splits, st); break;
+        case 15: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 4, A_KC, B_KC>(p, va, vb, splits, st); break;
         default: return launch_cfg<128, 128, 2, 2, 2, A_KC, B_KC>(p, va, vb, splits, st);
     }
 }
