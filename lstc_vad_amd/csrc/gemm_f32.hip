@@ -228,6 +228,130 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParam
     //   barrier: publishes tile t+1 and retires every read of tile t's stage
     //   phase 2: LDS-read the 1st-half fragments of tile t+1   -> hidden behind the 2nd-half MFMAs of tile t
     // so a wave reaches each MFMA block with its operands already in registers; only barrier skew is exposed.
+    if constexpr (PIPE == 4) {
+        // ---- LDS-DMA staging (global_load_lds_dwordx4): operand tiles go HBM/L2 -> LDS without passing through
+        // VGPRs, so the steady state has no ds_write (2.6 % of the PIPE 3 time) and no staging registers.
+        // A DMA wave-instruction writes 1 KB lane-linearly (base + 16*lane), so the LDS images are UNPADDED:
+        //   K-contiguous operand: [rows][32 floats]; bank conflicts of the ds_read_b128 fragment reads are removed
+        //     by XOR-ing the 16-B chunk index with (row>>1)&7 — applied to the per-lane SOURCE address of the DMA and
+        //     to the read address (cdna_hip_programming rule 21: same involution on both sides, linear destination);
+        //   k-major operand: [32][rows], naturally lane-linear (one piece = 2 k rows of 128 floats).
+        // Pipeline: tile t+2 is DMA'd into the stage tile t just vacated, right after the mid-tile barrier of
+        // iteration t; __syncthreads() of iteration t+1 (which carries s_waitcnt vmcnt(0)) publishes it.
+        static_assert(VA && VB, "LDS-DMA path needs 16-B aligned rows");
+        constexpr int ST = 32 * BM, STB = 32 * BN;          // floats per stage
+        float* const A4 = smem;
+        float* const B4 = smem + 2 * ST;
+        constexpr int PA = BM / 32, PB = BN / 32;           // 1-KB pieces per wave per stage (NT = 256: 4 waves)
+        static_assert(NT == 256, "piece assignment assumes 4 waves");
+        // per-lane source pointers of this wave's pieces at k = 0 (rows clamped; k advances by pointer arithmetic)
+        const float* ga[PA];
+        const float* gb[PB];
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const int pi = wave * PA + j;
+            if (A_KC) {
+                const int row = pi * 8 + (lane >> 3), cp = lane & 7;
+                ga[j] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + ((cp ^ ((row >> 1) & 7)) << 2);
+            } else {
+                const int f = pi * 256 + lane * 4;
+                ga[j] = p.A + (size_t)(f / BM) * p.lda + min(m0 + f % BM, p.M - 4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const int pi = wave * PB + j;
+            if (B_KC) {
+                const int row = pi * 8 + (lane >> 3), cp = lane & 7;
+                gb[j] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + ((cp ^ ((row >> 1) & 7)) << 2);
+            } else {
+                const int f = pi * 256 + lane * 4;
+                gb[j] = p.B + (size_t)(f / BN) * p.ldb + min(n0 + f % BN, p.N - 4);
+            }
+        }
+        const size_t a_kstep = A_KC ? (size_t)BK : (size_t)BK * p.lda;     // floats per K tile
+        const size_t b_kstep = B_KC ? (size_t)BK : (size_t)BK * p.ldb;
+        typedef __attribute__((address_space(1))) const void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        auto dma_a = [&](int j, int kt, int stage) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(ga[j] + (size_t)kt * a_kstep),
+                                             (lptr_t)(A4 + stage * ST + (wave * PA + j) * 256), 16, 0, 0);
+        };
+        auto dma_b = [&](int j, int kt, int stage) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(gb[j] + (size_t)kt * b_kstep),
+                                             (lptr_t)(B4 + stage * STB + (wave * PB + j) * 256), 16, 0, 0);
+        };
+        // fragment read from the unpadded images
+        auto frag = [&](const float* lds, bool kc, int R, int row, int half, float (&f)[8]) {
+            if (kc) {
+                const int c0 = 4 * h + 2 * half, sw = (row >> 1) & 7;
+                const float4 a = *reinterpret_cast<const float4*>(lds + row * 32 + ((c0 ^ sw) << 2));
+                const float4 b = *reinterpret_cast<const float4*>(lds + row * 32 + (((c0 + 1) ^ sw) << 2));
+                f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+            } else {
+                const float* q = lds + (16 * h + 8 * half) * R + row;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = q[j * R];
+            }
+        };
+        float fa0[TM][8], fb0[TN][8], fa1[TM][8], fb1[TN][8];
+        if (nkt > 0) {
+#pragma unroll
+            for (int j = 0; j < PA; ++j) dma_a(j, kt0, 0);
+#pragma unroll
+            for (int j = 0; j < PB; ++j) dma_b(j, kt0, 0);
+            if (nkt > 1) {
+#pragma unroll
+                for (int j = 0; j < PA; ++j) dma_a(j, kt0 + 1, 1);
+#pragma unroll
+                for (int j = 0; j < PB; ++j) dma_b(j, kt0 + 1, 1);
+            }
+        }
+        __syncthreads();
+        if (nkt > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) frag(A4, A_KC, BM, wm * WTM + i * 32 + l31, 0, fa0[i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) frag(B4, B_KC, BN, wn * WTN + j * 32 + l31, 0, fb0[j]);
+        }
+        for (int it = 0; it < nkt; ++it) {
+            const int cur = it & 1;
+            const float* a_lds = A4 + cur * ST;
+            const float* b_lds = B4 + cur * STB;
+            const float* a_nx = A4 + (cur ^ 1) * ST;
+            const float* b_nx = B4 + (cur ^ 1) * STB;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {           // phase 1: 2nd-half fragments of tile t behind its 1st-half MFMAs
+                if (kk < TM) frag(a_lds, A_KC, BM, wm * WTM + kk * 32 + l31, 1, fa1[kk < TM ? kk : 0]);
+                else if (kk - TM < TN) frag(b_lds, B_KC, BN, wn * WTN + (kk - TM) * 32 + l31, 1, fb1[kk - TM < TN ? kk - TM : 0]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][kk], fb0[j][kk], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();                           // tile t+1 landed (vmcnt(0)) and every read of tile t retired
+            const bool more1 = it + 1 < nkt, more2 = it + 2 < nkt;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {           // phase 2: DMA tile t+2 into the freed stage; frags of tile t+1
+                if (more2) {
+                    if (kk < PA) dma_a(kk < PA ? kk : 0, kt0 + it + 2, cur);
+                    else if (kk - PA < PB) dma_b(kk - PA < PB ? kk - PA : 0, kt0 + it + 2, cur);
+                }
+                if (more1) {
+                    if (kk < TM) frag(a_nx, A_KC, BM, wm * WTM + kk * 32 + l31, 0, fa0[kk < TM ? kk : 0]);
+                    else if (kk - TM < TN) frag(b_nx, B_KC, BN, wn * WTN + (kk - TM) * 32 + l31, 0, fb0[kk - TM < TN ? kk - TM : 0]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[i][kk], fb1[j][kk], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else
     if constexpr (PIPE == 0) {
         // Plain double buffering: global loads of tile t+1 issued before the MFMAs of tile t, LDS write after them,
         // one barrier at the end of the tile (fragment reads of the next tile are exposed after the barrier).
@@ -459,10 +583,14 @@ int launch_cfg(const GemmParams& p, bool va, bool vb, int splits, hipStream_t st
         }                                                                                                   \
         hipLaunchKernelGGL(kern, grid, block, lds, st, p);                                                  \
     } while (0)
-    if (va && vb) LSTC_GO(true, true);
-    else if (va) LSTC_GO(true, false);
-    else if (vb) LSTC_GO(false, true);
-    else LSTC_GO(false, false);
+    if constexpr ((PIPE & 15) == 4) {
+        LSTC_GO(true, true);               // LDS-DMA path: aligned operands only (caller guarantees va && vb)
+    } else {
+        if (va && vb) LSTC_GO(true, true);
+        else if (va) LSTC_GO(true, false);
+        else if (vb) LSTC_GO(false, true);
+        else LSTC_GO(false, false);
+    }
 #undef LSTC_GO
     return lstc_launch_status();
 }
@@ -477,7 +605,11 @@ int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipS
     //   3 = 128x128, pipeline + sched_group_barrier interleave (PIPE 2)           136 / 131 / 129
     //   8 = 128x128, pipeline + hand-interleaved k-step groups (PIPE 3)           138 / 136 / 138   <- default
     //   9 = 256x128, 4 waves x (128x64), one wave per SIMD, PIPE 3                125 / 124 / 134
+    //  10 = 128x128, LDS-DMA staging (global_load_lds, swizzled unpadded images)  105 / 119 / 134   (correct, slower:
+    //       the swizzled per-lane source addresses of K-contiguous operands and the one-iteration latency budget cost
+    //       more than the ds_write + staging registers they remove)
     //   2, 6, 5 = 256x128 with 8 waves (PIPE 1 / 2 / 0)                           115-126, never the best
+    //  12-15 = timing-only ablations of variant 8 (NT): no loads 142, no loads/LDS writes 146, +no barrier 146.5
     if (variant == 0) variant = 8;
     const int BM = (variant == 2 || variant == 5 || variant == 6 || variant == 9) ? 256 : 128, BN = 128;
     p.tilesM = (p.M + BM - 1) / BM;
@@ -491,6 +623,8 @@ int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipS
         case 7: return launch_cfg<128, 128, 2, 2, 1, A_KC, B_KC>(p, va, vb, splits, st);
         case 8: return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);
         case 9: return launch_cfg<256, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // 4 waves x (128x64): 1 wave/SIMD
+        case 10: case 11: if (va && vb && p.K % BK == 0) return launch_cfg<128, 128, 2, 2, 4, A_KC, B_KC>(p, true, true, splits, st);
+                 return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // LDS-DMA needs aligned rows, full K tiles
         case 12: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 1, A_KC, B_KC>(p, va, vb, splits, st); break;
         case 13: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 3, A_KC, B_KC>(p, va, vb, splits, st); break;
         case 14: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 7, A_KC, B_KC>(p, va, vb, splits, st); break;

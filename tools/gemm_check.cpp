@@ -138,6 +138,16 @@ int main(int argc, char** argv) {
         fails += check({256, 256, 128, 0, 0, 0, 1, 1});
         fails += check({256, 256, 128, 1, 0, 0, 1, 1});
         fails += check({384, 132, 260, 1, 0, 0, 1, 2});
+        // LDS-DMA variant (10): aligned leading dims (odd variant id would pad; 10 is even -> use sizes whose padded lds
+        // stay multiples of 4 is impossible, so these go through variant 11 = same kernel, no padding)
+        for (int tb : {1, 0}) {
+            fails += check({256, 256, 128, 0, tb, 0, 11, 1});
+            fails += check({300, 200, 96, 0, tb, ALL, 11, 1});
+            fails += check({1000, 260, 320, 0, tb, LSTC_EPI_BIAS | LSTC_EPI_RELU, 11, 1});
+        }
+        fails += check({256, 256, 128, 1, 0, 0, 11, 1});
+        fails += check({300, 200, 96, 1, 0, 0, 11, 1});
+        fails += check({384, 132, 512, 1, 0, 0, 11, 3});
         const int ALLB = LSTC_EPI_BIAS | LSTC_EPI_RELU | LSTC_EPI_RESIDUAL | LSTC_EPI_RELU_MASK | LSTC_EPI_ACCUM;
         for (int variant : {0, 1, 2}) {        // bf16-compute kernel; odd variant id -> aligned (vector) loads
             fails += check({300, 200, 100, 0, 1, 0, variant, 1, LSTC_BF16});
