@@ -286,6 +286,9 @@ int launch_cfg(const GemmParams& p, bool va, bool vb, int splits, hipStream_t st
 
 template <bool A_KC, bool B_KC>
 int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipStream_t st) {
+    // variant 0 = default: 256x128 (8 waves) except NT with deep K, where 128x128 measured faster (MI355X, LTN shapes,
+    // TFLOP/s 128x128 vs 256x128: NT K=2048 387/407, NT K=4096 395/374, NN 416/463, TN split-4 473/531); 1 = 128x128; 2 = 256x128
+    if (variant == 0) variant = (A_KC && B_KC && p.K >= 4096) ? 1 : 2;
     const int BM = variant == 2 ? 256 : 128, BN = 128;
     p.tilesM = (p.M + BM - 1) / BM;
     p.tilesN = (p.N + BN - 1) / BN;
