@@ -79,6 +79,10 @@ typedef struct LstcGemmDesc {
     int32_t split_k;                /* 0/1 = none; >1: K split over workgroups, partial sums added with f32 atomics
                                        into C, which the caller must have zeroed (only alpha epilogue allowed) */
     int32_t variant;                /* 0 = library default tile; >0 selects a tile variant (tuning / tests) */
+    int32_t batch;                  /* 0/1 = single problem; >1: `batch` independent problems of identical shape, problem z
+                                       uses A + z*batch_stride_a etc. (elements).  Per-head products of the last layer's
+                                       CLS attention (q_h W_k,h etc.).  Only alpha / ACCUM epilogues. */
+    int64_t batch_stride_a, batch_stride_b, batch_stride_c;
     const void* A;
     const void* B;
     void*       C;
@@ -132,6 +136,21 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream);
  * sequence ([N, ldq] / [N, ldo]) and probs is [N, H, S]. */
 int lstc_attn_cls_fwd(const LstcAttnDesc* d, void* stream);
 int lstc_attn_cls_bwd(const LstcAttnDesc* d, void* stream);
+
+/* Re-associated CLS attention of the last layer: with one query per (sequence, head) the key / value projections are
+ * never materialised — score[n,h,j] = u[n,h].x[n,j] with u = (q_h*scale) Wk_h, and o[n,h] = Wv_h (sum_j p[n,h,j] x[n,j]) —
+ * which removes the layer's two [N*S,d]x[d,H*dk] projection GEMMs and their four backward GEMMs (same reference lines
+ * as above: models/MultiHeadAttention.py:97-122 restricted to row 0).  U, Y: [N,H,d]; X, dX: [N,S,d]; W*, out, probs: [N,H,S].
+ *   lstc_cls_dot   out[n,h,j] = sum_c U[n,h,c] X[n,j,c];  mode 0 raw | 1 softmax (+dropout), probs saved |
+ *                  2 softmax/dropout backward: out = P*(dP - sum dP*P), dP = dot*keep
+ *   lstc_cls_wsum  Y[n,h,c]  = sum_j W[n,h,j] X[n,j,c]
+ *   lstc_cls_outer dX[n,j,c] = sum_h W1[n,h,j] U1[n,h,c] + W2[n,h,j] U2[n,h,c]
+ * Requirements: d % 4 == 0, 16-B aligned pointers, S <= 128, H <= 16. */
+int lstc_cls_dot(const float* U, const float* X, float* out, float* probs, int64_t N, int32_t S, int32_t H, int32_t d,
+                 int32_t mode, float dropout_p, uint64_t seed, void* stream);
+int lstc_cls_wsum(const float* W, const float* X, float* Y, int64_t N, int32_t S, int32_t H, int32_t d, void* stream);
+int lstc_cls_outer(const float* W1, const float* U1, const float* W2, const float* U2, float* dX, int64_t N, int32_t S,
+                   int32_t H, int32_t d, void* stream);
 
 /* ------------------------------------------------------------------- row-wise kernels */
 /* y = LayerNorm(x) * gamma + beta over the last dim (eps inside the sqrt, biased variance) —

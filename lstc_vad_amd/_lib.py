@@ -18,7 +18,8 @@ F32, BF16 = 0, 1
 EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_RESIDUAL, EPI_RELU_MASK, EPI_ACCUM, EPI_OUT_F32 = 1, 2, 4, 8, 16, 32, 64
 
 EXPORTS = (
-    "lstc_gemm", "lstc_attn_fwd", "lstc_attn_bwd", "lstc_attn_cls_fwd", "lstc_attn_cls_bwd", "lstc_layernorm_fwd", "lstc_layernorm_bwd",
+    "lstc_gemm", "lstc_attn_fwd", "lstc_attn_bwd", "lstc_attn_cls_fwd", "lstc_attn_cls_bwd", "lstc_cls_dot", "lstc_cls_wsum",
+    "lstc_cls_outer", "lstc_layernorm_fwd", "lstc_layernorm_bwd",
     "lstc_cls_concat_fwd", "lstc_cls_concat_bwd", "lstc_colsum", "lstc_dropout_apply", "lstc_dropout_mask",
     "lstc_head_out_fwd", "lstc_head_out_bwd", "lstc_vad_loss", "lstc_adagrad_step", "lstc_sqnorm_accum", "lstc_scale",
     "lstc_version", "lstc_strerror",
@@ -32,6 +33,7 @@ class GemmDesc(C.Structure):
                 ("dtype", C.c_int32), ("flags", C.c_int32),
                 ("alpha", C.c_float), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
                 ("ldr", C.c_int32), ("ld_relu", C.c_int32), ("split_k", C.c_int32), ("variant", C.c_int32),
+                ("batch", C.c_int32), ("batch_stride_a", C.c_int64), ("batch_stride_b", C.c_int64), ("batch_stride_c", C.c_int64),
                 ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
                 ("bias", C.c_void_p), ("residual", C.c_void_p), ("relu_src", C.c_void_p)]
 
@@ -76,6 +78,9 @@ def load():
         "lstc_attn_bwd": [C.POINTER(AttnDesc), vp],
         "lstc_attn_cls_fwd": [C.POINTER(AttnDesc), vp],
         "lstc_attn_cls_bwd": [C.POINTER(AttnDesc), vp],
+        "lstc_cls_dot": [vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, u64, vp],
+        "lstc_cls_wsum": [vp, vp, vp, i64, i32, i32, i32, vp],
+        "lstc_cls_outer": [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp],
         "lstc_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
         "lstc_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp],
         "lstc_cls_concat_fwd": [vp, vp, i64, vp, vp, vp, i64, i32, i32, vp],

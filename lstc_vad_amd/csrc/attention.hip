@@ -547,3 +547,243 @@ int lstc_attn_cls_bwd(const LstcAttnDesc* d, void* stream) {
 }
 
 }  // extern "C"
+
+// =====================================================================================================
+// Re-associated CLS attention for the last encoder layer ("assoc" path).
+// With ONE query per (sequence, head) the key/value projections never have to be materialised:
+//   score[n,h,j] = (q[n,h]*scale) . (Wk_h x[n,j]) = u[n,h] . x[n,j],        u[n,h] = (q[n,h]*scale) Wk_h   in R^d
+//   o[n,h]       = sum_j p[n,h,j] (Wv_h x[n,j])  = Wv_h xbar[n,h],           xbar[n,h] = sum_j p[n,h,j] x[n,j]
+// so the two [N*S, d] x [d, H*dk] projection GEMMs of the layer (and their four backward GEMMs, 5 TFLOP of the 43
+// per LTN step) are replaced by per-head [N, dk] x [dk, d] products (batched lstc_gemm) plus the three HBM-bound
+// streaming kernels below, each reading or writing X = [N, S, d] exactly once:
+//   cls_dot   : out[n,h,j] = sum_c U[n,h,c] X[n,j,c]      (+ softmax / dropout, or softmax backward, fused)
+//   cls_wsum  : Y[n,h,c]   = sum_j W[n,h,j] X[n,j,c]
+//   cls_outer : dX[n,j,c]  = sum_h W1[n,h,j] U1[n,h,c] + W2[n,h,j] U2[n,h,c]
+// One workgroup per sequence; U / W of the sequence sit in LDS, X streams through registers.
+// =====================================================================================================
+namespace {
+
+constexpr int ASSOC_MAXS = 128;
+
+// mode 0: raw dot products; 1: softmax over j, probs -> `probs`, dropout(probs) -> `out`;
+// mode 2: `out` = P * (dP - sum_j dP P), dP = dot * keep  (softmax + dropout backward; `probs` is an input)
+template <int HT>
+__global__ void __launch_bounds__(NT) cls_dot_kernel(const float* __restrict__ U, const float* __restrict__ X,
+                                                      float* __restrict__ out, float* __restrict__ probs, int S, int H, int d,
+                                                      int mode, DropKey dkey, int has_drop) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Ul = sm;                   // [H][d]
+    float* sc = sm + (size_t)H * d;   // [H][S]
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* Un = U + (size_t)n * H * d;
+    const float* Xn = X + (size_t)n * S * d;
+    const int d4 = d >> 2;
+    for (int i = threadIdx.x; i < H * d4; i += NT) reinterpret_cast<float4*>(Ul)[i] = reinterpret_cast<const float4*>(Un)[i];
+    __syncthreads();
+    for (int j = wave; j < S; j += NT / 64) {
+        float part[HT];
+#pragma unroll
+        for (int h = 0; h < HT; ++h) part[h] = 0.f;
+        for (int c = lane; c < d4; c += 64) {
+            const float4 x = reinterpret_cast<const float4*>(Xn + (size_t)j * d)[c];
+#pragma unroll
+            for (int h = 0; h < HT; ++h)
+                if (h < H) {
+                    const float4 u = reinterpret_cast<const float4*>(Ul + (size_t)h * d)[c];
+                    part[h] += (x.x * u.x + x.y * u.y) + (x.z * u.z + x.w * u.w);
+                }
+        }
+#pragma unroll
+        for (int h = 0; h < HT; ++h)
+            if (h < H) {
+                const float v = wave_sum(part[h]);
+                if (lane == 0) sc[h * S + j] = v;
+            }
+    }
+    __syncthreads();
+    for (int h = wave; h < H; h += NT / 64) {
+        float* row = sc + h * S;
+        float* orow = out + ((size_t)n * H + h) * S;
+        if (mode == 0) {
+            for (int j = lane; j < S; j += 64) orow[j] = row[j];
+            continue;
+        }
+        float* prow = probs + ((size_t)n * H + h) * S;
+        const uint32_t flat0 = ((uint32_t)n * H + h) * (uint32_t)(S * S);     // row 0 of the full [N,H,S,S] tensor
+        if (mode == 1) {
+            float v[2], m = -INFINITY;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = lane + 64 * jj;
+                v[jj] = j < S ? row[j] : -INFINITY;
+                m = fmaxf(m, v[jj]);
+            }
+            m = wave_max(m);
+            float s = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                v[jj] = (lane + 64 * jj < S) ? expf(v[jj] - m) : 0.f;
+                s += v[jj];
+            }
+            s = wave_sum(s);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = lane + 64 * jj;
+                if (j < S) {
+                    float pv = v[jj] / s;
+                    prow[j] = pv;
+                    if (has_drop) pv = drop_keep(flat0 + (uint32_t)j, dkey) ? pv * dkey.scale : 0.f;
+                    orow[j] = pv;
+                }
+            }
+        } else {
+            float pv[2], dp[2], rs = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = lane + 64 * jj;
+                pv[jj] = dp[jj] = 0.f;
+                if (j < S) {
+                    pv[jj] = prow[j];
+                    const float keep = has_drop ? (drop_keep(flat0 + (uint32_t)j, dkey) ? dkey.scale : 0.f) : 1.f;
+                    dp[jj] = row[j] * keep;
+                    rs += dp[jj] * pv[jj];
+                }
+            }
+            rs = wave_sum(rs);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = lane + 64 * jj;
+                if (j < S) orow[j] = pv[jj] * (dp[jj] - rs);
+            }
+        }
+    }
+}
+
+template <int HT>
+__global__ void __launch_bounds__(NT) cls_wsum_kernel(const float* __restrict__ W, const float* __restrict__ X,
+                                                       float* __restrict__ Y, int S, int H, int d) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // W[n]: [H][S]
+    const int n = blockIdx.x;
+    const float* Xn = X + (size_t)n * S * d;
+    for (int i = threadIdx.x; i < H * S; i += NT) sm[i] = W[(size_t)n * H * S + i];
+    __syncthreads();
+    const int d4 = d >> 2;
+    for (int c = threadIdx.x; c < d4; c += NT) {
+        float4 acc[HT];
+#pragma unroll
+        for (int h = 0; h < HT; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < S; ++j) {
+            const float4 x = reinterpret_cast<const float4*>(Xn + (size_t)j * d)[c];
+#pragma unroll
+            for (int h = 0; h < HT; ++h)
+                if (h < H) {
+                    const float w = sm[h * S + j];
+                    acc[h].x += w * x.x; acc[h].y += w * x.y; acc[h].z += w * x.z; acc[h].w += w * x.w;
+                }
+        }
+#pragma unroll
+        for (int h = 0; h < HT; ++h)
+            if (h < H) reinterpret_cast<float4*>(Y + ((size_t)n * H + h) * d)[c] = acc[h];
+    }
+}
+
+template <int HT>
+__global__ void __launch_bounds__(NT) cls_outer_kernel(const float* __restrict__ W1, const float* __restrict__ U1,
+                                                        const float* __restrict__ W2, const float* __restrict__ U2,
+                                                        float* __restrict__ dX, int S, int H, int d) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // W1[n], W2[n]: 2 x [H][S]
+    const int n = blockIdx.x;
+    for (int i = threadIdx.x; i < H * S; i += NT) {
+        sm[i] = W1[(size_t)n * H * S + i];
+        sm[H * S + i] = W2[(size_t)n * H * S + i];
+    }
+    __syncthreads();
+    const int d4 = d >> 2;
+    float* Dn = dX + (size_t)n * S * d;
+    for (int c = threadIdx.x; c < d4; c += NT) {
+        float4 u1[HT], u2[HT];
+#pragma unroll
+        for (int h = 0; h < HT; ++h) {
+            u1[h] = u2[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (h < H) {
+                u1[h] = reinterpret_cast<const float4*>(U1 + ((size_t)n * H + h) * d)[c];
+                u2[h] = reinterpret_cast<const float4*>(U2 + ((size_t)n * H + h) * d)[c];
+            }
+        }
+        for (int j = 0; j < S; ++j) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int h = 0; h < HT; ++h)
+                if (h < H) {
+                    const float a = sm[h * S + j], b = sm[H * S + h * S + j];
+                    o.x += a * u1[h].x + b * u2[h].x; o.y += a * u1[h].y + b * u2[h].y;
+                    o.z += a * u1[h].z + b * u2[h].z; o.w += a * u1[h].w + b * u2[h].w;
+                }
+            reinterpret_cast<float4*>(Dn + (size_t)j * d)[c] = o;
+        }
+    }
+}
+
+int assoc_check(const void* a, const void* b, const void* c, int64_t N, int S, int H, int d) {
+    if (!a || !b || !c) return LSTC_E_NULL;
+    if (N <= 0 || S < 1 || H <= 0 || d <= 0) return LSTC_E_SHAPE;
+    if (S > ASSOC_MAXS || H > 16) return LSTC_E_RANGE;
+    if (d % 4 != 0 || !aligned16(a) || !aligned16(b) || !aligned16(c)) return LSTC_E_ALIGN;
+    return 0;
+}
+
+#define LSTC_H_DISPATCH(KERN, H, ...)                                            \
+    do {                                                                         \
+        if ((H) <= 2) hipLaunchKernelGGL(KERN<2>, __VA_ARGS__);                  \
+        else if ((H) <= 4) hipLaunchKernelGGL(KERN<4>, __VA_ARGS__);             \
+        else if ((H) <= 8) hipLaunchKernelGGL(KERN<8>, __VA_ARGS__);             \
+        else hipLaunchKernelGGL(KERN<16>, __VA_ARGS__);                          \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int lstc_cls_dot(const float* U, const float* X, float* out, float* probs, int64_t N, int32_t S, int32_t H, int32_t d,
+                 int32_t mode, float dropout_p, uint64_t seed, void* stream) {
+    int rc = assoc_check(U, X, out, N, S, H, d);
+    if (rc) return rc;
+    if (mode < 0 || mode > 2) return LSTC_E_UNSUPPORTED;
+    if (mode != 0 && !probs) return LSTC_E_NULL;
+    if ((uint64_t)N * H * S * S > 0xffffffffull) return LSTC_E_RANGE;
+    const size_t lds = ((size_t)H * d + (size_t)H * S) * sizeof(float);
+    if (lds > 96 * 1024) return LSTC_E_RANGE;
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cls_dot_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cls_dot_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cls_dot_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cls_dot_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        once = true;
+    }
+    const DropKey dk = make_drop_key(dropout_p, seed);
+    const int has_drop = dropout_p > 0.f;
+    LSTC_H_DISPATCH(cls_dot_kernel, H, dim3((unsigned)N), dim3(NT), lds, (hipStream_t)stream, U, X, out, probs, S, H, d, mode, dk, has_drop);
+    return lstc_launch_status();
+}
+
+int lstc_cls_wsum(const float* W, const float* X, float* Y, int64_t N, int32_t S, int32_t H, int32_t d, void* stream) {
+    int rc = assoc_check(X, Y, X, N, S, H, d);
+    if (rc) return rc;
+    if (!W) return LSTC_E_NULL;
+    const size_t lds = (size_t)H * S * sizeof(float);
+    LSTC_H_DISPATCH(cls_wsum_kernel, H, dim3((unsigned)N), dim3(NT), lds, (hipStream_t)stream, W, X, Y, S, H, d);
+    return lstc_launch_status();
+}
+
+int lstc_cls_outer(const float* W1, const float* U1, const float* W2, const float* U2, float* dX, int64_t N, int32_t S,
+                   int32_t H, int32_t d, void* stream) {
+    int rc = assoc_check(U1, U2, dX, N, S, H, d);
+    if (rc) return rc;
+    if (!W1 || !W2) return LSTC_E_NULL;
+    const size_t lds = (size_t)2 * H * S * sizeof(float);
+    LSTC_H_DISPATCH(cls_outer_kernel, H, dim3((unsigned)N), dim3(NT), lds, (hipStream_t)stream, W1, U1, W2, U2, dX, S, H, d);
+    return lstc_launch_status();
+}
+
+}  // extern "C"

@@ -34,8 +34,9 @@ struct GemmParams {
     int flags;
     float alpha;
     DropKey dk;
-    int tilesM, tilesN;
+    int tilesM, tilesN, batch;
     int ktiles, ktiles_per_split;
+    long long batch_stride_a, batch_stride_b, batch_stride_c;   // elements between consecutive problems of a batch (grid.z)
 };
 
 template <int R>
@@ -144,7 +145,11 @@ __device__ __forceinline__ bf16x8 read_frag(const __bf16* __restrict__ lds, int 
 }
 
 template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC, bool VA, bool VB>
-__global__ void __launch_bounds__(WGM* WGN * 64) gemm_bf16c_kernel(const GemmParams p) {
+__global__ void __launch_bounds__(WGM* WGN * 64) gemm_bf16c_kernel(const GemmParams p_in) {
+    GemmParams p = p_in;
+    p.A += (size_t)blockIdx.z * p.batch_stride_a;
+    p.B += (size_t)blockIdx.z * p.batch_stride_b;
+    p.C += (size_t)blockIdx.z * p.batch_stride_c;
     constexpr int NT = WGM * WGN * 64;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -264,7 +269,7 @@ template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC>
 int launch_cfg(const GemmParams& p, bool va, bool vb, int splits, hipStream_t st) {
     constexpr int NT = WGM * WGN * 64;
     constexpr size_t lds = (size_t)(2 * stage_elems<BM, A_KC>() + 2 * stage_elems<BN, B_KC>()) * sizeof(__bf16);
-    dim3 grid(p.tilesM * p.tilesN, splits), block(NT);
+    dim3 grid(p.tilesM * p.tilesN, splits, p.batch), block(NT);
 #define LSTC_GO(VA, VB)                                                                                          \
     do {                                                                                                         \
         auto kern = gemm_bf16c_kernel<BM, BN, WGM, WGN, A_KC, B_KC, VA, VB>;                                     \
@@ -316,11 +321,17 @@ int lstc_gemm_bf16_impl(const LstcGemmDesc* d, hipStream_t st) {
     p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
     p.ldr = d->ldr; p.ld_relu = d->ld_relu; p.flags = d->flags; p.alpha = d->alpha;
     p.dk = make_drop_key(d->dropout_p, d->dropout_seed);
+    p.batch = d->batch > 1 ? d->batch : 1;
+    p.batch_stride_a = d->batch_stride_a; p.batch_stride_b = d->batch_stride_b; p.batch_stride_c = d->batch_stride_c;
+    if (p.batch > 1 && (d->flags & (LSTC_EPI_BIAS | LSTC_EPI_RESIDUAL | LSTC_EPI_RELU_MASK | LSTC_EPI_DROPOUT))) return LSTC_E_UNSUPPORTED;
+    if (p.batch > 65535) return LSTC_E_RANGE;
     p.ktiles = (d->K + BK - 1) / BK;
     p.ktiles_per_split = (p.ktiles + splits - 1) / splits;
     const int eff_splits = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
-    const bool va = aligned16(d->A) && (d->lda % 4 == 0) && ((d->transA ? d->M : d->K) % 4 == 0);
-    const bool vb = aligned16(d->B) && (d->ldb % 4 == 0) && ((d->transB ? d->K : d->N) % 4 == 0);
+    const bool va = aligned16(d->A) && (d->lda % 4 == 0) && ((d->transA ? d->M : d->K) % 4 == 0) &&
+                    (p.batch <= 1 || d->batch_stride_a % 4 == 0);
+    const bool vb = aligned16(d->B) && (d->ldb % 4 == 0) && ((d->transB ? d->K : d->N) % 4 == 0) &&
+                    (p.batch <= 1 || d->batch_stride_b % 4 == 0);
     if (!d->transA && d->transB) return launch_layout<true, true>(p, va, vb, eff_splits, d->variant & 15, st);
     if (!d->transA && !d->transB) return launch_layout<true, false>(p, va, vb, eff_splits, d->variant & 15, st);
     return launch_layout<false, false>(p, va, vb, eff_splits, d->variant & 15, st);

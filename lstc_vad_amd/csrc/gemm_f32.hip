@@ -43,8 +43,9 @@ struct GemmParams {
     int flags;
     float alpha;
     DropKey dk;
-    int tilesM, tilesN;
+    int tilesM, tilesN, batch;
     int ktiles, ktiles_per_split;
+    long long batch_stride_a, batch_stride_b, batch_stride_c;   // elements between consecutive problems of a batch (grid.z)
     int debug;     // timing-only ablations (tools/gemm_check): 1 = no global loads in the loop, 2 = no LDS writes, 4 = no barrier
 };
 
@@ -170,7 +171,11 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int row
 }
 
 template <int BM, int BN, int WGM, int WGN, int PIPE_ABL, bool A_KC, bool B_KC, bool VA, bool VB>
-__global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParams p) {
+__global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParams p_in) {
+    GemmParams p = p_in;
+    p.A += (size_t)blockIdx.z * p.batch_stride_a;
+    p.B += (size_t)blockIdx.z * p.batch_stride_b;
+    p.C += (size_t)blockIdx.z * p.batch_stride_c;
     constexpr int PIPE = PIPE_ABL & 15;
     constexpr int ABL = PIPE_ABL >> 4;     // timing-only ablation of the PIPE 3 body: 1 no global loads, 2 no LDS writes, 4 no barrier
     constexpr int NT = WGM * WGN * 64;
@@ -571,7 +576,7 @@ template <int BM, int BN, int WGM, int WGN, int PIPE, bool A_KC, bool B_KC>
 int launch_cfg(const GemmParams& p, bool va, bool vb, int splits, hipStream_t st) {
     constexpr int NT = WGM * WGN * 64;
     constexpr size_t lds = (size_t)(2 * stage_floats<BM, A_KC>() + 2 * stage_floats<BN, B_KC>()) * sizeof(float);
-    dim3 grid(p.tilesM * p.tilesN, splits), block(NT);
+    dim3 grid(p.tilesM * p.tilesN, splits, p.batch), block(NT);
 #define LSTC_GO(VA, VB)                                                                                     \
     do {                                                                                                    \
         auto kern = gemm_f32_kernel<BM, BN, WGM, WGN, PIPE, A_KC, B_KC, VA, VB>;                                  \
@@ -622,7 +627,7 @@ int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipS
         case 5: return launch_cfg<256, 128, 4, 2, 0, A_KC, B_KC>(p, va, vb, splits, st);
         case 7: return launch_cfg<128, 128, 2, 2, 1, A_KC, B_KC>(p, va, vb, splits, st);
         case 8: return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);
-        case 9: return launch_cfg<256, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // 4 waves x (128x64): 1 wave/SIMD
+        case 9: return launch_cfg<256, 128, 4, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // 8 waves x (64x64), PIPE 3
         case 10: case 11: if (va && vb && p.K % BK == 0) return launch_cfg<128, 128, 2, 2, 4, A_KC, B_KC>(p, true, true, splits, st);
                  return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // LDS-DMA needs aligned rows, full K tiles
         case 12: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 1, A_KC, B_KC>(p, va, vb, splits, st); break;
@@ -653,14 +658,20 @@ int lstc_gemm_f32_impl(const LstcGemmDesc* d, hipStream_t st) {
     p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
     p.ldr = d->ldr; p.ld_relu = d->ld_relu; p.flags = d->flags; p.alpha = d->alpha;
     p.dk = make_drop_key(d->dropout_p, d->dropout_seed);
+    p.batch = d->batch > 1 ? d->batch : 1;
+    p.batch_stride_a = d->batch_stride_a; p.batch_stride_b = d->batch_stride_b; p.batch_stride_c = d->batch_stride_c;
+    if (p.batch > 1 && (d->flags & (LSTC_EPI_BIAS | LSTC_EPI_RESIDUAL | LSTC_EPI_RELU_MASK | LSTC_EPI_DROPOUT))) return LSTC_E_UNSUPPORTED;
+    if (p.batch > 65535) return LSTC_E_RANGE;
     p.ktiles = (d->K + BK - 1) / BK;
     p.ktiles_per_split = (p.ktiles + splits - 1) / splits;
     p.debug = d->variant >> 4;
     const int eff_splits = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
     // float4 global loads need 16-B aligned rows; the contiguous extent must be a multiple of 4 so a
     // float4 is entirely inside or outside the matrix.
-    const bool va = aligned16(d->A) && (d->lda % 4 == 0) && ((d->transA ? d->M : d->K) % 4 == 0);
-    const bool vb = aligned16(d->B) && (d->ldb % 4 == 0) && ((d->transB ? d->K : d->N) % 4 == 0);
+    const bool va = aligned16(d->A) && (d->lda % 4 == 0) && ((d->transA ? d->M : d->K) % 4 == 0) &&
+                    (p.batch <= 1 || d->batch_stride_a % 4 == 0);
+    const bool vb = aligned16(d->B) && (d->ldb % 4 == 0) && ((d->transB ? d->K : d->N) % 4 == 0) &&
+                    (p.batch <= 1 || d->batch_stride_b % 4 == 0);
     if (!d->transA && d->transB) return launch_layout<true, true>(p, va, vb, eff_splits, d->variant, st);
     if (!d->transA && !d->transB) return launch_layout<true, false>(p, va, vb, eff_splits, d->variant, st);
     return launch_layout<false, false>(p, va, vb, eff_splits, d->variant, st);

@@ -311,6 +311,129 @@ class MHAFunction(torch.autograd.Function):
         return dx, dwq, dwk, dwv, dwfc, dln_w, dln_b, dtable, None, None
 
 
+def gemm_batched(a, b, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, batch, sa, sb, sc, alpha=1.0, a_off=0, b_off=0, c_off=0):
+    """``batch`` independent GEMMs of one shape in one launch (grid.z): problem z uses a + z*sa, b + z*sb, c + z*sc
+    (element strides).  ``a``/``b``/``c`` are the underlying tensors; leading dimensions are given explicitly because
+    the per-head operands are column slices of wider matrices."""
+    d = GemmDesc()
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, lda, ldb, ldc
+    d.transA, d.transB, d.dtype, d.flags, d.alpha = int(trans_a), int(trans_b), _compute_dtype, 0, float(alpha)
+    d.batch, d.batch_stride_a, d.batch_stride_b, d.batch_stride_c = batch, sa, sb, sc
+    d.A, d.B, d.C = dev_ptr(a) + 4 * a_off, dev_ptr(b) + 4 * b_off, dev_ptr(c) + 4 * c_off
+    if _gemm_prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().lstc_gemm(C.byref(d), stream_ptr()), "lstc_gemm(batched)")
+        e1.record()
+        _gemm_prof.append((2.0 * M * N * K * batch, e0, e1))
+        return c
+    check(_lib.load().lstc_gemm(C.byref(d), stream_ptr()), "lstc_gemm(batched)")
+    return c
+
+
+def cls_dot(u, x3, mode, probs=None, p_drop=0.0, seed=0):
+    N, S, dm = x3.shape
+    H = u.shape[1]
+    out = torch.empty((N, H, S), device=u.device, dtype=torch.float32)
+    if mode == 1:
+        probs = torch.empty((N, H, S), device=u.device, dtype=torch.float32)
+    check(_lib.load().lstc_cls_dot(dev_ptr(u), dev_ptr(x3), dev_ptr(out), dev_ptr(probs), N, S, H, dm, mode, float(p_drop),
+                                   int(seed), stream_ptr()), "lstc_cls_dot")
+    return out, probs
+
+
+def cls_wsum(w, x3):
+    N, S, dm = x3.shape
+    H = w.shape[1]
+    y = torch.empty((N, H, dm), device=w.device, dtype=torch.float32)
+    check(_lib.load().lstc_cls_wsum(dev_ptr(w), dev_ptr(x3), dev_ptr(y), N, S, H, dm, stream_ptr()), "lstc_cls_wsum")
+    return y
+
+
+def cls_outer(w1, u1, w2, u2, N, S, dm):
+    H = w1.shape[1]
+    dx = torch.empty((N, S, dm), device=w1.device, dtype=torch.float32)
+    check(_lib.load().lstc_cls_outer(dev_ptr(w1), dev_ptr(u1), dev_ptr(w2), dev_ptr(u2), dev_ptr(dx), N, S, H, dm,
+                                     stream_ptr()), "lstc_cls_outer")
+    return dx
+
+
+class MHAClsAssocFunction(torch.autograd.Function):
+    """Last-layer CLS attention with the key / value projections re-associated away (csrc/attention.hip, "assoc"):
+        u[n,h]  = (q[n,h] / sqrt(dk)) Wk_h          score[n,h,j] = u[n,h] . x[n,j]        (no K = X Wk^T GEMM)
+        xb[n,h] = sum_j Pd[n,h,j] x[n,j]            o[n,h]       = Wv_h xb[n,h]           (no V = X Wv^T GEMM)
+    Exactly models/MultiHeadAttention.py:93-126 for query row 0 — same values up to float re-association — but the two
+    [N*S, d] x [d, H*dk] projections and their four backward GEMMs (5 of the 43 TFLOP of an LTN step) become per-head
+    [N, dk] x [dk, d] products (one batched launch each) plus three passes over X."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, wfc, ln_w, ln_b, table, cfg):
+        N, S, dm = x.shape
+        H, dk, dv = cfg["n_head"], cfg["d_k"], cfg["d_v"]
+        training = cfg["training"]
+        p_attn = cfg["attn_dropout"] if training else 0.0
+        p_fc = cfg["fc_dropout"] if training else 0.0
+        ctx.table_shape = None if table is None else tuple(table.shape)
+        x = x.contiguous()
+        xc = x[:, 0, :]
+        scale = 1.0 / (dk ** 0.5)
+        qc = gemm(xc, wq, trans_b=True)                                                   # [N, H*dk]
+        u = torch.empty((N, H, dm), device=x.device, dtype=torch.float32)
+        gemm_batched(qc, wk, u, N, dm, dk, H * dk, dm, H * dm, False, False, H, dk, dk * dm, dm, alpha=scale)
+        seed_a = next_seed() if p_attn > 0 else 0
+        seed_f = next_seed() if p_fc > 0 else 0
+        if p_attn > 0:
+            _note(cfg["site"] + "attn_dropout#cls", p_attn, seed_a, (N, H, S, S))
+        if p_fc > 0:
+            _note(cfg["site"] + "dropout#cls", p_fc, seed_f, (N, dm))
+        pd, probs = cls_dot(u, x, 1, None, p_attn, seed_a)                                # dropped probs, probs
+        xb = cls_wsum(pd, x)                                                              # [N, H, d]
+        oc = torch.empty((N, H * dv), device=x.device, dtype=torch.float32)
+        gemm_batched(xb, wv, oc, N, dv, dm, H * dm, dm, H * dv, False, True, H, dm, dv * dm, dv)
+        y = gemm(oc, wfc, trans_b=True, dropout=(p_fc, seed_f), residual=xc)
+        if cfg["layer_norm"]:
+            z, mean, rstd = layernorm_fwd(y, ln_w, ln_b, 1e-6)
+        else:
+            z, mean, rstd = y, None, None
+        ctx.cfg = dict(cfg, N=N, S=S, p_attn=p_attn, p_fc=p_fc, seed_a=seed_a, seed_f=seed_f, scale=scale)
+        ctx.save_for_backward(x, wq, wk, wv, wfc, ln_w, qc, u, pd, probs, xb, oc, y if cfg["layer_norm"] else None, mean, rstd)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, wq, wk, wv, wfc, ln_w, qc, u, pd, probs, xb, oc, y, mean, rstd = ctx.saved_tensors
+        c = ctx.cfg
+        N, S, H, dk, dv, scale = c["N"], c["S"], c["n_head"], c["d_k"], c["d_v"], c["scale"]
+        dm = x.shape[-1]
+        xc = x[:, 0, :]
+        dz = dz.contiguous()
+        dln_w = dln_b = None
+        if c["layer_norm"]:
+            dy, dln_w, dln_b = layernorm_bwd(dz, y, ln_w, mean, rstd)
+        else:
+            dy = dz
+        df = dropout_apply(dy, c["p_fc"], c["seed_f"]) if c["p_fc"] > 0 else dy
+        dwfc = wgrad(df, oc)
+        doc = gemm(df, wfc)                                                               # [N, H*dv]
+        dxb = torch.empty((N, H, dm), device=x.device, dtype=torch.float32)
+        gemm_batched(doc, wv, dxb, N, dm, dv, H * dv, dm, H * dm, False, False, H, dv, dv * dm, dm)
+        dwv = torch.empty_like(wv)
+        gemm_batched(doc, xb, dwv, dv, dm, N, H * dv, H * dm, dm, True, False, H, dv, dm, dv * dm)
+        ds, _ = cls_dot(dxb, x, 2, probs, c["p_attn"], c["seed_a"])                       # d(logit) [N,H,S]
+        du = cls_wsum(ds, x)                                                              # [N, H, d]
+        dqc = torch.empty_like(qc)
+        gemm_batched(du, wk, dqc, N, dk, dm, H * dm, dm, H * dk, False, True, H, dm, dk * dm, dk, alpha=scale)
+        dwk = torch.empty_like(wk)
+        gemm_batched(qc, du, dwk, dk, dm, N, H * dk, H * dm, dm, True, False, H, dk, dm, dk * dm, alpha=scale)
+        dwq = wgrad(dqc, xc)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = cls_outer(pd, dxb, ds, u, N, S, dm)                                      # K/V paths, every token
+            gemm(dqc, wq, out=dx[:, 0, :], accumulate=True, residual=dy)                  # CLS rows: + dQ Wq + residual
+        dtable = None if ctx.table_shape is None else torch.zeros(ctx.table_shape, device=x.device, dtype=torch.float32)
+        return dx, dwq, dwk, dwv, dwfc, dln_w, dln_b, dtable, None
+
+
 def attn_cls_fwd(qc, k, v, N, S, H, dk, dv, p_drop, seed):
     oc = torch.empty((N, H * dv), device=qc.device, dtype=torch.float32)
     probs = torch.empty((N, H, S), device=qc.device, dtype=torch.float32)

@@ -7,7 +7,7 @@ arithmetic runs in ``MHAFunction`` (GEMM -> fused attention core -> GEMM epilogu
 import torch
 from torch import nn
 
-from ..functional import MHAClsFunction, MHAFunction
+from ..functional import MHAClsAssocFunction, MHAClsFunction, MHAFunction
 
 
 def relative_position_index_3d(window_depth: int, window_size: int) -> torch.Tensor:
@@ -58,13 +58,17 @@ class MultiHeadAttention(nn.Module):
             self.register_buffer("relative_position_index", relative_position_index_2d(window_size))
             nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
         self._site = ""
+        self.cls_assoc = True          # last-layer CLS attention without materialising K / V (see functional)
 
     def forward_cls(self, x):
         """CLS-query attention for the last encoder layer: x [N, S, d] -> [N, d] (== ``forward(x, x, x)[0][:, 0]``)."""
         cfg = dict(n_head=self.n_head, d_k=self.d_k, d_v=self.d_v, layer_norm=self.layerNorm_flag,
                    attn_dropout=self.attn_dropout.p, fc_dropout=self.dropout.p, training=self.training,
                    site=self._site)
-        return MHAClsFunction.apply(x, self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.fc.weight,
+        # re-associated form (no K/V projection GEMMs) whenever its alignment rules hold, else the K/V-projecting form
+        fn = MHAClsAssocFunction if (self.d_model % 4 == 0 and self.n_head <= 16 and x.shape[1] <= 128
+                                     and self.n_head * self.d_model <= 16384 and self.cls_assoc) else MHAClsFunction
+        return fn.apply(x, self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.fc.weight,
                                     self.layer_norm.weight if self.layerNorm_flag else None,
                                     self.layer_norm.bias if self.layerNorm_flag else None,
                                     self.relative_position_bias_table if (self.relative_pe or self.relative_pe_2D) else None,

