@@ -99,6 +99,8 @@ def main():
                     help="GEMM compute type: fp32 = exact-f32 MFMA (headline, parity mode); bf16 = bf16 MFMA on f32 storage")
     ap.add_argument("--h2d", action="store_true", help="also time the step with the batch arriving from pinned host memory "
                     "every step through lstc_vad_amd.feed.PinnedFeeder (reported as pcie_inclusive, never as value)")
+    ap.add_argument("--naive-last-layer", action="store_true", help="evaluate the last encoder layer for every token like the "
+                    "reference (A/B only: the default skips rows/projections nobody reads, with identical results)")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
@@ -135,7 +137,7 @@ def main():
     enc = Encoder(n_layers=3, n_head=8, d_k=256, d_v=256, MHA_attn_dropout=drops[0], MHA_fc_dropout=drops[1],
                   FFN_dropout=drops[2], weight_init=(mode != "LTN"), **ekw).to(dev).train()
     head = (Classifier(d, drops[3]) if mode == "LTN" else Regressor(d, drops[3])).to(dev).train()
-    ts = TrainStep(args, mode, enc, head, lr_encoder=1e-4, lr_head=1e-2, weight_decay=1e-3)
+    ts = TrainStep(args, mode, enc, head, lr_encoder=1e-4, lr_head=1e-2, weight_decay=1e-3, cls_only=not a.naive_last_layer)
 
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)      # every rank its own videos
     Lfeat = L if mode == "LTN" else 1
@@ -219,7 +221,8 @@ def main():
                "config": {"workload": f"{a.config}: {mode} full training step (fwd+loss+bwd+"
                                       f"{'allreduce+' if world > 1 else ''}Adagrad), per GPU B={2 * bs} videos x T={pn} parts x "
                                       f"L={L} snippets x P={P} patches, d_model={d}, n_hidden={ekw['d_inner']}, S={S}, "
-                                      f"{nseq} sequences/GPU/step, dropout={'off' if a.no_dropout else 'reference rates'}",
+                                      f"{nseq} sequences/GPU/step, dropout={'off' if a.no_dropout else 'reference rates'}, last layer: "
+                                      f"{'all tokens (naive)' if a.naive_last_layer else 'CLS token only, K/V projections re-associated (exact)'}",
                           "global_videos": 2 * bs * world, "parallelism": f"dp{world}"},
                "loss": scal[0], "roofline": roof}
         if pcie:

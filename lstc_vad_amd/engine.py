@@ -20,7 +20,10 @@ from .optim import Adagrad, clip_grad_norm_
 
 class TrainStep:
     def __init__(self, args, mode: str, encoder, head, lr_encoder: float, lr_head: float, weight_decay: float,
-                 group=None):
+                 group=None, cls_only: bool = True):
+        # cls_only=False evaluates the last encoder layer for every token like the reference does (its extra rows are
+        # never read); kept for A/B measurements — results are identical (tests/test_hip_parity.py)
+        self.cls_only = cls_only
         self.args, self.mode, self.encoder, self.head, self.group = args, mode, encoder, head, group
         self.optimizer = Adagrad([{"params": encoder.parameters(), "lr": lr_encoder},
                                   {"params": head.parameters(), "lr": lr_head}], weight_decay=weight_decay)
@@ -40,7 +43,10 @@ class TrainStep:
         a, d = self.args, norm_feats.shape[-1]
         tokens = a.part_len * a.n_patch if self.mode == "LTN" else a.n_patch
         # normal sequences first, abnormal second (A1); the cat itself is fused into the CLS-concat kernel
-        cls = self.encoder.forward_cls(norm_feats.float().reshape(-1, tokens, d), abnorm_feats.float().reshape(-1, tokens, d))
+        if self.cls_only:
+            cls = self.encoder.forward_cls(norm_feats.float().reshape(-1, tokens, d), abnorm_feats.float().reshape(-1, tokens, d))
+        else:
+            cls = self.encoder(self.sequences(norm_feats, abnorm_feats))[:, 0, :]
         outputs = self.head(cls)
         loss, scalars = training_loss(self.args, self.mode, outputs, abnorm_labs, group=self.group)
         return loss, scalars, outputs
