@@ -25,6 +25,8 @@ class TrainStep:
         # never read); kept for A/B measurements — results are identical (tests/test_hip_parity.py)
         self.cls_only = cls_only
         self.args, self.mode, self.encoder, self.head, self.group = args, mode, encoder, head, group
+        # MultiHeadAttention.fuse_qkv_() (one projection / dW / dX GEMM per layer instead of three) is available but
+        # not applied: measured 304.0 vs 301.3 ms per LTN step — the 128x128-tile GEMMs gain nothing from being wider.
         self.optimizer = Adagrad([{"params": encoder.parameters(), "lr": lr_encoder},
                                   {"params": head.parameters(), "lr": lr_head}], weight_decay=weight_decay)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1

@@ -230,8 +230,8 @@ def attn_fwd(q, k, v, N, S, H, dk, dv, table, index, p_drop, seed):
     return o, probs
 
 
-def attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, p_drop, seed):
-    dq, dk_, dv_ = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+def attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, p_drop, seed, out=None):
+    dq, dk_, dv_ = out if out is not None else (torch.empty_like(q), torch.empty_like(k), torch.empty_like(v))
     d = AttnDesc()
     d.N, d.S, d.H, d.dk, d.dv = N, S, H, dk, dv
     d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), do.stride(0)
@@ -250,6 +250,21 @@ def attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, p_drop, seed):
     return dq, dk_, dv_, dtable
 
 
+def _fused_qkv_weight(wq, wk, wv):
+    """[rows_q + rows_k + rows_v, d] view over the three projection weights when they are consecutive slices of one
+    buffer (MultiHeadAttention.fuse_qkv_), else None."""
+    try:
+        same = wq.untyped_storage().data_ptr() == wk.untyped_storage().data_ptr() == wv.untyped_storage().data_ptr()
+    except Exception:
+        return None
+    if not (same and wq.is_contiguous() and wk.is_contiguous() and wv.is_contiguous() and wq.shape[1] == wk.shape[1] == wv.shape[1]):
+        return None
+    if wk.storage_offset() != wq.storage_offset() + wq.numel() or wv.storage_offset() != wk.storage_offset() + wk.numel():
+        return None
+    rows = wq.shape[0] + wk.shape[0] + wv.shape[0]
+    return torch.as_strided(wq.detach(), (rows, wq.shape[1]), (wq.shape[1], 1), wq.storage_offset())
+
+
 # ------------------------------------------------------------------------------ autograd Functions
 class MHAFunction(torch.autograd.Function):
     """models/MultiHeadAttention.py:93-132 (self-attention) as one autograd node.
@@ -265,9 +280,14 @@ class MHAFunction(torch.autograd.Function):
         p_attn = cfg["attn_dropout"] if training else 0.0
         p_fc = cfg["fc_dropout"] if training else 0.0
         x2 = x.contiguous().view(N * S, dm)
-        q = gemm(x2, wq, trans_b=True)
-        k = gemm(x2, wk, trans_b=True)
-        v = gemm(x2, wv, trans_b=True)
+        wqkv = _fused_qkv_weight(wq, wk, wv)
+        if wqkv is not None:       # w_qs / w_ks / w_vs live in one buffer (MultiHeadAttention.fuse_qkv_): one GEMM, X read once
+            qkv = gemm(x2, wqkv, trans_b=True)
+            q, k, v = qkv[:, : H * dk], qkv[:, H * dk: 2 * H * dk], qkv[:, 2 * H * dk:]
+        else:
+            q = gemm(x2, wq, trans_b=True)
+            k = gemm(x2, wk, trans_b=True)
+            v = gemm(x2, wv, trans_b=True)
         seed_a = next_seed() if p_attn > 0 else 0
         seed_f = next_seed() if p_fc > 0 else 0
         if p_attn > 0:
@@ -300,14 +320,25 @@ class MHAFunction(torch.autograd.Function):
         df = dropout_apply(dy, c["p_fc"], c["seed_f"]) if c["p_fc"] > 0 else dy
         dwfc = wgrad(df, o)
         do = gemm(df, wfc)                                   # [M, H*dv]
-        dq, dk_, dv_, dtable = attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, c["p_attn"], c["seed_a"])
-        dwq, dwk, dwv = wgrad(dq, x2), wgrad(dk_, x2), wgrad(dv_, x2)
+        wqkv = _fused_qkv_weight(wq, wk, wv)
         dx = None
-        if ctx.needs_input_grad[0]:
-            dx = gemm(dq, wq, residual=dy)
-            gemm(dk_, wk, out=dx, accumulate=True)
-            gemm(dv_, wv, out=dx, accumulate=True)
-            dx = dx.view(N, S, -1)
+        if wqkv is not None:
+            rq, rk = wq.shape[0], wk.shape[0]
+            dqkv = torch.empty((N * S, wqkv.shape[0]), device=x2.device, dtype=torch.float32)
+            outs = (dqkv[:, :rq], dqkv[:, rq: rq + rk], dqkv[:, rq + rk:])
+            _, _, _, dtable = attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, c["p_attn"], c["seed_a"], out=outs)
+            dwqkv = wgrad(dqkv, x2)                               # one TN GEMM for the three weight gradients
+            dwq, dwk, dwv = dwqkv[:rq], dwqkv[rq: rq + rk], dwqkv[rq + rk:]
+            if ctx.needs_input_grad[0]:
+                dx = gemm(dqkv, wqkv, residual=dy).view(N, S, -1)   # dQ Wq + dK Wk + dV Wv + residual in one GEMM (K = 3*H*dk)
+        else:
+            dq, dk_, dv_, dtable = attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, c["p_attn"], c["seed_a"])
+            dwq, dwk, dwv = wgrad(dq, x2), wgrad(dk_, x2), wgrad(dv_, x2)
+            if ctx.needs_input_grad[0]:
+                dx = gemm(dq, wq, residual=dy)
+                gemm(dk_, wk, out=dx, accumulate=True)
+                gemm(dv_, wv, out=dx, accumulate=True)
+                dx = dx.view(N, S, -1)
         return dx, dwq, dwk, dwv, dwfc, dln_w, dln_b, dtable, None, None
 
 

@@ -60,6 +60,21 @@ class MultiHeadAttention(nn.Module):
         self._site = ""
         self.cls_assoc = True          # last-layer CLS attention without materialising K / V (see functional)
 
+    def fuse_qkv_(self):
+        """Re-home w_qs / w_ks / w_vs as consecutive row blocks of ONE [2*H*dk + H*dv, d_model] buffer (the Parameters,
+        their names and values are unchanged; only ``.data`` is re-pointed).  MHAFunction then runs one projection GEMM
+        instead of three (X is read once), one weight-gradient GEMM and one input-gradient GEMM.  Call after the module
+        sits on its final device; ``load_state_dict`` / the optimizer keep working (they update ``.data`` in place)."""
+        ws = [self.w_qs.weight, self.w_ks.weight, self.w_vs.weight]
+        flat = torch.empty((sum(w.shape[0] for w in ws), ws[0].shape[1]), device=ws[0].device, dtype=ws[0].dtype)
+        off = 0
+        with torch.no_grad():
+            for w in ws:
+                flat[off: off + w.shape[0]].copy_(w.data)
+                w.data = flat[off: off + w.shape[0]]
+                off += w.shape[0]
+        return self
+
     def forward_cls(self, x):
         """CLS-query attention for the last encoder layer: x [N, S, d] -> [N, d] (== ``forward(x, x, x)[0][:, 0]``)."""
         cfg = dict(n_head=self.n_head, d_k=self.d_k, d_v=self.d_v, layer_norm=self.layerNorm_flag,

@@ -344,9 +344,10 @@ def test_rccl_gradient_bucket_path_single_rank():
         dist.destroy_process_group()
         os.environ["LSTC_FORCE_DIST"] = "0"
     sc0, w0 = run(False)
-    assert torch.equal(sc0, sc1)
+    # not bitwise: the split-K weight-gradient GEMMs add their partial sums with f32 atomics (order varies run to run)
+    assert max_abs_diff(sc0, sc1) < 1e-6
     for k in w0:
-        assert torch.equal(w0[k], w1[k]), k
+        assert max_abs_diff(w0[k], w1[k]) < 1e-6, k
     assert abs(float(sc0[0]) - float(z["scalars_step2"][0])) < 1e-4
 
 
@@ -402,6 +403,32 @@ def test_bf16_compute_training_step_close_to_golden():
             # more where the hinge / bag-max selections sit close to a tie on this tiny d_model=32 case)
             cos = float((p.grad.cpu() * g).sum() / (p.grad.cpu().norm() * g.norm() + 1e-20))
             assert cos > 0.9, (k, cos)
+
+
+def test_fused_qkv_buffer_matches_separate_projections():
+    """MultiHeadAttention.fuse_qkv_ (w_qs/w_ks/w_vs as row blocks of one buffer -> one GEMM each for projection, weight
+    gradient and input gradient) must not change values, parameter names or the optimizer's view of the weights."""
+    z, mode, ekw, skw = load_case("ltn_sht")
+    d = ekw["d_model"]
+    args = _args(mode, skw)
+    nf, af, al = (torch.from_numpy(z[k]).to(DEV) for k in ("norm_feats", "abnorm_feats", "abnorm_labs"))
+    res = []
+    for fuse in (False, True):
+        enc, head = _models(mode, ekw, d)
+        enc.load_state_dict(sub(z, "enc_init."), strict=True)
+        head.load_state_dict(sub(z, "head_init."), strict=True)
+        enc, head = enc.to(DEV).train(), head.to(DEV).train()
+        if fuse:
+            for layer in enc.layer_stack:
+                layer.slf_attn.fuse_qkv_()
+            assert list(enc.state_dict().keys()) == list(sub(z, "enc_init.").keys())
+        enc_out, outputs, loss, sc = _step(enc, head, mode, args, nf, af, al, d, cls_only=False)
+        loss.backward()
+        res.append((enc_out.detach(), {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None}))
+    assert max_abs_diff(res[0][0], res[1][0]) < 1e-6
+    assert max_abs_diff(res[1][0], z["enc_out"]) < 1e-4
+    for k, g in res[0][1].items():
+        assert max_abs_diff(g, res[1][1][k]) < 2e-6 * float(g.abs().max()) + 1e-9, k
 
 
 def test_pinned_feeder_delivers_batches_in_order():
