@@ -46,6 +46,7 @@ struct GemmParams {
     int tilesM, tilesN, batch;
     int ktiles, ktiles_per_split;
     long long batch_stride_a, batch_stride_b, batch_stride_c;   // elements between consecutive problems of a batch (grid.z)
+    unsigned int a_bytes, b_bytes;   // operand extents for the buffer descriptors of PIPE 5 (operands < 4 GiB)
     int debug;     // timing-only ablations (tools/gemm_check): 1 = no global loads in the loop, 2 = no LDS writes, 4 = no barrier
 };
 
@@ -120,6 +121,24 @@ struct Stager {
             else v[i] = make_float4(p[min(c, r_total - 1)], p[min(c + 1, r_total - 1)], p[min(c + 2, r_total - 1)],
                                     p[min(c + 3, r_total - 1)]);
         }
+    }
+    // Per-lane byte offset of staged element i at K tile 0 (rows clamped); constant over the K loop, so the loop's loads
+    // need no vector address arithmetic: buffer_load voffset = this, soffset = K-tile byte offset (scalar).
+    __device__ __forceinline__ uint32_t voffset(int i, int ld, int r0, int r_total) const {
+        const int t = threadIdx.x;
+        if (KC) {
+            const int r = min(r0 + (t >> 3) + i * (NT / 8), r_total - 1);
+            return (uint32_t)(((size_t)r * ld + (t & 7) * 4) * sizeof(float));
+        }
+        constexpr int CPR = R / 4;
+        const int c = min(r0 + (t % CPR) * 4, r_total - 4);
+        return (uint32_t)(((size_t)(t / CPR + i * (NT / CPR)) * ld + c) * sizeof(float));
+    }
+    __device__ __forceinline__ void load_buf(int i, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
+        static_assert(VEC, "buffer path is for 16-B aligned operands");
+        typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
+        const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+        v[i] = __builtin_bit_cast(float4, x);
     }
     __device__ __forceinline__ void store_one(int i, float* __restrict__ lds) const {
         const int t = threadIdx.x;
@@ -413,12 +432,31 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParam
     // touches 8 separate 128-B lines holds the issue port for tens of cycles; clustered at the top of the tile they
     // delayed the MFMA stream of BOTH waves of the SIMD (measured: -11 % on the NT layout), spread two MFMAs apart
     // they disappear in the 64-cycle shadow of each MFMA.
-    auto tile_step = [&](int it, auto steady_tag) {
+    // PIPE 5 = PIPE 3 with fewer non-MFMA instructions in the steady loop (tools/mfma_issue_probe: every companion
+    // instruction costs the MFMA pipe ~7 idle cycles even at two waves per SIMD; PIPE 3 carried 72 per 64 MFMAs):
+    // global loads become buffer_load_dwordx4 with a loop-invariant per-lane voffset and a scalar K offset (no 64-bit
+    // vector address arithmetic), and the K loop is unrolled by two so LDS stage bases are immediates.
+    constexpr int NVA5 = Stager<BM, NT, A_KC, VA>::NV, NVB5 = Stager<BN, NT, B_KC, VB>::NV;
+    uint32_t voff_a[NVA5], voff_b[NVB5];
+    __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
+    if constexpr (PIPE == 5) {
+#pragma unroll
+        for (int e = 0; e < NVA5; ++e) voff_a[e] = sa.voffset(e, p.lda, m0, p.M);
+#pragma unroll
+        for (int e = 0; e < NVB5; ++e) voff_b[e] = sb.voffset(e, p.ldb, n0, p.N);
+        rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+        rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, (int)p.b_bytes, 0x00020000);
+    }
+    const uint32_t a_kbytes = (uint32_t)((A_KC ? (size_t)BK : (size_t)BK * p.lda) * sizeof(float));
+    const uint32_t b_kbytes = (uint32_t)((B_KC ? (size_t)BK : (size_t)BK * p.ldb) * sizeof(float));
+
+    auto tile_step = [&](int it, auto steady_tag, auto cur_tag) {
         constexpr bool STEADY = decltype(steady_tag)::value;
-        const int cur = it & 1;
+        constexpr int CC = decltype(cur_tag)::value;
+        const int cur = CC >= 0 ? CC : (it & 1);
         const float* a_lds = As + cur * A_ST;
         const float* b_lds = Bs + cur * B_ST;
-        if constexpr (STEADY && PIPE == 3) {
+        if constexpr (STEADY && (PIPE == 3 || PIPE == 5)) {
             // Hand-interleaved steady state: each group of TM*TN independent MFMAs (one k step, all accumulators)
             // carries at most one LDS write, one global load and one fragment read, pinned by sched_barrier so the
             // compiler neither clusters the memory instructions nor chains MFMAs on one accumulator.
@@ -428,6 +466,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParam
             float* a_st = As + (cur ^ 1) * A_ST;
             float* b_st = Bs + (cur ^ 1) * B_ST;
             const int k_next = (kt0 + it + 2) * BK;
+            const uint32_t soff_a = (uint32_t)(kt0 + it + 2) * a_kbytes, soff_b = (uint32_t)(kt0 + it + 2) * b_kbytes;
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 // k steps 0-3: LDS-write the staged tile t+1 (loaded one iteration ago); k steps 4-7: issue the global
@@ -443,7 +482,10 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParam
                             else if (e - NVA < NVB) sb.store_one(e - NVA, b_st);
                         }
                     } else {
-                        if constexpr (!(ABL & 1)) {
+                        if constexpr (PIPE == 5) {
+                            if (e < NVA) sa.load_buf(e, rsrc_a, voff_a[e < NVA ? e : 0], soff_a);
+                            else if (e - NVA < NVB) sb.load_buf(e - NVA, rsrc_b, voff_b[e - NVA < NVB ? e - NVA : 0], soff_b);
+                        } else if constexpr (!(ABL & 1)) {
                             if (e < NVA) sa.load_one(e, p.A, p.lda, m0, p.M, k_next);
                             else if (e - NVA < NVB) sb.load_one(e - NVA, p.B, p.ldb, n0, p.N, k_next);
                         }
@@ -532,8 +574,15 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParam
         __builtin_amdgcn_sched_barrier(0);
     };
     int it = 0;
-    for (; it + 3 < nkt; ++it) tile_step(it, std::true_type{});
-    for (; it < nkt; ++it) tile_step(it, std::false_type{});
+    using dyn = std::integral_constant<int, -1>;
+    if constexpr (PIPE == 5) {
+        for (; it + 4 < nkt; it += 2) {
+            tile_step(it, std::true_type{}, std::integral_constant<int, 0>{});
+            tile_step(it + 1, std::true_type{}, std::integral_constant<int, 1>{});
+        }
+    }
+    for (; it + 3 < nkt; ++it) tile_step(it, std::true_type{}, dyn{});
+    for (; it < nkt; ++it) tile_step(it, std::false_type{}, dyn{});
     }
 
     // ---- epilogue
@@ -588,8 +637,8 @@ int launch_cfg(const GemmParams& p, bool va, bool vb, int splits, hipStream_t st
         }                                                                                                   \
         hipLaunchKernelGGL(kern, grid, block, lds, st, p);                                                  \
     } while (0)
-    if constexpr ((PIPE & 15) == 4) {
-        LSTC_GO(true, true);               // LDS-DMA path: aligned operands only (caller guarantees va && vb)
+    if constexpr ((PIPE & 15) == 4 || (PIPE & 15) == 5) {
+        LSTC_GO(true, true);               // LDS-DMA / buffer-load paths: aligned operands only (caller guarantees va && vb)
     } else {
         if (va && vb) LSTC_GO(true, true);
         else if (va) LSTC_GO(true, false);
@@ -608,14 +657,16 @@ int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipS
     //   1 = 128x128, plain double buffering (PIPE 0)                              117 / 129 / 134
     //   7 = 128x128, mid-barrier software pipeline (PIPE 1)                       126 / 127 / 128
     //   3 = 128x128, pipeline + sched_group_barrier interleave (PIPE 2)           136 / 131 / 129
-    //   8 = 128x128, pipeline + hand-interleaved k-step groups (PIPE 3)           138 / 136 / 138   <- default
+    //   8 = 128x128, pipeline + hand-interleaved k-step groups (PIPE 3)           138 / 136 / 138   (fallback of 4)
+    //   4 = PIPE 3 + buffer loads with scalar K offset, K loop unrolled x2 (PIPE 5) 145 / 143 / 151   <- default
+    //       (steady loop: 49 instead of 72 non-MFMA instructions per 64 MFMAs; needs 16-B aligned operands < 4 GiB)
     //   9 = 256x128, 4 waves x (128x64), one wave per SIMD, PIPE 3                125 / 124 / 134
     //  10 = 128x128, LDS-DMA staging (global_load_lds, swizzled unpadded images)  105 / 119 / 134   (correct, slower:
     //       the swizzled per-lane source addresses of K-contiguous operands and the one-iteration latency budget cost
     //       more than the ds_write + staging registers they remove)
     //   2, 6, 5 = 256x128 with 8 waves (PIPE 1 / 2 / 0)                           115-126, never the best
     //  12-15 = timing-only ablations of variant 8 (NT): no loads 142, no loads/LDS writes 146, +no barrier 146.5
-    if (variant == 0) variant = 8;
+    if (variant == 0) variant = 4;
     const int BM = (variant == 2 || variant == 5 || variant == 6 || variant == 9) ? 256 : 128, BN = 128;
     p.tilesM = (p.M + BM - 1) / BM;
     p.tilesN = (p.N + BN - 1) / BN;
@@ -628,6 +679,8 @@ int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipS
         case 7: return launch_cfg<128, 128, 2, 2, 1, A_KC, B_KC>(p, va, vb, splits, st);
         case 8: return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);
         case 9: return launch_cfg<256, 128, 4, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // 8 waves x (64x64), PIPE 3
+        case 4: if (va && vb && p.a_bytes && p.b_bytes) return launch_cfg<128, 128, 2, 2, 5, A_KC, B_KC>(p, true, true, splits, st);
+                return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // buffer path: aligned, < 4 GiB operands
         case 10: case 11: if (va && vb && p.K % BK == 0) return launch_cfg<128, 128, 2, 2, 4, A_KC, B_KC>(p, true, true, splits, st);
                  return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // LDS-DMA needs aligned rows, full K tiles
         case 12: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 1, A_KC, B_KC>(p, va, vb, splits, st); break;
@@ -665,6 +718,11 @@ int lstc_gemm_f32_impl(const LstcGemmDesc* d, hipStream_t st) {
     p.ktiles = (d->K + BK - 1) / BK;
     p.ktiles_per_split = (p.ktiles + splits - 1) / splits;
     p.debug = d->variant >> 4;
+    const size_t a_ext = ((size_t)((d->transA ? d->K : d->M) - 1) * d->lda + (d->transA ? d->M : d->K)) * sizeof(float) + p.batch_stride_a * sizeof(float) * (size_t)(p.batch - 1) * 0;
+    const size_t b_ext = ((size_t)((d->transB ? d->N : d->K) - 1) * d->ldb + (d->transB ? d->K : d->N)) * sizeof(float);
+    const bool fits32 = a_ext < 0xffffffffull && b_ext < 0xffffffffull;
+    p.a_bytes = (unsigned int)(fits32 ? a_ext : 0);
+    p.b_bytes = (unsigned int)(fits32 ? b_ext : 0);
     const int eff_splits = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
     // float4 global loads need 16-B aligned rows; the contiguous extent must be a multiple of 4 so a
     // float4 is entirely inside or outside the matrix.

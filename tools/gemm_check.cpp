@@ -30,8 +30,9 @@ static float bf16_round(float x) {   // RNE to bfloat16, back to float (host mod
 
 static int check(const Case& c) {
     const int M = c.M, N = c.N, K = c.K;
-    const int lda = (c.tA ? M : K) + (c.variant % 2 ? 0 : 3);   // odd lds exercise the scalar path
-    const int ldb = (c.tB ? K : N) + (c.variant % 2 ? 0 : 1);
+    const bool pad = (c.variant % 2 == 0) && c.variant != 4;     // padded lds exercise the scalar-load path
+    const int lda = (c.tA ? M : K) + (pad ? 3 : 0);
+    const int ldb = (c.tB ? K : N) + (pad ? 1 : 0);
     const int ldc = N + 2, ldr = N + 1, ldm = N;
     const size_t na = (size_t)(c.tA ? K : M) * lda, nb = (size_t)(c.tB ? N : K) * ldb;
     auto hA = rnd(na, 1), hB = rnd(nb, 2), hbias = rnd(N, 3), hres = rnd((size_t)M * ldr, 4), hmask = rnd((size_t)M * ldm, 5);
@@ -148,6 +149,14 @@ int main(int argc, char** argv) {
         fails += check({256, 256, 128, 1, 0, 0, 11, 1});
         fails += check({300, 200, 96, 1, 0, 0, 11, 1});
         fails += check({384, 132, 512, 1, 0, 0, 11, 3});
+        for (int tb : {1, 0}) {      // buffer-load pipeline (variant 4), aligned operands, odd tile counts, K tails
+            fails += check({256, 256, 128, 0, tb, 0, 4, 1});
+            fails += check({300, 200, 100, 0, tb, ALL, 4, 1});
+            fails += check({1000, 260, 1000, 0, tb, LSTC_EPI_BIAS | LSTC_EPI_RELU, 4, 1});
+        }
+        fails += check({256, 256, 640, 1, 0, 0, 4, 1});
+        fails += check({300, 200, 1000, 1, 0, 0, 4, 1});
+        fails += check({384, 132, 2048, 1, 0, 0, 4, 3});
         const int ALLB = LSTC_EPI_BIAS | LSTC_EPI_RELU | LSTC_EPI_RESIDUAL | LSTC_EPI_RELU_MASK | LSTC_EPI_ACCUM;
         for (int variant : {0, 1, 2}) {        // bf16-compute kernel; odd variant id -> aligned (vector) loads
             fails += check({300, 200, 100, 0, 1, 0, variant, 1, LSTC_BF16});
