@@ -31,6 +31,12 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int LDK = 36;   // padded K stride of K-contiguous LDS images
+#ifndef LSTC_KCT
+#define LSTC_KCT 0
+#endif
+// LSTC_KCT = 1: K-contiguous operands are TRANSPOSED while they are written to LDS ([32][rows+1] image, 4 ds_write_b32 per
+// staged float4, conflict-free because rows+1 = 1 mod 32) and read back like k-major operands with ds_read_b32.
+constexpr bool KCT = LSTC_KCT != 0;
 
 struct GemmParams {
     const float* A;
@@ -143,7 +149,13 @@ struct Stager {
     __device__ __forceinline__ void store_one(int i, float* __restrict__ lds) const {
         const int t = threadIdx.x;
         if (KC) {
-            *reinterpret_cast<float4*>(lds + ((t >> 3) + i * (NT / 8)) * LDK + (t & 7) * 4) = v[i];
+            if (KCT) {
+                const int r = (t >> 3) + i * (NT / 8), c = (t & 7) * 4;
+                lds[(c + 0) * (R + 1) + r] = v[i].x; lds[(c + 1) * (R + 1) + r] = v[i].y;
+                lds[(c + 2) * (R + 1) + r] = v[i].z; lds[(c + 3) * (R + 1) + r] = v[i].w;
+            } else {
+                *reinterpret_cast<float4*>(lds + ((t >> 3) + i * (NT / 8)) * LDK + (t & 7) * 4) = v[i];
+            }
         } else {
             constexpr int CPR = R / 4;
             *reinterpret_cast<float4*>(lds + (t / CPR + i * (NT / CPR)) * R + (t % CPR) * 4) = v[i];
@@ -157,7 +169,12 @@ struct Stager {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int r = (t >> 3) + i * (NT / 8);
-                *reinterpret_cast<float4*>(lds + r * LDK + c) = v[i];
+                if (KCT) {
+                    lds[(c + 0) * (R + 1) + r] = v[i].x; lds[(c + 1) * (R + 1) + r] = v[i].y;
+                    lds[(c + 2) * (R + 1) + r] = v[i].z; lds[(c + 3) * (R + 1) + r] = v[i].w;
+                } else {
+                    *reinterpret_cast<float4*>(lds + r * LDK + c) = v[i];
+                }
             }
         } else {
             constexpr int CPR = R / 4;
@@ -172,12 +189,16 @@ struct Stager {
 };
 
 template <int R, bool KC>
-constexpr int stage_floats() { return KC ? R * LDK : BK * R; }
+constexpr int stage_floats() { return KC ? (KCT ? ((BK * (R + 1) + 3) / 4) * 4 : R * LDK) : BK * R; }
 
 // Reads this lane's 8 k-values (k = 16*h + 8*half + j) of operand row `row` from the LDS image.
 template <int R, bool KC>
 __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int row, int h, int half, float (&f)[8]) {
-    if (KC) {
+    if (KC && KCT) {
+        const float* p = lds + (16 * h + 8 * half) * (R + 1) + row;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = p[j * (R + 1)];
+    } else if (KC) {
         const float4* p = reinterpret_cast<const float4*>(lds + row * LDK + 16 * h + 8 * half);
         const float4 a = p[0], b = p[1];
         f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
@@ -450,8 +471,12 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParam
     const uint32_t a_kbytes = (uint32_t)((A_KC ? (size_t)BK : (size_t)BK * p.lda) * sizeof(float));
     const uint32_t b_kbytes = (uint32_t)((B_KC ? (size_t)BK : (size_t)BK * p.ldb) * sizeof(float));
 
+    // steady_tag: 0 = generic body (runtime conditions, checked loads); 1 = tiles t+1 and t+2 exist; 2 = only t+1 exists
+    // (no more loads); 3 = last tile.  Modes 2/3 keep the hand-interleaved form for the tail of the K loop (PIPE 5).
     auto tile_step = [&](int it, auto steady_tag, auto cur_tag) {
-        constexpr bool STEADY = decltype(steady_tag)::value;
+        constexpr int SMODE = decltype(steady_tag)::value;
+        constexpr bool STEADY = SMODE != 0;
+        constexpr bool HAS1 = SMODE == 1 || SMODE == 2, HAS2 = SMODE == 1;
         constexpr int CC = decltype(cur_tag)::value;
         const int cur = CC >= 0 ? CC : (it & 1);
         const float* a_lds = As + cur * A_ST;
@@ -467,6 +492,10 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParam
             float* b_st = Bs + (cur ^ 1) * B_ST;
             const int k_next = (kt0 + it + 2) * BK;
             const uint32_t soff_a = (uint32_t)(kt0 + it + 2) * a_kbytes, soff_b = (uint32_t)(kt0 + it + 2) * b_kbytes;
+            if constexpr (PIPE == 5 && HAS1) {
+                // the staged loads were issued 12+ k steps ago: ONE wait for all of them instead of one per LDS write
+                __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), lgkmcnt / expcnt untouched
+            }
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 // k steps 0-3: LDS-write the staged tile t+1 (loaded one iteration ago); k steps 4-7: issue the global
@@ -477,11 +506,11 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParam
                 for (int q = 0; q < 2 * MPK; ++q) {
                     const int e = (kk & 3) * 2 * MPK + q;
                     if (kk < 4) {
-                        if constexpr (!(ABL & 2)) {
+                        if constexpr (!(ABL & 2) && HAS1) {
                             if (e < NVA) sa.store_one(e, a_st);
                             else if (e - NVA < NVB) sb.store_one(e - NVA, b_st);
                         }
-                    } else {
+                    } else if constexpr (HAS2) {
                         if constexpr (PIPE == 5) {
                             if (e < NVA) sa.load_buf(e, rsrc_a, voff_a[e < NVA ? e : 0], soff_a);
                             else if (e - NVA < NVB) sb.load_buf(e - NVA, rsrc_b, voff_b[e - NVA < NVB ? e - NVA : 0], soff_b);
@@ -503,8 +532,10 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParam
             if constexpr (!(ABL & 4)) __syncthreads();
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
-                if (kk < TM) read_frag<BM, A_KC>(a_st, wm * WTM + kk * 32 + l31, h, 0, fa0[kk < TM ? kk : 0]);
-                else if (kk - TM < TN) read_frag<BN, B_KC>(b_st, wn * WTN + (kk - TM) * 32 + l31, h, 0, fb0[kk - TM < TN ? kk - TM : 0]);
+                if constexpr (HAS1) {
+                    if (kk < TM) read_frag<BM, A_KC>(a_st, wm * WTM + kk * 32 + l31, h, 0, fa0[kk < TM ? kk : 0]);
+                    else if (kk - TM < TN) read_frag<BN, B_KC>(b_st, wn * WTN + (kk - TM) * 32 + l31, h, 0, fb0[kk - TM < TN ? kk - TM : 0]);
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -575,14 +606,25 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParam
     };
     int it = 0;
     using dyn = std::integral_constant<int, -1>;
+    using gen = std::integral_constant<int, 0>;
+    using full = std::integral_constant<int, 1>;
     if constexpr (PIPE == 5) {
-        for (; it + 4 < nkt; it += 2) {
-            tile_step(it, std::true_type{}, std::integral_constant<int, 0>{});
-            tile_step(it + 1, std::true_type{}, std::integral_constant<int, 1>{});
+        // unchecked loads may fetch tile it+2 only if it is a full K tile: when this workgroup owns the final, partial
+        // K tile the interleaved form stops one iteration earlier and the generic (checked) body finishes the loop
+        const bool tail_ok = !(k_tail && kt1 == p.ktiles);
+        const int full_end = tail_ok ? nkt - 2 : nkt - 3;
+        for (; it + 1 < full_end; it += 2) {
+            tile_step(it, full{}, std::integral_constant<int, 0>{});
+            tile_step(it + 1, full{}, std::integral_constant<int, 1>{});
+        }
+        for (; it < full_end; ++it) tile_step(it, full{}, dyn{});
+        if (tail_ok) {
+            if (it + 1 < nkt) { tile_step(it, std::integral_constant<int, 2>{}, dyn{}); ++it; }
+            if (it < nkt) { tile_step(it, std::integral_constant<int, 3>{}, dyn{}); ++it; }
         }
     }
-    for (; it + 3 < nkt; ++it) tile_step(it, std::true_type{}, dyn{});
-    for (; it < nkt; ++it) tile_step(it, std::false_type{}, dyn{});
+    for (; it + 3 < nkt; ++it) tile_step(it, full{}, dyn{});
+    for (; it < nkt; ++it) tile_step(it, gen{}, dyn{});
     }
 
     // ---- epilogue
