@@ -2,7 +2,7 @@
 import collections, csv, glob, json, os, sys
 
 def stats(prof_dir, out_md, title):
-    f = glob.glob(os.path.join(prof_dir, "*", "*kernel_stats.csv"))[0]
+    f = glob.glob(os.path.join(prof_dir, "**", "*kernel_stats.csv"), recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     with open(out_md, "w") as o:
@@ -13,7 +13,7 @@ def stats(prof_dir, out_md, title):
         o.write(f"\ntotal GPU kernel time {tot/1e6:.1f} ms\n")
 
 def pmc(prof_dir, key="gemm"):
-    f = glob.glob(os.path.join(prof_dir, "*", "*counter_collection.csv"))[0]
+    f = glob.glob(os.path.join(prof_dir, "**", "*counter_collection.csv"), recursive=True)[0]
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     names = {}
     for r in csv.DictReader(open(f)):
