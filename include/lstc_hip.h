@@ -242,6 +242,14 @@ int lstc_sqnorm_accum(const float* x, int64_t n, float* out, void* stream);
 /* x *= alpha in place: applies the clip_grad_norm_ coefficient to a gradient tensor. */
 int lstc_scale(float* x, int64_t n, float alpha, void* stream);
 
+/* ------------------------------------------------------------------------- data feed
+ * dst[r, :] = src[idx[r], :] for r < n_rows, rows of `row_floats` contiguous floats (multiple of 4, 16-byte aligned
+ * bases).  Forms the [B, part_num*part_len, n_patch, d] training batch out of an HBM-resident feature bank from the
+ * clip indices the reference's sampler picks on the host (`feat[chosen[...], :]`, utils/load_dataset.py:88 +
+ * default collate), so no feature bytes cross PCIe per step.  idx entries must lie in [0, src_rows). */
+int lstc_gather_rows(const float* src, int64_t src_rows, const int64_t* idx, float* dst, int64_t n_rows,
+                     int64_t row_floats, void* stream);
+
 /* ------------------------------------------------------------------------------ misc */
 int lstc_version(void);
 const char* lstc_strerror(int code);

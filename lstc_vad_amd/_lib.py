@@ -22,6 +22,7 @@ EXPORTS = (
     "lstc_cls_outer", "lstc_layernorm_fwd", "lstc_layernorm_bwd",
     "lstc_cls_concat_fwd", "lstc_cls_concat_bwd", "lstc_colsum", "lstc_dropout_apply", "lstc_dropout_mask",
     "lstc_head_out_fwd", "lstc_head_out_bwd", "lstc_vad_loss", "lstc_adagrad_step", "lstc_sqnorm_accum", "lstc_scale",
+    "lstc_gather_rows",
     "lstc_version", "lstc_strerror",
 )
 
@@ -94,6 +95,7 @@ def load():
         "lstc_adagrad_step": [vp, vp, vp, i64, f32, f32, f32, f32, vp],
         "lstc_sqnorm_accum": [vp, i64, vp, vp],
         "lstc_scale": [vp, i64, f32, vp],
+        "lstc_gather_rows": [vp, i64, vp, vp, i64, i64, vp],
         "lstc_version": [],
     }
     for name, args in sig.items():

@@ -139,17 +139,23 @@ def train(script: str, argv=None):
                           temporal_only=getattr(args, "temporal_only", False), clip_grad=getattr(args, "clip_grad", False))
     ts = TrainStep(step_args, mode, enc, head, _get(args, "lr_encoder", pre, 1e-4), lr_head, args.weight_decay)
 
-    if not args.synthetic and getattr(args, "dataset_path", ""):
-        raise SystemExit("HDF5 feature loading is not built yet (h5py is unavailable in this image; SURVEY.md 8f-3). "
-                         "Run with --synthetic.")
-    n_pairs = args.synthetic_pairs or 2 * args.batch_size
-    thr = None if mode == "STN" else 0.65
-    pseudo = None
     ppath = getattr(args, "pseudo_labels_path", None) or getattr(args, "temporal_pseudo_path", None)
-    if ppath and ppath != "None" and os.path.exists(ppath if ppath.endswith(".npy") else ppath + ".npy"):
-        pseudo = np.load(ppath if ppath.endswith(".npy") else ppath + ".npy", allow_pickle=True).tolist()
-    data = SyntheticVideos(n_pairs, args.batch_size, args.part_num, part_len, args.n_patch, d_model, dev,
-                           seed=seed + 1000 * rank, sample=args.sample, pseudo_threshold=thr, pseudo_labels=pseudo)
+    if ppath in ("", "None"):
+        ppath = None
+    if ppath and not ppath.endswith(".npy"):
+        ppath += ".npy"                                     # Train/spatio_transformer_MIL_CE.py:142
+    real = (not args.synthetic) and bool(getattr(args, "dataset_path", ""))
+    if real:
+        data, eval_fn = _real_data(args, mode, part_len, ppath, dev, rank, world)
+    else:
+        n_pairs = args.synthetic_pairs or 2 * args.batch_size
+        thr = None if mode == "STN" else 0.65
+        pseudo = np.load(ppath, allow_pickle=True).tolist() if ppath and os.path.exists(ppath) else None
+        data = SyntheticVideos(n_pairs, args.batch_size, args.part_num, part_len, args.n_patch, d_model, dev,
+                               seed=seed + 1000 * rank, sample=args.sample, pseudo_threshold=thr, pseudo_labels=pseudo)
+        eval_fn = lambda: evaluate(enc, head, mode, data, part_len, roc_auc)
+    if hasattr(eval_fn, "bind"):
+        eval_fn.bind(enc, head)
     epochs = int(_get(args, "epochs", pre, 1))
     inter = int(getattr(args, "inter_epoch", 10))
     best_auc, it = 0.0, 0
@@ -170,7 +176,8 @@ def train(script: str, argv=None):
                 break
         data.shuffle_keys()
         if rank == 0 and epoch % inter == 0:
-            auc = evaluate(enc, head, mode, data, part_len, roc_auc)
+            auc = eval_fn()
+            enc.train(); head.train()
             logger.info('epoch {} test AUC {:.4f} (best {:.4f})'.format(epoch, auc, best_auc))
             if auc > best_auc:
                 best_auc = auc
@@ -186,6 +193,61 @@ def train(script: str, argv=None):
     if world > 1:
         dist.destroy_process_group()
     return best_auc
+
+
+class _HostPairs:
+    """Batches of a lazy / ten-crop dataset: items collated on the host (``DataLoader(batch_size, drop_last=True,
+    num_workers=0)`` order), staged through pinned memory, copied to the device."""
+
+    def __init__(self, dataset, batch_size, device):
+        self.ds, self.bs, self.device = dataset, batch_size, device
+
+    def __len__(self):
+        return len(self.ds) // self.bs
+
+    def __iter__(self):
+        import torch
+        for b in range(len(self)):
+            items = [self.ds[b * self.bs + j] for j in range(self.bs)]
+            yield tuple(torch.stack([it[k] for it in items]).pin_memory().to(self.device, non_blocking=True) for k in range(4))
+
+    def shuffle_keys(self):
+        self.ds.shuffle_keys()
+
+
+def _real_data(args, mode, part_len, pseudo_path, dev, rank, world):
+    """Feature-archive training source + evaluation closure for a Train/*.py run.  Dataset class per
+    script as upstream (e.g. Train/temporal_transformer_shanghaitech.py:45-51, Train/spatio_transformer_MIL_CE.py:114-149);
+    under torchrun every rank seeds ``np.random`` with ``seed + rank`` so the ranks draw different pairs (the reference's
+    DataLoader workers do the same with ``seed + worker_id``, :39-41)."""
+    import numpy as np
+    from . import load_dataset as lds
+    from .pipeline import evaluate_auc
+    dataset = str(getattr(args, "dataset", "SHT"))
+    np.random.seed(int(getattr(args, "seed", 0)) + rank)
+    common = dict(part_num=args.part_num, part_len=part_len, h5_path=args.dataset_path, train_txt=args.training_txt,
+                  n_patch=args.n_patch, sample=args.sample, pseudo_labels_path=pseudo_path if mode != "STN" else None)
+    if dataset == "UCF":
+        ds = lds.UCF_Train_Origin_Dataset(frames_per_clip=args.segment_len, **common)
+    elif dataset == "UBnormal":
+        ds = lds.UBnormal_Train_Origin_Dataset(**common)
+    elif mode == "STN_MIL_CE":
+        ds = lds.SH_Train_Origin_Dataset_MutualTraining(**common)
+    else:
+        ds = lds.SH_Train_Origin_Dataset(**common)
+    data = _HostPairs(ds, args.batch_size, dev) if ds.lazy else lds.ResidentPairs(ds, args.batch_size, dev)
+    masks = getattr(args, "test_mask_path", "") if dataset == "UCF" else getattr(args, "test_mask_dir", "")
+    test_arc = getattr(args, "test_dataset_path", "") or args.dataset_path
+    kind = "LTN" if mode == "LTN" else "STN"
+
+    def eval_fn():
+        if not getattr(args, "testing_txt", ""):
+            return 0.0
+        return evaluate_auc(_eval_models[0].eval(), _eval_models[1].eval(), kind, dataset, test_arc, args.testing_txt, masks,
+                            part_len, args.n_patch, args.segment_len)
+    _eval_models = []
+    eval_fn.bind = lambda enc, head: _eval_models.extend([enc, head])
+    return data, eval_fn
 
 
 def evaluate(enc, head, mode, data, part_len, roc_auc, segment_len=16):
@@ -245,7 +307,8 @@ def generate_pseudo_labels(script: str, argv=None):
                   max_position_tokens=args.max_position_tokens, relative_pe=args.relative_position_encoding,
                   window_size=args.window_size, window_depth=part_len if mode == "LTN" else 3,
                   conv_patch=args.conv_patch)
-    head = Classifier(args.d_model) if mode == "LTN" else Regressor(args.d_model)
+    # the spatio generator pairs a 1-layer encoder with a Classifier (Train/pseudo_labels_generator_spatio.py:53-56)
+    head = Classifier(args.d_model) if (mode == "LTN" or args.n_layers == 1) else Regressor(args.d_model)
     strip = lambda sd: {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
     enc_path = getattr(args, "temporal_model_path", "") if mode == "LTN" else getattr(args, "spatio_model_path", "")
     head_path = getattr(args, "classifier_model_path", "") if mode == "LTN" else getattr(args, "regression_model_path", "")
@@ -255,6 +318,13 @@ def generate_pseudo_labels(script: str, argv=None):
         else:
             print(f"[{script}] checkpoint {path!r} not found: scoring with the current initialisation", file=sys.stderr)
     enc, head = enc.to(dev).eval(), head.to(dev).eval()
+    if not args.synthetic and args.dataset_path:
+        from .pipeline import generate_pseudo_labels as run
+        out = run(enc, head, mode, args.dataset, args.dataset_path, args.training_txt, args.threshold, part_len=part_len,
+                  n_patch=args.n_patch, d_model=args.d_model, segment_len=args.segment_len,
+                  classifier_head=(mode == "STN" and args.n_layers == 1), out_path=args.pseudo_labels_path)
+        print(f"{'temporal' if mode == 'LTN' else 'spatio'} pseudo label generation finished.")
+        return out
     # same seed -> same synthetic training videos (keys, lengths) as the Train/*.py loops on rank 0
     data = SyntheticVideos(args.synthetic_pairs or 8, 1, 1, part_len, args.n_patch, args.d_model, dev,
                            seed=int(getattr(args, "seed", 0)))
@@ -301,6 +371,13 @@ def evaluate_cli(script: str, argv=None):
             print(f"[{script}] checkpoint {path!r} not found: evaluating the current initialisation", file=sys.stderr)
     enc, head = enc.to(dev).eval(), head.to(dev).eval()
     seg = getattr(args, "segment_len", 16)
+    if not args.synthetic and args.dataset_path:
+        from .pipeline import evaluate_auc
+        masks = args.test_mask_path if ucf else args.test_mask_dir
+        auc = evaluate_auc(enc, head, "LTN", "UCF" if ucf else args.dataset, args.dataset_path, args.testing_txt, masks,
+                           part_len, args.n_patch, seg)
+        print("auc = ", auc)
+        return auc
     data = SyntheticVideos(2, 1, 1, part_len, args.n_patch, args.d_model, dev, seed=0)
     scores, labels = [], []
     with torch.no_grad():

@@ -435,6 +435,19 @@ __global__ void __launch_bounds__(NT) scale_kernel(float* __restrict__ x, int64_
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) x[i] *= alpha;
 }
 
+// dst row r <- src row idx[r].  grid.x = row, grid.y = chunk of the row; float4 streaming copy (HBM-bound, 2 x bytes).
+__global__ void __launch_bounds__(NT) gather_rows_kernel(const float4* __restrict__ src, int64_t src_rows,
+                                                         const int64_t* __restrict__ idx, float4* __restrict__ dst,
+                                                         int64_t row_vec) {
+    const int64_t r = blockIdx.x;
+    int64_t s = idx[r];
+    s = s < 0 ? 0 : (s >= src_rows ? src_rows - 1 : s);          // never fault on a bad index
+    const float4* __restrict__ in = src + s * row_vec;
+    float4* __restrict__ out = dst + r * row_vec;
+    for (int64_t i = (int64_t)blockIdx.y * NT + threadIdx.x; i < row_vec; i += (int64_t)gridDim.y * NT)
+        out[i] = in[i];
+}
+
 inline int grid_for(int64_t work_items, int per_block, int cap = 2048) {
     int64_t g = (work_items + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -560,6 +573,20 @@ int lstc_scale(float* x, int64_t n, float alpha, void* stream) {
     if (!x) return LSTC_E_NULL;
     if (n <= 0) return LSTC_E_SHAPE;
     hipLaunchKernelGGL(scale_kernel, grid_for(n, NT * 4), NT, 0, (hipStream_t)stream, x, n, alpha);
+    return lstc_launch_status();
+}
+
+int lstc_gather_rows(const float* src, int64_t src_rows, const int64_t* idx, float* dst, int64_t n_rows,
+                     int64_t row_floats, void* stream) {
+    if (!src || !idx || !dst) return LSTC_E_NULL;
+    if (src_rows <= 0 || n_rows <= 0 || row_floats <= 0 || (row_floats & 3) || n_rows > 0x7fffffffLL) return LSTC_E_SHAPE;
+    if (!aligned16(src) || !aligned16(dst)) return LSTC_E_ALIGN;
+    const int64_t row_vec = row_floats / 4;
+    int chunks = (int)((row_vec + NT * 4 - 1) / (NT * 4));        // ~4 float4 per thread
+    if (chunks < 1) chunks = 1;
+    if (chunks > 64) chunks = 64;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n_rows, (unsigned)chunks), NT, 0, (hipStream_t)stream,
+                       (const float4*)src, src_rows, idx, (float4*)dst, row_vec);
     return lstc_launch_status();
 }
 

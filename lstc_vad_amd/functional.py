@@ -182,6 +182,20 @@ def dropout_apply(x: torch.Tensor, p: float, seed: int, out: Optional[torch.Tens
     return out
 
 
+def gather_rows(bank: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[r] = bank[idx[r]] over the leading dimension (``lstc_gather_rows``): forms a training batch from an
+    HBM-resident feature bank.  ``idx`` int64 on the same device; trailing dims of ``bank`` must hold a multiple of 4 floats."""
+    if bank.dtype != torch.float32 or idx.dtype != torch.int64 or not bank.is_contiguous():
+        raise TypeError("gather_rows: bank must be contiguous float32 and idx int64")
+    idx = idx.contiguous()
+    row = int(bank[0].numel())
+    if out is None:
+        out = torch.empty((idx.numel(),) + tuple(bank.shape[1:]), device=bank.device, dtype=torch.float32)
+    check(_lib.load().lstc_gather_rows(dev_ptr(bank), bank.shape[0], dev_ptr(idx), dev_ptr(out), idx.numel(), row,
+                                       stream_ptr()), "lstc_gather_rows")
+    return out
+
+
 def dropout_mask(shape, p: float, seed: int, device) -> torch.Tensor:
     m = torch.empty(shape, device=device, dtype=torch.uint8)
     check(_lib.load().lstc_dropout_mask(dev_ptr(m), m.numel(), float(p), int(seed), stream_ptr()), "lstc_dropout_mask")

@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Golden vectors for the stages around the training step, produced by the REAL reference.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_pipeline.py      # build container only
+
+What runs, unmodified, from /root/reference: the dataset classes and test loaders of ``utils/load_dataset.py``, the
+two pseudo-label generators (``Train/pseudo_labels_generator_{spatio,temporal}.generator``) and the two evaluation
+scripts (``Test/evaluation_shanghaitech_ubnormal.evaluation``, ``Test/evaluation_UCF.evaluation``).  The environment
+supplies what this container lacks: ``h5py`` is a stand-in module whose ``File`` serves the world's ``.npz`` archives
+with the ``h5[key][:]`` access pattern (the reference never uses anything else), ``cv2`` is a dead import, and
+``.cuda()`` is the identity (CPU run).  Inputs come from ``pipeline_world.build`` (portable generator).  Output:
+``tests/golden/pipeline.npz`` - expected outputs only (sampled clip fingerprints and labels, pseudo-label arrays,
+frame-level scores/labels, AUCs).
+"""
+import os
+import random
+import sys
+import tempfile
+import types
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+
+
+class _H5File:                     # h5py.File stand-in over an .npz archive
+    def __init__(self, path, mode="r"):
+        self._z = np.load(path, allow_pickle=False)
+
+    def __getitem__(self, key):
+        return self._z[key]        # ndarray: supports [:]
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self._z.close()
+        return False
+
+
+h5 = types.ModuleType("h5py"); h5.File = _H5File
+sys.modules["h5py"] = h5
+sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+sys.path.insert(0, REF)
+sys.path.insert(1, ROOT)
+sys.path.insert(2, HERE)
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.nn.Module.cuda = lambda self, *a, **k: self
+
+import utils.load_dataset as ref_ds                                  # noqa: E402  (reference)
+import Train.pseudo_labels_generator_spatio as ref_gen_s             # noqa: E402
+import Train.pseudo_labels_generator_temporal as ref_gen_t           # noqa: E402
+import Test.evaluation_shanghaitech_ubnormal as ref_eval_sht         # noqa: E402
+import Test.evaluation_UCF as ref_eval_ucf                           # noqa: E402
+from models.Encoder import Encoder as RefEncoder                     # noqa: E402
+from models.Regressor import Regressor as RefRegressor               # noqa: E402
+from models.Classifier import Classifier as RefClassifier            # noqa: E402
+
+import pipeline_world as pw                                          # noqa: E402
+from pipeline_cases import DATASET_CASES, build_dataset              # noqa: E402
+
+torch.set_num_threads(4)
+OUT = {}
+THR_UCF, THR_STN = 0.25, 0.34      # thresholds inside the score ranges of the synthetic world
+
+
+def fingerprint(t):
+    """Identify the sampled clips without storing them: first scalar of every clip row + an exact f64 checksum."""
+    a = t.numpy()
+    first = a.reshape(a.shape[0], -1)[:, 0].copy()
+    return first, np.array([a.astype(np.float64).sum()])
+
+
+def run_datasets(W):
+    for name, spec in DATASET_CASES.items():
+        np.random.seed(spec["seed"]); random.seed(spec["seed"])
+        ds = build_dataset(ref_ds, spec, W)
+        firsts, sums, labs, crops = [], [], [], []
+        for epoch in range(2):
+            for i in range(len(ds)):
+                item = ds[i]
+                for j in (0, 2):
+                    f, s = fingerprint(item[j]); firsts.append(f); sums.append(s)
+                    labs.append(item[j + 1].numpy().reshape(-1))
+                if len(item) == 5:
+                    crops.append(item[4])
+            ds.shuffle_keys()
+        OUT[f"ds/{name}/first"] = np.concatenate(firsts)
+        OUT[f"ds/{name}/sum"] = np.concatenate(sums)
+        OUT[f"ds/{name}/labs"] = np.concatenate(labs)
+        OUT[f"ds/{name}/shape"] = np.array(item[0].shape)
+        OUT[f"ds/{name}/lab_shape"] = np.array(item[1].shape)
+        OUT[f"ds/{name}/crops"] = np.array(crops, np.int64)
+        OUT[f"ds/{name}/len"] = np.array([len(ds)])
+
+
+def run_test_loaders(W):
+    for tag, fn, args in (("sht", ref_ds.shanghaitech_test, (W["sht_test"], W["sht_masks"], W["sht_feats"])),
+                          ("ubn", ref_ds.UBnormal_test, (W["ubn_test"], W["ubn_masks"], W["ubn_feats"]))):
+        feats, labels, annos, names = fn(*args, return_names=True)
+        OUT[f"tl/{tag}/n_clips"] = np.array([f.shape[0] for f in feats])
+        OUT[f"tl/{tag}/abnormal"] = np.array([l == "Abnormal" for l in labels])
+        OUT[f"tl/{tag}/anno_len"] = np.array([len(a) for a in annos])
+        OUT[f"tl/{tag}/anno_sum"] = np.array([float(np.sum(a)) for a in annos])
+    for i, line in enumerate(open(W["ucf_test"]).readlines()):
+        feats, anno, n_frames, key = ref_ds.UCF_test(line, W["ucf_feats"], W["ucf_gt"], 16, return_name=True)
+        OUT[f"tl/ucf/{i}"] = np.array([feats.shape[0], len(anno), float(np.sum(anno)), n_frames])
+
+
+def gen_args(**kw):
+    base = dict(dataset="SHT", segment_len=16, n_patch=16, n_head=2, n_hidden=64, d_k=16, d_v=16, n_layers=3, d_model=32,
+                MHA_layerNorm=True, FFN_layerNorm=True, position_dropout=0.1, encoder_weight_init=False,
+                position_encoding=False, CLS_learned=False, max_position_tokens=100, relative_position_encoding=True,
+                window_size=4, conv_patch=False, part_len=3, data_parallel=False, threshold=0.5)
+    base.update(kw)
+    return Namespace(**base)
+
+
+def run_generators(W, tmp):
+    def load(path):
+        d = np.load(path, allow_pickle=True).tolist()
+        return d
+    # temporal, SHT, DataParallel-prefixed checkpoints
+    p = os.path.join(tmp, "pl_t_sht.npy")
+    ref_gen_t.generator(gen_args(dataset_path=W["sht_feats"], training_txt=W["sht_train"], temporal_model_path=W["ltn_sht_enc.ckpt"],
+                                 classifier_model_path=W["ltn_sht_cls.ckpt"], pseudo_labels_path=p, data_parallel=True,
+                                 threshold=0.45))
+    for k, v in load(p).items():
+        OUT[f"pl/t_sht/{k}"] = np.asarray(v, np.float32)
+    # temporal, UBnormal list dialect (same model)
+    p = os.path.join(tmp, "pl_t_ubn.npy")
+    ref_gen_t.generator(gen_args(dataset="UBnormal", dataset_path=W["ubn_feats"], training_txt=W["ubn_train"],
+                                 temporal_model_path=W["ltn_sht_enc.ckpt"], classifier_model_path=W["ltn_sht_cls.ckpt"],
+                                 pseudo_labels_path=p, data_parallel=True, threshold=0.45))
+    for k, v in load(p).items():
+        OUT[f"pl/t_ubn/{k}"] = np.asarray(v, np.float32)
+    # temporal, UCF (32 bins)
+    p = os.path.join(tmp, "pl_t_ucf.npy")
+    ref_gen_t.generator(gen_args(dataset="UCF", n_patch=9, part_len=2, dataset_path=W["ucf_feats"], training_txt=W["ucf_train"],
+                                 temporal_model_path=W["ltn_ucf_enc.ckpt"], classifier_model_path=W["ltn_ucf_cls.ckpt"],
+                                 pseudo_labels_path=p, threshold=THR_UCF))
+    for k, v in load(p).items():
+        OUT[f"pl/t_ucf/{k}"] = np.asarray(v, np.float32)
+    # spatio, SHT
+    p = os.path.join(tmp, "pl_s_sht.npy")
+    ref_gen_s.generator(gen_args(n_hidden=47, MHA_layerNorm=False, relative_position_encoding=False,
+                                 dataset_path=W["sht_feats"], training_txt=W["sht_train"],
+                                 spatio_model_path=W["stn_sht_enc.ckpt"], regression_model_path=W["stn_sht_reg.ckpt"],
+                                 pseudo_labels_path=p, threshold=THR_STN))
+    for k, v in load(p).items():
+        OUT[f"pl/s_sht/{k}"] = np.asarray(v, np.float32)
+
+
+def run_evals(W):
+    captured = {}
+
+    def capture(scores, labels, logger):
+        captured["s"] = np.asarray(scores, np.float32).reshape(-1)
+        captured["l"] = np.asarray(labels, np.float64).reshape(-1)
+        from utils.eval_utils import eval as ref_auc
+        captured["auc"] = ref_auc(scores, labels, logger)
+        return captured["auc"]
+
+    ev = dict(segment_len=16, part_len=3, n_patch=16, d_model=32, temporal_n_head=2, temporal_n_hidden=64, temporal_d_k=16,
+              temporal_d_v=16, temporal_n_layers=3, temporal_MHA_layerNorm=True, temporal_FFN_layerNorm=True,
+              temporal_relative_position_encoding=True, window_size=4, temporal_data_parallel=True)
+    ref_eval_sht.eval = capture
+    ref_eval_sht.evaluation(Namespace(dataset="SHT", testing_txt=W["sht_test"], test_mask_dir=W["sht_masks"],
+                                      dataset_path=W["sht_feats"], temporal_model_path=W["ltn_sht_enc.ckpt"],
+                                      classifier_model_path=W["ltn_sht_cls.ckpt"], **ev))
+    OUT["ev/sht/scores"], OUT["ev/sht/labels"], OUT["ev/sht/auc"] = captured["s"], captured["l"], np.array([captured["auc"]])
+    ref_eval_sht.evaluation(Namespace(dataset="UBnormal", testing_txt=W["ubn_test"], test_mask_dir=W["ubn_masks"],
+                                      dataset_path=W["ubn_feats"], temporal_model_path=W["ltn_sht_enc.ckpt"],
+                                      classifier_model_path=W["ltn_sht_cls.ckpt"], **ev))
+    OUT["ev/ubn/scores"], OUT["ev/ubn/labels"], OUT["ev/ubn/auc"] = captured["s"], captured["l"], np.array([captured["auc"]])
+    ref_eval_ucf.eval = capture
+    ev_u = dict(ev); ev_u.update(part_len=2, n_patch=9, relative_position_encoding=True)
+    ref_eval_ucf.evaluation(Namespace(testing_txt=W["ucf_test"], test_mask_path=W["ucf_gt"], dataset_path=W["ucf_feats"],
+                                      temporal_model_path=W["ltn_ucf_enc.ckpt"], classifier_model_path=W["ltn_ucf_cls.ckpt"],
+                                      **ev_u))
+    OUT["ev/ucf/scores"], OUT["ev/ucf/labels"], OUT["ev/ucf/auc"] = captured["s"], captured["l"], np.array([captured["auc"]])
+
+
+def main():
+    with tempfile.TemporaryDirectory() as tmp:
+        W = pw.build(os.path.join(tmp, "world"), RefEncoder, RefRegressor, RefClassifier)
+        run_datasets(W)
+        run_test_loaders(W)
+        run_generators(W, tmp)
+        run_evals(W)
+    np.savez_compressed(os.path.join(HERE, "pipeline.npz"), **OUT)
+    print("pipeline.npz:", len(OUT), "arrays,", os.path.getsize(os.path.join(HERE, "pipeline.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+"""GPU parity of the stages around the training step: the HIP model behind pseudo-label generation,
+evaluation and the HBM-resident batch source, against fixtures produced by the reference's own scripts
+(tests/golden/make_golden_pipeline.py) and against the host dataset path."""
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+import pipeline_world as pw                                   # noqa: E402
+from pipeline_cases import DATASET_CASES, build_dataset       # noqa: E402
+from lstc_vad_amd import functional as F                      # noqa: E402
+from lstc_vad_amd import load_dataset as ds_mod               # noqa: E402
+from lstc_vad_amd import pipeline                             # noqa: E402
+from lstc_vad_amd.models import Classifier, Encoder, Regressor  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(HERE, "golden", "pipeline.npz"))
+DEV = torch.device("cuda", 0)
+TOL = 2e-5          # fp32 scores through 3 layers; the reference side ran torch-CPU
+
+
+@pytest.fixture(scope="module")
+def world(tmp_path_factory):
+    return pw.build(str(tmp_path_factory.mktemp("world")), Encoder, Regressor, Classifier)
+
+
+def _load(world, enc_ckpt, enc_kw, head_ckpt, head_cls):
+    strip = lambda sd: {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+    enc = Encoder(**enc_kw)
+    enc.load_state_dict(strip(torch.load(world[enc_ckpt], map_location="cpu")), strict=True)
+    head = head_cls(32)
+    head.load_state_dict(strip(torch.load(world[head_ckpt], map_location="cpu")), strict=True)
+    return enc.to(DEV).eval(), head.to(DEV).eval()
+
+
+def _check_pseudo(out, prefix, thr):
+    keys = [k[len(prefix):] for k in G.files if k.startswith(prefix)]
+    assert list(out.keys()) == keys
+    for k in keys:
+        ref, got = G[prefix + k], out[k]
+        assert got.shape == ref.shape and got.dtype == np.float32
+        near = np.abs(np.where(ref > 0, ref, got) - thr) < 1e-4       # scores sitting on the threshold may flip
+        assert np.all(np.abs(got - ref)[~near] < TOL), (k, np.abs(got - ref).max())
+
+
+def test_pseudo_labels_match_reference_generators(world, tmp_path):
+    enc, head = _load(world, "ltn_sht_enc.ckpt", pw.LTN_SHT, "ltn_sht_cls.ckpt", Classifier)
+    p = str(tmp_path / "pl.npy")
+    out = pipeline.generate_pseudo_labels(enc, head, "LTN", "SHT", world["sht_feats"], world["sht_train"], 0.45, part_len=3,
+                                          out_path=p)
+    _check_pseudo(out, "pl/t_sht/", 0.45)
+    back = np.load(p, allow_pickle=True).tolist()
+    assert list(back) == list(out)
+    out = pipeline.generate_pseudo_labels(enc, head, "LTN", "UBnormal", world["ubn_feats"], world["ubn_train"], 0.45, part_len=3)
+    _check_pseudo(out, "pl/t_ubn/", 0.45)
+    enc, head = _load(world, "ltn_ucf_enc.ckpt", pw.LTN_UCF, "ltn_ucf_cls.ckpt", Classifier)
+    out = pipeline.generate_pseudo_labels(enc, head, "LTN", "UCF", world["ucf_feats"], world["ucf_train"], 0.25, part_len=2,
+                                          n_patch=9)
+    _check_pseudo(out, "pl/t_ucf/", 0.25)
+    enc, head = _load(world, "stn_sht_enc.ckpt", pw.STN_SHT, "stn_sht_reg.ckpt", Regressor)
+    out = pipeline.generate_pseudo_labels(enc, head, "STN", "SHT", world["sht_feats"], world["sht_train"], 0.34)
+    _check_pseudo(out, "pl/s_sht/", 0.34)
+
+
+def test_evaluation_matches_reference_scripts(world):
+    enc, head = _load(world, "ltn_sht_enc.ckpt", pw.LTN_SHT, "ltn_sht_cls.ckpt", Classifier)
+    for tag, dataset, txt, masks, feats in (("sht", "SHT", "sht_test", "sht_masks", "sht_feats"),
+                                             ("ubn", "UBnormal", "ubn_test", "ubn_masks", "ubn_feats")):
+        auc, s, l = pipeline.evaluate_auc(enc, head, "LTN", dataset, world[feats], world[txt], world[masks], 3, 16,
+                                          return_frames=True)
+        assert np.max(np.abs(s - G[f"ev/{tag}/scores"])) < TOL
+        assert np.array_equal(l, G[f"ev/{tag}/labels"])
+        assert abs(auc - float(G[f"ev/{tag}/auc"][0])) < 1e-6
+    enc, head = _load(world, "ltn_ucf_enc.ckpt", pw.LTN_UCF, "ltn_ucf_cls.ckpt", Classifier)
+    auc, s, l = pipeline.evaluate_auc(enc, head, "LTN", "UCF", world["ucf_feats"], world["ucf_test"], world["ucf_gt"], 2, 9,
+                                      return_frames=True)
+    assert np.max(np.abs(s - G["ev/ucf/scores"])) < TOL and np.array_equal(l, G["ev/ucf/labels"])
+    assert abs(auc - float(G["ev/ucf/auc"][0])) < 1e-6
+
+
+def test_gather_rows_is_an_exact_row_copy():
+    g = torch.Generator().manual_seed(3)
+    for rows, shape in ((37, (4,)), (200, (16, 32)), (64, (16, 2048))):
+        bank = torch.randn((rows,) + shape, generator=g).to(DEV)
+        idx = torch.randint(0, rows, (3 * rows + 5,), generator=g).to(DEV)
+        assert torch.equal(F.gather_rows(bank, idx), bank[idx])
+    with pytest.raises(RuntimeError):
+        F.gather_rows(torch.zeros(4, 3, device=DEV), torch.zeros(2, dtype=torch.int64, device=DEV))     # 3 floats: not x4
+
+
+@pytest.mark.parametrize("name", ["sh_uniform", "sh_random_pseudo", "ubn_uniform", "ubn_random"])
+def test_resident_pairs_serve_the_host_batches(world, name):
+    """Batches gathered out of HBM == default-collated dataset items with the same seeds (which the CPU suite pins to the
+    reference's classes)."""
+    spec = DATASET_CASES[name]
+    np.random.seed(spec["seed"]); random.seed(spec["seed"])
+    host = build_dataset(ds_mod, spec, world)
+    bs = 2
+    host_batches = []
+    for _ in range(2):
+        for b in range(len(host) // bs):
+            items = [host[b * bs + j] for j in range(bs)]
+            host_batches.append([torch.stack([it[k].reshape(it[k].shape[0], -1) if k % 2 else it[k] for it in items])
+                                 for k in range(4)])
+        host.shuffle_keys()
+    np.random.seed(spec["seed"]); random.seed(spec["seed"])
+    res = ds_mod.ResidentPairs(build_dataset(ds_mod, spec, world), bs, DEV)
+    got = []
+    for _ in range(2):
+        got.extend([[t.cpu() for t in batch] for batch in res])
+        res.shuffle_keys()
+    assert len(got) == len(host_batches) > 0
+    for a, b in zip(got, host_batches):
+        for k in range(4):
+            assert torch.equal(a[k], b[k]), (name, k)
+
+
+def _run(script_dir, script, argv):
+    env = dict(os.environ, PYTHONPATH=ROOT, HIP_VISIBLE_DEVICES="0")
+    return subprocess.run([sys.executable, script] + argv, cwd=os.path.join(ROOT, script_dir), env=env, capture_output=True,
+                          text=True, timeout=600)
+
+
+def test_reference_command_lines_on_feature_archives(world, tmp_path):
+    """The Train/ and Test/ entry points with the reference's own flags, on archive files: generator -> LTN training with
+    those pseudo labels -> evaluation script on the saved checkpoint."""
+    model = ["--d_model", "32", "--n_head", "2", "--d_k", "16", "--d_v", "16", "--n_hidden", "64", "--MHA_layerNorm",
+             "--FFN_layerNorm", "--relative_position_encoding", "--part_len", "3"]
+    pl = str(tmp_path / "pl_cli.npy")
+    r = _run("Train", "pseudo_labels_generator_temporal.py", model + [
+        "--dataset", "SHT", "--dataset_path", world["sht_feats"], "--training_txt", world["sht_train"], "--data_parallel",
+        "--temporal_model_path", world["ltn_sht_enc.ckpt"], "--classifier_model_path", world["ltn_sht_cls.ckpt"],
+        "--pseudo_labels_path", pl, "--threshold", "0.45"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    _check_pseudo(np.load(pl, allow_pickle=True).tolist(), "pl/t_sht/", 0.45)
+    save = str(tmp_path / "ckpt")
+    r = _run("Train", "temporal_transformer_shanghaitech.py", model + [
+        "--dataset_path", world["sht_feats"], "--training_txt", world["sht_train"], "--testing_txt", world["sht_test"],
+        "--test_mask_dir", world["sht_masks"], "--pseudo_labels_path", pl, "--batch_size", "2", "--part_num", "3",
+        "--epochs", "2", "--inter_epoch", "1", "--model_save_dir", save, "--log_dir", str(tmp_path / "log")])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "test AUC" in r.stderr and "MIL_loss" in r.stderr
+    saved = sorted(os.listdir(save))
+    enc_ckpt = [f for f in saved if f.startswith("temporal_model")][-1]
+    cls_ckpt = [f for f in saved if f.startswith("classifier_model")][-1]
+    ev = ["--d_model", "32", "--temporal_n_head", "2", "--temporal_d_k", "16", "--temporal_d_v", "16", "--temporal_n_hidden", "64",
+          "--temporal_MHA_layerNorm", "--temporal_FFN_layerNorm", "--temporal_relative_position_encoding", "--part_len", "3"]
+    r = _run("Test", "evaluation_shanghaitech_ubnormal.py", ev + [
+        "--dataset", "SHT", "--dataset_path", world["sht_feats"], "--testing_txt", world["sht_test"], "--test_mask_dir",
+        world["sht_masks"], "--temporal_model_path", os.path.join(save, enc_ckpt), "--classifier_model_path",
+        os.path.join(save, cls_ckpt)])
+    assert r.returncode == 0, r.stderr[-2000:]
+    auc = float(r.stdout.strip().split("auc = ")[-1])
+    assert abs(auc - float(enc_ckpt.rsplit("_", 1)[-1])) < 1e-3        # the file name carries the AUC to 4 decimals

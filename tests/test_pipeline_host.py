@@ -1,0 +1,183 @@
+"""CPU tests of the stages around the training step: dataset classes / test loaders against fixtures made
+by the reference's own classes (tests/golden/make_golden_pipeline.py), archive backends, and the host logic of
+pseudo-label generation / evaluation with the ORACLE standing in for the device model (the product path has no CPU
+model; here only the file formats, part arithmetic, thresholds and frame expansion are under test)."""
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+import pipeline_world as pw                                   # noqa: E402
+from pipeline_cases import DATASET_CASES, build_dataset       # noqa: E402
+from lstc_vad_amd import load_dataset as ds_mod               # noqa: E402
+from lstc_vad_amd import pipeline                             # noqa: E402
+from lstc_vad_amd.archive import FeatureArchive               # noqa: E402
+from lstc_vad_amd.models import Classifier, Encoder, Regressor  # noqa: E402
+from oracle import lstc_oracle as orc                         # noqa: E402
+
+G = np.load(os.path.join(HERE, "golden", "pipeline.npz"))
+
+
+@pytest.fixture(scope="module")
+def world(tmp_path_factory):
+    return pw.build(str(tmp_path_factory.mktemp("world")), Encoder, Regressor, Classifier)
+
+
+def _fingerprint(t):
+    a = t.numpy()
+    return a.reshape(a.shape[0], -1)[:, 0].copy(), np.array([a.astype(np.float64).sum()])
+
+
+@pytest.mark.parametrize("name", list(DATASET_CASES))
+def test_dataset_classes_sample_like_the_reference(world, name):
+    """Same seeds -> the same clips, labels, crops and shapes as utils/load_dataset.py, item by item over two epochs."""
+    spec = DATASET_CASES[name]
+    np.random.seed(spec["seed"]); random.seed(spec["seed"])
+    ds = build_dataset(ds_mod, spec, world)
+    assert len(ds) == int(G[f"ds/{name}/len"][0])
+    firsts, sums, labs, crops = [], [], [], []
+    for _ in range(2):
+        for i in range(len(ds)):
+            item = ds[i]
+            for j in (0, 2):
+                f, s = _fingerprint(item[j]); firsts.append(f); sums.append(s)
+                labs.append(item[j + 1].numpy().reshape(-1))
+                assert item[j].dtype == torch.float32 and item[j + 1].dtype == torch.float32
+            if len(item) == 5:
+                crops.append(item[4])
+        ds.shuffle_keys()
+    assert np.array_equal(np.concatenate(firsts), G[f"ds/{name}/first"])
+    assert np.array_equal(np.concatenate(sums), G[f"ds/{name}/sum"])
+    assert np.array_equal(np.concatenate(labs), G[f"ds/{name}/labs"])
+    assert np.array_equal(np.array(item[0].shape), G[f"ds/{name}/shape"])
+    assert np.array_equal(np.array(item[1].shape), G[f"ds/{name}/lab_shape"])
+    assert np.array_equal(np.array(crops, np.int64), G[f"ds/{name}/crops"])
+
+
+def test_test_loaders_match_reference(world):
+    for tag, fn, args in (("sht", ds_mod.shanghaitech_test, (world["sht_test"], world["sht_masks"], world["sht_feats"])),
+                          ("ubn", ds_mod.UBnormal_test, (world["ubn_test"], world["ubn_masks"], world["ubn_feats"]))):
+        feats, labels, annos, names = fn(*args, return_names=True)
+        assert np.array_equal([f.shape[0] for f in feats], G[f"tl/{tag}/n_clips"])
+        assert np.array_equal([l == "Abnormal" for l in labels], G[f"tl/{tag}/abnormal"])
+        assert np.array_equal([len(a) for a in annos], G[f"tl/{tag}/anno_len"])
+        assert np.array_equal([float(np.sum(a)) for a in annos], G[f"tl/{tag}/anno_sum"])
+        assert len(fn(*args)) == 3
+    for i, line in enumerate(open(world["ucf_test"]).readlines()):
+        feats, anno, n_frames, key = ds_mod.UCF_test(line, world["ucf_feats"], world["ucf_gt"], 16, return_name=True)
+        assert np.array_equal([feats.shape[0], len(anno), float(np.sum(anno)), n_frames], G[f"tl/ucf/{i}"])
+
+
+def test_archive_backends_agree(world):
+    with FeatureArchive(world["sht_feats"]) as a, FeatureArchive(world["sht_feats_dir"]) as b:
+        assert sorted(a.keys()) == sorted(b.keys())
+        for k in a.keys():
+            assert k in b and np.array_equal(np.asarray(a[k]), np.asarray(b[k]))
+    with pytest.raises(FileNotFoundError):
+        FeatureArchive(os.path.join(world["root"], "missing.npz"))
+    fake = os.path.join(world["root"], "fake.h5")
+    open(fake, "wb").write(b"\x89HDF\r\n\x1a\n")
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(RuntimeError, match="h5py"):
+            FeatureArchive(fake)
+
+
+def test_missing_pseudo_label_file_exits_like_reference(world):
+    with pytest.raises(SystemExit):
+        ds_mod.SH_Train_Origin_Dataset(3, 2, world["sht_feats"], world["sht_train"], 16, "uniform",
+                                       pseudo_labels_path=os.path.join(world["root"], "nope.npy"))
+
+
+# ---- host logic of the stages, oracle as the model -------------------------------------------------------------------
+
+class _OracleEncoder:
+    """Duck-typed stand-in for ``lstc_vad_amd.models.Encoder`` on CPU (tests only)."""
+
+    def __init__(self, ckpt, kw):
+        sd = torch.load(ckpt, map_location="cpu")
+        self.P = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+        kw = dict(kw); kw.pop("n_layers")
+        self.cfg = orc.EncoderCfg(n_layers=3, **kw)
+        self.layer_norm = types.SimpleNamespace(normalized_shape=(kw["d_model"],))
+
+    def parameters(self):
+        yield torch.zeros(1)
+
+    def forward_cls(self, x):
+        return orc.encoder_forward(self.P, x, self.cfg, training=False)[:, 0, :]
+
+
+class _OracleHead:
+    def __init__(self, ckpt, kind):
+        sd = torch.load(ckpt, map_location="cpu")
+        self.P = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+        self.kind = kind
+
+    def __call__(self, feats):
+        return orc.head_forward(self.P, feats, self.kind, training=False)
+
+
+def _check_pseudo(out, prefix, thr):
+    keys = [k[len(prefix):] for k in G.files if k.startswith(prefix)]
+    assert list(out.keys()) == keys                       # insertion order = list-file order, as np.save pickles it
+    for k in keys:
+        ref, got = G[prefix + k], out[k]
+        assert got.shape == ref.shape and got.dtype == np.float32
+        near = np.abs(np.where(ref > 0, ref, got) - thr) < 1e-5       # a score sitting on the threshold may flip
+        assert np.all(np.abs(got - ref)[~near] < 2e-6), k
+        assert (ref > 0).any() or (ref == 0).all()
+
+
+def test_pseudo_label_generation_host_logic(world, tmp_path):
+    enc = _OracleEncoder(world["ltn_sht_enc.ckpt"], pw.LTN_SHT); head = _OracleHead(world["ltn_sht_cls.ckpt"], "classifier")
+    p = str(tmp_path / "pl.npy")
+    out = pipeline.generate_pseudo_labels(enc, head, "LTN", "SHT", world["sht_feats"], world["sht_train"], 0.45, part_len=3,
+                                          out_path=p)
+    _check_pseudo(out, "pl/t_sht/", 0.45)
+    back = np.load(p, allow_pickle=True).tolist()         # the reference's reader (utils/load_dataset.py:20)
+    assert list(back) == list(out) and all(np.array_equal(back[k], out[k]) for k in out)
+    out = pipeline.generate_pseudo_labels(enc, head, "LTN", "UBnormal", world["ubn_feats"], world["ubn_train"], 0.45, part_len=3)
+    _check_pseudo(out, "pl/t_ubn/", 0.45)
+    enc = _OracleEncoder(world["ltn_ucf_enc.ckpt"], pw.LTN_UCF); head = _OracleHead(world["ltn_ucf_cls.ckpt"], "classifier")
+    out = pipeline.generate_pseudo_labels(enc, head, "LTN", "UCF", world["ucf_feats"], world["ucf_train"], 0.25, part_len=2,
+                                          n_patch=9)
+    _check_pseudo(out, "pl/t_ucf/", 0.25)
+    enc = _OracleEncoder(world["stn_sht_enc.ckpt"], pw.STN_SHT); head = _OracleHead(world["stn_sht_reg.ckpt"], "regressor")
+    out = pipeline.generate_pseudo_labels(enc, head, "STN", "SHT", world["sht_feats"], world["sht_train"], 0.34)
+    _check_pseudo(out, "pl/s_sht/", 0.34)
+
+
+def test_evaluation_host_logic(world):
+    enc = _OracleEncoder(world["ltn_sht_enc.ckpt"], pw.LTN_SHT); head = _OracleHead(world["ltn_sht_cls.ckpt"], "classifier")
+    for tag, dataset, txt, masks, feats in (("sht", "SHT", "sht_test", "sht_masks", "sht_feats"),
+                                             ("ubn", "UBnormal", "ubn_test", "ubn_masks", "ubn_feats")):
+        auc, s, l = pipeline.evaluate_auc(enc, head, "LTN", dataset, world[feats], world[txt], world[masks], 3, 16,
+                                          return_frames=True)
+        assert s.shape == G[f"ev/{tag}/scores"].shape
+        assert np.max(np.abs(s - G[f"ev/{tag}/scores"])) < 2e-6
+        assert np.array_equal(l, G[f"ev/{tag}/labels"])
+        assert abs(auc - float(G[f"ev/{tag}/auc"][0])) < 1e-9
+    enc = _OracleEncoder(world["ltn_ucf_enc.ckpt"], pw.LTN_UCF); head = _OracleHead(world["ltn_ucf_cls.ckpt"], "classifier")
+    auc, s, l = pipeline.evaluate_auc(enc, head, "LTN", "UCF", world["ucf_feats"], world["ucf_test"], world["ucf_gt"], 2, 9,
+                                      return_frames=True)
+    assert np.max(np.abs(s - G["ev/ucf/scores"])) < 2e-6 and np.array_equal(l, G["ev/ucf/labels"])
+    assert abs(auc - float(G["ev/ucf/auc"][0])) < 1e-9
+
+
+def test_utils_import_shim(world):
+    """``from utils.load_dataset import ...`` / ``from utils.eval_utils import eval`` as the reference scripts spell it."""
+    import utils.eval_utils as ue
+    import utils.load_dataset as ul
+    import utils.utils as uu
+    assert ul.SH_Train_Origin_Dataset is ds_mod.SH_Train_Origin_Dataset and ul.UCF_test is ds_mod.UCF_test
+    assert ue.eval([0.1, 0.9, 0.3], [0, 1, 0], None) == 1.0
+    assert uu.get_video_names(world["sht_test"], abnormal=True, normal=False) == [n for n, l, _ in pw.SHT_TEST if l]
