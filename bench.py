@@ -92,7 +92,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="ltn_sht", choices=list(CONFIGS))
+    ap.add_argument("--config", default="ltn_sht", choices=list(CONFIGS) + ["mixed_ubn_sht"],
+                    help="mixed_ubn_sht = BASELINE config 5: half the videos UBnormal (d=1024, L=5), half SHT (d=2048, L=3), two "
+                         "model pairs stepped in one iteration (lstc_vad_amd.engine.MixedStep)")
     ap.add_argument("--batch_size", type=int, default=32, help="normal/abnormal pairs per GPU (B = 2*batch_size videos)")
     ap.add_argument("--part_num", type=int, default=32)
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
@@ -127,25 +129,40 @@ def main():
     from lstc_vad_amd.models import Classifier, Encoder, Regressor
 
     Fn.set_compute_dtype(a.dtype)
-    mode, ekw, skw, drops = CONFIGS[a.config]
-    if a.no_dropout:
-        drops = (0.0, 0.0, 0.0, 0.0)
-    bs, pn, L, P, d = a.batch_size, a.part_num, skw["part_len"], skw["n_patch"], ekw["d_model"]
-    args = Namespace(batch_size=bs, part_num=pn, part_len=L, n_patch=P, lambda_1=0.01, lambda_MIL=1.0, lambda_CE=0.8,
-                     lambda_BCE=1.0, lambda_normal=0.2, lambda_abnormal=2.0, temporal_only=False, clip_grad=False)
-    torch.manual_seed(0)       # same replica on every rank
-    enc = Encoder(n_layers=3, n_head=8, d_k=256, d_v=256, MHA_attn_dropout=drops[0], MHA_fc_dropout=drops[1],
-                  FFN_dropout=drops[2], weight_init=(mode != "LTN"), **ekw).to(dev).train()
-    head = (Classifier(d, drops[3]) if mode == "LTN" else Regressor(d, drops[3])).to(dev).train()
-    ts = TrainStep(args, mode, enc, head, lr_encoder=1e-4, lr_head=1e-2, weight_decay=1e-3, cls_only=not a.naive_last_layer)
+    from lstc_vad_amd.engine import MixedStep
 
-    gen = torch.Generator(device=dev).manual_seed(1000 + rank)      # every rank its own videos
-    Lfeat = L if mode == "LTN" else 1
-    T = pn * L if mode == "LTN" else pn * L
-    nf = 0.5 * torch.relu(torch.randn(bs, T, P, d, device=dev, generator=gen))
-    af = 0.5 * torch.relu(torch.randn(bs, T, P, d, device=dev, generator=gen))
-    u = torch.rand(bs, T, 1, device=dev, generator=gen)
-    al = torch.where(u > 0.9, u, torch.zeros_like(u))            # pseudo labels, rule of README.md:27
+    def make(cfg_name, bs, seed_off=0):
+        mode, ekw, skw, drops = CONFIGS[cfg_name]
+        if a.no_dropout:
+            drops = (0.0, 0.0, 0.0, 0.0)
+        pn, L, P, d = a.part_num, skw["part_len"], skw["n_patch"], ekw["d_model"]
+        args = Namespace(batch_size=bs, part_num=pn, part_len=L, n_patch=P, lambda_1=0.01, lambda_MIL=1.0, lambda_CE=0.8,
+                         lambda_BCE=1.0, lambda_normal=0.2, lambda_abnormal=2.0, temporal_only=False, clip_grad=False)
+        torch.manual_seed(seed_off)       # same replica on every rank
+        enc = Encoder(n_layers=3, n_head=8, d_k=256, d_v=256, MHA_attn_dropout=drops[0], MHA_fc_dropout=drops[1],
+                      FFN_dropout=drops[2], weight_init=(mode != "LTN"), **ekw).to(dev).train()
+        head = (Classifier(d, drops[3]) if mode == "LTN" else Regressor(d, drops[3])).to(dev).train()
+        ts = TrainStep(args, mode, enc, head, lr_encoder=1e-4, lr_head=1e-2, weight_decay=1e-3, cls_only=not a.naive_last_layer)
+        gen = torch.Generator(device=dev).manual_seed(1000 + rank + 97 * seed_off)      # every rank its own videos
+        T = pn * L
+        nf = 0.5 * torch.relu(torch.randn(bs, T, P, d, device=dev, generator=gen))
+        af = 0.5 * torch.relu(torch.randn(bs, T, P, d, device=dev, generator=gen))
+        u = torch.rand(bs, T, 1, device=dev, generator=gen)
+        al = torch.where(u > 0.9, u, torch.zeros_like(u))            # pseudo labels, rule of README.md:27
+        return ts, (nf, af, al)
+
+    mixed = a.config == "mixed_ubn_sht"
+    if mixed:
+        parts = [make("ltn_ubnormal", a.batch_size // 2, 0), make("ltn_sht", a.batch_size // 2, 1)]
+        ms_ = MixedStep([p[0] for p in parts])
+        run_step = lambda: ms_.step([p[1] for p in parts])[-1]
+        names = ["ltn_ubnormal", "ltn_sht"]
+    else:
+        ts, (nf, af, al) = make(a.config, a.batch_size)
+        run_step = lambda: ts.step(nf, af, al)
+        names = [a.config]
+    mode, ekw, skw, drops = CONFIGS[names[-1]]
+    bs, pn, L, P, d = (a.batch_size // 2 if mixed else a.batch_size), a.part_num, skw["part_len"], skw["n_patch"], ekw["d_model"]
 
     def sync():
         if world > 1:
@@ -153,13 +170,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        ts.step(nf, af, al)
+        run_step()
     sync()
     prof = None if a.no_gemm_events else []
     Fn.set_gemm_profiling(prof)
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        sc = ts.step(nf, af, al)
+        sc = run_step()
     sync()
     dt = time.perf_counter() - t0
     Fn.set_gemm_profiling(None)
@@ -169,7 +186,7 @@ def main():
         dt = float(tt.item())
     scal = [float(x) for x in sc.cpu()]
     pcie = None
-    if a.h2d and world == 1:
+    if a.h2d and world == 1 and not mixed:
         from lstc_vad_amd.feed import PinnedFeeder
         host = tuple(t.cpu() for t in (nf, torch.zeros_like(al), af, al))
         feeder = PinnedFeeder((host for _ in range(a.steps + 2)), dev)
@@ -184,12 +201,18 @@ def main():
                 "batch_MB": round(sum(t.numel() * 4 for t in host) / 1e6, 1),
                 "note": "batch copied pageable->pinned->HBM every step on a side stream, overlapped with the previous step"}
 
-    snippets_per_step = 2 * bs * pn * L * world
+    snippets_per_step = sum(2 * bs * pn * CONFIGS[n][2]["part_len"] for n in names) * world
     value = snippets_per_step * a.steps / dt
     if rank == 0:
         S = 1 + (L * P if mode == "LTN" else P)
         nseq = 2 * bs * pn * (1 if mode == "LTN" else L)
         f_seq = train_flops_per_sequence(S, d, 2048, ekw["d_inner"], 3, 2 if mode == "LTN" else 1)
+        alg_flops = 0.0
+        for n in names:
+            m_, e_, s_, _ = CONFIGS[n]
+            S_ = 1 + (s_["part_len"] * s_["n_patch"] if m_ == "LTN" else s_["n_patch"])
+            alg_flops += train_flops_per_sequence(S_, e_["d_model"], 2048, e_["d_inner"], 3, 2 if m_ == "LTN" else 1) * \
+                2 * bs * pn * (1 if m_ == "LTN" else s_["part_len"])
         roof = None
         if prof:
             fl = sum(p[0] for p in prof)
@@ -199,7 +222,7 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "gemm_pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get(a.config)
+                    traffic = None if mixed else json.load(open(pmc)).get(a.config)
                 except Exception:
                     traffic = None
             peak = FP32_MFMA_PEAK_TFLOPS if a.dtype == "fp32" else 2500.0
@@ -211,26 +234,28 @@ def main():
                     "gemm_flops_per_step": fl / a.steps,
                     # SURVEY 8(d) counts the full last layer; the step skips its dead rows (only the CLS token of the
                     # last layer is read), so executed GEMM FLOPs < algorithmic FLOPs.  frac is on EXECUTED work.
-                    "step_algorithmic_tflop": round(f_seq * nseq / 1e12, 3),
+                    "step_algorithmic_tflop": round(alg_flops / 1e12, 3),
                     "step_executed_gemm_tflop": round(fl / a.steps / 1e12, 3),
                     "step_frac_of_peak_executed": round(fl / a.steps / (dt / a.steps) / 1e12 / peak, 4)}
         out = {"metric": "snippets/sec training step (B=64,T=32,P=16,d=2048)", "value": round(value, 1),
                "unit": "snippets/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32" if a.dtype == "fp32" else "bf16 (f32 storage/accumulate)", "data": "synthetic",
-               "config": {"workload": f"{a.config}: {mode} full training step (fwd+loss+bwd+"
+               "config": {"workload": ("mixed batch (BASELINE config 5): per GPU 32 UBnormal videos (d=1024, L=5, S=81) + 32 SHT "
+                                       "videos (d=2048, L=3, S=49), two model pairs, one iteration; second model: " if mixed else "") +
+                                      f"{names[-1]}: {mode} full training step (fwd+loss+bwd+"
                                       f"{'allreduce+' if world > 1 else ''}Adagrad), per GPU B={2 * bs} videos x T={pn} parts x "
                                       f"L={L} snippets x P={P} patches, d_model={d}, n_hidden={ekw['d_inner']}, S={S}, "
                                       f"{nseq} sequences/GPU/step, dropout={'off' if a.no_dropout else 'reference rates'}, last layer: "
                                       f"{'all tokens (naive)' if a.naive_last_layer else 'CLS token only, K/V projections re-associated (exact)'}",
-                          "global_videos": 2 * bs * world, "parallelism": f"dp{world}"},
+                          "global_videos": 2 * bs * world * len(names), "parallelism": f"dp{world}"},
                "loss": scal[0], "roofline": roof}
         if pcie:
             out["pcie_inclusive"] = pcie
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not mixed:
             # torch-CPU sgemm on the GPU box's host peaks at 16-32 threads (tools/cpu_threads_scan.py: 1.3 TFLOP/s
             # at 16-32, 0.5 at 128 of 256 hardware threads), so the baseline uses min(32, available) threads
-            out["cpu_baseline"] = cpu_baseline(a.config, min(32, len(os.sched_getaffinity(0))))
+            out["cpu_baseline"] = cpu_baseline(names[-1], min(32, len(os.sched_getaffinity(0))))
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()

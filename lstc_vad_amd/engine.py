@@ -69,3 +69,37 @@ class TrainStep:
             clip_grad_norm_(self.head.parameters(), 10)
         self.optimizer.step()
         return scalars
+
+
+class MixedStep:
+    """Several (encoder, head) replicas with different feature widths stepped in ONE iteration - BASELINE config 5
+    (UBnormal d_model=1024 / part_len=5 mixed with ShanghaiTech d_model=2048 / part_len=3 in one batch).
+
+    Videos of different datasets cannot share a tensor (different d_model and part_len), so the batch is a list of
+    per-dataset sub-batches, each with its own model pair.  All forwards and backwards are issued first; every model's
+    gradient buckets are reduced asynchronously as its backward produces them, so the all-reduces of model k overlap the
+    compute of model k+1 ("gradients of both in one all-reduce bucket stream"); only then come the waits, the optional
+    clipping and the Adagrad steps."""
+
+    def __init__(self, steps):
+        self.steps = list(steps)
+
+    def step(self, batches):
+        """``batches``: one ``(norm_feats, abnorm_feats, abnorm_labs)`` per TrainStep.  Returns the per-model scalar tensors."""
+        scalars = []
+        for ts, (nf, af, al) in zip(self.steps, batches):
+            loss, sc, _ = ts.forward_loss(nf, af, al)
+            if ts.reducer is not None:
+                ts.reducer.zero_grad()
+            else:
+                ts.optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            scalars.append(sc)
+        for ts in self.steps:
+            if ts.reducer is not None:
+                ts.reducer.finish()
+            if getattr(ts.args, "clip_grad", False):
+                clip_grad_norm_(ts.encoder.parameters(), 10)
+                clip_grad_norm_(ts.head.parameters(), 10)
+            ts.optimizer.step()
+        return scalars

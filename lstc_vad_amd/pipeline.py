@@ -9,7 +9,9 @@ archives, with the reference's file formats.
 * ``evaluate_auc``            - Test/evaluation_shanghaitech_ubnormal.py:69-96, Test/evaluation_UCF.py:47-88 and the
   in-loop evaluation of the train scripts: frame-level ROC-AUC over the whole test list.
 
-Both stages keep features on the device and batch all parts of a video (``lstc_vad_amd.scoring``).
+Both stages keep features on the device and pool the parts of many videos (``pool_sequences``, default 2048 - the
+sequence count of a headline training step) into each launch sequence (``lstc_vad_amd.scoring``); the reference scores
+one part per launch.
 """
 from __future__ import annotations
 
@@ -39,26 +41,41 @@ def _dev(a, device, n_patch=None):
 
 @torch.no_grad()
 def generate_pseudo_labels(enc, head, mode, dataset, dataset_path, training_txt, threshold, part_len=1, n_patch=16,
-                           d_model=None, segment_len=16, classifier_head=False, out_path=None):
+                           d_model=None, segment_len=16, classifier_head=False, out_path=None, pool_sequences=2048):
     """mode 'STN' | 'LTN'; dataset 'SHT' | 'UCF' | 'UBnormal'.  Returns the dict (and writes it when ``out_path``)."""
     device = next(enc.parameters()).device
     d_model = d_model or enc.layer_norm.normalized_shape[0]
-    out = {}
+    out, pool = {}, []            # pool: (key, sequences, ranges) of videos waiting to be scored together
+
+    def flush():
+        if not pool:
+            return
+        sc = scoring.ltn_sequence_scores(enc, head, [q for _, seqs, _ in pool for q in seqs])
+        off = 0
+        for key, seqs, ranges in pool:
+            v = sc[off:off + len(seqs)]; off += len(seqs)
+            s = torch.cat([x.repeat(e - b) for x, (b, e) in zip(v, ranges)]).reshape(-1, 1)
+            out[key + ".npy"] = torch.where(s > threshold, s, torch.zeros_like(s)).cpu().numpy()
+        pool.clear()
+
     with FeatureArchive(dataset_path) as arc:
         for line, key in _train_keys(dataset, training_txt):
             if mode == "STN":
                 s = scoring.stn_clip_scores(enc, head, _dev(arc[key + ".npy"], device), classifier_head).reshape(-1, 1)
-            elif dataset == "UCF":
+                out[key + ".npy"] = torch.where(s > threshold, s, torch.zeros_like(s)).cpu().numpy()
+                continue
+            if dataset == "UCF":
                 feats, n_frames = UCF_train(line, dataset_path, segment_len)
                 f = _dev(feats, device).view(-1, n_patch, d_model)
-                sc, ranges, _ = scoring.ltn_ucf_bin_scores(enc, head, f, n_frames, part_len, segment_len,
-                                                            normalize=False, rewindow=False)
-                s = torch.cat([v.repeat(e - b) for v, (b, e) in zip(sc, ranges)]).reshape(-1, 1)
+                seqs, ranges, _ = scoring.ltn_ucf_bin_sequences(f, n_frames, part_len, segment_len, normalize=False,
+                                                                rewindow=False)
             else:
-                sc, ranges = scoring.ltn_part_scores(enc, head, _dev(arc[key + ".npy"], device), part_len, tail="short")
-                s = torch.cat([v.repeat(e - b) for v, (b, e) in zip(sc, ranges)]).reshape(-1, 1)
-            s = torch.where(s > threshold, s, torch.zeros_like(s))
-            out[key + ".npy"] = s.cpu().numpy()
+                seqs, ranges = scoring.ltn_part_sequences(_dev(arc[key + ".npy"], device), part_len, tail="short")
+            out[key + ".npy"] = None              # keep the list-file key order of the saved dict
+            pool.append((key, seqs, ranges))
+            if sum(len(p[1]) for p in pool) >= pool_sequences:
+                flush()
+        flush()
     if out_path:
         np.save(out_path, out)
     return out
@@ -66,39 +83,54 @@ def generate_pseudo_labels(enc, head, mode, dataset, dataset_path, training_txt,
 
 @torch.no_grad()
 def evaluate_auc(enc, head, mode, dataset, dataset_path, testing_txt, masks, part_len, n_patch, segment_len=16,
-                 return_frames=False):
+                 return_frames=False, pool_sequences=2048):
     """``masks``: directory of ``<video>.npy`` frame masks (SHT / UBnormal, ``--test_mask_dir``) or the ground-truth
     archive (UCF, ``--test_mask_path``).  LTN only scores parts; STN scores clips (in-loop evaluation of the spatio
     scripts, Train/spatio_transformer_shanghaitech.py:118-150: every clip's score x segment_len)."""
     device = next(enc.parameters()).device
-    scores, labels = [], []
+    scores, labels, pool = [], [], []          # pool: (slot in scores/labels, sequences, expand-to-frames closure)
+
+    def flush():
+        if not pool:
+            return
+        sc = scoring.ltn_sequence_scores(enc, head, [q for _, seqs, _ in pool for q in seqs]).cpu().numpy()
+        off = 0
+        for slot, seqs, expand in pool:
+            scores[slot], labels[slot] = expand(sc[off:off + len(seqs)]); off += len(seqs)
+        pool.clear()
+
+    def stn(f, anno):
+        sc = scoring.stn_clip_scores(enc, head, f).reshape(-1).cpu().numpy()
+        s = np.repeat(sc, segment_len)
+        scores.append(s); labels.append(np.asarray(anno[:s.shape[0]]))
+
     if dataset == "UCF":
         for line in open(testing_txt, "r").readlines():
             feats, anno, n_frames, _ = UCF_test(line, dataset_path, masks, segment_len, return_name=True)
             f = _dev(feats, device)
             f = f.view(-1, n_patch, f.shape[-1])
-            if mode == "LTN":
-                sc, ranges, r = scoring.ltn_ucf_bin_scores(enc, head, f, n_frames, part_len, segment_len,
-                                                           normalize=True, rewindow=True)
-                s, l = scoring.frame_scores_ucf(sc.cpu().numpy(), ranges, r, anno, segment_len)
-            else:
-                sc = scoring.stn_clip_scores(enc, head, f).reshape(-1).cpu().numpy()
-                s = np.repeat(sc, segment_len)
-                l = np.asarray(anno[:s.shape[0]])
-            scores.append(s); labels.append(l)
+            if mode != "LTN":
+                stn(f, anno); continue
+            seqs, ranges, r = scoring.ltn_ucf_bin_sequences(f, n_frames, part_len, segment_len, normalize=True, rewindow=True)
+            scores.append(None); labels.append(None)
+            pool.append((len(scores) - 1, seqs,
+                         lambda v, ranges=ranges, r=r, anno=anno: scoring.frame_scores_ucf(v, ranges, r, anno, segment_len)))
+            if sum(len(p[1]) for p in pool) >= pool_sequences:
+                flush()
     else:
         loader = shanghaitech_test if dataset in ("SHT", "MT_SHT") else UBnormal_test
         feats_l, _, annos = loader(testing_txt, masks, dataset_path)
         for feats, anno in zip(feats_l, annos):
             f = _dev(feats, device, n_patch)
-            if mode == "LTN":
-                sc, ranges = scoring.ltn_part_scores(enc, head, f, part_len, tail="rewindow")
-                s, l = scoring.frame_scores_sht(sc.cpu().numpy(), ranges, anno, segment_len)
-            else:
-                sc = scoring.stn_clip_scores(enc, head, f).reshape(-1).cpu().numpy()
-                s = np.repeat(sc, segment_len)
-                l = np.asarray(anno[:s.shape[0]])
-            scores.append(s); labels.append(l)
+            if mode != "LTN":
+                stn(f, anno); continue
+            seqs, ranges = scoring.ltn_part_sequences(f, part_len, tail="rewindow")
+            scores.append(None); labels.append(None)
+            pool.append((len(scores) - 1, seqs,
+                         lambda v, ranges=ranges, anno=anno: scoring.frame_scores_sht(v, ranges, anno, segment_len)))
+            if sum(len(p[1]) for p in pool) >= pool_sequences:
+                flush()
+    flush()
     s, l = np.concatenate(scores), np.concatenate(labels)
     auc = roc_auc(s, l)
     return (auc, s, l) if return_frames else auc

@@ -2,8 +2,9 @@
 
 The reference pushes ONE part of one video through the model per launch sequence (batch 1, e.g.
 Test/evaluation_shanghaitech_ubnormal.py:75-92).  Sequences are independent, so here every part of a video that has
-the same length goes through the encoder as one batch (``Encoder.forward_cls``: only the CLS row is computed in the
-last layer); results are identical row by row (``test_full_width_scores_match_oracle`` checks batch invariance).
+the same length goes through the encoder as one batch - and ``pipeline`` pools the parts of many videos into those
+batches (``ltn_sequence_scores``; ``Encoder.forward_cls``: only the CLS row is computed in the last layer); results
+are identical row by row (``test_full_width_scores_match_oracle`` checks batch invariance).
 
 Recipes (all return per-part scores plus the ``(beg, end)`` clip ranges they stand for):
 
@@ -30,16 +31,23 @@ def part_ranges(n: int, part_len: int):
     return [(i * part_len, n if i == n_parts - 1 else (i + 1) * part_len) for i in range(n_parts)]
 
 
-def _ltn_scores(enc, head, seqs):
-    """seqs: list of [len_i * P, d] tensors -> tensor [len(seqs)] of P(abnormal); same-length sequences share a batch."""
+def ltn_sequence_scores(enc, head, seqs, max_batch=4096):
+    """seqs: list of [len_i * P, d] tensors (any mix of videos) -> tensor [len(seqs)] of P(abnormal).  Same-length
+    sequences share a batch of up to ``max_batch`` rows, so a whole test set is scored in a handful of launch sequences
+    that fill the GPU like a training step does."""
     out = torch.empty(len(seqs), device=seqs[0].device, dtype=torch.float32)
     by_len = {}
     for i, s in enumerate(seqs):
         by_len.setdefault(s.shape[0], []).append(i)
     for ids in by_len.values():
-        x = torch.stack([seqs[i] for i in ids])
-        out[torch.tensor(ids, device=out.device)] = head(enc.forward_cls(x)).view(-1, 2)[:, 1]
+        for c in range(0, len(ids), max_batch):
+            chunk = ids[c:c + max_batch]
+            x = torch.stack([seqs[i] for i in chunk])
+            out[torch.tensor(chunk, device=out.device)] = head(enc.forward_cls(x)).view(-1, 2)[:, 1]
     return out
+
+
+_ltn_scores = ltn_sequence_scores
 
 
 def stn_clip_scores(enc, head, feats, classifier_head=False):
@@ -49,8 +57,8 @@ def stn_clip_scores(enc, head, feats, classifier_head=False):
     return y[:, 1] if classifier_head else y
 
 
-def ltn_part_scores(enc, head, feats, part_len, tail="rewindow"):
-    """feats [n_clips, P, d] -> (scores [n_parts], [(beg, end)])."""
+def ltn_part_sequences(feats, part_len, tail="rewindow"):
+    """feats [n_clips, P, d] -> (list of [len*P, d] sequences, [(beg, end)])."""
     n, P, d = feats.shape
     ranges = part_ranges(n, part_len)
     seqs = []
@@ -60,7 +68,13 @@ def ltn_part_scores(enc, head, feats, part_len, tail="rewindow"):
         else:
             part = feats[beg:end]
         seqs.append(part.reshape(-1, d))
-    return _ltn_scores(enc, head, seqs), ranges
+    return seqs, ranges
+
+
+def ltn_part_scores(enc, head, feats, part_len, tail="rewindow"):
+    """feats [n_clips, P, d] -> (scores [n_parts], [(beg, end)])."""
+    seqs, ranges = ltn_part_sequences(feats, part_len, tail)
+    return ltn_sequence_scores(enc, head, seqs), ranges
 
 
 def ucf_bins(feats, n_frames, segment_len=16, max_clips=32):
@@ -74,8 +88,8 @@ def ucf_bins(feats, n_frames, segment_len=16, max_clips=32):
     return torch.stack(rows), r
 
 
-def ltn_ucf_bin_scores(enc, head, feats, n_frames, part_len, segment_len=16, normalize=True, rewindow=True, max_clips=32):
-    """-> (scores [n_parts], [(beg, end)] in bin units, r).  ``rewindow`` moves a short tail part back so that it spans
+def ltn_ucf_bin_sequences(feats, n_frames, part_len, segment_len=16, normalize=True, rewindow=True, max_clips=32):
+    """-> (sequences, [(beg, end)] in bin units, r).  ``rewindow`` moves a short tail part back so that it spans
     ``part_len`` bins (Test/evaluation_UCF.py:66-67 - there ``beg`` itself moves, so the frames it labels move too)."""
     bins, r = ucf_bins(feats, n_frames, segment_len, max_clips)
     d = bins.shape[-1]
@@ -87,7 +101,12 @@ def ltn_ucf_bin_scores(enc, head, feats, n_frames, part_len, segment_len=16, nor
     seqs = [bins[b:e].reshape(-1, d) for b, e in ranges]
     if normalize:
         seqs = [torch.nn.functional.normalize(s, p=2, dim=-1) for s in seqs]
-    return _ltn_scores(enc, head, seqs), ranges, r
+    return seqs, ranges, r
+
+
+def ltn_ucf_bin_scores(enc, head, feats, n_frames, part_len, segment_len=16, normalize=True, rewindow=True, max_clips=32):
+    seqs, ranges, r = ltn_ucf_bin_sequences(feats, n_frames, part_len, segment_len, normalize, rewindow, max_clips)
+    return ltn_sequence_scores(enc, head, seqs), ranges, r
 
 
 def frame_scores_sht(scores, ranges, anno, segment_len=16):

@@ -117,3 +117,84 @@ def test_bucket_order_and_unused_parameters():
     assert ids == {id(p) for p in enc.used_parameters()} | {id(p) for p in head.parameters()}
     assert id(enc.layer_norm.weight) not in ids and id(enc.layer_stack[0].slf_attn.layer_norm.weight) not in ids
     assert b[1][0] is next(iter(enc.layer_stack[2].parameters()))      # last layer first (backward order)
+
+
+def _mixed_worker(rank, world, port, q):
+    """engine.MixedStep on gloo: two model pairs of different widths, both backward passes issued before any wait; the
+    reduced gradients must equal the single-process gradients over the union of the shards."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from types import SimpleNamespace
+    from lstc_vad_amd.dist import GradAllReducer
+    from lstc_vad_amd.engine import MixedStep
+
+    class SGD:                                   # plain in-place update: keeps the arithmetic easy to restate
+        def __init__(self, params): self.params = list(params)
+        def zero_grad(self, set_to_none=True): pass
+        def step(self):
+            with torch.no_grad():
+                for p in self.params:
+                    p -= 0.1 * p.grad
+
+    class TinyStep:                              # the attributes MixedStep touches on a TrainStep
+        def __init__(self, d, seed):
+            g = torch.Generator().manual_seed(seed)
+            self.encoder = torch.nn.Linear(d, 5)
+            self.head = torch.nn.Linear(5, 1)
+            with torch.no_grad():
+                for p in list(self.encoder.parameters()) + list(self.head.parameters()):
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+            self.args = SimpleNamespace(clip_grad=False)
+            self.reducer = GradAllReducer([list(self.head.parameters()), list(self.encoder.parameters())])
+            self.optimizer = SGD(list(self.encoder.parameters()) + list(self.head.parameters()))
+
+        def forward_loss(self, nf, af, al):
+            y = self.head(torch.tanh(self.encoder(torch.cat([nf, af], 0))))
+            loss = (y ** 2).sum() + (y[nf.shape[0]:] * al).sum()
+            return loss, loss.detach(), y
+
+    def data(d, seed):
+        g = torch.Generator().manual_seed(seed)
+        return torch.randn(4, d, generator=g), torch.randn(4, d, generator=g), torch.rand(4, 1, generator=g)
+
+    steps = [TinyStep(3, 1), TinyStep(7, 2)]
+    full = [data(3, 11), data(7, 12)]
+    h = 4 // world
+    shard = [tuple(t[rank * h:(rank + 1) * h] for t in b) for b in full]
+    MixedStep(steps).step(shard)
+    # single-process restatement on the full batches
+    worst = 0.0
+    for (d, seed), b, ts in zip(((3, 1), (7, 2)), full, steps):
+        ref = TinyStep.__new__(TinyStep)
+        g = torch.Generator().manual_seed(seed)
+        ref.encoder, ref.head = torch.nn.Linear(d, 5), torch.nn.Linear(5, 1)
+        with torch.no_grad():
+            for p in list(ref.encoder.parameters()) + list(ref.head.parameters()):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+        loss, _, _ = TinyStep.forward_loss(ref, *b)
+        loss.backward()
+        for p, r in zip(list(ts.encoder.parameters()) + list(ts.head.parameters()),
+                        list(ref.encoder.parameters()) + list(ref.head.parameters())):
+            worst = max(worst, float((p.detach() - (r.detach() - 0.1 * r.grad)).abs().max()))
+    if rank == 0:
+        q.put(worst)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_mixed_step_two_models_one_reduction_stream():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mixed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    worst = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert worst < 1e-6

@@ -513,3 +513,28 @@ def test_headline_size_properties():
                 if phase == 1:
                     tot += s5
         assert max_abs_diff(tot, sc) < 5e-6
+
+
+def test_mixed_step_equals_reference_golden_for_both_datasets():
+    """BASELINE config 5 (UBnormal d=1024/L=5 mixed with SHT d=2048/L=3 in one iteration), reduced width: one
+    engine.MixedStep over two model pairs reproduces, for EACH pair, the reference's weights after two Adagrad steps."""
+    from lstc_vad_amd.engine import MixedStep, TrainStep
+    steps, batches, goldens = [], [], []
+    for name in ("ltn_ubnormal", "ltn_sht"):
+        z, mode, ekw, skw = load_case(name)
+        enc, head = _models(mode, ekw, ekw["d_model"])
+        enc.load_state_dict(sub(z, "enc_init."), strict=True); head.load_state_dict(sub(z, "head_init."), strict=True)
+        enc, head = enc.to(DEV).train(), head.to(DEV).train()
+        steps.append(TrainStep(_args(mode, skw), mode, enc, head, lr_encoder=1e-4, lr_head=1e-2, weight_decay=1e-3))
+        batches.append(tuple(torch.from_numpy(z[k]).to(DEV) for k in ("norm_feats", "abnorm_feats", "abnorm_labs")))
+        goldens.append(z)
+    mixed = MixedStep(steps)
+    first = mixed.step(batches)
+    mixed.step(batches)
+    for ts, z, sc in zip(steps, goldens, first):
+        assert abs(float(sc[0]) - float(z["scalars"][0])) < 2e-5
+        for prefix, mod, lim in (("enc_after2.", ts.encoder, 1e-3), ("head_after2.", ts.head, 1e-2)):
+            ref = sub(z, prefix)
+            for k, v in mod.state_dict().items():
+                if v.is_floating_point():       # Adagrad's first steps are sign-like: a few near-zero grads may flip
+                    assert float(((v.cpu() - ref[k]).abs() > 5e-5).float().mean()) <= lim, k
