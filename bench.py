@@ -97,8 +97,9 @@ def main():
                          "model pairs stepped in one iteration (lstc_vad_amd.engine.MixedStep)")
     ap.add_argument("--batch_size", type=int, default=32, help="normal/abnormal pairs per GPU (B = 2*batch_size videos)")
     ap.add_argument("--part_num", type=int, default=32)
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
-                    help="GEMM compute type: fp32 = exact-f32 MFMA (headline, parity mode); bf16 = bf16 MFMA on f32 storage")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "f32x3"],
+                    help="GEMM compute type: fp32 = exact-f32 MFMA (headline, parity mode); f32x3 = f32-accurate products on the bf16 "
+                         "matrix cores (3 bf16 planes per operand, 6 plane products, csrc/gemm_pk.hip); bf16 = bf16 MFMA on f32 storage")
     ap.add_argument("--h2d", action="store_true", help="also time the step with the batch arriving from pinned host memory "
                     "every step through lstc_vad_amd.feed.PinnedFeeder (reported as pcie_inclusive, never as value)")
     ap.add_argument("--naive-last-layer", action="store_true", help="evaluate the last encoder layer for every token like the "
@@ -174,12 +175,15 @@ def main():
     sync()
     prof = None if a.no_gemm_events else []
     Fn.set_gemm_profiling(prof)
+    pack_prof = [] if (prof is not None and a.dtype == "f32x3") else None
+    Fn._pack_prof = pack_prof
     t0 = time.perf_counter()
     for _ in range(a.steps):
         sc = run_step()
     sync()
     dt = time.perf_counter() - t0
     Fn.set_gemm_profiling(None)
+    Fn._pack_prof = None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -225,9 +229,13 @@ def main():
                     traffic = None if mixed else json.load(open(pmc)).get(a.config)
                 except Exception:
                     traffic = None
-            peak = FP32_MFMA_PEAK_TFLOPS if a.dtype == "fp32" else 2500.0
-            roof = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)" if a.dtype == "fp32" else
-                    "gemm_bf16c_kernel (v_mfma_f32_32x32x16_bf16, f32 operands in HBM)", "achieved": round(ach, 2),
+            # f32x3: six bf16 MFMA products per f32 product -> the f32-equivalent ceiling is the bf16 peak / 6
+            peak = FP32_MFMA_PEAK_TFLOPS if a.dtype == "fp32" else (round(2500.0 / 6, 1) if a.dtype == "f32x3" else 2500.0)
+            kname = {"fp32": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+                     "f32x3": "gemm_pk_kernel (6 x v_mfma_f32_32x32x16_bf16 per f32 product, packed 3-plane operands; small "
+                              "products on gemm_f32_kernel)",
+                     "bf16": "gemm_bf16c_kernel (v_mfma_f32_32x32x16_bf16, f32 operands in HBM)"}[a.dtype]
+            roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "launches_per_step": len(prof) // a.steps,
                     "gemm_ms_per_step": round(ms / a.steps, 3),
@@ -237,10 +245,16 @@ def main():
                     "step_algorithmic_tflop": round(alg_flops / 1e12, 3),
                     "step_executed_gemm_tflop": round(fl / a.steps / 1e12, 3),
                     "step_frac_of_peak_executed": round(fl / a.steps / (dt / a.steps) / 1e12 / peak, 4)}
+            if pack_prof:
+                pms = sum(q[1].elapsed_time(q[2]) for q in pack_prof)
+                roof["pack_ms_per_step"] = round(pms / a.steps, 3)
+                roof["pack_launches_per_step"] = len(pack_prof) // a.steps
+                roof["pack_input_GBps"] = round(sum(q[0] for q in pack_prof) / (pms * 1e-3) / 1e9, 1)
         out = {"metric": "snippets/sec training step (B=64,T=32,P=16,d=2048)", "value": round(value, 1),
                "unit": "snippets/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32" if a.dtype == "fp32" else "bf16 (f32 storage/accumulate)", "data": "synthetic",
+               "vs_baseline": None, "dtype": {"fp32": "f32", "f32x3": "f32 (operands split into 3 bf16 planes, 6 bf16-MFMA products, f32 accumulate)",
+                         "bf16": "bf16 (f32 storage/accumulate)"}[a.dtype], "data": "synthetic",
                "config": {"workload": ("mixed batch (BASELINE config 5): per GPU 32 UBnormal videos (d=1024, L=5, S=81) + 32 SHT "
                                        "videos (d=2048, L=3, S=49), two model pairs, one iteration; second model: " if mixed else "") +
                                       f"{names[-1]}: {mode} full training step (fwd+loss+bwd+"

@@ -38,7 +38,7 @@ enum {
     LSTC_E_RANGE = -5               /* size exceeds a documented limit (e.g. sequence length, 32-bit indexing) */
 };
 
-enum { LSTC_F32 = 0, LSTC_BF16 = 1 };
+enum { LSTC_F32 = 0, LSTC_BF16 = 1, LSTC_F32X3 = 2 };
 
 /* ----------------------------------------------------------------------------- GEMM
  * C[M,N] = epilogue( alpha * op(A)[M,K] * op(B)[K,N] )
@@ -59,6 +59,9 @@ enum { LSTC_F32 = 0, LSTC_BF16 = 1 };
  * 1/(1-p); lstc_dropout_mask() / lstc_dropout_apply() regenerate the same mask.
  * dtype LSTC_F32: exact f32 MFMA (v_mfma_f32_32x32x2_f32) — bitwise a k-ordered fmaf chain.
  * dtype LSTC_BF16: A/B bf16, f32 accumulate; C bf16 unless LSTC_EPI_OUT_F32.
+ * dtype LSTC_F32X3: f32-accurate product on the bf16 matrix cores; A and B are PACKED operands produced by lstc_pack3
+ *   for the logical [M,K] and [N,K] matrices (transA/transB/lda/ldb are ignored - transposition happens in the pack);
+ *   C, bias, residual, relu_src and the epilogue are f32 exactly as for LSTC_F32; no batch.
  */
 enum {
     LSTC_EPI_BIAS = 1, LSTC_EPI_RELU = 2, LSTC_EPI_DROPOUT = 4, LSTC_EPI_RESIDUAL = 8,
@@ -92,6 +95,16 @@ typedef struct LstcGemmDesc {
 } LstcGemmDesc;
 
 int lstc_gemm(const LstcGemmDesc* d, void* stream);
+
+/* Operand packing for LSTC_F32X3.  Writes the [rows, K] operand (row = an output row of A's side or an output column of
+ * B's side, K = the contraction) as 128-row x 32-k tiles, each tile = three 8-KB bf16 planes h, m, l with
+ * x = h + m + l exactly (h = bf16(x), m = bf16(x-h), l = bf16(x-h-m)), stored in the LDS image layout the GEMM streams
+ * with global_load_lds (csrc/gemm_pk.hip); rows and K are zero-padded to the tile.
+ *   k_major = 0: src is [rows, K] with K contiguous (ld >= K)  - X of X*W^T, W of X*W^T, dY of dY*W
+ *   k_major = 1: src is [K, rows] with rows contiguous (ld >= rows) - W of dY*W, dY and X of dY^T*X
+ * dst needs lstc_pack3_bytes(rows, K) bytes, 16-B aligned.  The same nn.Linear products as lstc_gemm (see above). */
+int64_t lstc_pack3_bytes(int64_t rows, int64_t K);
+int lstc_pack3(const float* src, int64_t rows, int64_t K, int64_t ld, int32_t k_major, void* dst, void* stream);
 
 /* ------------------------------------------------------------------------ attention
  * Fused core of models/MultiHeadAttention.py:103-122 for one layer, all sequences, heads:

@@ -3,6 +3,7 @@
 
 int lstc_gemm_f32_impl(const LstcGemmDesc* d, hipStream_t st);
 int lstc_gemm_bf16_impl(const LstcGemmDesc* d, hipStream_t st) __attribute__((weak));
+int lstc_gemm_f32x3_impl(const LstcGemmDesc* d, hipStream_t st);
 
 extern "C" {
 
@@ -11,6 +12,7 @@ int lstc_gemm(const LstcGemmDesc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == LSTC_F32) return lstc_gemm_f32_impl(d, st);
     if (d->dtype == LSTC_BF16 && lstc_gemm_bf16_impl) return lstc_gemm_bf16_impl(d, st);
+    if (d->dtype == LSTC_F32X3) return lstc_gemm_f32x3_impl(d, st);
     return LSTC_E_UNSUPPORTED;
 }
 

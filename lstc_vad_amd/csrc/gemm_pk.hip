@@ -1,0 +1,311 @@
+// f32-accurate GEMM on the bf16 matrix cores over PACKED, pre-split operands (LstcGemmDesc.dtype = LSTC_F32X3).
+//
+// Arithmetic.  Every f32 x is written x = h + m + l EXACTLY with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)
+// (round-to-nearest-even; 3 x 8 significand bits = the 24 of an f32).  A dot product is then the sum over plane pairs;
+// the six pairs {hh, hm, mh, mm, hl, lh} leave out only terms below 2^-26 |a||b| (ml, lm, ll), each bf16 x bf16 product
+// is exact in f32 and v_mfma_f32_32x32x16_bf16 accumulates in f32.  Measured against f64 (tools/x3_probe.hip, K = 2048,
+// activations x weights): rms error 1.06e-7 of the result vs 0.92e-7 for a sequential f32 fma chain - f32 accuracy.
+// The bf16 MFMA runs at 16x the rate of v_mfma_f32_32x32x2_f32, so six per k16 block cost 192 cycles against 512.
+//
+// Data movement.  Splitting rewrites an operand anyway, so the same pass PACKS it (lstc_pack3): the matrix is cut into
+// 128-row x 32-k tiles and each plane of a tile is stored as the exact 8-KB LDS image the kernel reads - unpadded rows of
+// four 16-B chunks, chunk index XOR-ed with (row >> 2) & 3, which puts the 16 lanes of every ds_read_b128 lane group on
+// 16 distinct 16-B slots (MI355X_MICROARCH, LDS table).  Transposition happens in the pack pass too, so ONE NT kernel
+// serves forward (X W^T), input-gradient (dY W) and weight-gradient (dY^T X) products.  The GEMM streams tiles with
+// global_load_lds_dwordx4 (1 KB contiguous per wave-instruction, no staging registers, no ds_write) into a 3-stage LDS
+// ring: tile t+3 is requested during the second half of tile t, two K tiles ahead of its use.
+//
+// Schedule per K tile and wave (one wave per SIMD, 4 waves, 128x128 tile, 64x64 per wave): phase 1 = 24 MFMAs on k-step 0
+// fragments while the k-step 1 fragments are read; s_waitcnt vmcnt(12) + raw s_barrier (tile t+1 published, stage t free);
+// phase 2 = 24 MFMAs on k-step 1 while tile t+3 is requested and the k-step 0 fragments of tile t+1 are read.
+// Steady loop (3 tiles): 144 MFMA, 72 ds_read_b128, 36 global_load_lds, ~40 scalar/VALU.
+#include "lstc_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int NT = 256;
+constexpr int PK_IMG = 4096;            // bf16 elements of one plane image (128 rows x 32 k)
+constexpr int PK_TILE = 3 * PK_IMG;     // one packed tile: planes h, m, l
+constexpr int PK_STAGE = 2 * PK_TILE;   // A tile then B tile
+constexpr int PK_NSTAGE = 3;
+
+__device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)v;
+    const float r1 = v - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+// ---- pack, K-contiguous source [rows, K] (ld): one workgroup per (row block, k block) tile; thread -> two 16-B chunks.
+__global__ void __launch_bounds__(NT) pack3_kc_kernel(const float* __restrict__ x, int rows, int K, long long ld,
+                                                      __bf16* __restrict__ out, int KB) {
+    const int kb = blockIdx.x % KB, rb = blockIdx.x / KB;
+    bf16x8* o = reinterpret_cast<bf16x8*>(out) + (size_t)blockIdx.x * 3 * 512;
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int s = threadIdx.x + q * NT;          // chunk id inside the tile: row r = s / 4, chunk c = s % 4
+        const int r = s >> 2, c = s & 3;
+        const int row = rb * 128 + r, k0 = kb * 32 + c * 8;
+        float v[8];
+        if (row < rows && k0 + 8 <= K && vec) {
+            const float4 a = *reinterpret_cast<const float4*>(x + (size_t)row * ld + k0);
+            const float4 b = *reinterpret_cast<const float4*>(x + (size_t)row * ld + k0 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (row < rows && k0 + j < K) ? x[(size_t)row * ld + k0 + j] : 0.f;
+        }
+        bf16x8 hh, mm, ll;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { __bf16 h, m, l; split3(v[j], h, m, l); hh[j] = h; mm[j] = m; ll[j] = l; }
+        const int slot = r * 4 + (c ^ ((r >> 2) & 3));
+        o[slot] = hh; o[512 + slot] = mm; o[1024 + slot] = ll;
+    }
+}
+
+// ---- pack, k-major source [K, rows] (ld): the packed operand's row index runs along the source's contiguous dimension.
+// Thread -> one packed row (feature) and 16 of the tile's 32 k (source rows): coalesced reads along the features.
+__global__ void __launch_bounds__(NT) pack3_km_kernel(const float* __restrict__ x, int rows, int K, long long ld,
+                                                      __bf16* __restrict__ out, int KB) {
+    const int kb = blockIdx.x % KB, rb = blockIdx.x / KB;
+    bf16x8* o = reinterpret_cast<bf16x8*>(out) + (size_t)blockIdx.x * 3 * 512;
+    const int r = threadIdx.x & 127, half = threadIdx.x >> 7;
+    const int row = rb * 128 + r;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+        const int c = half * 2 + cc, k0 = kb * 32 + c * 8;
+        bf16x8 hh, mm, ll;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = (row < rows && k0 + j < K) ? x[(size_t)(k0 + j) * ld + row] : 0.f;
+            __bf16 h, m, l; split3(v, h, m, l); hh[j] = h; mm[j] = m; ll[j] = l;
+        }
+        const int slot = r * 4 + (c ^ ((r >> 2) & 3));
+        o[slot] = hh; o[512 + slot] = mm; o[1024 + slot] = ll;
+    }
+}
+
+struct PkParams {
+    const __bf16* A;
+    const __bf16* B;
+    float* C;
+    const float* bias;
+    const float* res;
+    const float* relu_src;
+    int M, N, ldc, ldr, ld_relu, flags;
+    float alpha;
+    DropKey dk;
+    int tilesN, KB, ktiles_per_split;
+};
+
+// plane pairs by decreasing magnitude: hh, hm, mh, mm, hl, lh
+__device__ __forceinline__ constexpr int pa(int q) { return q == 0 ? 0 : q == 1 ? 0 : q == 2 ? 1 : q == 3 ? 1 : q == 4 ? 0 : 2; }
+__device__ __forceinline__ constexpr int pb(int q) { return q == 0 ? 0 : q == 1 ? 1 : q == 2 ? 0 : q == 3 ? 1 : q == 4 ? 2 : 0; }
+
+template <int SMODE, int CUR>
+struct StepTag { static constexpr int smode = SMODE, cur = CUR; };
+
+__global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem_pk[];
+    __bf16* const smem = smem_pk;
+    int pid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = pid & 7, idx = pid >> 3, q = nwg >> 3, r = nwg & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mb = pid / p.tilesN, nb = pid % p.tilesN;
+    const int kt0 = blockIdx.y * p.ktiles_per_split;
+    const int nkt = min(p.KB, kt0 + p.ktiles_per_split) - kt0;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    // a stage is 48 pieces of 1 KB: pieces 0..23 = the 24 contiguous KB of the A tile, 24..47 = the B tile; wave w moves
+    // pieces 12w .. 12w+11 (waves 0,1: A; waves 2,3: B).  gbase is wave-uniform (SGPRs); the lane adds 16 B * lane.
+    const __bf16* gbase = (wave < 2 ? p.A + ((size_t)mb * p.KB + kt0) * PK_TILE : p.B + ((size_t)nb * p.KB + kt0) * PK_TILE) +
+                          (size_t)(wave & 1) * 12 * 512;
+    const int ldst = wave * 12 * 512;
+    // piece j = 4 * (j / 4) + (j % 4): the low part rides in the instruction's immediate offset (applies to both sides)
+#define DMA_ONE(j, kt, stage)                                                                                          \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gbase + (size_t)(kt) * PK_TILE + ((j) >> 2) * 2048 + lane * 8),           \
+                                     (lptr_t)(smem + (stage) * PK_STAGE + ldst + ((j) >> 2) * 2048), 16, ((j) & 3) * 1024, 0)
+#define DMA_TILE(kt, stage)                                                                                            \
+    do {                                                                                                               \
+        DMA_ONE(0, kt, stage); DMA_ONE(1, kt, stage); DMA_ONE(2, kt, stage); DMA_ONE(3, kt, stage);                    \
+        DMA_ONE(4, kt, stage); DMA_ONE(5, kt, stage); DMA_ONE(6, kt, stage); DMA_ONE(7, kt, stage);                    \
+        DMA_ONE(8, kt, stage); DMA_ONE(9, kt, stage); DMA_ONE(10, kt, stage); DMA_ONE(11, kt, stage);                  \
+    } while (0)
+    // fragment of k-step ks: rows tile0 + l31, logical 16-B chunk 2h + ks (any K permutation shared by A and B is fine)
+    const int rowa0 = wm * 64 + l31, rowb0 = wn * 64 + l31;
+    auto rd = [&](const __bf16* img, int row, int ks) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(img + (row * 4 + ((2 * h + ks) ^ ((row >> 2) & 3))) * 8);
+    };
+    bf16x8 f0a[3][2], f0b[3][2], f1a[3][2], f1b[3][2];
+    // read order = order of first use by the plane-pair rounds (lh, hl, mm, mh, hm, hh): A.l, B.h, A.h, B.l, A.m, B.m
+    auto frag_one = [&](int e, const __bf16* s, int ks, bf16x8 (&fa)[3][2], bf16x8 (&fb)[3][2]) {
+        const int g = e >> 1, i = e & 1;
+        const int pl = g == 0 ? 2 : g == 1 ? 0 : g == 2 ? 0 : g == 3 ? 2 : 1;
+        if ((g & 1) == 0) fa[pl][i] = rd(s + pl * PK_IMG, rowa0 + i * 32, ks);
+        else fb[pl][i] = rd(s + (3 + pl) * PK_IMG, rowb0 + i * 32, ks);
+    };
+    // ---- prologue: tiles 0, 1, 2 -> stages 0, 1, 2 (K index clamped: the in-order vmcnt bookkeeping is then the same on
+    // every path into the loop; sched_barriers keep the issue order)
+    DMA_TILE(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    DMA_TILE(min(1, nkt - 1), 1);
+    __builtin_amdgcn_sched_barrier(0);
+    DMA_TILE(min(2, nkt - 1), 2);
+    __builtin_amdgcn_s_waitcnt(0x4F78);              // vmcnt(24): tile 0 landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int e = 0; e < 12; ++e) frag_one(e, smem, 0, f0a, f0b);
+
+    auto step = [&](int it, auto tag) {
+        // SMODE 1: tiles t+1..t+3 exist; 4: t+1, t+2 exist (nothing more to request); 2: only t+1; 3: last tile
+        constexpr int SMODE = decltype(tag)::smode;
+        constexpr int CUR = decltype(tag)::cur;              // stage of tile t (0..2)
+        constexpr int NXT = (CUR + 1) % 3;
+        constexpr bool HAS1 = SMODE != 3, HAS3 = SMODE == 1;
+        const __bf16* s_cur = smem + CUR * PK_STAGE;
+        const __bf16* s_nxt = smem + NXT * PK_STAGE;
+#define PK_MMA(FA, FB, q)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[pa(q)][i], FB[pb(q)][j], acc[i][j], 0, 0, 0);  \
+    __builtin_amdgcn_sched_barrier(0)
+#define PK_R1(r)                                                                                            \
+    frag_one(2 * (r), s_cur, 1, f1a, f1b); frag_one(2 * (r) + 1, s_cur, 1, f1a, f1b);                        \
+    PK_MMA(f0a, f0b, 5 - (r))
+#define PK_R2(r)                                                                                            \
+    if (HAS3) { DMA_ONE(2 * (r), it + 3, CUR); DMA_ONE(2 * (r) + 1, it + 3, CUR); }                          \
+    if (HAS1) { frag_one(2 * (r), s_nxt, 0, f0a, f0b); frag_one(2 * (r) + 1, s_nxt, 0, f0a, f0b); }          \
+    PK_MMA(f1a, f1b, 5 - (r))
+        PK_R1(0); PK_R1(1); PK_R1(2); PK_R1(3); PK_R1(4); PK_R1(5);
+        // tile t+1 must have landed (requested two K tiles ago); tile t+2's 12 requests may stay in flight.
+        // Raw s_barrier: __syncthreads() adds a fence that drains EVERY LDS-DMA in flight (vmcnt(0)).
+        if (SMODE == 1 || SMODE == 4) __builtin_amdgcn_s_waitcnt(0x007C);     // vmcnt(12) lgkmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(0x0070);                              // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        PK_R2(0); PK_R2(1); PK_R2(2); PK_R2(3); PK_R2(4); PK_R2(5);
+#undef PK_MMA
+#undef PK_R1
+#undef PK_R2
+    };
+    int it = 0;
+    for (; it + 5 < nkt; it += 3) {
+        step(it, StepTag<1, 0>{});
+        step(it + 1, StepTag<1, 1>{});
+        step(it + 2, StepTag<1, 2>{});
+    }
+    for (; it < nkt; it += 3) {      // tail (it % 3 == 0): 1..5 tiles left
+        const int rem = nkt - it;
+        if (rem >= 4) step(it, StepTag<1, 0>{}); else if (rem == 3) step(it, StepTag<4, 0>{}); else if (rem == 2) step(it, StepTag<2, 0>{}); else step(it, StepTag<3, 0>{});
+        if (rem >= 5) step(it + 1, StepTag<1, 1>{}); else if (rem == 4) step(it + 1, StepTag<4, 1>{}); else if (rem == 3) step(it + 1, StepTag<2, 1>{}); else if (rem == 2) step(it + 1, StepTag<3, 1>{});
+        if (rem >= 6) step(it + 2, StepTag<1, 2>{}); else if (rem == 5) step(it + 2, StepTag<4, 2>{}); else if (rem == 4) step(it + 2, StepTag<2, 2>{}); else if (rem == 3) step(it + 2, StepTag<3, 2>{});
+    }
+#undef DMA_ONE
+#undef DMA_TILE
+
+    // ---- epilogue (semantics of gemm_f32.hip)
+    const int flags = p.flags;
+    const bool atomic = gridDim.y > 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = nb * 128 + wn * 64 + j * 32 + l31;
+        if (col >= p.N) continue;
+        const float bv = (flags & LSTC_EPI_BIAS) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rbase = mb * 128 + wm * 64 + i * 32 + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] * p.alpha;
+                float* cp = p.C + (size_t)row * p.ldc + col;
+                if (atomic) {
+                    atomicAdd(cp, v);
+                    continue;
+                }
+                v += bv;
+                if (flags & LSTC_EPI_RELU) v = fmaxf(v, 0.f);
+                if (flags & LSTC_EPI_DROPOUT) {
+                    const uint32_t idx = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+                    v = drop_keep(idx, p.dk) ? v * p.dk.scale : 0.f;
+                }
+                if (flags & LSTC_EPI_RESIDUAL) v += p.res[(size_t)row * p.ldr + col];
+                if (flags & LSTC_EPI_RELU_MASK) v = p.relu_src[(size_t)row * p.ld_relu + col] > 0.f ? v : 0.f;
+                if (flags & LSTC_EPI_ACCUM) v += *cp;
+                *cp = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Packed-operand GEMM behind lstc_gemm (dtype LSTC_F32X3): d->A / d->B point to lstc_pack3 outputs for [M, K] / [N, K].
+int lstc_gemm_f32x3_impl(const LstcGemmDesc* d, hipStream_t st) {
+    if (!d->A || !d->B || !d->C) return LSTC_E_NULL;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->ldc < d->N) return LSTC_E_SHAPE;
+    if (d->batch > 1) return LSTC_E_UNSUPPORTED;
+    if ((d->flags & LSTC_EPI_BIAS) && !d->bias) return LSTC_E_NULL;
+    if ((d->flags & LSTC_EPI_RESIDUAL) && (!d->residual || d->ldr < d->N)) return LSTC_E_NULL;
+    if ((d->flags & LSTC_EPI_RELU_MASK) && (!d->relu_src || d->ld_relu < d->N)) return LSTC_E_NULL;
+    if ((d->flags & LSTC_EPI_DROPOUT) && (uint64_t)d->M * (uint64_t)d->N > 0xffffffffull) return LSTC_E_RANGE;
+    if (!aligned16(d->A) || !aligned16(d->B)) return LSTC_E_ALIGN;
+    const int splits = d->split_k > 1 ? d->split_k : 1;
+    if (splits > 1 && d->flags != 0) return LSTC_E_UNSUPPORTED;
+    PkParams p;
+    p.A = (const __bf16*)d->A; p.B = (const __bf16*)d->B; p.C = (float*)d->C;
+    p.bias = d->bias; p.res = (const float*)d->residual; p.relu_src = (const float*)d->relu_src;
+    p.M = d->M; p.N = d->N; p.ldc = d->ldc; p.ldr = d->ldr; p.ld_relu = d->ld_relu; p.flags = d->flags; p.alpha = d->alpha;
+    p.dk = make_drop_key(d->dropout_p, d->dropout_seed);
+    p.KB = (d->K + 31) / 32;
+    p.ktiles_per_split = (p.KB + splits - 1) / splits;
+    const int eff_splits = (p.KB + p.ktiles_per_split - 1) / p.ktiles_per_split;
+    const int tilesM = (d->M + 127) / 128;
+    p.tilesN = (d->N + 127) / 128;
+    constexpr size_t lds = (size_t)PK_NSTAGE * PK_STAGE * sizeof(__bf16);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_pk_kernel, dim3(tilesM * p.tilesN, eff_splits), dim3(NT), lds, st, p);
+    return lstc_launch_status();
+}
+
+extern "C" {
+
+int64_t lstc_pack3_bytes(int64_t rows, int64_t K) {
+    if (rows <= 0 || K <= 0) return 0;
+    return ((rows + 127) / 128) * ((K + 31) / 32) * (int64_t)PK_TILE * (int64_t)sizeof(__bf16);
+}
+
+int lstc_pack3(const float* src, int64_t rows, int64_t K, int64_t ld, int32_t k_major, void* dst, void* stream) {
+    if (!src || !dst) return LSTC_E_NULL;
+    if (rows <= 0 || K <= 0 || ld < (k_major ? rows : K)) return LSTC_E_SHAPE;
+    if (!aligned16(dst)) return LSTC_E_ALIGN;
+    const int64_t RB = (rows + 127) / 128, KB = (K + 31) / 32;
+    if (RB * KB > 0x7fffffffLL || rows > 0x7fffffffLL || K > 0x7fffffffLL) return LSTC_E_RANGE;
+    if (k_major)
+        hipLaunchKernelGGL(pack3_km_kernel, dim3((unsigned)(RB * KB)), dim3(NT), 0, (hipStream_t)stream, src, (int)rows, (int)K,
+                           (long long)ld, (__bf16*)dst, (int)KB);
+    else
+        hipLaunchKernelGGL(pack3_kc_kernel, dim3((unsigned)(RB * KB)), dim3(NT), 0, (hipStream_t)stream, src, (int)rows, (int)K,
+                           (long long)ld, (__bf16*)dst, (int)KB);
+    return lstc_launch_status();
+}
+
+}  // extern "C"

@@ -63,19 +63,103 @@ _compute_dtype = F32      # LstcGemmDesc.dtype used by every GEMM: F32 = exact f
 
 
 def set_compute_dtype(name: str):
-    """"fp32" (default; exact-f32 MFMA, the parity mode) or "bf16" (operands rounded to bf16 inside the GEMM, f32
-    accumulate and f32 storage everywhere: BASELINE.json configs 3 / 5).  Attention, LayerNorm, loss and Adagrad stay f32."""
+    """"fp32" (default; exact-f32 MFMA, the parity mode), "f32x3" (f32-accurate products on the bf16 matrix cores: every
+    operand split exactly into three bf16 planes, six plane products, f32 accumulation - csrc/gemm_pk.hip; small GEMMs stay
+    on the exact-f32 kernel) or "bf16" (operands rounded to bf16 inside the GEMM, f32 accumulate and f32 storage everywhere:
+    BASELINE.json configs 3 / 5).  Attention, LayerNorm, loss and Adagrad stay f32."""
     global _compute_dtype
     if name in ("fp32", "f32", "float32"):
         _compute_dtype = F32
     elif name in ("bf16", "bfloat16"):
         _compute_dtype = _lib.BF16
+    elif name in ("f32x3", "fp32x3"):
+        _compute_dtype = _lib.F32X3
     else:
         raise ValueError(name)
 
 
 def get_compute_dtype() -> str:
-    return "bf16" if _compute_dtype == _lib.BF16 else "fp32"
+    return {_lib.BF16: "bf16", _lib.F32X3: "f32x3"}.get(_compute_dtype, "fp32")
+
+
+# ---- packed operands of the f32x3 GEMM (csrc/gemm_pk.hip) ------------------------------------------------------------
+class Packed:
+    """An operand as lstc_pack3 leaves it: logical [rows, K], three bf16 planes in the GEMM's LDS-image tiling."""
+    __slots__ = ("buf", "rows", "K")
+
+    def __init__(self, buf, rows, K):
+        self.buf, self.rows, self.K = buf, rows, K
+
+
+_pack_prof = None          # list of (bytes_in, start_event, end_event) while bench.py profiles
+_wpack_cache = {}          # (data_ptr, shape, k_major) -> (epoch, version, Packed): weights are packed once per optimizer step
+_wepoch = 0
+_memo_stack = []           # activation packs made inside one autograd-node body are shared by the GEMMs of that body
+_x3_min = (256, 256, 1 << 30)   # min(M, N), K, M*N*K from which a product goes to the packed kernel
+
+
+def set_x3_threshold(min_mn=256, min_k=256, min_mnk=1 << 30):
+    """Size from which f32x3 mode uses the packed kernel (tests set 0, 0, 0 to push the reduced-width cases through it)."""
+    global _x3_min
+    _x3_min = (int(min_mn), int(min_k), int(min_mnk))
+
+
+def bump_weight_epoch():
+    """Invalidate the packed-weight cache (the optimizer rewrote the weights through raw pointers)."""
+    global _wepoch
+    _wepoch += 1
+    if len(_wpack_cache) > 256:
+        _wpack_cache.clear()
+
+
+class pack_memo:
+    """``with pack_memo():`` - activation operands packed inside the block are reused by later GEMMs of the block (X feeds
+    the Q, K and V projections; the k-major pack of X feeds three weight gradients)."""
+
+    def __enter__(self):
+        _memo_stack.append({})
+        return self
+
+    def __exit__(self, *exc):
+        _memo_stack.pop()
+        return False
+
+
+def pack3(t: torch.Tensor, k_major: bool = False) -> Packed:
+    """Pack a 2-D f32 operand for the f32x3 GEMM.  ``k_major`` = the contraction runs along dim 0 of ``t``."""
+    pt, r, c, ld = _mat(t)
+    rows, K = (c, r) if k_major else (r, c)
+    lib = _lib.load()
+    buf = torch.empty((int(lib.lstc_pack3_bytes(rows, K)),), device=t.device, dtype=torch.uint8)
+    if _pack_prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.lstc_pack3(pt, rows, K, ld, int(k_major), dev_ptr(buf), stream_ptr()), "lstc_pack3")
+        e1.record()
+        _pack_prof.append((4.0 * rows * K, e0, e1))
+    else:
+        check(lib.lstc_pack3(pt, rows, K, ld, int(k_major), dev_ptr(buf), stream_ptr()), "lstc_pack3")
+    return Packed(buf, rows, K)
+
+
+def _packed_operand(t, k_major):
+    if isinstance(t, Packed):
+        return t
+    if t.is_leaf and t.requires_grad:                      # a weight: one pack per optimizer step and layout
+        key = (t.data_ptr(), tuple(t.shape), k_major)
+        hit = _wpack_cache.get(key)
+        if hit is not None and hit[0] == _wepoch and hit[1] == t._version:
+            return hit[2]
+        pk = pack3(t.detach(), k_major)
+        _wpack_cache[key] = (_wepoch, t._version, pk)
+        return pk
+    if _memo_stack:
+        key = (t.data_ptr(), tuple(t.shape), t.stride(), k_major)
+        hit = _memo_stack[-1].get(key)
+        if hit is None:
+            hit = _memo_stack[-1][key] = pack3(t, k_major)
+        return hit
+    return pack3(t, k_major)
 
 
 def set_gemm_profiling(sink):
@@ -96,22 +180,39 @@ def _mat(t: torch.Tensor):
 def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out: Optional[torch.Tensor] = None,
          bias=None, relu=False, dropout=None, residual=None, relu_mask=None, accumulate=False, alpha=1.0,
          split_k=1, variant=0) -> torch.Tensor:
-    """``out = epi(alpha * op(a) @ op(b))`` through ``lstc_gemm`` (include/lstc_hip.h)."""
-    pa, ar, ac, lda = _mat(a)
-    pb, br, bc, ldb = _mat(b)
-    M, K = (ac, ar) if trans_a else (ar, ac)
-    Kb, N = (bc, br) if trans_b else (br, bc)
+    """``out = epi(alpha * op(a) @ op(b))`` through ``lstc_gemm`` (include/lstc_hip.h).  ``a`` / ``b`` may be ``Packed``
+    operands (f32x3 mode): then they stand for the logical [M, K] / [N, K] matrices and trans_a / trans_b are moot."""
+    dev = (a.buf if isinstance(a, Packed) else a).device
+    if isinstance(a, Packed):
+        M, K, lda, pa = a.rows, a.K, a.K, None
+    else:
+        pa, ar, ac, lda = _mat(a)
+        M, K = (ac, ar) if trans_a else (ar, ac)
+    if isinstance(b, Packed):
+        N, Kb, ldb, pb = b.rows, b.K, b.K, None
+    else:
+        pb, br, bc, ldb = _mat(b)
+        Kb, N = (bc, br) if trans_b else (br, bc)
     if K != Kb:
         raise RuntimeError(f"gemm inner dims differ: {K} vs {Kb}")
+    dtype = _compute_dtype
+    if dtype == _lib.F32X3:
+        # small products (heads of 512 / 32 columns, the CLS-only last layer) stay on the exact-f32 kernel
+        if isinstance(a, Packed) or isinstance(b, Packed) or (min(M, N) >= _x3_min[0] and K >= _x3_min[1] and M * N * K >= _x3_min[2]):
+            a = _packed_operand(a, trans_a)
+            b = _packed_operand(b, not trans_b)
+            pa, pb = dev_ptr(a.buf), dev_ptr(b.buf)
+        else:
+            dtype = F32
     if out is None:
-        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+        out = torch.empty((M, N), device=dev, dtype=torch.float32)
         if split_k > 1:
             out.zero_()
     pc, cr, cc, ldc = _mat(out)
     assert (cr, cc) == (M, N)
     d = GemmDesc()
     d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, lda, ldb, ldc
-    d.transA, d.transB, d.dtype = int(trans_a), int(trans_b), _compute_dtype
+    d.transA, d.transB, d.dtype = int(trans_a), int(trans_b), dtype
     flags = 0
     if bias is not None:
         flags |= EPI_BIAS
@@ -362,7 +463,8 @@ def gemm_batched(a, b, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, batch, sa, s
     the per-head operands are column slices of wider matrices."""
     d = GemmDesc()
     d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, lda, ldb, ldc
-    d.transA, d.transB, d.dtype, d.flags, d.alpha = int(trans_a), int(trans_b), _compute_dtype, 0, float(alpha)
+    d.transA, d.transB, d.flags, d.alpha = int(trans_a), int(trans_b), 0, float(alpha)
+    d.dtype = F32 if _compute_dtype == _lib.F32X3 else _compute_dtype          # the packed kernel has no batch mode
     d.batch, d.batch_stride_a, d.batch_stride_b, d.batch_stride_c = batch, sa, sb, sc
     d.A, d.B, d.C = dev_ptr(a) + 4 * a_off, dev_ptr(b) + 4 * b_off, dev_ptr(c) + 4 * c_off
     if _gemm_prof is not None:
@@ -777,3 +879,17 @@ class VadLossFunction(torch.autograd.Function):
     def backward(ctx, gloss, _gs):
         (dout,) = ctx.saved_tensors
         return dout * gloss, None, None, None
+
+
+# Activation packs (f32x3 mode) are shared between the GEMMs of one forward / backward body.
+def _with_pack_memo(fn):
+    def wrapped(*args, **kwargs):
+        with pack_memo():
+            return fn(*args, **kwargs)
+    wrapped.__doc__ = fn.__doc__
+    return wrapped
+
+
+for _cls in (MHAFunction, MHAClsFunction, MHAClsAssocFunction, FFNFunction, HeadFunction):
+    _cls.forward = staticmethod(_with_pack_memo(_cls.forward))
+    _cls.backward = staticmethod(_with_pack_memo(_cls.backward))

@@ -42,6 +42,8 @@ class Adagrad(torch.optim.Optimizer):
                 check(lib.lstc_adagrad_step(dev_ptr(p.data), dev_ptr(g), dev_ptr(state["sum"]), p.numel(),
                                             float(group["lr"]), float(group["weight_decay"]), float(group["eps"]),
                                             gs, st), "lstc_adagrad_step")
+        from .functional import bump_weight_epoch
+        bump_weight_epoch()          # weights changed through raw pointers: packed copies (f32x3 GEMM) are stale
         return None
 
 

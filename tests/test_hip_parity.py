@@ -538,3 +538,50 @@ def test_mixed_step_equals_reference_golden_for_both_datasets():
             for k, v in mod.state_dict().items():
                 if v.is_floating_point():       # Adagrad's first steps are sign-like: a few near-zero grads may flip
                     assert float(((v.cpu() - ref[k]).abs() > 5e-5).float().mean()) <= lim, k
+
+
+# ---- f32x3 mode: f32-accurate products on the bf16 matrix cores (csrc/gemm_pk.hip) -----------------------------------
+
+@pytest.fixture
+def f32x3_everywhere():
+    """Every GEMM of the block goes through lstc_pack3 + the packed kernel, whatever its size."""
+    from lstc_vad_amd import functional as Fn
+    Fn.set_compute_dtype("f32x3"); Fn.set_x3_threshold(0, 0, 0)
+    yield Fn
+    Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
+
+
+def test_f32x3_gemm_matches_f64_like_the_f32_kernel(f32x3_everywhere):
+    """All three product forms + epilogues; error against an f64 product is within 1.5x of the exact-f32 kernel's."""
+    Fn = f32x3_everywhere
+    g = torch.Generator().manual_seed(5)
+    for (M, N, K, ta, tb) in ((1000, 384, 520, False, True), (1000, 384, 520, False, False), (384, 260, 3000, True, False)):
+        a = torch.randn((K, M) if ta else (M, K), generator=g)
+        b = torch.randn((N, K) if tb else (K, N), generator=g) * 0.05
+        ref = (a.t() if ta else a).double() @ (b.t() if tb else b).double()
+        ad, bd = a.to(DEV), b.to(DEV)
+        Fn.set_compute_dtype("f32x3")
+        c3 = Fn.gemm(ad, bd, trans_a=ta, trans_b=tb, split_k=2 if ta else 1).cpu().double()
+        Fn.set_compute_dtype("fp32")
+        c1 = Fn.gemm(ad, bd, trans_a=ta, trans_b=tb).cpu().double()
+        e3, e1 = float((c3 - ref).abs().max()), float((c1 - ref).abs().max())
+        assert e3 <= 1.5 * e1 + 1e-7, (M, N, K, ta, tb, e3, e1)
+    Fn.set_compute_dtype("f32x3")
+    x = torch.randn(700, 300, generator=g).to(DEV); w = (torch.randn(260, 300, generator=g) * 0.1).to(DEV)
+    bias = torch.randn(260, generator=g).to(DEV); res = torch.randn(700, 260, generator=g).to(DEV)
+    y3 = Fn.gemm(x, w, trans_b=True, bias=bias, relu=True, dropout=(0.3, 77), residual=res)
+    Fn.set_compute_dtype("fp32")
+    y1 = Fn.gemm(x, w, trans_b=True, bias=bias, relu=True, dropout=(0.3, 77), residual=res)
+    assert max_abs_diff(y3, y1) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["ltn_sht", "stn_mil_ce", "ltn_ubnormal"])
+def test_f32x3_training_step_matches_reference_golden(name, f32x3_everywhere):
+    """The golden two-step training test, every product on the packed bf16-plane kernel, SAME tolerances as f32."""
+    test_training_step_matches_reference_golden(name, True)
+    test_training_step_matches_reference_golden(name, False)
+
+
+def test_f32x3_full_width_scores_match_oracle(f32x3_everywhere):
+    f32x3_everywhere.set_x3_threshold()          # production thresholds: big products packed, small ones exact f32
+    test_full_width_scores_match_oracle()

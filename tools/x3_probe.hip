@@ -1,0 +1,534 @@
+// Feasibility probe: f32-accurate GEMM on the bf16 matrix cores ("bf16x6").
+//
+// x = h + m + l exactly with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (RNE; 3 x 8 significand bits = 24).
+// a.b = sum over plane pairs; the 6 pairs {hh, hm, mh, mm, hl, lh} leave out terms <= 2^-26 |a||b| (below f32 epsilon),
+// each bf16 product is exact in f32 and the MFMA accumulates in f32.  v_mfma_f32_32x32x16_bf16 runs at 16x the rate of
+// v_mfma_f32_32x32x2_f32, so 6 of them per k16 block cost 192 cycles against 512 for 8 f32 MFMAs (2.67x).
+//
+// This file measures (a) the achievable rate of an NT kernel over pre-split planes and (b) its error against an f64
+// reference next to the error of a sequential f32 fma chain.  Build: hipcc -O3 --offload-arch=gfx950 tools/x3_probe.hip
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+// ---- split: f32 [rows, K] (ld) -> planes [3][rows][Kp] bf16, zero padded to Kp
+__global__ void split3_kernel(const float* __restrict__ x, int rows, int K, int ld, __bf16* __restrict__ out, int Kp) {
+    const size_t plane = (size_t)rows * Kp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / Kp), k = (int)(i % Kp);
+        const float v = k < K ? x[(size_t)r * ld + k] : 0.f;
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const __bf16 l = (__bf16)(r1 - (float)m);
+        out[i] = h; out[plane + i] = m; out[2 * plane + i] = l;
+    }
+}
+
+constexpr int BK = 32, LD = 40;      // bf16 per LDS row (80 B: conflict-free ds_read_b128 across 16 rows)
+constexpr int BM = 128, BN = 128, NT = 256;
+constexpr int PLANE_ST = 128 * LD;   // elements of one plane image
+constexpr int STAGE = 6 * PLANE_ST;  // A planes 0..2, B planes 3..5
+
+struct Stage {
+    uint4 v[12];
+    const __bf16* g[4];
+    size_t plane[2];
+    int loff;
+    __device__ __forceinline__ void load(int k0) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            v[2 * p] = *reinterpret_cast<const uint4*>(g[0] + p * plane[0] + k0);
+            v[2 * p + 1] = *reinterpret_cast<const uint4*>(g[1] + p * plane[0] + k0);
+            v[6 + 2 * p] = *reinterpret_cast<const uint4*>(g[2] + p * plane[1] + k0);
+            v[6 + 2 * p + 1] = *reinterpret_cast<const uint4*>(g[3] + p * plane[1] + k0);
+        }
+    }
+    __device__ __forceinline__ void store(__bf16* s) const {
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            *reinterpret_cast<uint4*>(s + p * PLANE_ST + loff) = v[2 * p];
+            *reinterpret_cast<uint4*>(s + p * PLANE_ST + loff + 64 * LD) = v[2 * p + 1];
+        }
+    }
+};
+
+// plane pairs by decreasing magnitude: hh, hm, mh, mm, hl, lh, ml, lm, ll
+__device__ __forceinline__ constexpr int pa(int q) { return q == 0 ? 0 : q == 1 ? 0 : q == 2 ? 1 : q == 3 ? 1 : q == 4 ? 0 : q == 5 ? 2 : q == 6 ? 1 : 2; }
+__device__ __forceinline__ constexpr int pb(int q) { return q == 0 ? 0 : q == 1 ? 1 : q == 2 ? 0 : q == 3 ? 1 : q == 4 ? 2 : q == 5 ? 0 : q == 6 ? 2 : q == 7 ? 1 : 2; }
+
+template <int NPROD>
+__global__ void __launch_bounds__(NT, 1) gemm_x3_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ B,
+                                                      float* __restrict__ C, int M, int N, int Kp, int tilesN) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+    const size_t planeA = (size_t)M * Kp, planeB = (size_t)N * Kp;
+    int pid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = pid & 7, idx = pid >> 3, q = nwg >> 3, r = nwg & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (pid / tilesN) * BM, n0 = (pid % tilesN) * BN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging: thread t -> chunk (t&3) of rows (t>>2) and (t>>2)+64, for each of the 6 planes
+    const int chunk = t & 3, srow = t >> 2;
+    const __bf16* g0 = A + (size_t)min(m0 + srow, M - 1) * Kp + chunk * 8;
+    const __bf16* g1 = A + (size_t)min(m0 + srow + 64, M - 1) * Kp + chunk * 8;
+    const __bf16* g2 = B + (size_t)min(n0 + srow, N - 1) * Kp + chunk * 8;
+    const __bf16* g3 = B + (size_t)min(n0 + srow + 64, N - 1) * Kp + chunk * 8;
+    const int loff = srow * LD + chunk * 8;
+    uint4 v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11;
+#define X3_LOAD(k0)                                                                                     \
+    do {                                                                                                \
+        v0 = *reinterpret_cast<const uint4*>(g0 + (k0)); v1 = *reinterpret_cast<const uint4*>(g1 + (k0)); \
+        v2 = *reinterpret_cast<const uint4*>(g0 + planeA + (k0)); v3 = *reinterpret_cast<const uint4*>(g1 + planeA + (k0)); \
+        v4 = *reinterpret_cast<const uint4*>(g0 + 2 * planeA + (k0)); v5 = *reinterpret_cast<const uint4*>(g1 + 2 * planeA + (k0)); \
+        v6 = *reinterpret_cast<const uint4*>(g2 + (k0)); v7 = *reinterpret_cast<const uint4*>(g3 + (k0)); \
+        v8 = *reinterpret_cast<const uint4*>(g2 + planeB + (k0)); v9 = *reinterpret_cast<const uint4*>(g3 + planeB + (k0)); \
+        v10 = *reinterpret_cast<const uint4*>(g2 + 2 * planeB + (k0)); v11 = *reinterpret_cast<const uint4*>(g3 + 2 * planeB + (k0)); \
+    } while (0)
+#define X3_ST(p_, lo_, hi_)                                                       \
+    *reinterpret_cast<uint4*>(sdst + (p_) * PLANE_ST + loff) = lo_;               \
+    *reinterpret_cast<uint4*>(sdst + (p_) * PLANE_ST + loff + 64 * LD) = hi_
+#define X3_STORE(s_)                                                                                    \
+    do {                                                                                                \
+        __bf16* sdst = (s_);                                                                            \
+        X3_ST(0, v0, v1); X3_ST(1, v2, v3); X3_ST(2, v4, v5); X3_ST(3, v6, v7); X3_ST(4, v8, v9); X3_ST(5, v10, v11); \
+    } while (0)
+    const int nkt = Kp / BK;
+    X3_LOAD(0);
+    X3_STORE(smem);
+    __syncthreads();
+    for (int it = 0; it < nkt; ++it) {
+        const __bf16* s = smem + (it & 1) * STAGE;
+        if (it + 1 < nkt) X3_LOAD((it + 1) * BK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[3][2], b[3][2];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[p][i] = *reinterpret_cast<const bf16x8*>(s + p * PLANE_ST + (wm * 64 + i * 32 + l31) * LD + 16 * h + 8 * ks);
+                    b[p][i] = *reinterpret_cast<const bf16x8*>(s + (3 + p) * PLANE_ST + (wn * 64 + i * 32 + l31) * LD + 16 * h + 8 * ks);
+                }
+            // small terms first; one MFMA per accumulator per round so consecutive MFMAs are independent
+#define X3_MM(PA_, PB_)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                    \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA_][i], b[PB_][j], acc[i][j], 0, 0, 0)
+            if (NPROD > 8) { X3_MM(2, 2); }
+            if (NPROD > 7) { X3_MM(2, 1); }
+            if (NPROD > 6) { X3_MM(1, 2); }
+            if (NPROD > 5) { X3_MM(2, 0); }
+            if (NPROD > 4) { X3_MM(0, 2); }
+            if (NPROD > 3) { X3_MM(1, 1); }
+            X3_MM(1, 0);
+            X3_MM(0, 1);
+            X3_MM(0, 0);
+#undef X3_MM
+        }
+        if (it + 1 < nkt) X3_STORE(smem + ((it + 1) & 1) * STAGE);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        if (col >= N) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+                if (row < M) C[(size_t)row * N + col] = acc[i][j][r];
+            }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// v1: software-pipelined version (one wave per SIMD, 512-register budget).  Per K tile two phases of 24 MFMAs; phase 1
+// carries the LDS stores of tile t+1 and the fragment reads of k-step 1 of tile t, phase 2 (after the one barrier) the
+// global loads of tile t+2 and the fragment reads of k-step 0 of tile t+1: one memory instruction per MFMA, every MFMA's
+// operands were read a whole phase earlier.
+typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
+
+template <int SMODE, int CUR>
+struct StepTag { static constexpr int smode = SMODE, cur = CUR; };
+
+template <int ABL>
+__global__ void __launch_bounds__(NT, 1) gemm_x3p_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ B,
+                                                          float* __restrict__ C, int M, int N, int Kp, int tilesN) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+    const size_t planeA = (size_t)M * Kp, planeB = (size_t)N * Kp;
+    int pid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = pid & 7, idx = pid >> 3, q = nwg >> 3, r = nwg & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (pid / tilesN) * BM, n0 = (pid % tilesN) * BN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int chunk = t & 3, srow = t >> 2;
+    __amdgpu_buffer_rsrc_t rs[6];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        rs[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(A + p * planeA), 0, (int)(planeA * 2), 0x00020000);
+        rs[3 + p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(B + p * planeB), 0, (int)(planeB * 2), 0x00020000);
+    }
+    uint32_t voff[4];
+    voff[0] = (uint32_t)(((size_t)min(m0 + srow, M - 1) * Kp + chunk * 8) * 2);
+    voff[1] = (uint32_t)(((size_t)min(m0 + srow + 64, M - 1) * Kp + chunk * 8) * 2);
+    voff[2] = (uint32_t)(((size_t)min(n0 + srow, N - 1) * Kp + chunk * 8) * 2);
+    voff[3] = (uint32_t)(((size_t)min(n0 + srow + 64, N - 1) * Kp + chunk * 8) * 2);
+    const int loff = srow * LD + chunk * 8;
+    u32x4 sv[2][12];                                // two staged tiles (t+1, t+2): e = 2 * plane-image + half
+    bf16x8 f0a[3][2], f0b[3][2], f1a[3][2], f1b[3][2];
+    const int nkt = Kp / BK;
+
+#define GLOAD_ONE(SET, e, soff) sv[SET][e] = __builtin_amdgcn_raw_buffer_load_b128(rs[(e) >> 1], voff[((e) >= 6 ? 2 : 0) + ((e) & 1)], soff, 0)
+#define LSTORE_ONE(SET, e, s) *reinterpret_cast<u32x4*>((s) + ((e) >> 1) * PLANE_ST + loff + ((e) & 1) * 64 * LD) = sv[SET][e]
+    auto rd = [&](const __bf16* s, int pi, int tile0, int ks) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(s + pi * PLANE_ST + (tile0 + l31) * LD + 16 * h + 8 * ks);
+    };
+    // fragment read number e (0..11) of k-step ks from stage s into (fa, fb)
+    auto frag_one = [&](int e, const __bf16* s, int ks, bf16x8 (&fa)[3][2], bf16x8 (&fb)[3][2]) {
+        const int p = (e % 6) >> 1, i = e & 1;
+        if (e < 6) fa[p][i] = rd(s, p, wm * 64 + i * 32, ks);
+        else fb[p][i] = rd(s, 3 + p, wn * 64 + i * 32, ks);
+    };
+
+    // ---- prologue
+#pragma unroll
+    for (int e = 0; e < 12; ++e) GLOAD_ONE(0, e, 0);
+#pragma unroll
+    for (int e = 0; e < 12; ++e) LSTORE_ONE(0, e, smem);
+    // unconditional (K offsets clamped) so that the in-order vmcnt bookkeeping is the same on every path into the loop
+#pragma unroll
+    for (int e = 0; e < 12; ++e) GLOAD_ONE(1, e, (uint32_t)(min(1, nkt - 1) * BK * 2));
+    __builtin_amdgcn_sched_barrier(0);          // keep the issue order tile 1 -> tile 2: vmcnt is in-order
+#pragma unroll
+    for (int e = 0; e < 12; ++e) GLOAD_ONE(0, e, (uint32_t)(min(2, nkt - 1) * BK * 2));
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 12; ++e) frag_one(e, smem, 0, f0a, f0b);
+
+    auto step = [&](int it, auto tag) {
+        // SMODE 1: tiles t+1..t+3 exist; 4: t+1, t+2 exist (no more loads); 2: only t+1; 3: last tile
+        constexpr int SMODE = decltype(tag)::smode;
+        constexpr int CUR = decltype(tag)::cur;              // LDS stage of tile t; tile t+1 sits in register set CUR ^ 1
+        constexpr bool HAS1 = SMODE != 3, HAS2 = SMODE == 1;
+        const __bf16* s_cur = smem + CUR * STAGE;
+        __bf16* s_nxt = smem + (CUR ^ 1) * STAGE;
+        const uint32_t soff = (uint32_t)(it + 3) * (BK * 2);
+        // tile t+1 was requested three phases ago; the 12 loads of tile t+2 may stay in flight (in-order return)
+        if ((SMODE == 1 || SMODE == 4) && !(ABL & 1)) __builtin_amdgcn_s_waitcnt(0x0F7C);     // vmcnt(12)
+        else if (HAS1) __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
+#pragma unroll
+        for (int q = 5; q >= 0; --q) {
+            const int r = 5 - q;
+            if (HAS1 && !(ABL & 2)) { LSTORE_ONE(CUR ^ 1, 2 * r, s_nxt); LSTORE_ONE(CUR ^ 1, 2 * r + 1, s_nxt); }
+            if (!(ABL & 4)) { frag_one(2 * r, s_cur, 1, f1a, f1b); frag_one(2 * r + 1, s_cur, 1, f1a, f1b); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0a[pa(q)][i], f0b[pb(q)][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!(ABL & 8)) __syncthreads();
+#pragma unroll
+        for (int q = 5; q >= 0; --q) {
+            const int r = 5 - q;
+            if (HAS2 && !(ABL & 1)) { GLOAD_ONE(CUR ^ 1, 2 * r, soff); GLOAD_ONE(CUR ^ 1, 2 * r + 1, soff); }
+            if (HAS1 && !(ABL & 4)) { frag_one(2 * r, s_nxt, 0, f0a, f0b); frag_one(2 * r + 1, s_nxt, 0, f0a, f0b); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1a[pa(q)][i], f1b[pb(q)][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    int it = 0;
+    for (; it + 4 < nkt; it += 2) {
+        step(it, StepTag<1, 0>{});
+        step(it + 1, StepTag<1, 1>{});
+    }
+    // tail: it is even; remaining tiles nkt - it in {1, 2, 3, 4}
+    const int rem = nkt - it;
+    if (rem == 4) { step(it, StepTag<1, 0>{}); step(it + 1, StepTag<4, 1>{}); step(it + 2, StepTag<2, 0>{}); step(it + 3, StepTag<3, 1>{}); }
+    else if (rem == 3) { step(it, StepTag<4, 0>{}); step(it + 1, StepTag<2, 1>{}); step(it + 2, StepTag<3, 0>{}); }
+    else if (rem == 2) { step(it, StepTag<2, 0>{}); step(it + 1, StepTag<3, 1>{}); }
+    else if (rem == 1) { step(it, StepTag<3, 0>{}); }
+#undef GLOAD_ONE
+#undef LSTORE_ONE
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        if (col >= N) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+                if (row < M) C[(size_t)row * N + col] = acc[i][j][r];
+            }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// v2: PACKED operands + LDS-DMA.  The split pass already rewrites every operand, so it also packs it: the matrix is cut
+// into 128-row x 32-k tiles, each plane of a tile is stored as the exact 8-KB LDS image the GEMM wants (unpadded rows of
+// 4 x 16-B chunks, chunk index XOR-ed with (row>>2)&3 so that every ds_read_b128 lane group hits 16 distinct 16-B slots).
+// The GEMM then streams whole tiles with global_load_lds_dwordx4: 1 KB contiguous per wave-instruction, no staging
+// registers, no ds_write; three LDS stages give a prefetch distance of two K tiles.
+__global__ void pack3_kernel(const float* __restrict__ x, int rows, int K, int ld, __bf16* __restrict__ out, int RB, int KB) {
+    const size_t nchunk = (size_t)RB * 128 * KB * 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunk; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % ((size_t)KB * 4)), rg = (int)(i / ((size_t)KB * 4));
+        const int rb = rg >> 7, r = rg & 127, kb = cg >> 2, c = cg & 3;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = cg * 8 + j;
+            v[j] = (rg < rows && k < K) ? x[(size_t)rg * ld + k] : 0.f;
+        }
+        bf16x8 hh, mm, ll;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const __bf16 h = (__bf16)v[j];
+            const float r1 = v[j] - (float)h;
+            const __bf16 m = (__bf16)r1;
+            hh[j] = h; mm[j] = m; ll[j] = (__bf16)(r1 - (float)m);
+        }
+        const size_t tile = ((size_t)rb * KB + kb) * 3;
+        const int slot = r * 4 + (c ^ ((r >> 2) & 3));
+        bf16x8* o = reinterpret_cast<bf16x8*>(out);
+        o[(tile + 0) * 512 + slot] = hh;
+        o[(tile + 1) * 512 + slot] = mm;
+        o[(tile + 2) * 512 + slot] = ll;
+    }
+}
+
+constexpr int PK_IMG = 4096;            // bf16 elements of one plane image (128 rows x 32 k)
+constexpr int PK_STAGE = 6 * PK_IMG;    // A planes 0..2 then B planes 0..2
+constexpr int PK_NSTAGE = 3;
+
+template <int ABL>
+__global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ B,
+                                                         float* __restrict__ C, int M, int N, int KB, int tilesN) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+    int pid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = pid & 7, idx = pid >> 3, q = nwg >> 3, r = nwg & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mb = pid / tilesN, nb = pid % tilesN;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    // a stage is 48 pieces of 1 KB: pieces 0..23 = the 24 contiguous KB of the A tile, 24..47 = the B tile; wave w moves
+    // pieces 12w .. 12w+11 (waves 0,1: A; waves 2,3: B)
+    const __bf16* gbase = (wave < 2 ? A + (size_t)mb * KB * 3 * PK_IMG : B + (size_t)nb * KB * 3 * PK_IMG) +
+                          (size_t)(wave & 1) * 12 * 512;          // wave-uniform (SGPR) base; the lane adds 16 B * lane
+    const int ldst = wave * 12 * 512;           // element offset of this wave's first piece inside a stage
+    // piece j = 4 * (j / 4) + (j % 4): the low part rides in the instruction's immediate offset (applies to both sides)
+#define DMA_ONE(j, kt, stage)                                                                                          \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gbase + (size_t)(kt) * 3 * PK_IMG + ((j) >> 2) * 2048 + lane * 8),        \
+                                     (lptr_t)(smem + (stage) * PK_STAGE + ldst + ((j) >> 2) * 2048), 16, ((j) & 3) * 1024, 0)
+#define DMA_TILE(kt, stage)                                                                                            \
+    do {                                                                                                               \
+        DMA_ONE(0, kt, stage); DMA_ONE(1, kt, stage); DMA_ONE(2, kt, stage); DMA_ONE(3, kt, stage);                    \
+        DMA_ONE(4, kt, stage); DMA_ONE(5, kt, stage); DMA_ONE(6, kt, stage); DMA_ONE(7, kt, stage);                    \
+        DMA_ONE(8, kt, stage); DMA_ONE(9, kt, stage); DMA_ONE(10, kt, stage); DMA_ONE(11, kt, stage);                  \
+    } while (0)
+    // fragment: rows tile0 + l31, logical 16-B chunk c = 2h + ks
+    const int rowa0 = wm * 64 + l31, rowb0 = wn * 64 + l31;
+    auto rd = [&](const __bf16* img, int row, int ks) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(img + (row * 4 + ((2 * h + ks) ^ ((row >> 2) & 3))) * 8);
+    };
+    bf16x8 f0a[3][2], f0b[3][2], f1a[3][2], f1b[3][2];
+    // read order = order of first use by the plane-pair rounds (lh, hl, mm, mh, hm, hh): A.l, B.h, A.h, B.l, A.m, B.m
+    auto frag_one = [&](int e, const __bf16* s, int ks, bf16x8 (&fa)[3][2], bf16x8 (&fb)[3][2]) {
+        const int g = e >> 1, i = e & 1;
+        const int p = g == 0 ? 2 : g == 1 ? 0 : g == 2 ? 0 : g == 3 ? 2 : 1;
+        if ((g & 1) == 0) fa[p][i] = rd(s + p * PK_IMG, rowa0 + i * 32, ks);
+        else fb[p][i] = rd(s + (3 + p) * PK_IMG, rowb0 + i * 32, ks);
+    };
+    const int nkt = KB;
+    // ---- prologue: tiles 0, 1, 2 -> stages 0, 1, 2 (K index clamped: same in-order vmcnt bookkeeping on every path)
+    DMA_TILE(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    DMA_TILE(min(1, nkt - 1), 1);
+    __builtin_amdgcn_sched_barrier(0);
+    DMA_TILE(min(2, nkt - 1), 2);
+    __builtin_amdgcn_s_waitcnt(0x4F78);              // vmcnt(24): tile 0 landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int e = 0; e < 12; ++e) frag_one(e, smem, 0, f0a, f0b);
+
+    auto step = [&](int it, auto tag) {
+        // SMODE 1: tiles t+1..t+3 exist; 4: t+1, t+2 exist (nothing more to request); 2: only t+1; 3: last tile
+        constexpr int SMODE = decltype(tag)::smode;
+        constexpr int CUR = decltype(tag)::cur;              // stage of tile t (0..2)
+        constexpr int NXT = (CUR + 1) % 3;
+        constexpr bool HAS1 = SMODE != 3, HAS3 = SMODE == 1;
+        const __bf16* s_cur = smem + CUR * PK_STAGE;
+        const __bf16* s_nxt = smem + NXT * PK_STAGE;
+#define PK_MMA(FA, FB, q)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[pa(q)][i], FB[pb(q)][j], acc[i][j], 0, 0, 0);  \
+    __builtin_amdgcn_sched_barrier(0)
+#define PK_R1(r)                                                                                            \
+    if (!(ABL & 4)) { frag_one(2 * (r), s_cur, 1, f1a, f1b); frag_one(2 * (r) + 1, s_cur, 1, f1a, f1b); }    \
+    PK_MMA(f0a, f0b, 5 - (r))
+#define PK_R2(r)                                                                                            \
+    if (HAS3 && !(ABL & 1)) { DMA_ONE(2 * (r), it + 3, CUR); DMA_ONE(2 * (r) + 1, it + 3, CUR); }            \
+    if (HAS1 && !(ABL & 4)) { frag_one(2 * (r), s_nxt, 0, f0a, f0b); frag_one(2 * (r) + 1, s_nxt, 0, f0a, f0b); } \
+    PK_MMA(f1a, f1b, 5 - (r))
+        PK_R1(0); PK_R1(1); PK_R1(2); PK_R1(3); PK_R1(4); PK_R1(5);
+        // tile t+1 must have landed (requested two K tiles ago); tile t+2's 12 requests may stay in flight.
+        // raw s_barrier: __syncthreads() would add a fence that drains EVERY LDS-DMA in flight (vmcnt(0))
+        if (!(ABL & 1)) {
+            if (SMODE == 1 || SMODE == 4) __builtin_amdgcn_s_waitcnt(0x007C);     // vmcnt(12) lgkmcnt(0)
+            else __builtin_amdgcn_s_waitcnt(0x0070);                              // vmcnt(0) lgkmcnt(0)
+        } else __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0)
+        if (!(ABL & 8)) __builtin_amdgcn_s_barrier();
+        PK_R2(0); PK_R2(1); PK_R2(2); PK_R2(3); PK_R2(4); PK_R2(5);
+    };
+    int it = 0;
+    for (; it + 5 < nkt; it += 3) {
+        step(it, StepTag<1, 0>{});
+        step(it + 1, StepTag<1, 1>{});
+        step(it + 2, StepTag<1, 2>{});
+    }
+    // tail (it % 3 == 0): remaining tiles in {1..5}
+    for (; it < nkt; it += 3) {
+        const int rem = nkt - it;
+        if (rem >= 4) step(it, StepTag<1, 0>{}); else if (rem == 3) step(it, StepTag<4, 0>{}); else if (rem == 2) step(it, StepTag<2, 0>{}); else step(it, StepTag<3, 0>{});
+        if (rem >= 5) step(it + 1, StepTag<1, 1>{}); else if (rem == 4) step(it + 1, StepTag<4, 1>{}); else if (rem == 3) step(it + 1, StepTag<2, 1>{}); else if (rem == 2) step(it + 1, StepTag<3, 1>{});
+        if (rem >= 6) step(it + 2, StepTag<1, 2>{}); else if (rem == 5) step(it + 2, StepTag<4, 2>{}); else if (rem == 4) step(it + 2, StepTag<2, 2>{}); else if (rem == 3) step(it + 2, StepTag<3, 2>{});
+    }
+#undef DMA_ONE
+#undef DMA_TILE
+#undef PK_MMA
+#undef PK_R1
+#undef PK_R2
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = nb * 128 + wn * 64 + j * 32 + l31;
+        if (col >= N) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mb * 128 + wm * 64 + i * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+                if (row < M) C[(size_t)row * N + col] = acc[i][j][r];
+            }
+    }
+}
+
+static double urand(uint64_t& s) { s = s * 6364136223846793005ull + 1442695040888963407ull; return (double)(s >> 11) / 9007199254740992.0; }
+
+template <int NPROD>
+void run(int M, int N, int K, int iters, const float* dA, const float* dB, const std::vector<float>& hA, const std::vector<float>& hB) {
+    const int Kp = (K + 31) / 32 * 32;
+    const int RBa = (M + 127) / 128, RBb = (N + 127) / 128, KBk = Kp / 32;
+    __bf16 *pA, *pB; float* dC;
+    CK(hipMalloc(&pA, (size_t)3 * RBa * 128 * Kp * 2)); CK(hipMalloc(&pB, (size_t)3 * RBb * 128 * Kp * 2)); CK(hipMalloc(&dC, (size_t)M * N * 4));
+    hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+    const int tilesM = (M + BM - 1) / BM, tilesN = (N + BN - 1) / BN;
+    const size_t lds = NPROD >= 100 ? PK_NSTAGE * PK_STAGE * sizeof(__bf16) : 2 * STAGE * sizeof(__bf16);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<(NPROD >= 60 ? 6 : NPROD)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3p_kernel<(NPROD >= 60 && NPROD < 100 ? NPROD - 60 : 0)>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE * 2));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pk_kernel<(NPROD >= 100 ? NPROD - 100 : 0)>), hipFuncAttributeMaxDynamicSharedMemorySize, PK_NSTAGE * PK_STAGE * 2));
+    float ms_split = 0, ms_gemm = 0;
+    for (int it = 0; it < iters + 1; ++it) {
+        CK(hipEventRecord(e0));
+        if (NPROD >= 100) {
+            hipLaunchKernelGGL(pack3_kernel, 4096, 256, 0, 0, dA, M, K, K, pA, RBa, KBk);
+            hipLaunchKernelGGL(pack3_kernel, 1024, 256, 0, 0, dB, N, K, K, pB, RBb, KBk);
+        } else {
+            hipLaunchKernelGGL(split3_kernel, 4096, 256, 0, 0, dA, M, K, K, pA, Kp);
+            hipLaunchKernelGGL(split3_kernel, 1024, 256, 0, 0, dB, N, K, K, pB, Kp);
+        }
+        CK(hipEventRecord(e1));
+        if (NPROD >= 100) hipLaunchKernelGGL(gemm_pk_kernel<(NPROD >= 100 ? NPROD - 100 : 0)>, tilesM * tilesN, NT, lds, 0, pA, pB, dC, M, N, KBk, tilesN);
+        else if (NPROD >= 60) hipLaunchKernelGGL(gemm_x3p_kernel<(NPROD >= 100 ? 0 : NPROD - 60)>, tilesM * tilesN, NT, lds, 0, pA, pB, dC, M, N, Kp, tilesN);
+        else hipLaunchKernelGGL(gemm_x3_kernel<(NPROD >= 60 ? 6 : NPROD)>, tilesM * tilesN, NT, lds, 0, pA, pB, dC, M, N, Kp, tilesN);
+        CK(hipEventRecord(e2));
+        CK(hipEventSynchronize(e2));
+        if (it) { float a, b; CK(hipEventElapsedTime(&a, e0, e1)); CK(hipEventElapsedTime(&b, e1, e2)); ms_split += a; ms_gemm += b; }
+    }
+    ms_split /= iters; ms_gemm /= iters;
+    std::vector<float> hC((size_t)M * N);
+    CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
+    // accuracy on sampled entries vs f64; next to a sequential f32 fma chain
+    uint64_t s = 99; double e_x = 0, e_f = 0, m_x = 0, m_f = 0, scale = 0; const int ns = 20000;
+    for (int q = 0; q < ns; ++q) {
+        const int i = (int)(urand(s) * M), j = (int)(urand(s) * N);
+        double ref = 0, mag = 0; float f = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float a = hA[(size_t)i * K + k], b = hB[(size_t)j * K + k];
+            ref += (double)a * b; mag += std::fabs((double)a * b); f = fmaf(a, b, f);
+        }
+        const double dx = std::fabs(hC[(size_t)i * N + j] - ref), df = std::fabs((double)f - ref);
+        e_x += dx * dx; e_f += df * df; m_x = std::fmax(m_x, dx / mag); m_f = std::fmax(m_f, df / mag); scale += mag;
+    }
+    printf("x%d M=%d N=%d K=%d: gemm %.3f ms = %.1f TFLOP/s-equivalent; split %.3f ms | rms err %.3e (f32 fma chain %.3e), max err/sum|ab| %.3e (f32 %.3e)\n",
+           NPROD, M, N, K, ms_gemm, 2.0 * M * N * K / ms_gemm * 1e-9, ms_split, std::sqrt(e_x / ns), std::sqrt(e_f / ns), m_x, m_f);
+    CK(hipFree(pA)); CK(hipFree(pB)); CK(hipFree(dC));
+}
+
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 100352, N = argc > 2 ? atoi(argv[2]) : 2048, K = argc > 3 ? atoi(argv[3]) : 2048;
+    const int iters = argc > 4 ? atoi(argv[4]) : 5;
+    std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+    uint64_t s = 1;
+    for (auto& v : hA) { const double u = urand(s) * 2 - 1; v = (float)(u > 0 ? u * 0.5 : 0.0); }   // relu-like activations
+    for (auto& v : hB) v = (float)((urand(s) * 2 - 1) * 0.03);
+    float *dA, *dB;
+    CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4));
+    CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+    run<100>(M, N, K, iters, dA, dB, hA, hB);
+    run<60>(M, N, K, iters, dA, dB, hA, hB);
+    if (argc > 5) {
+        run<101>(M, N, K, iters, dA, dB, hA, hB); run<104>(M, N, K, iters, dA, dB, hA, hB); run<108>(M, N, K, iters, dA, dB, hA, hB); run<113>(M, N, K, iters, dA, dB, hA, hB);
+        run<61>(M, N, K, iters, dA, dB, hA, hB); run<62>(M, N, K, iters, dA, dB, hA, hB); run<64>(M, N, K, iters, dA, dB, hA, hB);
+        run<68>(M, N, K, iters, dA, dB, hA, hB); run<63>(M, N, K, iters, dA, dB, hA, hB); run<67>(M, N, K, iters, dA, dB, hA, hB); run<75>(M, N, K, iters, dA, dB, hA, hB);
+    }
+    return 0;
+}
