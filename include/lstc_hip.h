@@ -60,7 +60,9 @@ enum { LSTC_F32 = 0, LSTC_BF16 = 1, LSTC_F32X3 = 2 };
  * dtype LSTC_F32: exact f32 MFMA (v_mfma_f32_32x32x2_f32) — bitwise a k-ordered fmaf chain.
  * dtype LSTC_BF16: A/B bf16, f32 accumulate; C bf16 unless LSTC_EPI_OUT_F32.
  * dtype LSTC_F32X3: f32-accurate product on the bf16 matrix cores; A and B are PACKED operands produced by lstc_pack3
- *   for the logical [M,K] and [N,K] matrices (transA/transB/lda/ldb are ignored - transposition happens in the pack);
+ *   (lda/ldb ignored).  (transA, transB) = (0, 1): packs of the [M,K] and [N,K] matrices (lstc_pack3 transposes k-major
+ *   sources on the way).  (1, 0): packs of the k-major SOURCES [K,M] and [K,N] themselves - the weight-gradient product
+ *   dY^T X reuses the packs the forward / input-gradient products made of X and dY; needs M, N, K multiples of 128.
  *   C, bias, residual, relu_src and the epilogue are f32 exactly as for LSTC_F32; no batch.
  */
 enum {

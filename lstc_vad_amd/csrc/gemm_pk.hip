@@ -99,6 +99,7 @@ struct PkParams {
     float alpha;
     DropKey dk;
     int tilesN, KB, ktiles_per_split;
+    int fbA, fbB;        // TR mode: 32-feature blocks per token row-block of the A / B packs (= ceil(M/32), ceil(N/32))
 };
 
 // plane pairs by decreasing magnitude: hh, hm, mh, mm, hl, lh
@@ -108,6 +109,11 @@ __device__ __forceinline__ constexpr int pb(int q) { return q == 0 ? 0 : q == 1 
 template <int SMODE, int CUR>
 struct StepTag { static constexpr int smode = SMODE, cur = CUR; };
 
+// TR = false: operands packed as [M, K] / [N, K] (K along the 32-wide tile dimension), fragments by ds_read_b128.
+// TR = true (weight gradients, C = dY^T X): operands are the packs of the SOURCE matrices [K = tokens, M] / [K, N] as the
+// forward / input-gradient products already made them; a K step is 32 tokens = a contiguous 2-KB slice of each plane image,
+// and the fragments (8 consecutive tokens of one feature) come out of ds_read_b64_tr_b16, the hardware transpose read.
+template <bool TR>
 __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 smem_pk[];
     __bf16* const smem = smem_pk;
@@ -131,33 +137,74 @@ __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
 
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    // a stage is 48 pieces of 1 KB: pieces 0..23 = the 24 contiguous KB of the A tile, 24..47 = the B tile; wave w moves
-    // pieces 12w .. 12w+11 (waves 0,1: A; waves 2,3: B).  gbase is wave-uniform (SGPRs); the lane adds 16 B * lane.
-    const __bf16* gbase = (wave < 2 ? p.A + ((size_t)mb * p.KB + kt0) * PK_TILE : p.B + ((size_t)nb * p.KB + kt0) * PK_TILE) +
-                          (size_t)(wave & 1) * 12 * 512;
+    // a stage is 48 pieces of 1 KB: pieces 0..23 = the A tile, 24..47 = the B tile; wave w moves pieces 12w .. 12w+11
+    // (waves 0,1: A; waves 2,3: B).  gbase is wave-uniform (SGPRs); the lane adds 16 B * lane.
+    //   TR = false: the 24 KB of a packed tile are contiguous; piece j = 4 * (j / 4) + (j % 4), the low part rides in
+    //     the instruction's immediate offset (it applies to the global and the LDS side alike).
+    //   TR = true: K step kt = tokens 32 kt .. 32 kt + 31 = slice (kt % 4) of token block kt / 4; for each of the wave's
+    //     two 32-feature blocks and three planes one 2-KB slice = 2 pieces (immediate offset 0 / 1024).
+    const int opb = wave < 2 ? mb : nb, fb = wave < 2 ? p.fbA : p.fbB;
+    const __bf16* gbase = TR ? (wave < 2 ? p.A : p.B) + ((size_t)opb * 4 + (wave & 1) * 2) * PK_TILE
+                             : (wave < 2 ? p.A + ((size_t)mb * p.KB + kt0) * PK_TILE : p.B + ((size_t)nb * p.KB + kt0) * PK_TILE) +
+                                   (size_t)(wave & 1) * 12 * 512;
     const int ldst = wave * 12 * 512;
-    // piece j = 4 * (j / 4) + (j % 4): the low part rides in the instruction's immediate offset (applies to both sides)
+    auto koff = [&](int kt) -> size_t {      // element offset of K step kt (relative to kt0 for TR = false)
+        if (TR) { const int k = kt0 + kt; return ((size_t)(k >> 2) * fb) * PK_TILE + (size_t)(k & 3) * 1024; }
+        return (size_t)kt * PK_TILE;
+    };
+    // TR = true issues the DMA through inline asm: with the builtin the compiler knows these instructions write LDS, cannot
+    // tell the ds_read_b64_tr_b16 fragment reads apart from their destinations and drains vmcnt(0) before every read
+    // (2.7x slower).  All vmcnt waits of this kernel are explicit anyway (s_waitcnt before the barriers).
 #define DMA_ONE(j, kt, stage)                                                                                          \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gbase + (size_t)(kt) * PK_TILE + ((j) >> 2) * 2048 + lane * 8),           \
-                                     (lptr_t)(smem + (stage) * PK_STAGE + ldst + ((j) >> 2) * 2048), 16, ((j) & 3) * 1024, 0)
+    do {                                                                                                               \
+        if (TR) {                                                                                                      \
+            const __bf16* g_ = gbase + koff(kt) + ((j) / 6) * PK_TILE + (((j) % 6) >> 1) * PK_IMG + lane * 8;           \
+            const uint32_t l_ = (uint32_t)(((stage) * PK_STAGE + ldst + ((j) >> 1) * 1024) * 2);                        \
+            asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off offset:%2"                               \
+                         :: "v"(g_), "s"(l_), "n"(((j) & 1) * 1024) : "memory");                                       \
+        } else                                                                                                         \
+            __builtin_amdgcn_global_load_lds((gptr_t)(gbase + koff(kt) + ((j) >> 2) * 2048 + lane * 8),                 \
+                                             (lptr_t)(smem + (stage) * PK_STAGE + ldst + ((j) >> 2) * 2048), 16, ((j) & 3) * 1024, 0); \
+    } while (0)
 #define DMA_TILE(kt, stage)                                                                                            \
     do {                                                                                                               \
         DMA_ONE(0, kt, stage); DMA_ONE(1, kt, stage); DMA_ONE(2, kt, stage); DMA_ONE(3, kt, stage);                    \
         DMA_ONE(4, kt, stage); DMA_ONE(5, kt, stage); DMA_ONE(6, kt, stage); DMA_ONE(7, kt, stage);                    \
         DMA_ONE(8, kt, stage); DMA_ONE(9, kt, stage); DMA_ONE(10, kt, stage); DMA_ONE(11, kt, stage);                  \
     } while (0)
-    // fragment of k-step ks: rows tile0 + l31, logical 16-B chunk 2h + ks (any K permutation shared by A and B is fine)
+    // TR = false: fragment of k-step ks = row tile0 + l31, logical 16-B chunk 2h + ks (any K permutation shared by A, B).
+    // TR = true: stage layout per operand [feature block 0..3][plane][32 tokens x 64 B]; lane (h, g = 16-lane group & 1,
+    //   q, pp) addresses token 16 ks + 8 h + q (+4), features 16 g + 4 pp .. + 3 and receives feature lane & 31.
     const int rowa0 = wm * 64 + l31, rowb0 = wn * 64 + l31;
+    const int trq = (lane >> 2) & 3, trchunk = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1), trsub = (lane & 1) * 4;
     auto rd = [&](const __bf16* img, int row, int ks) -> bf16x8 {
         return *reinterpret_cast<const bf16x8*>(img + (row * 4 + ((2 * h + ks) ^ ((row >> 2) & 3))) * 8);
+    };
+    auto rd_tr = [&](const __bf16* img, int ks) -> bf16x8 {
+        typedef short short4v __attribute__((ext_vector_type(4)));
+        typedef short short8v __attribute__((ext_vector_type(8)));
+        typedef short4v __attribute__((address_space(3))) * lds_ptr;
+        const int t0 = 16 * ks + 8 * h + trq, t1 = t0 + 4;
+        const __bf16* a0 = img + t0 * 32 + ((trchunk ^ ((t0 >> 2) & 3)) * 8) + trsub;
+        const __bf16* a1 = img + t1 * 32 + ((trchunk ^ ((t1 >> 2) & 3)) * 8) + trsub;
+        const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0));
+        const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a1));
+        short8v f;
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        return __builtin_bit_cast(bf16x8, f);
     };
     bf16x8 f0a[3][2], f0b[3][2], f1a[3][2], f1b[3][2];
     // read order = order of first use by the plane-pair rounds (lh, hl, mm, mh, hm, hh): A.l, B.h, A.h, B.l, A.m, B.m
     auto frag_one = [&](int e, const __bf16* s, int ks, bf16x8 (&fa)[3][2], bf16x8 (&fb)[3][2]) {
         const int g = e >> 1, i = e & 1;
         const int pl = g == 0 ? 2 : g == 1 ? 0 : g == 2 ? 0 : g == 3 ? 2 : 1;
-        if ((g & 1) == 0) fa[pl][i] = rd(s + pl * PK_IMG, rowa0 + i * 32, ks);
-        else fb[pl][i] = rd(s + (3 + pl) * PK_IMG, rowb0 + i * 32, ks);
+        if (TR) {
+            if ((g & 1) == 0) fa[pl][i] = rd_tr(s + ((2 * wm + i) * 3 + pl) * 1024, ks);
+            else fb[pl][i] = rd_tr(s + PK_TILE + ((2 * wn + i) * 3 + pl) * 1024, ks);
+        } else {
+            if ((g & 1) == 0) fa[pl][i] = rd(s + pl * PK_IMG, rowa0 + i * 32, ks);
+            else fb[pl][i] = rd(s + (3 + pl) * PK_IMG, rowb0 + i * 32, ks);
+        }
     };
     // ---- prologue: tiles 0, 1, 2 -> stages 0, 1, 2 (K index clamped: the in-order vmcnt bookkeeping is then the same on
     // every path into the loop; sched_barriers keep the issue order)
@@ -271,7 +318,13 @@ int lstc_gemm_f32x3_impl(const LstcGemmDesc* d, hipStream_t st) {
     p.bias = d->bias; p.res = (const float*)d->residual; p.relu_src = (const float*)d->relu_src;
     p.M = d->M; p.N = d->N; p.ldc = d->ldc; p.ldr = d->ldr; p.ld_relu = d->ld_relu; p.flags = d->flags; p.alpha = d->alpha;
     p.dk = make_drop_key(d->dropout_p, d->dropout_seed);
+    // (transA, transB) = (0, 1): A, B are packs of [M, K], [N, K];  (1, 0): packs of the k-major sources [K, M], [K, N]
+    const bool tr = d->transA != 0 && d->transB == 0;
+    if (!tr && !(d->transA == 0 && d->transB != 0)) return LSTC_E_UNSUPPORTED;
     p.KB = (d->K + 31) / 32;
+    p.fbA = (d->M + 31) / 32; p.fbB = (d->N + 31) / 32;
+    // TR mode streams whole 128-token row blocks of the source packs and 4 feature blocks per 128 outputs
+    if (tr && ((d->K % 128) != 0 || (d->M % 128) != 0 || (d->N % 128) != 0)) return LSTC_E_SHAPE;
     p.ktiles_per_split = (p.KB + splits - 1) / splits;
     const int eff_splits = (p.KB + p.ktiles_per_split - 1) / p.ktiles_per_split;
     const int tilesM = (d->M + 127) / 128;
@@ -279,10 +332,12 @@ int lstc_gemm_f32x3_impl(const LstcGemmDesc* d, hipStream_t st) {
     constexpr size_t lds = (size_t)PK_NSTAGE * PK_STAGE * sizeof(__bf16);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pk_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pk_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(gemm_pk_kernel, dim3(tilesM * p.tilesN, eff_splits), dim3(NT), lds, st, p);
+    if (tr) hipLaunchKernelGGL(gemm_pk_kernel<true>, dim3(tilesM * p.tilesN, eff_splits), dim3(NT), lds, st, p);
+    else hipLaunchKernelGGL(gemm_pk_kernel<false>, dim3(tilesM * p.tilesN, eff_splits), dim3(NT), lds, st, p);
     return lstc_launch_status();
 }
 

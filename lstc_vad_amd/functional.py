@@ -236,15 +236,31 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
         flags |= EPI_ACCUM
     d.flags, d.alpha, d.split_k, d.variant = flags, float(alpha), int(split_k), int(variant)
     d.A, d.B, d.C = pa, pb, pc
+    if dtype == _lib.F32X3:
+        d.transA, d.transB = 0, 1              # packs of [M, K] and [N, K]
+    _launch_gemm(d, 2.0 * M * N * K)
+    return out
+
+
+def _launch_gemm(d, flops):
     if _gemm_prof is not None:                 # bench.py: HIP events on the launch stream around every GEMM
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         check(_lib.load().lstc_gemm(C.byref(d), stream_ptr()), "lstc_gemm")
         e1.record()
-        _gemm_prof.append((2.0 * M * N * K, e0, e1))
-        return out
+        _gemm_prof.append((flops, e0, e1))
+        return
     check(_lib.load().lstc_gemm(C.byref(d), stream_ptr()), "lstc_gemm")
-    return out
+
+
+def maybe_pack(t: torch.Tensor):
+    """Packed form of an activation [rows, K] when f32x3 mode would route its products to the packed kernel, else None.
+    Lets a forward body pack X once, feed several GEMMs and keep the pack for the weight gradient of the backward."""
+    if _compute_dtype != _lib.F32X3 or t.shape[0] < max(_x3_min[0], 1) or t.shape[1] < _x3_min[1]:
+        return None
+    if t.shape[0] * t.shape[1] * max(_x3_min[0], 1) < _x3_min[2]:
+        return None
+    return _packed_operand(t, False)
 
 
 def _wgrad_split(m_out: int, n_out: int) -> int:
@@ -257,9 +273,25 @@ def _wgrad_split(m_out: int, n_out: int) -> int:
     return s
 
 
-def wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dW[out, in] = dy[M, out]^T @ x[M, in]  (autograd of nn.Linear's weight)."""
-    s = _wgrad_split(dy.shape[1], x.shape[1]) if dy.shape[0] >= 4096 else 1
+def wgrad(dy: torch.Tensor, x: torch.Tensor, x_pack: Optional[Packed] = None) -> torch.Tensor:
+    """dW[out, in] = dy[T, out]^T @ x[T, in]  (autograd of nn.Linear's weight).  f32x3 mode: the contraction runs over the
+    tokens, i.e. along the ROWS of the packs that the forward (X) and input-gradient (dY) products already made, so those
+    packs are reused through the transposed-read form of the packed kernel (``x_pack`` = the forward's pack of ``x``)."""
+    T, O = dy.shape
+    I = x.shape[1]
+    s = _wgrad_split(O, I) if T >= 4096 else 1
+    if _compute_dtype == _lib.F32X3 and T % 128 == 0 and O % 128 == 0 and I % 128 == 0 and \
+            (x_pack is not None or (min(O, I) >= _x3_min[0] and T >= _x3_min[1] and T * O * I >= _x3_min[2])):
+        ap = _packed_operand(dy, False)
+        bp = x_pack if x_pack is not None else _packed_operand(x, False)
+        out = torch.zeros((O, I), device=dy.device, dtype=torch.float32) if s > 1 else \
+            torch.empty((O, I), device=dy.device, dtype=torch.float32)
+        d = GemmDesc()
+        d.M, d.N, d.K, d.lda, d.ldb, d.ldc = O, I, T, O, I, I
+        d.transA, d.transB, d.dtype, d.flags, d.alpha, d.split_k = 1, 0, _lib.F32X3, 0, 1.0, s
+        d.A, d.B, d.C = dev_ptr(ap.buf), dev_ptr(bp.buf), dev_ptr(out)
+        _launch_gemm(d, 2.0 * O * I * T)
+        return out
     return gemm(dy, x, trans_a=True, trans_b=False, split_k=s)
 
 
@@ -395,14 +427,16 @@ class MHAFunction(torch.autograd.Function):
         p_attn = cfg["attn_dropout"] if training else 0.0
         p_fc = cfg["fc_dropout"] if training else 0.0
         x2 = x.contiguous().view(N * S, dm)
+        xp = maybe_pack(x2)            # f32x3: one pack of X feeds Q, K, V now and the three weight gradients later
+        xa = xp if xp is not None else x2
         wqkv = _fused_qkv_weight(wq, wk, wv)
         if wqkv is not None:       # w_qs / w_ks / w_vs live in one buffer (MultiHeadAttention.fuse_qkv_): one GEMM, X read once
-            qkv = gemm(x2, wqkv, trans_b=True)
+            qkv = gemm(xa, wqkv, trans_b=True)
             q, k, v = qkv[:, : H * dk], qkv[:, H * dk: 2 * H * dk], qkv[:, 2 * H * dk:]
         else:
-            q = gemm(x2, wq, trans_b=True)
-            k = gemm(x2, wk, trans_b=True)
-            v = gemm(x2, wv, trans_b=True)
+            q = gemm(xa, wq, trans_b=True)
+            k = gemm(xa, wk, trans_b=True)
+            v = gemm(xa, wv, trans_b=True)
         seed_a = next_seed() if p_attn > 0 else 0
         seed_f = next_seed() if p_fc > 0 else 0
         if p_attn > 0:
@@ -410,11 +444,13 @@ class MHAFunction(torch.autograd.Function):
         if p_fc > 0:
             _note(cfg["site"] + "dropout", p_fc, seed_f, (N, S, dm))
         o, probs = attn_fwd(q, k, v, N, S, H, dk, dv, table, index, p_attn, seed_a)
-        y = gemm(o, wfc, trans_b=True, dropout=(p_fc, seed_f), residual=x2)
+        op = maybe_pack(o)
+        y = gemm(op if op is not None else o, wfc, trans_b=True, dropout=(p_fc, seed_f), residual=x2)
         if cfg["layer_norm"]:
             z, mean, rstd = layernorm_fwd(y, ln_w, ln_b, 1e-6)
         else:
             z, mean, rstd = y, None, None
+        ctx.packs = (xp, op) if training else (None, None)
         ctx.cfg = dict(cfg, N=N, S=S, p_attn=p_attn, p_fc=p_fc, seed_a=seed_a, seed_f=seed_f)
         ctx.save_for_backward(x2, wq, wk, wv, wfc, ln_w, table, index, q, k, v, o, probs,
                               y if cfg["layer_norm"] else None, mean, rstd)
@@ -433,7 +469,8 @@ class MHAFunction(torch.autograd.Function):
         else:
             dy = dz2
         df = dropout_apply(dy, c["p_fc"], c["seed_f"]) if c["p_fc"] > 0 else dy
-        dwfc = wgrad(df, o)
+        xp, op = ctx.packs
+        dwfc = wgrad(df, o, op)
         do = gemm(df, wfc)                                   # [M, H*dv]
         wqkv = _fused_qkv_weight(wq, wk, wv)
         dx = None
@@ -442,13 +479,13 @@ class MHAFunction(torch.autograd.Function):
             dqkv = torch.empty((N * S, wqkv.shape[0]), device=x2.device, dtype=torch.float32)
             outs = (dqkv[:, :rq], dqkv[:, rq: rq + rk], dqkv[:, rq + rk:])
             _, _, _, dtable = attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, c["p_attn"], c["seed_a"], out=outs)
-            dwqkv = wgrad(dqkv, x2)                               # one TN GEMM for the three weight gradients
+            dwqkv = wgrad(dqkv, x2, xp)                           # one TN GEMM for the three weight gradients
             dwq, dwk, dwv = dwqkv[:rq], dwqkv[rq: rq + rk], dwqkv[rq + rk:]
             if ctx.needs_input_grad[0]:
                 dx = gemm(dqkv, wqkv, residual=dy).view(N, S, -1)   # dQ Wq + dK Wk + dV Wv + residual in one GEMM (K = 3*H*dk)
         else:
             dq, dk_, dv_, dtable = attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, c["p_attn"], c["seed_a"])
-            dwq, dwk, dwv = wgrad(dq, x2), wgrad(dk_, x2), wgrad(dv_, x2)
+            dwq, dwk, dwv = wgrad(dq, x2, xp), wgrad(dk_, x2, xp), wgrad(dv_, x2, xp)
             if ctx.needs_input_grad[0]:
                 dx = gemm(dq, wq, residual=dy)
                 gemm(dk_, wk, out=dx, accumulate=True)
@@ -687,8 +724,11 @@ class FFNFunction(torch.autograd.Function):
         seed = next_seed() if p > 0 else 0
         if p > 0:
             _note(cfg["site"] + "dropout", p, seed, shape)
-        h1 = gemm(x2, w1, trans_b=True, bias=b1, relu=True)
-        y = gemm(h1, w2, trans_b=True, bias=b2, dropout=(p, seed), residual=x2)
+        xp = maybe_pack(x2)
+        h1 = gemm(xp if xp is not None else x2, w1, trans_b=True, bias=b1, relu=True)
+        hp = maybe_pack(h1)
+        y = gemm(hp if hp is not None else h1, w2, trans_b=True, bias=b2, dropout=(p, seed), residual=x2)
+        ctx.packs = (xp, hp) if cfg["training"] else (None, None)
         if cfg["layer_norm"]:
             z, mean, rstd = layernorm_fwd(y, ln_w, ln_b, 1e-6)
         else:
@@ -708,11 +748,12 @@ class FFNFunction(torch.autograd.Function):
         else:
             dy = dz2
         df = dropout_apply(dy, c["p"], c["seed"]) if c["p"] > 0 else dy
+        xp, hp = ctx.packs
         db2 = colsum(df)
-        dw2 = wgrad(df, h1)
+        dw2 = wgrad(df, h1, hp)
         dh1 = gemm(df, w2, relu_mask=h1)                     # [M, F], relu' fused
         db1 = colsum(dh1)
-        dw1 = wgrad(dh1, x2)
+        dw1 = wgrad(dh1, x2, xp)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = gemm(dh1, w1, residual=dy).view(c["shape"])

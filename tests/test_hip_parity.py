@@ -585,3 +585,25 @@ def test_f32x3_training_step_matches_reference_golden(name, f32x3_everywhere):
 def test_f32x3_full_width_scores_match_oracle(f32x3_everywhere):
     f32x3_everywhere.set_x3_threshold()          # production thresholds: big products packed, small ones exact f32
     test_full_width_scores_match_oracle()
+
+
+def test_f32x3_weight_gradient_reuses_forward_packs(f32x3_everywhere):
+    """dW = dY^T X through the transposed-read form of the packed kernel (packs of the [T, out] / [T, in] sources, as the
+    forward and input-gradient products make them) == the k-major-pack form == the exact-f32 kernel, to f32 accuracy."""
+    Fn = f32x3_everywhere
+    g = torch.Generator().manual_seed(9)
+    T, O, I = 1152, 256, 384
+    dy = torch.randn(T, O, generator=g).to(DEV); x = torch.randn(T, I, generator=g).to(DEV)
+    ref = dy.cpu().double().t() @ x.cpu().double()
+    xp = Fn.maybe_pack(x)
+    assert xp is not None
+    for split in (False, True):
+        got = Fn.wgrad(dy if not split else torch.cat([dy] * 4), x if not split else torch.cat([x] * 4),
+                       None if split else xp)
+        scale = 4.0 if split else 1.0
+        assert float((got.cpu().double() - scale * ref).abs().max()) < 2e-4 * scale
+    Fn.set_compute_dtype("fp32")
+    e1 = float((Fn.wgrad(dy, x).cpu().double() - ref).abs().max())        # the exact-f32 kernel's own distance from f64
+    Fn.set_compute_dtype("f32x3")
+    e3 = float((Fn.wgrad(dy, x, xp).cpu().double() - ref).abs().max())
+    assert e3 <= 1.5 * e1 + 1e-6, (e3, e1)
