@@ -98,8 +98,8 @@ def main():
     ap.add_argument("--batch_size", type=int, default=32, help="normal/abnormal pairs per GPU (B = 2*batch_size videos)")
     ap.add_argument("--part_num", type=int, default=32)
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "f32x3"],
-                    help="GEMM compute type: fp32 = exact-f32 MFMA (headline, parity mode); f32x3 = f32-accurate products on the bf16 "
-                         "matrix cores (3 bf16 planes per operand, 6 plane products, csrc/gemm_pk.hip); bf16 = bf16 MFMA on f32 storage")
+                    help="GEMM compute type: fp32 = exact-f32 MFMA (headline, parity mode); f32x3 = f32-accurate products on the 16-bit "
+                         "matrix cores (2 scaled f16 planes per operand, 3 plane products, csrc/gemm_pk.hip); bf16 = bf16 MFMA on f32 storage")
     ap.add_argument("--h2d", action="store_true", help="also time the step with the batch arriving from pinned host memory "
                     "every step through lstc_vad_amd.feed.PinnedFeeder (reported as pcie_inclusive, never as value)")
     ap.add_argument("--naive-last-layer", action="store_true", help="evaluate the last encoder layer for every token like the "
@@ -229,10 +229,10 @@ def main():
                     traffic = None if mixed else json.load(open(pmc)).get(a.config)
                 except Exception:
                     traffic = None
-            # f32x3: six bf16 MFMA products per f32 product -> the f32-equivalent ceiling is the bf16 peak / 6
-            peak = FP32_MFMA_PEAK_TFLOPS if a.dtype == "fp32" else (round(2500.0 / 6, 1) if a.dtype == "f32x3" else 2500.0)
+            # f32x3: three f16 MFMA products per f32 product -> the f32-equivalent ceiling is the 16-bit peak / 3
+            peak = FP32_MFMA_PEAK_TFLOPS if a.dtype == "fp32" else (round(2500.0 / 3, 1) if a.dtype == "f32x3" else 2500.0)
             kname = {"fp32": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
-                     "f32x3": "gemm_pk_kernel (6 x v_mfma_f32_32x32x16_bf16 per f32 product, packed 3-plane operands; small "
+                     "f32x3": "gemm_pk_kernel (3 x v_mfma_f32_32x32x16_f16 per f32 product, packed 2-plane operands; small "
                               "products on gemm_f32_kernel)",
                      "bf16": "gemm_bf16c_kernel (v_mfma_f32_32x32x16_bf16, f32 operands in HBM)"}[a.dtype]
             roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2),
@@ -253,7 +253,7 @@ def main():
         out = {"metric": "snippets/sec training step (B=64,T=32,P=16,d=2048)", "value": round(value, 1),
                "unit": "snippets/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": {"fp32": "f32", "f32x3": "f32 (operands split into 3 bf16 planes, 6 bf16-MFMA products, f32 accumulate)",
+               "vs_baseline": None, "dtype": {"fp32": "f32", "f32x3": "f32 (operands split into 2 scaled f16 planes, 3 f16-MFMA products, f32 accumulate)",
                          "bf16": "bf16 (f32 storage/accumulate)"}[a.dtype], "data": "synthetic",
                "config": {"workload": ("mixed batch (BASELINE config 5): per GPU 32 UBnormal videos (d=1024, L=5, S=81) + 32 SHT "
                                        "videos (d=2048, L=3, S=49), two model pairs, one iteration; second model: " if mixed else "") +

@@ -59,7 +59,7 @@ enum { LSTC_F32 = 0, LSTC_BF16 = 1, LSTC_F32X3 = 2 };
  * 1/(1-p); lstc_dropout_mask() / lstc_dropout_apply() regenerate the same mask.
  * dtype LSTC_F32: exact f32 MFMA (v_mfma_f32_32x32x2_f32) — bitwise a k-ordered fmaf chain.
  * dtype LSTC_BF16: A/B bf16, f32 accumulate; C bf16 unless LSTC_EPI_OUT_F32.
- * dtype LSTC_F32X3: f32-accurate product on the bf16 matrix cores; A and B are PACKED operands produced by lstc_pack3
+ * dtype LSTC_F32X3: f32-accurate product on the 16-bit matrix cores (3 f16 plane products per f32 product); A and B are PACKED operands produced by lstc_pack3
  *   (lda/ldb ignored).  (transA, transB) = (0, 1): packs of the [M,K] and [N,K] matrices (lstc_pack3 transposes k-major
  *   sources on the way).  (1, 0): packs of the k-major SOURCES [K,M] and [K,N] themselves - the weight-gradient product
  *   dY^T X reuses the packs the forward / input-gradient products made of X and dY; needs M, N, K multiples of 128.
@@ -98,12 +98,14 @@ typedef struct LstcGemmDesc {
 
 int lstc_gemm(const LstcGemmDesc* d, void* stream);
 
-/* Operand packing for LSTC_F32X3.  Writes the [rows, K] operand (row = an output row of A's side or an output column of
- * B's side, K = the contraction) as 128-row x 32-k tiles, each tile = three 8-KB bf16 planes h, m, l with
- * x = h + m + l exactly (h = bf16(x), m = bf16(x-h), l = bf16(x-h-m)), stored in the LDS image layout the GEMM streams
- * with global_load_lds (csrc/gemm_pk.hip); rows and K are zero-padded to the tile.
+/* Operand packing for LSTC_F32X3.  The tensor is scaled by the power of two s that puts its largest magnitude in
+ * [2^14, 2^15) and written as 128-row x 32-k tiles (row = an output row of A's side or an output column of B's side, K = the
+ * contraction); each tile = two 8-KB f16 planes h = f16(x s), l = f16(x s - h), stored in the LDS image layout the GEMM
+ * streams with global_load_lds (csrc/gemm_pk.hip); rows and K are zero-padded to the tile; a 256-B trailer carries the
+ * tensor's absmax bits and 1/s (the GEMM epilogue multiplies by 1/(s_a s_b)).  Three launches: memset, absmax, pack.
  *   k_major = 0: src is [rows, K] with K contiguous (ld >= K)  - X of X*W^T, W of X*W^T, dY of dY*W
- *   k_major = 1: src is [K, rows] with rows contiguous (ld >= rows) - W of dY*W, dY and X of dY^T*X
+ *   k_major = 1: src is [K, rows] with rows contiguous (ld >= rows) - W of dY*W (and dY, X of dY^T*X when the
+ *                (1, 0) form of lstc_gemm is not applicable)
  * dst needs lstc_pack3_bytes(rows, K) bytes, 16-B aligned.  The same nn.Linear products as lstc_gemm (see above). */
 int64_t lstc_pack3_bytes(int64_t rows, int64_t K);
 int lstc_pack3(const float* src, int64_t rows, int64_t K, int64_t ld, int32_t k_major, void* dst, void* stream);

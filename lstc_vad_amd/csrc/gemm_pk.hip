@@ -1,48 +1,81 @@
-// f32-accurate GEMM on the bf16 matrix cores over PACKED, pre-split operands (LstcGemmDesc.dtype = LSTC_F32X3).
+// f32-accurate GEMM on the 16-bit matrix cores over PACKED, pre-split operands (LstcGemmDesc.dtype = LSTC_F32X3).
 //
-// Arithmetic.  Every f32 x is written x = h + m + l EXACTLY with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)
-// (round-to-nearest-even; 3 x 8 significand bits = the 24 of an f32).  A dot product is then the sum over plane pairs;
-// the six pairs {hh, hm, mh, mm, hl, lh} leave out only terms below 2^-26 |a||b| (ml, lm, ll), each bf16 x bf16 product
-// is exact in f32 and v_mfma_f32_32x32x16_bf16 accumulates in f32.  Measured against f64 (tools/x3_probe.hip, K = 2048,
-// activations x weights): rms error 1.06e-7 of the result vs 0.92e-7 for a sequential f32 fma chain - f32 accuracy.
-// The bf16 MFMA runs at 16x the rate of v_mfma_f32_32x32x2_f32, so six per k16 block cost 192 cycles against 512.
+// Arithmetic.  An operand tensor is scaled by a power of two s (exact) so that its largest magnitude lies in [2^14, 2^15),
+// then every element is written x*s = h + l + d with h = f16(x*s), l = f16(x*s - h) (round-to-nearest-even): two 11-bit
+// significands, |d| <= 2^-24 |x*s| - the representation error of an f32 itself - for every element within 2^-17 of the
+// tensor's maximum (smaller ones keep an ABSOLUTE error below 2^-39 of the maximum).  A dot product is the sum of the
+// three plane products {hh, hl, lh}; each f16 x f16 product is exact in f32, v_mfma_f32_32x32x16_f16 accumulates in f32
+// and the epilogue multiplies by 1/(s_a s_b), again exact.  Measured against f64 (tools/x3_probe.hip, K = 2048,
+// activations x weights): rms error 0.82e-7 of the result vs 0.92e-7 for a sequential f32 fma chain - f32 accuracy.
+// The 16-bit MFMA runs at 16x the rate of v_mfma_f32_32x32x2_f32, so three per k16 block cost 96 cycles against 512.
+// (A first version used three bf16 planes and six products - no scaling, 1.6x slower; tools/x3_probe.hip keeps it.)
 //
 // Data movement.  Splitting rewrites an operand anyway, so the same pass PACKS it (lstc_pack3): the matrix is cut into
 // 128-row x 32-k tiles and each plane of a tile is stored as the exact 8-KB LDS image the kernel reads - unpadded rows of
 // four 16-B chunks, chunk index XOR-ed with (row >> 2) & 3, which puts the 16 lanes of every ds_read_b128 lane group on
-// 16 distinct 16-B slots (MI355X_MICROARCH, LDS table).  Transposition happens in the pack pass too, so ONE NT kernel
-// serves forward (X W^T), input-gradient (dY W) and weight-gradient (dY^T X) products.  The GEMM streams tiles with
-// global_load_lds_dwordx4 (1 KB contiguous per wave-instruction, no staging registers, no ds_write) into a 3-stage LDS
-// ring: tile t+3 is requested during the second half of tile t, two K tiles ahead of its use.
+// 16 distinct 16-B slots (MI355X_MICROARCH, LDS table).  Transposition happens in the pack pass too, so forward (X W^T)
+// and input-gradient (dY W) products share ONE NT kernel; weight gradients (dY^T X) reuse those very packs through
+// ds_read_b64_tr_b16 (TR form).  The GEMM streams tiles with global_load_lds_dwordx4 (1 KB contiguous per
+// wave-instruction, no staging registers, no ds_write) into a 3-stage LDS ring: tile t+3 is requested during the second
+// half of tile t, two K tiles ahead of its use.
 //
-// Schedule per K tile and wave (one wave per SIMD, 4 waves, 128x128 tile, 64x64 per wave): phase 1 = 24 MFMAs on k-step 0
-// fragments while the k-step 1 fragments are read; s_waitcnt vmcnt(12) + raw s_barrier (tile t+1 published, stage t free);
-// phase 2 = 24 MFMAs on k-step 1 while tile t+3 is requested and the k-step 0 fragments of tile t+1 are read.
-// Steady loop (3 tiles): 144 MFMA, 72 ds_read_b128, 36 global_load_lds, ~40 scalar/VALU.
+// Schedule per K tile and wave (one wave per SIMD, 4 waves, 128x128 tile, 64x64 per wave): phase 1 = 12 MFMAs on k-step 0
+// fragments while the k-step 1 fragments are read; s_waitcnt vmcnt(8) + raw s_barrier (tile t+1 published, stage t free);
+// phase 2 = 12 MFMAs on k-step 1 while tile t+3 is requested and the k-step 0 fragments of tile t+1 are read.
 #include "lstc_common.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pk_t;
+typedef _Float16 pkx8 __attribute__((ext_vector_type(8)));
 
 constexpr int NT = 256;
-constexpr int PK_IMG = 4096;            // bf16 elements of one plane image (128 rows x 32 k)
-constexpr int PK_TILE = 3 * PK_IMG;     // one packed tile: planes h, m, l
+constexpr int PK_IMG = 4096;            // f16 elements of one plane image (128 rows x 32 k)
+constexpr int PK_TILE = 2 * PK_IMG;     // one packed tile: planes h, l
 constexpr int PK_STAGE = 2 * PK_TILE;   // A tile then B tile
 constexpr int PK_NSTAGE = 3;
+constexpr int PK_TRAILER = 256;         // bytes after the tiles: [0] absmax bits (u32), [1] 1/scale (f32)
 
-__device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)v;
-    const float r1 = v - (float)h;
-    m = (__bf16)r1;
-    l = (__bf16)(r1 - (float)m);
+__device__ __forceinline__ void split2(float v, float scale, pk_t& h, pk_t& l) {
+    const float xs = v * scale;
+    h = (pk_t)xs;
+    l = (pk_t)(xs - (float)h);
+}
+
+// scale = 2^(14 - floor(log2(absmax))): the tensor's largest magnitude lands in [2^14, 2^15) (f16 max = 65504)
+__device__ __forceinline__ float scale_from_absmax_bits(uint32_t bits) {
+    int e = (int)((bits >> 23) & 0xff) - 127;             // floor(log2(absmax)) for normal numbers
+    if (bits == 0u || e > 127) return 1.f;                // all-zero tensor (or inf / nan): leave as is
+    int se = 14 - e;
+    se = se > 126 ? 126 : (se < -126 ? -126 : se);
+    return __uint_as_float((uint32_t)(se + 127) << 23);
+}
+
+__global__ void __launch_bounds__(NT) absmax_kernel(const float* __restrict__ x, long long rows, long long cols, long long ld,
+                                                    uint32_t* __restrict__ out) {
+    float m = 0.f;
+    const long long n = rows * cols;
+    if (ld == cols && (n & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {      // contiguous: float4 stream
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < (n >> 2); i += (long long)gridDim.x * NT) {
+            const float4 v = x4[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+    } else {
+        for (long long r = blockIdx.x; r < rows; r += gridDim.x)
+            for (long long c = threadIdx.x; c < cols; c += NT) m = fmaxf(m, fabsf(x[r * ld + c]));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bits
 }
 
 // ---- pack, K-contiguous source [rows, K] (ld): one workgroup per (row block, k block) tile; thread -> two 16-B chunks.
 __global__ void __launch_bounds__(NT) pack3_kc_kernel(const float* __restrict__ x, int rows, int K, long long ld,
-                                                      __bf16* __restrict__ out, int KB) {
+                                                      pk_t* __restrict__ out, int KB, uint32_t* __restrict__ trailer) {
     const int kb = blockIdx.x % KB, rb = blockIdx.x / KB;
-    bf16x8* o = reinterpret_cast<bf16x8*>(out) + (size_t)blockIdx.x * 3 * 512;
+    const float scale = scale_from_absmax_bits(trailer[0]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(trailer)[1] = 1.f / scale;
+    pkx8* o = reinterpret_cast<pkx8*>(out) + (size_t)blockIdx.x * 2 * 512;
     const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -58,39 +91,41 @@ __global__ void __launch_bounds__(NT) pack3_kc_kernel(const float* __restrict__ 
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = (row < rows && k0 + j < K) ? x[(size_t)row * ld + k0 + j] : 0.f;
         }
-        bf16x8 hh, mm, ll;
+        pkx8 hh, ll;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { __bf16 h, m, l; split3(v[j], h, m, l); hh[j] = h; mm[j] = m; ll[j] = l; }
+        for (int j = 0; j < 8; ++j) { pk_t h, l; split2(v[j], scale, h, l); hh[j] = h; ll[j] = l; }
         const int slot = r * 4 + (c ^ ((r >> 2) & 3));
-        o[slot] = hh; o[512 + slot] = mm; o[1024 + slot] = ll;
+        o[slot] = hh; o[512 + slot] = ll;
     }
 }
 
 // ---- pack, k-major source [K, rows] (ld): the packed operand's row index runs along the source's contiguous dimension.
 // Thread -> one packed row (feature) and 16 of the tile's 32 k (source rows): coalesced reads along the features.
 __global__ void __launch_bounds__(NT) pack3_km_kernel(const float* __restrict__ x, int rows, int K, long long ld,
-                                                      __bf16* __restrict__ out, int KB) {
+                                                      pk_t* __restrict__ out, int KB, uint32_t* __restrict__ trailer) {
     const int kb = blockIdx.x % KB, rb = blockIdx.x / KB;
-    bf16x8* o = reinterpret_cast<bf16x8*>(out) + (size_t)blockIdx.x * 3 * 512;
+    const float scale = scale_from_absmax_bits(trailer[0]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(trailer)[1] = 1.f / scale;
+    pkx8* o = reinterpret_cast<pkx8*>(out) + (size_t)blockIdx.x * 2 * 512;
     const int r = threadIdx.x & 127, half = threadIdx.x >> 7;
     const int row = rb * 128 + r;
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
         const int c = half * 2 + cc, k0 = kb * 32 + c * 8;
-        bf16x8 hh, mm, ll;
+        pkx8 hh, ll;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float v = (row < rows && k0 + j < K) ? x[(size_t)(k0 + j) * ld + row] : 0.f;
-            __bf16 h, m, l; split3(v, h, m, l); hh[j] = h; mm[j] = m; ll[j] = l;
+            pk_t h, l; split2(v, scale, h, l); hh[j] = h; ll[j] = l;
         }
         const int slot = r * 4 + (c ^ ((r >> 2) & 3));
-        o[slot] = hh; o[512 + slot] = mm; o[1024 + slot] = ll;
+        o[slot] = hh; o[512 + slot] = ll;
     }
 }
 
 struct PkParams {
-    const __bf16* A;
-    const __bf16* B;
+    const pk_t* A;
+    const pk_t* B;
     float* C;
     const float* bias;
     const float* res;
@@ -99,12 +134,14 @@ struct PkParams {
     float alpha;
     DropKey dk;
     int tilesN, KB, ktiles_per_split;
+    const float* inv_a;  // 1/scale of the A and B packs (their trailers)
+    const float* inv_b;
     int fbA, fbB;        // TR mode: 32-feature blocks per token row-block of the A / B packs (= ceil(M/32), ceil(N/32))
 };
 
-// plane pairs by decreasing magnitude: hh, hm, mh, mm, hl, lh
-__device__ __forceinline__ constexpr int pa(int q) { return q == 0 ? 0 : q == 1 ? 0 : q == 2 ? 1 : q == 3 ? 1 : q == 4 ? 0 : 2; }
-__device__ __forceinline__ constexpr int pb(int q) { return q == 0 ? 0 : q == 1 ? 1 : q == 2 ? 0 : q == 3 ? 1 : q == 4 ? 2 : 0; }
+// plane pairs by decreasing magnitude: q = 0: hh, 1: hl, 2: lh
+__device__ __forceinline__ constexpr int pa(int q) { return q == 2 ? 1 : 0; }
+__device__ __forceinline__ constexpr int pb(int q) { return q == 1 ? 1 : 0; }
 
 template <int SMODE, int CUR>
 struct StepTag { static constexpr int smode = SMODE, cur = CUR; };
@@ -115,8 +152,8 @@ struct StepTag { static constexpr int smode = SMODE, cur = CUR; };
 // and the fragments (8 consecutive tokens of one feature) come out of ds_read_b64_tr_b16, the hardware transpose read.
 template <bool TR>
 __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
-    extern __shared__ __attribute__((aligned(16))) __bf16 smem_pk[];
-    __bf16* const smem = smem_pk;
+    extern __shared__ __attribute__((aligned(16))) pk_t smem_pk[];
+    pk_t* const smem = smem_pk;
     int pid = blockIdx.x;
     {
         const int nwg = gridDim.x, xcd = pid & 7, idx = pid >> 3, q = nwg >> 3, r = nwg & 7;
@@ -137,17 +174,17 @@ __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
 
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    // a stage is 48 pieces of 1 KB: pieces 0..23 = the A tile, 24..47 = the B tile; wave w moves pieces 12w .. 12w+11
+    // a stage is 32 pieces of 1 KB: pieces 0..15 = the A tile, 16..31 = the B tile; wave w moves pieces 8w .. 8w+7
     // (waves 0,1: A; waves 2,3: B).  gbase is wave-uniform (SGPRs); the lane adds 16 B * lane.
-    //   TR = false: the 24 KB of a packed tile are contiguous; piece j = 4 * (j / 4) + (j % 4), the low part rides in
+    //   TR = false: the 16 KB of a packed tile are contiguous; piece j = 4 * (j / 4) + (j % 4), the low part rides in
     //     the instruction's immediate offset (it applies to the global and the LDS side alike).
     //   TR = true: K step kt = tokens 32 kt .. 32 kt + 31 = slice (kt % 4) of token block kt / 4; for each of the wave's
-    //     two 32-feature blocks and three planes one 2-KB slice = 2 pieces (immediate offset 0 / 1024).
+    //     two 32-feature blocks and two planes one 2-KB slice = 2 pieces (immediate offset 0 / 1024).
     const int opb = wave < 2 ? mb : nb, fb = wave < 2 ? p.fbA : p.fbB;
-    const __bf16* gbase = TR ? (wave < 2 ? p.A : p.B) + ((size_t)opb * 4 + (wave & 1) * 2) * PK_TILE
+    const pk_t* gbase = TR ? (wave < 2 ? p.A : p.B) + ((size_t)opb * 4 + (wave & 1) * 2) * PK_TILE
                              : (wave < 2 ? p.A + ((size_t)mb * p.KB + kt0) * PK_TILE : p.B + ((size_t)nb * p.KB + kt0) * PK_TILE) +
-                                   (size_t)(wave & 1) * 12 * 512;
-    const int ldst = wave * 12 * 512;
+                                   (size_t)(wave & 1) * 8 * 512;
+    const int ldst = wave * 8 * 512;
     auto koff = [&](int kt) -> size_t {      // element offset of K step kt (relative to kt0 for TR = false)
         if (TR) { const int k = kt0 + kt; return ((size_t)(k >> 2) * fb) * PK_TILE + (size_t)(k & 3) * 1024; }
         return (size_t)kt * PK_TILE;
@@ -158,7 +195,7 @@ __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
 #define DMA_ONE(j, kt, stage)                                                                                          \
     do {                                                                                                               \
         if (TR) {                                                                                                      \
-            const __bf16* g_ = gbase + koff(kt) + ((j) / 6) * PK_TILE + (((j) % 6) >> 1) * PK_IMG + lane * 8;           \
+            const pk_t* g_ = gbase + koff(kt) + ((j) >> 2) * PK_TILE + (((j) & 3) >> 1) * PK_IMG + lane * 8;            \
             const uint32_t l_ = (uint32_t)(((stage) * PK_STAGE + ldst + ((j) >> 1) * 1024) * 2);                        \
             asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off offset:%2"                               \
                          :: "v"(g_), "s"(l_), "n"(((j) & 1) * 1024) : "memory");                                       \
@@ -170,40 +207,39 @@ __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
     do {                                                                                                               \
         DMA_ONE(0, kt, stage); DMA_ONE(1, kt, stage); DMA_ONE(2, kt, stage); DMA_ONE(3, kt, stage);                    \
         DMA_ONE(4, kt, stage); DMA_ONE(5, kt, stage); DMA_ONE(6, kt, stage); DMA_ONE(7, kt, stage);                    \
-        DMA_ONE(8, kt, stage); DMA_ONE(9, kt, stage); DMA_ONE(10, kt, stage); DMA_ONE(11, kt, stage);                  \
     } while (0)
     // TR = false: fragment of k-step ks = row tile0 + l31, logical 16-B chunk 2h + ks (any K permutation shared by A, B).
     // TR = true: stage layout per operand [feature block 0..3][plane][32 tokens x 64 B]; lane (h, g = 16-lane group & 1,
     //   q, pp) addresses token 16 ks + 8 h + q (+4), features 16 g + 4 pp .. + 3 and receives feature lane & 31.
     const int rowa0 = wm * 64 + l31, rowb0 = wn * 64 + l31;
     const int trq = (lane >> 2) & 3, trchunk = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1), trsub = (lane & 1) * 4;
-    auto rd = [&](const __bf16* img, int row, int ks) -> bf16x8 {
-        return *reinterpret_cast<const bf16x8*>(img + (row * 4 + ((2 * h + ks) ^ ((row >> 2) & 3))) * 8);
+    auto rd = [&](const pk_t* img, int row, int ks) -> pkx8 {
+        return *reinterpret_cast<const pkx8*>(img + (row * 4 + ((2 * h + ks) ^ ((row >> 2) & 3))) * 8);
     };
-    auto rd_tr = [&](const __bf16* img, int ks) -> bf16x8 {
+    auto rd_tr = [&](const pk_t* img, int ks) -> pkx8 {
         typedef short short4v __attribute__((ext_vector_type(4)));
         typedef short short8v __attribute__((ext_vector_type(8)));
         typedef short4v __attribute__((address_space(3))) * lds_ptr;
         const int t0 = 16 * ks + 8 * h + trq, t1 = t0 + 4;
-        const __bf16* a0 = img + t0 * 32 + ((trchunk ^ ((t0 >> 2) & 3)) * 8) + trsub;
-        const __bf16* a1 = img + t1 * 32 + ((trchunk ^ ((t1 >> 2) & 3)) * 8) + trsub;
+        const pk_t* a0 = img + t0 * 32 + ((trchunk ^ ((t0 >> 2) & 3)) * 8) + trsub;
+        const pk_t* a1 = img + t1 * 32 + ((trchunk ^ ((t1 >> 2) & 3)) * 8) + trsub;
         const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0));
         const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a1));
         short8v f;
         f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-        return __builtin_bit_cast(bf16x8, f);
+        return __builtin_bit_cast(pkx8, f);
     };
-    bf16x8 f0a[3][2], f0b[3][2], f1a[3][2], f1b[3][2];
-    // read order = order of first use by the plane-pair rounds (lh, hl, mm, mh, hm, hh): A.l, B.h, A.h, B.l, A.m, B.m
-    auto frag_one = [&](int e, const __bf16* s, int ks, bf16x8 (&fa)[3][2], bf16x8 (&fb)[3][2]) {
+    pkx8 f0a[2][2], f0b[2][2], f1a[2][2], f1b[2][2];
+    // read order = order of first use by the plane-pair rounds (lh, hl, hh): A.l, B.h, A.h, B.l
+    auto frag_one = [&](int e, const pk_t* s, int ks, pkx8 (&fa)[2][2], pkx8 (&fb)[2][2]) {
         const int g = e >> 1, i = e & 1;
-        const int pl = g == 0 ? 2 : g == 1 ? 0 : g == 2 ? 0 : g == 3 ? 2 : 1;
+        const int pl = (g == 0 || g == 3) ? 1 : 0;
         if (TR) {
-            if ((g & 1) == 0) fa[pl][i] = rd_tr(s + ((2 * wm + i) * 3 + pl) * 1024, ks);
-            else fb[pl][i] = rd_tr(s + PK_TILE + ((2 * wn + i) * 3 + pl) * 1024, ks);
+            if ((g & 1) == 0) fa[pl][i] = rd_tr(s + ((2 * wm + i) * 2 + pl) * 1024, ks);
+            else fb[pl][i] = rd_tr(s + PK_TILE + ((2 * wn + i) * 2 + pl) * 1024, ks);
         } else {
             if ((g & 1) == 0) fa[pl][i] = rd(s + pl * PK_IMG, rowa0 + i * 32, ks);
-            else fb[pl][i] = rd(s + (3 + pl) * PK_IMG, rowb0 + i * 32, ks);
+            else fb[pl][i] = rd(s + (2 + pl) * PK_IMG, rowb0 + i * 32, ks);
         }
     };
     // ---- prologue: tiles 0, 1, 2 -> stages 0, 1, 2 (K index clamped: the in-order vmcnt bookkeeping is then the same on
@@ -213,10 +249,10 @@ __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
     DMA_TILE(min(1, nkt - 1), 1);
     __builtin_amdgcn_sched_barrier(0);
     DMA_TILE(min(2, nkt - 1), 2);
-    __builtin_amdgcn_s_waitcnt(0x4F78);              // vmcnt(24): tile 0 landed (this wave's pieces)
+    __builtin_amdgcn_s_waitcnt(0x4F70);              // vmcnt(16): tile 0 landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int e = 0; e < 12; ++e) frag_one(e, smem, 0, f0a, f0b);
+    for (int e = 0; e < 8; ++e) frag_one(e, smem, 0, f0a, f0b);
 
     auto step = [&](int it, auto tag) {
         // SMODE 1: tiles t+1..t+3 exist; 4: t+1, t+2 exist (nothing more to request); 2: only t+1; 3: last tile
@@ -224,26 +260,30 @@ __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
         constexpr int CUR = decltype(tag)::cur;              // stage of tile t (0..2)
         constexpr int NXT = (CUR + 1) % 3;
         constexpr bool HAS1 = SMODE != 3, HAS3 = SMODE == 1;
-        const __bf16* s_cur = smem + CUR * PK_STAGE;
-        const __bf16* s_nxt = smem + NXT * PK_STAGE;
+        const pk_t* s_cur = smem + CUR * PK_STAGE;
+        const pk_t* s_nxt = smem + NXT * PK_STAGE;
 #define PK_MMA(FA, FB, q)                                                                                  \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[pa(q)][i], FB[pb(q)][j], acc[i][j], 0, 0, 0);  \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[pa(q)][i], FB[pb(q)][j], acc[i][j], 0, 0, 0);   \
     __builtin_amdgcn_sched_barrier(0)
+    // three rounds of 4 MFMAs per phase; the 8 fragment reads / 8 DMA pieces of a phase are dealt 3, 3, 2
 #define PK_R1(r)                                                                                            \
-    frag_one(2 * (r), s_cur, 1, f1a, f1b); frag_one(2 * (r) + 1, s_cur, 1, f1a, f1b);                        \
-    PK_MMA(f0a, f0b, 5 - (r))
+    frag_one(3 * (r), s_cur, 1, f1a, f1b); frag_one(3 * (r) + 1, s_cur, 1, f1a, f1b);                        \
+    if ((r) < 2) frag_one(3 * (r) + 2, s_cur, 1, f1a, f1b);                                                  \
+    PK_MMA(f0a, f0b, 2 - (r))
 #define PK_R2(r)                                                                                            \
-    if (HAS3) { DMA_ONE(2 * (r), it + 3, CUR); DMA_ONE(2 * (r) + 1, it + 3, CUR); }                          \
-    if (HAS1) { frag_one(2 * (r), s_nxt, 0, f0a, f0b); frag_one(2 * (r) + 1, s_nxt, 0, f0a, f0b); }          \
-    PK_MMA(f1a, f1b, 5 - (r))
-        PK_R1(0); PK_R1(1); PK_R1(2); PK_R1(3); PK_R1(4); PK_R1(5);
-        // tile t+1 must have landed (requested two K tiles ago); tile t+2's 12 requests may stay in flight.
+    if (HAS3) { DMA_ONE(3 * (r), it + 3, CUR); DMA_ONE(3 * (r) + 1, it + 3, CUR); }                          \
+    if (HAS3 && (r) < 2) { DMA_ONE(((r) < 2 ? 3 * (r) + 2 : 0), it + 3, CUR); }                              \
+    if (HAS1) { frag_one(3 * (r), s_nxt, 0, f0a, f0b); frag_one(3 * (r) + 1, s_nxt, 0, f0a, f0b); }          \
+    if (HAS1 && (r) < 2) frag_one(3 * (r) + 2, s_nxt, 0, f0a, f0b);                                          \
+    PK_MMA(f1a, f1b, 2 - (r))
+        PK_R1(0); PK_R1(1); PK_R1(2);
+        // tile t+1 must have landed (requested two K tiles ago); tile t+2's 8 requests may stay in flight.
         // Raw s_barrier: __syncthreads() adds a fence that drains EVERY LDS-DMA in flight (vmcnt(0)).
-        if (SMODE == 1 || SMODE == 4) __builtin_amdgcn_s_waitcnt(0x007C);     // vmcnt(12) lgkmcnt(0)
+        if (SMODE == 1 || SMODE == 4) __builtin_amdgcn_s_waitcnt(0x0078);     // vmcnt(8) lgkmcnt(0)
         else __builtin_amdgcn_s_waitcnt(0x0070);                              // vmcnt(0) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
-        PK_R2(0); PK_R2(1); PK_R2(2); PK_R2(3); PK_R2(4); PK_R2(5);
+        PK_R2(0); PK_R2(1); PK_R2(2);
 #undef PK_MMA
 #undef PK_R1
 #undef PK_R2
@@ -266,6 +306,7 @@ __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
     // ---- epilogue (semantics of gemm_f32.hip)
     const int flags = p.flags;
     const bool atomic = gridDim.y > 1;
+    const float alpha = p.alpha * p.inv_a[0] * p.inv_b[0];       // undo the operands' power-of-two scales (exact)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = nb * 128 + wn * 64 + j * 32 + l31;
@@ -278,7 +319,7 @@ __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 if (row >= p.M) continue;
-                float v = acc[i][j][r] * p.alpha;
+                float v = acc[i][j][r] * alpha;
                 float* cp = p.C + (size_t)row * p.ldc + col;
                 if (atomic) {
                     atomicAdd(cp, v);
@@ -314,7 +355,7 @@ int lstc_gemm_f32x3_impl(const LstcGemmDesc* d, hipStream_t st) {
     const int splits = d->split_k > 1 ? d->split_k : 1;
     if (splits > 1 && d->flags != 0) return LSTC_E_UNSUPPORTED;
     PkParams p;
-    p.A = (const __bf16*)d->A; p.B = (const __bf16*)d->B; p.C = (float*)d->C;
+    p.A = (const pk_t*)d->A; p.B = (const pk_t*)d->B; p.C = (float*)d->C;
     p.bias = d->bias; p.res = (const float*)d->residual; p.relu_src = (const float*)d->relu_src;
     p.M = d->M; p.N = d->N; p.ldc = d->ldc; p.ldr = d->ldr; p.ld_relu = d->ld_relu; p.flags = d->flags; p.alpha = d->alpha;
     p.dk = make_drop_key(d->dropout_p, d->dropout_seed);
@@ -323,13 +364,19 @@ int lstc_gemm_f32x3_impl(const LstcGemmDesc* d, hipStream_t st) {
     if (!tr && !(d->transA == 0 && d->transB != 0)) return LSTC_E_UNSUPPORTED;
     p.KB = (d->K + 31) / 32;
     p.fbA = (d->M + 31) / 32; p.fbB = (d->N + 31) / 32;
+    {   // trailers of the packs: after rows/128 x K/32 tiles of the packed [rows, K] matrix
+        const int64_t ra = tr ? d->K : d->M, ka = tr ? d->M : d->K, rb_ = tr ? d->K : d->N, kb_ = tr ? d->N : d->K;
+        const int64_t ta = ((ra + 127) / 128) * ((ka + 31) / 32), tb = ((rb_ + 127) / 128) * ((kb_ + 31) / 32);
+        p.inv_a = reinterpret_cast<const float*>(p.A + ta * PK_TILE) + 1;
+        p.inv_b = reinterpret_cast<const float*>(p.B + tb * PK_TILE) + 1;
+    }
     // TR mode streams whole 128-token row blocks of the source packs and 4 feature blocks per 128 outputs
     if (tr && ((d->K % 128) != 0 || (d->M % 128) != 0 || (d->N % 128) != 0)) return LSTC_E_SHAPE;
     p.ktiles_per_split = (p.KB + splits - 1) / splits;
     const int eff_splits = (p.KB + p.ktiles_per_split - 1) / p.ktiles_per_split;
     const int tilesM = (d->M + 127) / 128;
     p.tilesN = (d->N + 127) / 128;
-    constexpr size_t lds = (size_t)PK_NSTAGE * PK_STAGE * sizeof(__bf16);
+    constexpr size_t lds = (size_t)PK_NSTAGE * PK_STAGE * sizeof(pk_t);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pk_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -345,7 +392,7 @@ extern "C" {
 
 int64_t lstc_pack3_bytes(int64_t rows, int64_t K) {
     if (rows <= 0 || K <= 0) return 0;
-    return ((rows + 127) / 128) * ((K + 31) / 32) * (int64_t)PK_TILE * (int64_t)sizeof(__bf16);
+    return ((rows + 127) / 128) * ((K + 31) / 32) * (int64_t)PK_TILE * (int64_t)sizeof(pk_t) + PK_TRAILER;
 }
 
 int lstc_pack3(const float* src, int64_t rows, int64_t K, int64_t ld, int32_t k_major, void* dst, void* stream) {
@@ -354,12 +401,18 @@ int lstc_pack3(const float* src, int64_t rows, int64_t K, int64_t ld, int32_t k_
     if (!aligned16(dst)) return LSTC_E_ALIGN;
     const int64_t RB = (rows + 127) / 128, KB = (K + 31) / 32;
     if (RB * KB > 0x7fffffffLL || rows > 0x7fffffffLL || K > 0x7fffffffLL) return LSTC_E_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t* trailer = reinterpret_cast<uint32_t*>(reinterpret_cast<pk_t*>(dst) + RB * KB * PK_TILE);
+    hipError_t e = hipMemsetAsync(trailer, 0, 16, st);
+    if (e != hipSuccess) return (int)e;
+    const int64_t srows = k_major ? K : rows, scols = k_major ? rows : K;          // the source as stored
+    hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(NT), 0, st, src, (long long)srows, (long long)scols, (long long)ld, trailer);
     if (k_major)
-        hipLaunchKernelGGL(pack3_km_kernel, dim3((unsigned)(RB * KB)), dim3(NT), 0, (hipStream_t)stream, src, (int)rows, (int)K,
-                           (long long)ld, (__bf16*)dst, (int)KB);
+        hipLaunchKernelGGL(pack3_km_kernel, dim3((unsigned)(RB * KB)), dim3(NT), 0, st, src, (int)rows, (int)K,
+                           (long long)ld, (pk_t*)dst, (int)KB, trailer);
     else
-        hipLaunchKernelGGL(pack3_kc_kernel, dim3((unsigned)(RB * KB)), dim3(NT), 0, (hipStream_t)stream, src, (int)rows, (int)K,
-                           (long long)ld, (__bf16*)dst, (int)KB);
+        hipLaunchKernelGGL(pack3_kc_kernel, dim3((unsigned)(RB * KB)), dim3(NT), 0, st, src, (int)rows, (int)K,
+                           (long long)ld, (pk_t*)dst, (int)KB, trailer);
     return lstc_launch_status();
 }
 

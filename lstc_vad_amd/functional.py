@@ -63,9 +63,9 @@ _compute_dtype = F32      # LstcGemmDesc.dtype used by every GEMM: F32 = exact f
 
 
 def set_compute_dtype(name: str):
-    """"fp32" (default; exact-f32 MFMA, the parity mode), "f32x3" (f32-accurate products on the bf16 matrix cores: every
-    operand split exactly into three bf16 planes, six plane products, f32 accumulation - csrc/gemm_pk.hip; small GEMMs stay
-    on the exact-f32 kernel) or "bf16" (operands rounded to bf16 inside the GEMM, f32 accumulate and f32 storage everywhere:
+    """"fp32" (default; exact-f32 MFMA, the parity mode), "f32x3" (f32-accurate products on the 16-bit matrix cores: every
+    operand scaled by a power of two and split into two f16 planes, three plane products, f32 accumulation -
+    csrc/gemm_pk.hip; small GEMMs stay on the exact-f32 kernel) or "bf16" (operands rounded to bf16 inside the GEMM, f32 accumulate and f32 storage everywhere:
     BASELINE.json configs 3 / 5).  Attention, LayerNorm, loss and Adagrad stay f32."""
     global _compute_dtype
     if name in ("fp32", "f32", "float32"):
@@ -84,7 +84,7 @@ def get_compute_dtype() -> str:
 
 # ---- packed operands of the f32x3 GEMM (csrc/gemm_pk.hip) ------------------------------------------------------------
 class Packed:
-    """An operand as lstc_pack3 leaves it: logical [rows, K], three bf16 planes in the GEMM's LDS-image tiling."""
+    """An operand as lstc_pack3 leaves it: logical [rows, K], two f16 planes in the GEMM's LDS-image tiling + scale."""
     __slots__ = ("buf", "rows", "K")
 
     def __init__(self, buf, rows, K):

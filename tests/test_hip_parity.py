@@ -290,7 +290,11 @@ def test_full_width_scores_match_oracle():
         assert max_abs_diff(got_enc, ref_enc) < 5e-4                # post-LN activations are O(1..5)
         big = torch.cat([x.to(DEV), 0.5 * torch.relu(torch.randn(250, 48, 2048, device=DEV))], 0)
         got_big = enc(big)
-        assert torch.equal(got_big[:6], got_enc)                    # bit-exact batch invariance
+        from lstc_vad_amd import functional as Fn
+        if Fn.get_compute_dtype() == "fp32":
+            assert torch.equal(got_big[:6], got_enc)                # bit-exact batch invariance
+        else:       # f32x3: the per-tensor power-of-two scale depends on the batch, so invariance holds to f32 rounding
+            assert max_abs_diff(got_big[:6], got_enc) < 5e-6
 
 
 @pytest.mark.parametrize("name", ["ltn_sht", "stn_sht", "ltn_ucf", "stn_relpe2d_extras"])

@@ -461,6 +461,167 @@ __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const __bf16* __restrict
     }
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// ---------------------------------------------------------------------------------------------------------------------
+// v3: as v2 with TWO f16 planes and three products (hh, hl, lh); operands pre-scaled by a power of two.  v2 text: PACKED operands + LDS-DMA.  The split pass already rewrites every operand, so it also packs it: the matrix is cut
+// into 128-row x 32-k tiles, each plane of a tile is stored as the exact 8-KB LDS image the GEMM wants (unpadded rows of
+// 4 x 16-B chunks, chunk index XOR-ed with (row>>2)&3 so that every ds_read_b128 lane group hits 16 distinct 16-B slots).
+// The GEMM then streams whole tiles with global_load_lds_dwordx4: 1 KB contiguous per wave-instruction, no staging
+// registers, no ds_write; three LDS stages give a prefetch distance of two K tiles.
+__global__ void pack2h_kernel(const float* __restrict__ x, int rows, int K, int ld, _Float16* __restrict__ out, int RB, int KB, float scale) {
+    const size_t nchunk = (size_t)RB * 128 * KB * 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunk; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % ((size_t)KB * 4)), rg = (int)(i / ((size_t)KB * 4));
+        const int rb = rg >> 7, r = rg & 127, kb = cg >> 2, c = cg & 3;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = cg * 8 + j;
+            v[j] = (rg < rows && k < K) ? x[(size_t)rg * ld + k] : 0.f;
+        }
+        f16x8 hh, ll;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xs = v[j] * scale;
+            const _Float16 h = (_Float16)xs;
+            hh[j] = h; ll[j] = (_Float16)(xs - (float)h);
+        }
+        const size_t tile = ((size_t)rb * KB + kb) * 2;
+        const int slot = r * 4 + (c ^ ((r >> 2) & 3));
+        f16x8* o = reinterpret_cast<f16x8*>(out);
+        o[(tile + 0) * 512 + slot] = hh;
+        o[(tile + 1) * 512 + slot] = ll;
+    }
+}
+
+constexpr int P2_IMG = 4096;            // bf16 elements of one plane image (128 rows x 32 k)
+constexpr int P2_STAGE = 4 * P2_IMG;    // A planes 0..1 then B planes 0..1
+constexpr int P2_NSTAGE = 3;
+
+template <int ABL>
+__global__ void __launch_bounds__(NT, 1) gemm_pk2_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ B,
+                                                         float* __restrict__ C, int M, int N, int KB, int tilesN, float inv_scale) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem_raw2[];
+    _Float16* const smem = reinterpret_cast<_Float16*>(smem_raw2);
+    int pid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = pid & 7, idx = pid >> 3, q = nwg >> 3, r = nwg & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mb = pid / tilesN, nb = pid % tilesN;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    // a stage is 48 pieces of 1 KB: pieces 0..23 = the 24 contiguous KB of the A tile, 24..47 = the B tile; wave w moves
+    // pieces 12w .. 12w+11 (waves 0,1: A; waves 2,3: B)
+    const _Float16* gbase = (wave < 2 ? A + (size_t)mb * KB * 2 * P2_IMG : B + (size_t)nb * KB * 2 * P2_IMG) +
+                          (size_t)(wave & 1) * 8 * 512;          // wave-uniform (SGPR) base; the lane adds 16 B * lane
+    const int ldst = wave * 8 * 512;           // element offset of this wave's first piece inside a stage
+    // piece j = 4 * (j / 4) + (j % 4): the low part rides in the instruction's immediate offset (applies to both sides)
+#define DMA_ONE(j, kt, stage)                                                                                          \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gbase + (size_t)(kt) * 2 * P2_IMG + ((j) >> 2) * 2048 + lane * 8),        \
+                                     (lptr_t)(smem + (stage) * P2_STAGE + ldst + ((j) >> 2) * 2048), 16, ((j) & 3) * 1024, 0)
+#define DMA_TILE(kt, stage)                                                                                            \
+    do {                                                                                                               \
+        DMA_ONE(0, kt, stage); DMA_ONE(1, kt, stage); DMA_ONE(2, kt, stage); DMA_ONE(3, kt, stage);                    \
+        DMA_ONE(4, kt, stage); DMA_ONE(5, kt, stage); DMA_ONE(6, kt, stage); DMA_ONE(7, kt, stage);                    \
+    } while (0)
+    // fragment: rows tile0 + l31, logical 16-B chunk c = 2h + ks
+    const int rowa0 = wm * 64 + l31, rowb0 = wn * 64 + l31;
+    auto rd = [&](const _Float16* img, int row, int ks) -> f16x8 {
+        return *reinterpret_cast<const f16x8*>(img + (row * 4 + ((2 * h + ks) ^ ((row >> 2) & 3))) * 8);
+    };
+    f16x8 f0a[2][2], f0b[2][2], f1a[2][2], f1b[2][2];
+    // read order = order of first use by the plane-pair rounds (lh, hl, mm, mh, hm, hh): A.l, B.h, A.h, B.l, A.m, B.m
+    auto frag_one = [&](int e, const _Float16* s, int ks, f16x8 (&fa)[2][2], f16x8 (&fb)[2][2]) {
+        const int g = e >> 1, i = e & 1;
+        const int p = g == 0 ? 1 : g == 1 ? 0 : g == 2 ? 0 : 1;       // A.l, B.h, A.h, B.l
+        if ((g & 1) == 0) fa[p][i] = rd(s + p * P2_IMG, rowa0 + i * 32, ks);
+        else fb[p][i] = rd(s + (2 + p) * P2_IMG, rowb0 + i * 32, ks);
+    };
+    const int nkt = KB;
+    // ---- prologue: tiles 0, 1, 2 -> stages 0, 1, 2 (K index clamped: same in-order vmcnt bookkeeping on every path)
+    DMA_TILE(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    DMA_TILE(min(1, nkt - 1), 1);
+    __builtin_amdgcn_sched_barrier(0);
+    DMA_TILE(min(2, nkt - 1), 2);
+    __builtin_amdgcn_s_waitcnt(0x4F70);              // vmcnt(16): tile 0 landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) frag_one(e, smem, 0, f0a, f0b);
+
+    auto step = [&](int it, auto tag) {
+        // SMODE 1: tiles t+1..t+3 exist; 4: t+1, t+2 exist (nothing more to request); 2: only t+1; 3: last tile
+        constexpr int SMODE = decltype(tag)::smode;
+        constexpr int CUR = decltype(tag)::cur;              // stage of tile t (0..2)
+        constexpr int NXT = (CUR + 1) % 3;
+        constexpr bool HAS1 = SMODE != 3, HAS3 = SMODE == 1;
+        const _Float16* s_cur = smem + CUR * P2_STAGE;
+        const _Float16* s_nxt = smem + NXT * P2_STAGE;
+#define PK_MMA(FA, FB, q)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[(q) == 2 ? 1 : 0][i], FB[(q) == 1 ? 1 : 0][j], acc[i][j], 0, 0, 0);  \
+    __builtin_amdgcn_sched_barrier(0)
+#define PK_R1(r)                                                                                            \
+    if (!(ABL & 4)) { frag_one(3 * (r), s_cur, 1, f1a, f1b); frag_one(3 * (r) + 1, s_cur, 1, f1a, f1b); if ((r) < 2) frag_one(3 * (r) + 2, s_cur, 1, f1a, f1b); } \
+    PK_MMA(f0a, f0b, 2 - (r))
+#define PK_R2(r)                                                                                            \
+    if (HAS3 && !(ABL & 1)) { DMA_ONE(3 * (r), it + 3, CUR); DMA_ONE(3 * (r) + 1, it + 3, CUR); if ((r) < 2) DMA_ONE(((r) < 2 ? 3 * (r) + 2 : 0), it + 3, CUR); } \
+    if (HAS1 && !(ABL & 4)) { frag_one(3 * (r), s_nxt, 0, f0a, f0b); frag_one(3 * (r) + 1, s_nxt, 0, f0a, f0b); if ((r) < 2) frag_one(3 * (r) + 2, s_nxt, 0, f0a, f0b); } \
+    PK_MMA(f1a, f1b, 2 - (r))
+        PK_R1(0); PK_R1(1); PK_R1(2);
+        // tile t+1 must have landed (requested two K tiles ago); tile t+2's 12 requests may stay in flight.
+        // raw s_barrier: __syncthreads() would add a fence that drains EVERY LDS-DMA in flight (vmcnt(0))
+        if (!(ABL & 1)) {
+            if (SMODE == 1 || SMODE == 4) __builtin_amdgcn_s_waitcnt(0x0078);     // vmcnt(8) lgkmcnt(0)
+            else __builtin_amdgcn_s_waitcnt(0x0070);                              // vmcnt(0) lgkmcnt(0)
+        } else __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0)
+        if (!(ABL & 8)) __builtin_amdgcn_s_barrier();
+        PK_R2(0); PK_R2(1); PK_R2(2);
+    };
+    int it = 0;
+    for (; it + 5 < nkt; it += 3) {
+        step(it, StepTag<1, 0>{});
+        step(it + 1, StepTag<1, 1>{});
+        step(it + 2, StepTag<1, 2>{});
+    }
+    // tail (it % 3 == 0): remaining tiles in {1..5}
+    for (; it < nkt; it += 3) {
+        const int rem = nkt - it;
+        if (rem >= 4) step(it, StepTag<1, 0>{}); else if (rem == 3) step(it, StepTag<4, 0>{}); else if (rem == 2) step(it, StepTag<2, 0>{}); else step(it, StepTag<3, 0>{});
+        if (rem >= 5) step(it + 1, StepTag<1, 1>{}); else if (rem == 4) step(it + 1, StepTag<4, 1>{}); else if (rem == 3) step(it + 1, StepTag<2, 1>{}); else if (rem == 2) step(it + 1, StepTag<3, 1>{});
+        if (rem >= 6) step(it + 2, StepTag<1, 2>{}); else if (rem == 5) step(it + 2, StepTag<4, 2>{}); else if (rem == 4) step(it + 2, StepTag<2, 2>{}); else if (rem == 3) step(it + 2, StepTag<3, 2>{});
+    }
+#undef DMA_ONE
+#undef DMA_TILE
+#undef PK_MMA
+#undef PK_R1
+#undef PK_R2
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = nb * 128 + wn * 64 + j * 32 + l31;
+        if (col >= N) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mb * 128 + wm * 64 + i * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+                if (row < M) C[(size_t)row * N + col] = acc[i][j][r] * inv_scale;
+            }
+    }
+}
+
 static double urand(uint64_t& s) { s = s * 6364136223846793005ull + 1442695040888963407ull; return (double)(s >> 11) / 9007199254740992.0; }
 
 template <int NPROD>
@@ -471,14 +632,18 @@ void run(int M, int N, int K, int iters, const float* dA, const float* dB, const
     CK(hipMalloc(&pA, (size_t)3 * RBa * 128 * Kp * 2)); CK(hipMalloc(&pB, (size_t)3 * RBb * 128 * Kp * 2)); CK(hipMalloc(&dC, (size_t)M * N * 4));
     hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
     const int tilesM = (M + BM - 1) / BM, tilesN = (N + BN - 1) / BN;
-    const size_t lds = NPROD >= 100 ? PK_NSTAGE * PK_STAGE * sizeof(__bf16) : 2 * STAGE * sizeof(__bf16);
+    const size_t lds = NPROD >= 200 ? P2_NSTAGE * P2_STAGE * 2 : NPROD >= 100 ? PK_NSTAGE * PK_STAGE * sizeof(__bf16) : 2 * STAGE * sizeof(__bf16);
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<(NPROD >= 60 ? 6 : NPROD)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3p_kernel<(NPROD >= 60 && NPROD < 100 ? NPROD - 60 : 0)>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE * 2));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pk_kernel<(NPROD >= 100 ? NPROD - 100 : 0)>), hipFuncAttributeMaxDynamicSharedMemorySize, PK_NSTAGE * PK_STAGE * 2));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pk_kernel<(NPROD >= 100 && NPROD < 200 ? NPROD - 100 : 0)>), hipFuncAttributeMaxDynamicSharedMemorySize, PK_NSTAGE * PK_STAGE * 2));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pk2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, P2_NSTAGE * P2_STAGE * 2));
     float ms_split = 0, ms_gemm = 0;
     for (int it = 0; it < iters + 1; ++it) {
         CK(hipEventRecord(e0));
-        if (NPROD >= 100) {
+        if (NPROD >= 200) {
+            hipLaunchKernelGGL(pack2h_kernel, 4096, 256, 0, 0, dA, M, K, K, (_Float16*)pA, RBa, KBk, 32768.f);
+            hipLaunchKernelGGL(pack2h_kernel, 1024, 256, 0, 0, dB, N, K, K, (_Float16*)pB, RBb, KBk, 524288.f);
+        } else if (NPROD >= 100) {
             hipLaunchKernelGGL(pack3_kernel, 4096, 256, 0, 0, dA, M, K, K, pA, RBa, KBk);
             hipLaunchKernelGGL(pack3_kernel, 1024, 256, 0, 0, dB, N, K, K, pB, RBb, KBk);
         } else {
@@ -486,7 +651,8 @@ void run(int M, int N, int K, int iters, const float* dA, const float* dB, const
             hipLaunchKernelGGL(split3_kernel, 1024, 256, 0, 0, dB, N, K, K, pB, Kp);
         }
         CK(hipEventRecord(e1));
-        if (NPROD >= 100) hipLaunchKernelGGL(gemm_pk_kernel<(NPROD >= 100 ? NPROD - 100 : 0)>, tilesM * tilesN, NT, lds, 0, pA, pB, dC, M, N, KBk, tilesN);
+        if (NPROD >= 200) hipLaunchKernelGGL(gemm_pk2_kernel<0>, tilesM * tilesN, NT, lds, 0, (const _Float16*)pA, (const _Float16*)pB, dC, M, N, KBk, tilesN, 1.f / (32768.f * 524288.f));
+        else if (NPROD >= 100) hipLaunchKernelGGL(gemm_pk_kernel<(NPROD >= 100 && NPROD < 200 ? NPROD - 100 : 0)>, tilesM * tilesN, NT, lds, 0, pA, pB, dC, M, N, KBk, tilesN);
         else if (NPROD >= 60) hipLaunchKernelGGL(gemm_x3p_kernel<(NPROD >= 100 ? 0 : NPROD - 60)>, tilesM * tilesN, NT, lds, 0, pA, pB, dC, M, N, Kp, tilesN);
         else hipLaunchKernelGGL(gemm_x3_kernel<(NPROD >= 60 ? 6 : NPROD)>, tilesM * tilesN, NT, lds, 0, pA, pB, dC, M, N, Kp, tilesN);
         CK(hipEventRecord(e2));
@@ -523,6 +689,7 @@ int main(int argc, char** argv) {
     float *dA, *dB;
     CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4));
     CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+    run<200>(M, N, K, iters, dA, dB, hA, hB);
     run<100>(M, N, K, iters, dA, dB, hA, hB);
     run<60>(M, N, K, iters, dA, dB, hA, hB);
     if (argc > 5) {
