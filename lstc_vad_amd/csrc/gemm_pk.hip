@@ -520,6 +520,182 @@ __global__ void __launch_bounds__(NT, 1) gemm_pk256_kernel(const PkParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Two-stage, two-workgroups-per-CU form of the 128x128 kernel (64 KB of LDS and <= 256 registers per workgroup): the
+// prologue (tile requests before the first MFMA) and the epilogue of one workgroup overlap the K loop of the other,
+// which matters for the K = 2048 products (64 K steps per workgroup).
+
+template <bool TR>
+__global__ void __launch_bounds__(NT, 2) gemm_pk2s_kernel(const PkParams p) {
+    extern __shared__ __attribute__((aligned(16))) pk_t smem_pk[];
+    pk_t* const smem = smem_pk;
+    int pid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = pid & 7, idx = pid >> 3, q = nwg >> 3, r = nwg & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mb = pid / p.tilesN, nb = pid % p.tilesN;
+    const int kt0 = blockIdx.y * p.ktiles_per_split;
+    const int nkt = min(p.KB, kt0 + p.ktiles_per_split) - kt0;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // pieces as in gemm_pk_kernel: a stage = [A tile 16 KB][B tile 16 KB]; wave w moves 8 pieces of its operand's tile
+    const int opb = wave < 2 ? mb : nb, fb = wave < 2 ? p.fbA : p.fbB;
+    const pk_t* gbase = TR ? (wave < 2 ? p.A : p.B) + ((size_t)opb * 4 + (wave & 1) * 2) * PK_TILE
+                           : (wave < 2 ? p.A + ((size_t)mb * p.KB + kt0) * PK_TILE : p.B + ((size_t)nb * p.KB + kt0) * PK_TILE) +
+                                 (size_t)(wave & 1) * 8 * 512;
+    const int ldst = wave * 8 * 512;
+    auto koff = [&](int kt) -> size_t {
+        if (TR) { const int k = kt0 + kt; return ((size_t)(k >> 2) * fb) * PK_TILE + (size_t)(k & 3) * 1024; }
+        return (size_t)kt * PK_TILE;
+    };
+    // piece j (0..7).  NT: contiguous, j = 4 (j / 4) + (j % 4) with the low part as immediate offset.  TR: feature block
+    // j / 4, plane (j % 4) / 2, half j % 2.  SGPR base + 32-bit lane offset (saddr form), inline asm (see gemm_pk_kernel).
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+#define S2_DMA(j, kt, stage)                                                                                           \
+    do {                                                                                                               \
+        const pk_t* g_ = TR ? gbase + koff(kt) + ((j) >> 2) * PK_TILE + (((j) & 3) >> 1) * PK_IMG                       \
+                            : gbase + koff(kt) + ((j) >> 2) * 2048;                                                     \
+        const uint32_t l_ = (uint32_t)(((stage) * PK_STAGE + ldst + (TR ? ((j) >> 1) * 1024 : ((j) >> 2) * 2048)) * 2); \
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"                                    \
+                     :: "v"(lane_off), "s"(g_), "s"(l_), "n"(TR ? ((j) & 1) * 1024 : ((j) & 3) * 1024) : "memory");    \
+    } while (0)
+#define S2_DMA_TILE(kt, stage)                                                                                         \
+    do {                                                                                                               \
+        S2_DMA(0, kt, stage); S2_DMA(1, kt, stage); S2_DMA(2, kt, stage); S2_DMA(3, kt, stage);                        \
+        S2_DMA(4, kt, stage); S2_DMA(5, kt, stage); S2_DMA(6, kt, stage); S2_DMA(7, kt, stage);                        \
+    } while (0)
+    const int trq = (lane >> 2) & 3, trchunk = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1), trsub = (lane & 1) * 4;
+    auto rd = [&](const pk_t* img, int row, int ks) -> pkx8 {
+        return *reinterpret_cast<const pkx8*>(img + (row * 4 + ((2 * h + ks) ^ ((row >> 2) & 3))) * 8);
+    };
+    auto rd_tr = [&](const pk_t* img, int ks) -> pkx8 {
+        typedef short short4v __attribute__((ext_vector_type(4)));
+        typedef short short8v __attribute__((ext_vector_type(8)));
+        typedef short4v __attribute__((address_space(3))) * lds_ptr;
+        const int t0 = 16 * ks + 8 * h + trq, t1 = t0 + 4;
+        const pk_t* a0 = img + t0 * 32 + ((trchunk ^ ((t0 >> 2) & 3)) * 8) + trsub;
+        const pk_t* a1 = img + t1 * 32 + ((trchunk ^ ((t1 >> 2) & 3)) * 8) + trsub;
+        const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0));
+        const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a1));
+        short8v f;
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        return __builtin_bit_cast(pkx8, f);
+    };
+    const int rowa0 = wm * 64 + l31, rowb0 = wn * 64 + l31;
+    pkx8 f0a[2][2], f0b[2][2], f1a[2][2], f1b[2][2];
+    // fragment e (0..7) in order of first use by the rounds (lh, hl, hh): A.l, B.h, A.h, B.l (two each)
+    auto frag_one = [&](int e, const pk_t* s, int ks, pkx8 (&fa)[2][2], pkx8 (&fb)[2][2]) {
+        const int g = e >> 1, i = e & 1;
+        const int pl = (g == 0 || g == 3) ? 1 : 0;
+        if (TR) {
+            if ((g & 1) == 0) fa[pl][i] = rd_tr(s + ((2 * wm + i) * 2 + pl) * 1024, ks);
+            else fb[pl][i] = rd_tr(s + PK_TILE + ((2 * wn + i) * 2 + pl) * 1024, ks);
+        } else {
+            if ((g & 1) == 0) fa[pl][i] = rd(s + pl * PK_IMG, rowa0 + i * 32, ks);
+            else fb[pl][i] = rd(s + (2 + pl) * PK_IMG, rowb0 + i * 32, ks);
+        }
+    };
+    // ---- prologue: tiles 0, 1 -> stages 0, 1 (K index clamped so that every path into the loop has the same vmcnt state)
+    S2_DMA_TILE(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    S2_DMA_TILE(min(1, nkt - 1), 1);
+    __builtin_amdgcn_s_waitcnt(0x0F78);              // vmcnt(8): tile 0 landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) frag_one(e, smem, 0, f0a, f0b);
+
+    auto step = [&](int it, auto tag) {
+        // SMODE 1: tiles t+1, t+2 exist; 2: only t+1 (nothing more to request); 3: last tile
+        constexpr int SMODE = decltype(tag)::smode;
+        constexpr int CUR = decltype(tag)::cur;              // stage of tile t (0..1)
+        constexpr bool HAS1 = SMODE != 3, HAS2 = SMODE == 1;
+        const pk_t* s_cur = smem + CUR * PK_STAGE;
+        const pk_t* s_nxt = smem + (CUR ^ 1) * PK_STAGE;
+        // a round = product q on the four accumulators: 4 independent MFMAs; 3 rounds per phase
+#define S2_MMA(FA, FB, q)                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                   \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[pa(q)][i], FB[pb(q)][j], acc[i][j], 0, 0, 0);       \
+    __builtin_amdgcn_sched_barrier(0)
+#define S2_R1(r)                                                                                                \
+    frag_one(3 * (r), s_cur, 1, f1a, f1b); frag_one(3 * (r) + 1, s_cur, 1, f1a, f1b);                            \
+    if ((r) < 2) frag_one(3 * (r) + 2, s_cur, 1, f1a, f1b);                                                      \
+    S2_MMA(f0a, f0b, 2 - (r))
+        S2_R1(0); S2_R1(1); S2_R1(2);
+        // tile t+1 (requested one and a half phases ago) must have landed: nothing newer is in flight.  The second
+        // workgroup of the CU covers what this wait exposes.
+        __builtin_amdgcn_s_waitcnt(0x0070);                  // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+#define S2_R2(r)                                                                                                \
+    if (HAS2) { S2_DMA(3 * (r), it + 2, CUR); S2_DMA(3 * (r) + 1, it + 2, CUR); }                                 \
+    if (HAS2 && (r) < 2) { S2_DMA(((r) < 2 ? 3 * (r) + 2 : 0), it + 2, CUR); }                                   \
+    if (HAS1) { frag_one(3 * (r), s_nxt, 0, f0a, f0b); frag_one(3 * (r) + 1, s_nxt, 0, f0a, f0b); }              \
+    if (HAS1 && (r) < 2) frag_one(3 * (r) + 2, s_nxt, 0, f0a, f0b);                                              \
+    S2_MMA(f1a, f1b, 2 - (r))
+        S2_R2(0); S2_R2(1); S2_R2(2);
+#undef S2_MMA
+#undef S2_R1
+#undef S2_R2
+    };
+    int it = 0;
+    for (; it + 3 < nkt; it += 2) {
+        step(it, StepTag<1, 0>{});
+        step(it + 1, StepTag<1, 1>{});
+    }
+    {   // tail (it even): 1..3 tiles left
+        const int rem = nkt - it;
+        if (rem == 3) { step(it, StepTag<1, 0>{}); step(it + 1, StepTag<2, 1>{}); step(it + 2, StepTag<3, 0>{}); }
+        else if (rem == 2) { step(it, StepTag<2, 0>{}); step(it + 1, StepTag<3, 1>{}); }
+        else if (rem == 1) { step(it, StepTag<3, 0>{}); }
+    }
+#undef S2_DMA
+#undef S2_DMA_TILE
+
+    const int flags = p.flags;
+    const bool atomic = gridDim.y > 1;
+    const float alpha = p.alpha * p.inv_a[0] * p.inv_b[0];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = nb * 128 + wn * 64 + j * 32 + l31;
+        if (col >= p.N) continue;
+        const float bv = (flags & LSTC_EPI_BIAS) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rbase = mb * 128 + wm * 64 + i * 32 + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] * alpha;
+                float* cp = p.C + (size_t)row * p.ldc + col;
+                if (atomic) {
+                    atomicAdd(cp, v);
+                    continue;
+                }
+                v += bv;
+                if (flags & LSTC_EPI_RELU) v = fmaxf(v, 0.f);
+                if (flags & LSTC_EPI_DROPOUT) {
+                    const uint32_t idx = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+                    v = drop_keep(idx, p.dk) ? v * p.dk.scale : 0.f;
+                }
+                if (flags & LSTC_EPI_RESIDUAL) v += p.res[(size_t)row * p.ldr + col];
+                if (flags & LSTC_EPI_RELU_MASK) v = p.relu_src[(size_t)row * p.ld_relu + col] > 0.f ? v : 0.f;
+                if (flags & LSTC_EPI_ACCUM) v += *cp;
+                *cp = v;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // Packed-operand GEMM behind lstc_gemm (dtype LSTC_F32X3): d->A / d->B point to lstc_pack3 outputs for [M, K] / [N, K].
@@ -574,6 +750,20 @@ int lstc_gemm_f32x3_impl(const LstcGemmDesc* d, hipStream_t st) {
     }
     const int tilesM = (d->M + 127) / 128;
     p.tilesN = (d->N + 127) / 128;
+    // default (variant 0 / 3): the two-stage kernel, two workgroups per CU - 2.44 / 4.30 / 4.93 ms against 2.63 / 4.56 /
+    // 5.39 ms of the three-stage one (variant 1) on the 100352 x {2048 x 2048, 2048 x 4096, 4096 x 2048} forward shapes
+    if (d->variant != 1) {
+        constexpr size_t lds3 = (size_t)2 * PK_STAGE * sizeof(pk_t);
+        static bool attr3 = false;
+        if (!attr3) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pk2s_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pk2s_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            attr3 = true;
+        }
+        if (tr) hipLaunchKernelGGL(gemm_pk2s_kernel<true>, dim3(tilesM * p.tilesN, eff_splits), dim3(NT), lds3, st, p);
+        else hipLaunchKernelGGL(gemm_pk2s_kernel<false>, dim3(tilesM * p.tilesN, eff_splits), dim3(NT), lds3, st, p);
+        return lstc_launch_status();
+    }
     constexpr size_t lds = (size_t)PK_NSTAGE * PK_STAGE * sizeof(pk_t);
     static bool attr_done = false;
     if (!attr_done) {

@@ -54,9 +54,9 @@ static int check(const Case& c) {
     if (c.dtype == LSTC_F32X3) {     // operands go through lstc_pack3: A as [M, K], B as [N, K]
         CK(hipMalloc(&pA, lstc_pack3_bytes(M, K))); CK(hipMalloc(&pB, lstc_pack3_bytes(N, K)));
         int r1, r2;
-        if (c.variant == 7 || c.variant == 8) {            // weight-gradient form (7: 128-tile kernel, 8: 256-tile kernel): packs of the SOURCES [K, M], [K, N] + transposed reads
+        if (c.variant >= 7 && c.variant <= 9) {            // weight-gradient form (7: 128-tile kernel, 8: 256-tile, 9: 2-stage 128-tile): packs of the SOURCES [K, M], [K, N] + transposed reads
             r1 = lstc_pack3(dA, K, M, lda, 0, pA, nullptr); r2 = lstc_pack3(dB, K, N, ldb, 0, pB, nullptr);
-            d.transA = 1; d.transB = 0; d.variant = c.variant == 8 ? 2 : 1;
+            d.transA = 1; d.transB = 0; d.variant = c.variant == 8 ? 2 : c.variant == 9 ? 3 : 1;   /* 7 -> three-stage kernel */
         } else {
             r1 = lstc_pack3(dA, M, K, lda, c.tA ? 1 : 0, pA, nullptr); r2 = lstc_pack3(dB, N, K, ldb, c.tB ? 0 : 1, pB, nullptr);
             d.transA = 0; d.transB = 1;
@@ -125,18 +125,18 @@ static void timeit(int M, int N, int K, int tA, int tB, int variant, int split, 
         CK(hipMalloc(&pA, lstc_pack3_bytes(M, K))); CK(hipMalloc(&pB, lstc_pack3_bytes(N, K)));
         for (int rep = 0; rep < 2; ++rep) {
             CK(hipEventRecord(e0, nullptr));
-            if (variant == 7 || variant == 8) lstc_pack3(dA, K, M, lda, 0, pA, nullptr); else lstc_pack3(dA, M, K, lda, tA ? 1 : 0, pA, nullptr);
+            if (variant >= 7 && variant <= 9) lstc_pack3(dA, K, M, lda, 0, pA, nullptr); else lstc_pack3(dA, M, K, lda, tA ? 1 : 0, pA, nullptr);
             CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
             float msa; CK(hipEventElapsedTime(&msa, e0, e1));
             CK(hipEventRecord(e0, nullptr));
-            if (variant == 7 || variant == 8) lstc_pack3(dB, K, N, ldb, 0, pB, nullptr); else lstc_pack3(dB, N, K, ldb, tB ? 0 : 1, pB, nullptr);
+            if (variant >= 7 && variant <= 9) lstc_pack3(dB, K, N, ldb, 0, pB, nullptr); else lstc_pack3(dB, N, K, ldb, tB ? 0 : 1, pB, nullptr);
             CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
             float msb; CK(hipEventElapsedTime(&msb, e0, e1));
             if (rep) printf("PACK A [%d x %d]%s %.3f ms (%.2f TB/s)   B [%d x %d]%s %.3f ms\n", M, K, tA ? " k-major" : "", msa,
                             10.0 * M * K / (msa * 1e-3) / 1e12, N, K, tB ? "" : " k-major", msb);
         }
         d.A = pA; d.B = pB;
-        if (variant == 7 || variant == 8) { d.transA = 1; d.transB = 0; d.variant = variant == 8 ? 2 : 1; } else { d.transA = 0; d.transB = 1; }
+        if (variant >= 7 && variant <= 9) { d.transA = 1; d.transB = 0; d.variant = variant == 8 ? 2 : variant == 9 ? 3 : 1; } else { d.transA = 0; d.transB = 1; }
     }
     for (int i = 0; i < 6; ++i) { int rc = lstc_gemm(&d, nullptr); if (rc) { printf("rc=%d\n", rc); return; } }   // clock ramp
     CK(hipDeviceSynchronize());
@@ -218,6 +218,9 @@ int main(int argc, char** argv) {
             fails += check({300, 520, 100 + 32 * split, 0, 1, ALLB, 2, 1, LSTC_F32X3});     // 256x256-tile kernel, ragged NT
             fails += check({512, 256, 96, 0, 0, LSTC_EPI_RELU_MASK, 2, 1, LSTC_F32X3});
             fails += check({260, 130, 515, 1, 0, 0, 2, split, LSTC_F32X3});
+            fails += check({256, 384, 640, 1, 0, 0, 9, split, LSTC_F32X3});                  // 2-stage kernel, TR
+            fails += check({300, 520, 100 + 32 * split, 0, 1, ALLB, 3, 1, LSTC_F32X3});     // 2-stage kernel, ragged NT
+            fails += check({130, 260, 515 + 32 * split, 1, 0, 0, 3, split, LSTC_F32X3});
         }
         printf("%s: %d failing cases\n", fails ? "FAILED" : "ALL PASS", fails);
     }
