@@ -65,8 +65,17 @@ __global__ void __launch_bounds__(NT) absmax_kernel(const float* __restrict__ x,
         for (long long r = blockIdx.x; r < rows; r += gridDim.x)
             for (long long c = threadIdx.x; c < cols; c += NT) m = fmaxf(m, fabsf(x[r * ld + c]));
     }
+    // one atomic per workgroup: thousands of atomics on ONE address serialise (~10 ns each)
+    __shared__ float red[NT / 64];
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bits
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float mm = red[0];
+#pragma unroll
+        for (int w = 1; w < NT / 64; ++w) mm = fmaxf(mm, red[w]);
+        atomicMax(out, __float_as_uint(mm));                               // non-negative floats order like their bits
+    }
 }
 
 // ---- pack, K-contiguous source [rows, K] (ld): one workgroup per (row block, k block) tile; thread -> two 16-B chunks.
@@ -796,7 +805,9 @@ int lstc_pack3(const float* src, int64_t rows, int64_t K, int64_t ld, int32_t k_
     hipError_t e = hipMemsetAsync(trailer, 0, 16, st);
     if (e != hipSuccess) return (int)e;
     const int64_t srows = k_major ? K : rows, scols = k_major ? rows : K;          // the source as stored
-    hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(NT), 0, st, src, (long long)srows, (long long)scols, (long long)ld, trailer);
+    const int64_t nel = rows * K;
+    const unsigned ablocks = (unsigned)(nel >= (1 << 24) ? 1024 : (nel + 16383) / 16384 > 0 ? (nel + 16383) / 16384 : 1);
+    hipLaunchKernelGGL(absmax_kernel, dim3(ablocks), dim3(NT), 0, st, src, (long long)srows, (long long)scols, (long long)ld, trailer);
     if (k_major)
         hipLaunchKernelGGL(pack3_km_kernel, dim3((unsigned)(RB * KB)), dim3(NT), 0, st, src, (int)rows, (int)K,
                            (long long)ld, (pk_t*)dst, (int)KB, trailer);
