@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
+    ap.add_argument("--no-f32x3", action="store_true", help="skip the second timed pass in f32x3 mode (reported as the \"f32x3\" "
+                    "object of the JSON line; `value` is always the --dtype mode, exact-f32 MFMA by default)")
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -189,6 +191,30 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     scal = [float(x) for x in sc.cpu()]
+    # ---- second pass: the same K steps with the big products on the 16-bit matrix cores (f32-accurate split operands,
+    # csrc/gemm_pk.hip).  Reported next to the headline, never as `value`.
+    x3 = None
+    if a.dtype == "fp32" and not a.no_f32x3:
+        Fn.set_compute_dtype("f32x3")
+        for _ in range(max(1, a.warmup)):
+            run_step()
+        sync()
+        gp, pp = ([], []) if prof is not None else (None, None)
+        Fn.set_gemm_profiling(gp)
+        Fn._pack_prof = pp
+        t3 = time.perf_counter()
+        for _ in range(a.steps):
+            sc3 = run_step()
+        sync()
+        dt3 = time.perf_counter() - t3
+        Fn.set_gemm_profiling(None)
+        Fn._pack_prof = None
+        Fn.set_compute_dtype("fp32")
+        if world > 1:
+            tt = torch.tensor([dt3], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt3 = float(tt.item())
+        x3 = {"dt": dt3, "gp": gp, "pp": pp, "loss": float(sc3.cpu()[0])}
     pcie = None
     if a.h2d and world == 1 and not mixed:
         from lstc_vad_amd.feed import PinnedFeeder
@@ -264,6 +290,24 @@ def main():
                                       f"{'all tokens (naive)' if a.naive_last_layer else 'CLS token only, K/V projections re-associated (exact)'}",
                           "global_videos": 2 * bs * world * len(names), "parallelism": f"dp{world}"},
                "loss": scal[0], "roofline": roof}
+        if x3 is not None:
+            o3 = {"value": round(snippets_per_step * a.steps / x3["dt"], 1), "unit": "snippets/s",
+                  "ms_per_step": round(1e3 * x3["dt"] / a.steps, 3), "loss": x3["loss"],
+                  "dtype": "f32 storage and accumulation; products of the large GEMMs on the f16 matrix cores: operands scaled by a "
+                           "power of two and split into two f16 planes (x*s = h + l to 2^-24), three plane products hh + hl + lh",
+                  "accuracy": "error against f64 <= the exact-f32 MFMA kernel's (tests/test_hip_parity.py::test_f32x3_*, "
+                              "tools/x3_probe.hip: rms 0.82e-7 vs 0.92e-7 for an f32 fma chain); golden training parity at the f32 tolerances"}
+            if x3["gp"]:
+                fl3 = sum(q[0] for q in x3["gp"])
+                ms3 = sum(q[1].elapsed_time(q[2]) for q in x3["gp"])
+                pk3 = round(2500.0 / 3, 1)
+                o3["roofline"] = {"bound": "mfma", "kernel": "gemm_pk2s_kernel (3 x v_mfma_f32_32x32x16_f16 per f32 product)",
+                                  "achieved": round(fl3 / (ms3 * 1e-3) / 1e12, 2), "peak": pk3, "unit": "TFLOP/s (f32-equivalent)",
+                                  "frac": round(fl3 / (ms3 * 1e-3) / 1e12 / pk3, 4), "gemm_ms_per_step": round(ms3 / a.steps, 3)}
+                if x3["pp"]:
+                    pms = sum(q[1].elapsed_time(q[2]) for q in x3["pp"])
+                    o3["roofline"]["pack_ms_per_step"] = round(pms / a.steps, 3)
+            out["f32x3"] = o3
         if pcie:
             out["pcie_inclusive"] = pcie
         if world == 1 and not a.no_cpu_baseline and not mixed:
