@@ -17,6 +17,9 @@ from lstc_vad_amd.models import Classifier, Encoder                  # noqa: E40
 
 def main():
     dev = torch.device("cuda", 0)
+    from lstc_vad_amd import functional as Fn0
+    if len(sys.argv) > 1:
+        Fn0.set_compute_dtype(sys.argv[1])          # fp32 (default) | f32x3 | bf16
     torch.manual_seed(0)
     enc = Encoder(n_layers=3, n_head=8, d_k=256, d_v=256, d_model=2048, d_inner=4096, MHA_layerNorm=True, FFN_layerNorm=True,
                   relative_pe=True, window_size=4, window_depth=3, weight_init=False).to(dev).eval()
@@ -55,13 +58,27 @@ def main():
             t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize()
             res[name] = (time.perf_counter() - t0, out)
     diff = max(float((a - b).abs().max()) for a, b in zip(res["batched"][1], res["one_part_per_launch"][1]))
-    print(json.dumps({"workload": "LTN-SHT frame-level scoring, 64 synthetic test videos, %d clips, d=2048, S=49" % clips,
+    # data feed: one headline batch (2 x 32 videos x 96 clips x 16 x 2048 f32 = 805 MB) gathered out of an HBM-resident bank
+    from lstc_vad_amd import functional as Fn
+    bank = torch.cat(videos)                                              # [6061 clips, 16, 2048]
+    idx = torch.from_numpy(rs.randint(0, bank.shape[0], size=2 * 32 * 96)).to(dev)
+    out = Fn.gather_rows(bank, idx)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        Fn.gather_rows(bank, idx, out=out)
+    e1.record(); torch.cuda.synchronize()
+    gms = e0.elapsed_time(e1) / 10
+    gather = {"batch_MB": round(out.numel() * 4 / 1e6, 1), "ms": round(gms, 4),
+              "GBps_read_plus_write": round(2 * out.numel() * 4 / (gms * 1e-3) / 1e9, 1), "hbm_peak_GBps": 8000}
+    print(json.dumps({"gemm_mode": Fn0.get_compute_dtype(), "workload": "LTN-SHT frame-level scoring, 64 synthetic test videos, %d clips, d=2048, S=49" % clips,
                       "pooled_across_videos_clips_per_s": round(clips / res["pooled"][0], 1),
                       "pooled_max_abs_diff_vs_per_video": max(float((a - b).abs().max()) for a, b in zip(res["pooled"][1], res["batched"][1])),
                       "batched_per_video_clips_per_s": round(clips / res["batched"][0], 1),
                       "reference_launch_pattern_clips_per_s": round(clips / res["one_part_per_launch"][0], 1),
                       "speedup_pooled_vs_reference_pattern": round(res["one_part_per_launch"][0] / res["pooled"][0], 2),
-                      "max_abs_score_diff": diff}))
+                      "max_abs_score_diff": diff, "lstc_gather_rows": gather}))
 
 
 if __name__ == "__main__":
