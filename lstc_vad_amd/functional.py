@@ -92,7 +92,6 @@ class Packed:
 
 
 _pack_prof = None          # list of (bytes_in, start_event, end_event) while bench.py profiles
-_wpack_cache = {}          # (data_ptr, shape, k_major) -> (epoch, version, Packed): weights are packed once per optimizer step
 _wepoch = 0
 _memo_stack = []           # activation packs made inside one autograd-node body are shared by the GEMMs of that body
 _x3_min = (256, 256, 1 << 30)   # min(M, N), K, M*N*K from which a product goes to the packed kernel
@@ -108,8 +107,6 @@ def bump_weight_epoch():
     """Invalidate the packed-weight cache (the optimizer rewrote the weights through raw pointers)."""
     global _wepoch
     _wepoch += 1
-    if len(_wpack_cache) > 256:
-        _wpack_cache.clear()
 
 
 class pack_memo:
@@ -146,12 +143,14 @@ def _packed_operand(t, k_major):
     if isinstance(t, Packed):
         return t
     if t.is_leaf and t.requires_grad:                      # a weight: one pack per optimizer step and layout
-        key = (t.data_ptr(), tuple(t.shape), k_major)
-        hit = _wpack_cache.get(key)
-        if hit is not None and hit[0] == _wepoch and hit[1] == t._version:
+        # cached ON the parameter object (a key built from data_ptr would outlive the tensor and hand a stale pack to the
+        # next model that lands on the same address); autograd returns the same object from ctx.saved_tensors for leaves
+        cache = t.__dict__.setdefault("_lstc_packs", {})
+        hit = cache.get(k_major)
+        if hit is not None and hit[0] == _wepoch and hit[1] == t._version and hit[3] == t.data_ptr():
             return hit[2]
         pk = pack3(t.detach(), k_major)
-        _wpack_cache[key] = (_wepoch, t._version, pk)
+        cache[k_major] = (_wepoch, t._version, pk, t.data_ptr())
         return pk
     if _memo_stack:
         key = (t.data_ptr(), tuple(t.shape), t.stride(), k_major)
