@@ -350,187 +350,6 @@ __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 256x256 tile, 128x128 per wave (16 accumulators = 256 AGPRs): the 128x128-tile kernel moves 4 B per 64 MACs out of L2
-// and stalls at ~10 TB/s of L2->LDS traffic (both the bf16x6 and the f16x3 forms did); this one moves half of that.
-// A wave's 128 rows of A (and of B) are exactly one packed row block, so the stage is [A block 0][A block 1][B block 0]
-// [B block 1], each 16 KB = planes h, l; wave w DMAs one whole 16-KB packed tile per K step (16 pieces).  Two LDS stages
-// of 64 KB: tile t+2 is requested right after the mid-tile barrier of tile t into the stage tile t just vacated, and is
-// needed at the mid-tile barrier of tile t+1 (~72 MFMAs = 2300 cycles later).  TR form: [8 feature blocks][2 planes][2 KB]
-// per operand, wave w moves feature blocks 4 (w & 1) .. + 3 of its operand.
-constexpr int BG_STAGE = 4 * PK_TILE;       // 64 KB
-
-template <bool TR>
-__global__ void __launch_bounds__(NT, 1) gemm_pk256_kernel(const PkParams p) {
-    extern __shared__ __attribute__((aligned(16))) pk_t smem_pk[];
-    pk_t* const smem = smem_pk;
-    int pid = blockIdx.x;
-    {
-        const int nwg = gridDim.x, xcd = pid & 7, idx = pid >> 3, q = nwg >> 3, r = nwg & 7;
-        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int mb = pid / p.tilesN, nb = pid % p.tilesN;          // 256-row / 256-column tile indices
-    const int kt0 = blockIdx.y * p.ktiles_per_split;
-    const int nkt = min(p.KB, kt0 + p.ktiles_per_split) - kt0;
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, h = lane >> 5;
-    floatx16 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // wave w: operand A (w < 2) or B, its 128-row block (w & 1) of the tile.  NT: the packed tile (2 * blk + (w & 1), kt) is
-    // 16 contiguous KB.  TR: feature blocks 8 * blk + 4 (w & 1) .. + 3, each two 2-KB plane slices per K step.
-    const int opb = wave < 2 ? mb : nb, fb = wave < 2 ? p.fbA : p.fbB;
-    const pk_t* gbase = TR ? (wave < 2 ? p.A : p.B) + ((size_t)opb * 8 + (wave & 1) * 4) * PK_TILE
-                           : (wave < 2 ? p.A : p.B) + (((size_t)opb * 2 + (wave & 1)) * p.KB + kt0) * PK_TILE;
-    const int ldst = wave * PK_TILE;            // element offset of the wave's 16 KB inside a stage
-    auto koff = [&](int kt) -> size_t {
-        if (TR) { const int k = kt0 + kt; return ((size_t)(k >> 2) * fb) * PK_TILE + (size_t)(k & 3) * 1024; }
-        return (size_t)kt * PK_TILE;
-    };
-    // piece j (0..15).  NT: contiguous, j = 4 (j / 4) + (j % 4) with the low part as immediate offset.  TR: feature block
-    // j / 4, plane (j % 4) / 2, half j % 2 (immediate offset).  Inline asm: see the 128-tile kernel.
-    // SGPR base + 32-bit lane offset (saddr form): no per-piece address VGPRs
-    const uint32_t lane_off = (uint32_t)lane * 16u;
-#define BG_DMA(j, kt, stage)                                                                                           \
-    do {                                                                                                               \
-        const pk_t* g_ = TR ? gbase + koff(kt) + ((j) >> 2) * PK_TILE + (((j) & 3) >> 1) * PK_IMG                       \
-                            : gbase + koff(kt) + ((j) >> 2) * 2048;                                                     \
-        const uint32_t l_ = (uint32_t)(((stage) * BG_STAGE + ldst + (TR ? ((j) >> 1) * 1024 : ((j) >> 2) * 2048)) * 2); \
-        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"                                    \
-                     :: "v"(lane_off), "s"(g_), "s"(l_), "n"(TR ? ((j) & 1) * 1024 : ((j) & 3) * 1024) : "memory");    \
-    } while (0)
-#define BG_DMA_TILE(kt, stage)                                                                                         \
-    do {                                                                                                               \
-        BG_DMA(0, kt, stage); BG_DMA(1, kt, stage); BG_DMA(2, kt, stage); BG_DMA(3, kt, stage);                        \
-        BG_DMA(4, kt, stage); BG_DMA(5, kt, stage); BG_DMA(6, kt, stage); BG_DMA(7, kt, stage);                        \
-        BG_DMA(8, kt, stage); BG_DMA(9, kt, stage); BG_DMA(10, kt, stage); BG_DMA(11, kt, stage);                      \
-        BG_DMA(12, kt, stage); BG_DMA(13, kt, stage); BG_DMA(14, kt, stage); BG_DMA(15, kt, stage);                    \
-    } while (0)
-    const int trq = (lane >> 2) & 3, trchunk = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1), trsub = (lane & 1) * 4;
-    auto rd = [&](const pk_t* img, int row, int ks) -> pkx8 {
-        return *reinterpret_cast<const pkx8*>(img + (row * 4 + ((2 * h + ks) ^ ((row >> 2) & 3))) * 8);
-    };
-    auto rd_tr = [&](const pk_t* img, int ks) -> pkx8 {
-        typedef short short4v __attribute__((ext_vector_type(4)));
-        typedef short short8v __attribute__((ext_vector_type(8)));
-        typedef short4v __attribute__((address_space(3))) * lds_ptr;
-        const int t0 = 16 * ks + 8 * h + trq, t1 = t0 + 4;
-        const pk_t* a0 = img + t0 * 32 + ((trchunk ^ ((t0 >> 2) & 3)) * 8) + trsub;
-        const pk_t* a1 = img + t1 * 32 + ((trchunk ^ ((t1 >> 2) & 3)) * 8) + trsub;
-        const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0));
-        const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a1));
-        short8v f;
-        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-        return __builtin_bit_cast(pkx8, f);
-    };
-    pkx8 f0a[2][4], f0b[2][4], f1a[2][4], f1b[2][4];
-    // fragment e (0..15) in order of first use by the rounds (lh, hl, hh): A.l[0..3], B.h[0..3], A.h[0..3], B.l[0..3]
-    auto frag_one = [&](int e, const pk_t* s, int ks, pkx8 (&fa)[2][4], pkx8 (&fb)[2][4]) {
-        const int g = e >> 2, i = e & 3;
-        const int pl = (g == 0 || g == 3) ? 1 : 0;
-        if (TR) {
-            if ((g & 1) == 0) fa[pl][i] = rd_tr(s + ((4 * wm + i) * 2 + pl) * 1024, ks);
-            else fb[pl][i] = rd_tr(s + 2 * PK_TILE + ((4 * wn + i) * 2 + pl) * 1024, ks);
-        } else {
-            if ((g & 1) == 0) fa[pl][i] = rd(s + (wm * 2 + pl) * PK_IMG, i * 32 + l31, ks);
-            else fb[pl][i] = rd(s + 2 * PK_TILE + (wn * 2 + pl) * PK_IMG, i * 32 + l31, ks);
-        }
-    };
-    // ---- prologue: tiles 0, 1 -> stages 0, 1 (K index clamped so that every path into the loop has the same vmcnt state)
-    BG_DMA_TILE(0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    BG_DMA_TILE(min(1, nkt - 1), 1);
-    __builtin_amdgcn_s_waitcnt(0x4F70);              // vmcnt(16): tile 0 landed (this wave's pieces)
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int e = 0; e < 16; ++e) frag_one(e, smem, 0, f0a, f0b);
-
-    auto step = [&](int it, auto tag) {
-        // SMODE 1: tiles t+1, t+2 exist; 2: only t+1 (nothing more to request); 3: last tile
-        constexpr int SMODE = decltype(tag)::smode;
-        constexpr int CUR = decltype(tag)::cur;              // stage of tile t (0..1)
-        constexpr bool HAS1 = SMODE != 3, HAS2 = SMODE == 1;
-        const pk_t* s_cur = smem + CUR * BG_STAGE;
-        const pk_t* s_nxt = smem + (CUR ^ 1) * BG_STAGE;
-        // a round = product q on the four accumulators of row i: 4 independent MFMAs
-#define BG_MMA(FA, FB, q, i)                                                                                   \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[pa(q)][i], FB[pb(q)][j], acc[i][j], 0, 0, 0);       \
-    __builtin_amdgcn_sched_barrier(0)
-        // phase 1: 12 rounds on k-step 0; the 16 fragments of k-step 1 are read during rounds 0..7
-#define BG_R1(r)                                                                                                \
-    if ((r) < 8) { frag_one(2 * (r), s_cur, 1, f1a, f1b); frag_one(2 * (r) + 1, s_cur, 1, f1a, f1b); }           \
-    BG_MMA(f0a, f0b, 2 - (r) / 4, (r) & 3)
-        BG_R1(0); BG_R1(1); BG_R1(2); BG_R1(3); BG_R1(4); BG_R1(5); BG_R1(6); BG_R1(7); BG_R1(8); BG_R1(9); BG_R1(10); BG_R1(11);
-        // tile t+1 (requested one and a half phases ago) must have landed: nothing newer is in flight
-        __builtin_amdgcn_s_waitcnt(0x0070);                  // vmcnt(0) lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        // phase 2: 12 rounds on k-step 1; tile t+2 is requested (16 pieces, rounds 0..7), k-step 0 of tile t+1 is read
-#define BG_R2(r)                                                                                                \
-    if (HAS2 && (r) < 8) { BG_DMA(2 * ((r) & 7), it + 2, CUR); BG_DMA(2 * ((r) & 7) + 1, it + 2, CUR); }          \
-    if (HAS1 && (r) >= 4) { frag_one(2 * ((r) - 4), s_nxt, 0, f0a, f0b); frag_one(2 * ((r) - 4) + 1, s_nxt, 0, f0a, f0b); } \
-    BG_MMA(f1a, f1b, 2 - (r) / 4, (r) & 3)
-        BG_R2(0); BG_R2(1); BG_R2(2); BG_R2(3); BG_R2(4); BG_R2(5); BG_R2(6); BG_R2(7); BG_R2(8); BG_R2(9); BG_R2(10); BG_R2(11);
-#undef BG_MMA
-#undef BG_R1
-#undef BG_R2
-    };
-    int it = 0;
-    for (; it + 3 < nkt; it += 2) {
-        step(it, StepTag<1, 0>{});
-        step(it + 1, StepTag<1, 1>{});
-    }
-    {   // tail (it even): 1..3 tiles left
-        const int rem = nkt - it;
-        if (rem == 3) { step(it, StepTag<1, 0>{}); step(it + 1, StepTag<2, 1>{}); step(it + 2, StepTag<3, 0>{}); }
-        else if (rem == 2) { step(it, StepTag<2, 0>{}); step(it + 1, StepTag<3, 1>{}); }
-        else if (rem == 1) { step(it, StepTag<3, 0>{}); }
-    }
-#undef BG_DMA
-#undef BG_DMA_TILE
-
-    const int flags = p.flags;
-    const bool atomic = gridDim.y > 1;
-    const float alpha = p.alpha * p.inv_a[0] * p.inv_b[0];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = nb * 256 + wn * 128 + j * 32 + l31;
-        if (col >= p.N) continue;
-        const float bv = (flags & LSTC_EPI_BIAS) ? p.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rbase = mb * 256 + wm * 128 + i * 32 + 4 * h;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] * alpha;
-                float* cp = p.C + (size_t)row * p.ldc + col;
-                if (atomic) {
-                    atomicAdd(cp, v);
-                    continue;
-                }
-                v += bv;
-                if (flags & LSTC_EPI_RELU) v = fmaxf(v, 0.f);
-                if (flags & LSTC_EPI_DROPOUT) {
-                    const uint32_t idx = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
-                    v = drop_keep(idx, p.dk) ? v * p.dk.scale : 0.f;
-                }
-                if (flags & LSTC_EPI_RESIDUAL) v += p.res[(size_t)row * p.ldr + col];
-                if (flags & LSTC_EPI_RELU_MASK) v = p.relu_src[(size_t)row * p.ld_relu + col] > 0.f ? v : 0.f;
-                if (flags & LSTC_EPI_ACCUM) v += *cp;
-                *cp = v;
-            }
-        }
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------
 // Two-stage, two-workgroups-per-CU form of the 128x128 kernel (64 KB of LDS and <= 256 registers per workgroup): the
 // prologue (tile requests before the first MFMA) and the epilogue of one workgroup overlap the K loop of the other,
 // which matters for the K = 2048 products (64 K steps per workgroup).
@@ -739,24 +558,9 @@ int lstc_gemm_f32x3_impl(const LstcGemmDesc* d, hipStream_t st) {
     if (tr && ((d->K % 128) != 0 || (d->M % 128) != 0 || (d->N % 128) != 0)) return LSTC_E_SHAPE;
     p.ktiles_per_split = (p.KB + splits - 1) / splits;
     const int eff_splits = (p.KB + p.ktiles_per_split - 1) / p.ktiles_per_split;
-    // variant 2 selects the 256x256-tile kernel.  It is correct in every form (tools/gemm_check) but not the default:
-    // measured 3.33 / 5.22 ms against 2.57 / 4.48 ms of the 128x128 kernel on the K = 2048 / 4096 forward shapes (its
-    // 2-stage ring leaves 1.5 phases between a request and its use) and on par for the K = 100352 weight gradients.
-    const bool big = d->variant == 2 && (!tr || ((d->M % 256) == 0 && (d->N % 256) == 0));
-    if (big) {
-        const int tM = (d->M + 255) / 256;
-        p.tilesN = (d->N + 255) / 256;
-        constexpr size_t lds2 = (size_t)2 * BG_STAGE * sizeof(pk_t);
-        static bool attr2 = false;
-        if (!attr2) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pk256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pk256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            attr2 = true;
-        }
-        if (tr) hipLaunchKernelGGL(gemm_pk256_kernel<true>, dim3(tM * p.tilesN, eff_splits), dim3(NT), lds2, st, p);
-        else hipLaunchKernelGGL(gemm_pk256_kernel<false>, dim3(tM * p.tilesN, eff_splits), dim3(NT), lds2, st, p);
-        return lstc_launch_status();
-    }
+    // (A 256x256-tile form - 16 accumulators per wave, half the L2 traffic - was built and measured: correct, but 3.33 /
+    // 5.22 ms against 2.57 / 4.48 ms on the K = 2048 / 4096 forward shapes, its two 64-KB stages leaving 1.5 phases between
+    // a request and its use, and its 256 accumulators spilling around the K loop; removed.)
     const int tilesM = (d->M + 127) / 128;
     p.tilesN = (d->N + 127) / 128;
     // default (variant 0 / 3): the two-stage kernel, two workgroups per CU - 2.44 / 4.30 / 4.93 ms against 2.63 / 4.56 /
@@ -789,9 +593,7 @@ extern "C" {
 
 int64_t lstc_pack3_bytes(int64_t rows, int64_t K) {
     if (rows <= 0 || K <= 0) return 0;
-    // one spare row block when the count is odd: the 256-row kernel may stream it (its products are never stored)
-    const int64_t rb = (rows + 127) / 128;
-    return (rb + (rb & 1)) * ((K + 31) / 32) * (int64_t)PK_TILE * (int64_t)sizeof(pk_t) + PK_TRAILER;
+    return ((rows + 127) / 128) * ((K + 31) / 32) * (int64_t)PK_TILE * (int64_t)sizeof(pk_t) + PK_TRAILER;
 }
 
 int lstc_pack3(const float* src, int64_t rows, int64_t K, int64_t ld, int32_t k_major, void* dst, void* stream) {
