@@ -51,7 +51,15 @@ def build_parser(script: str) -> argparse.ArgumentParser:
     p.add_argument("--synthetic_pairs", type=int, default=0, help="normal/abnormal pairs in the synthetic set (default 2*batch_size)")
     p.add_argument("--steps", type=int, default=0, help="stop after this many optimisation steps (0 = run all epochs)")
     p.add_argument("--log_dir", type=str, default="", help="log / checkpoint directory (default: ./log/<dataset>)")
+    p.add_argument("--compute_dtype", type=str, default=os.environ.get("LSTC_COMPUTE_DTYPE", "fp32"), choices=["fp32", "f32x3", "bf16"],
+                   help="GEMM arithmetic: fp32 = exact-f32 MFMA (reference numerics); f32x3 = f32-accurate products on the f16 "
+                        "matrix cores (2x faster); bf16 = bf16 matrix cores on f32 storage (BASELINE configs 3 / 5)")
     return p
+
+
+def _apply_compute_dtype(args):
+    from . import functional as Fn
+    Fn.set_compute_dtype(getattr(args, "compute_dtype", "fp32"))
 
 
 def _get(args, name, prefix="", default=None):
@@ -89,6 +97,7 @@ def train(script: str, argv=None):
     random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
     if not torch.cuda.is_available():
         raise SystemExit("no HIP device visible: the LSTC_VAD training path here is MI355X-only (no CPU fallback)")
+    _apply_compute_dtype(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -298,6 +307,7 @@ def generate_pseudo_labels(script: str, argv=None):
     from .models import Classifier, Encoder, Regressor
     if not torch.cuda.is_available():
         raise SystemExit("no HIP device visible: MI355X-only path")
+    _apply_compute_dtype(args)
     dev = torch.device("cuda", 0)
     part_len = getattr(args, "part_len", 1)
     enc = Encoder(n_layers=args.n_layers, n_head=args.n_head, d_k=args.d_k, d_v=args.d_v, d_model=args.d_model,
@@ -354,6 +364,7 @@ def evaluate_cli(script: str, argv=None):
     from .models import Classifier, Encoder
     if not torch.cuda.is_available():
         raise SystemExit("no HIP device visible: MI355X-only path")
+    _apply_compute_dtype(args)
     dev = torch.device("cuda", 0)
     ucf = script.endswith("UCF")
     part_len = 2 if ucf else args.part_len

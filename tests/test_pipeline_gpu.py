@@ -160,3 +160,17 @@ def test_reference_command_lines_on_feature_archives(world, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     auc = float(r.stdout.strip().split("auc = ")[-1])
     assert abs(auc - float(enc_ckpt.rsplit("_", 1)[-1])) < 1e-3        # the file name carries the AUC to 4 decimals
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32x3"])
+def test_coteaching_loop_chain(dtype, tmp_path):
+    """BASELINE config 3 in miniature (STN -> pseudo labels -> LTN -> pseudo labels -> STN with MIL + BCE), five CLI
+    processes chained by .npy files, in the bf16 GEMM mode the config is quoted in and in f32x3."""
+    out = str(tmp_path / "coteach")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "coteach_loop_synthetic.sh"), out, dtype], capture_output=True,
+                       text=True, timeout=900, env=dict(os.environ, PYTHONPATH=ROOT, HIP_VISIBLE_DEVICES="0"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    for f in ("STN_pseudo_labels.npy", "LTN_pseudo_labels.npy"):
+        d = np.load(os.path.join(out, f), allow_pickle=True).tolist()
+        assert len(d) == 16 and all(v.ndim == 2 and v.shape[1] == 1 and np.isfinite(v).all() for v in d.values())
+    assert "spatio_loss" in r.stdout + r.stderr

@@ -4,7 +4,8 @@
 set -e
 cd "$(dirname "$0")/../Train"
 O=${1:-../gpurun_out/coteach}; mkdir -p $O
-M="--d_model 128 --d_k 16 --d_v 16 --n_patch 16 --synthetic --synthetic_pairs 8"
+DT=${2:-fp32}        # fp32 | f32x3 | bf16 (BASELINE config 3 is quoted in bf16)
+M="--d_model 128 --d_k 16 --d_v 16 --n_patch 16 --synthetic --synthetic_pairs 8 --compute_dtype $DT"
 python spatio_transformer_shanghaitech.py $M --n_hidden 203 --FFN_layerNorm --encoder_weight_init --regressor_weight_init --batch_size 4 --part_num 4 --part_len 2 --steps 6 --inter_epoch 100 --log_dir $O/stn 2>&1 | tail -1
 python pseudo_labels_generator_spatio.py $M --n_hidden 203 --FFN_layerNorm --threshold 0.5 --pseudo_labels_path $O/STN_pseudo_labels.npy 2>&1 | tail -1
 python temporal_transformer_shanghaitech.py $M --n_hidden 256 --part_len 3 --MHA_layerNorm --FFN_layerNorm --relative_position_encoding --pseudo_labels_path $O/STN_pseudo_labels.npy --batch_size 4 --part_num 4 --steps 6 --inter_epoch 100 --log_dir $O/ltn 2>&1 | tail -1
