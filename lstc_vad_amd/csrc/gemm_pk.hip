@@ -78,33 +78,53 @@ __global__ void __launch_bounds__(NT) absmax_kernel(const float* __restrict__ x,
     }
 }
 
-// ---- pack, K-contiguous source [rows, K] (ld): one workgroup per (row block, k block) tile; thread -> two 16-B chunks.
+// ---- pack, K-contiguous source [rows, K] (ld): one workgroup per row block and PK_KPB consecutive k blocks; per tile a
+// thread converts two 32-B source chunks.  All 8 * 2 loads of a thread are issued before the first store (memory-level
+// parallelism: one tile per workgroup left the kernel latency-bound at 4.3 TB/s).
+constexpr int PK_KPB = 4;
 __global__ void __launch_bounds__(NT) pack3_kc_kernel(const float* __restrict__ x, int rows, int K, long long ld,
                                                       pk_t* __restrict__ out, int KB, uint32_t* __restrict__ trailer) {
-    const int kb = blockIdx.x % KB, rb = blockIdx.x / KB;
+    const int kgroups = (KB + PK_KPB - 1) / PK_KPB;
+    const int kb0 = (blockIdx.x % kgroups) * PK_KPB, rb = blockIdx.x / kgroups;
     const float scale = scale_from_absmax_bits(trailer[0]);
     if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(trailer)[1] = 1.f / scale;
-    pkx8* o = reinterpret_cast<pkx8*>(out) + (size_t)blockIdx.x * 2 * 512;
     const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    float4 va[PK_KPB][2], vb[PK_KPB][2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int s = threadIdx.x + q * NT;          // chunk id inside the tile: row r = s / 4, chunk c = s % 4
-        const int r = s >> 2, c = s & 3;
-        const int row = rb * 128 + r, k0 = kb * 32 + c * 8;
-        float v[8];
-        if (row < rows && k0 + 8 <= K && vec) {
-            const float4 a = *reinterpret_cast<const float4*>(x + (size_t)row * ld + k0);
-            const float4 b = *reinterpret_cast<const float4*>(x + (size_t)row * ld + k0 + 4);
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        } else {
+    for (int tI = 0; tI < PK_KPB; ++tI)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (row < rows && k0 + j < K) ? x[(size_t)row * ld + k0 + j] : 0.f;
+        for (int q = 0; q < 2; ++q) {
+            const int s = threadIdx.x + q * NT;      // chunk id inside the tile: row r = s / 4, chunk c = s % 4
+            const int row = rb * 128 + (s >> 2), k0 = (kb0 + tI) * 32 + (s & 3) * 8;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a;
+            if (row < rows && kb0 + tI < KB) {
+                const float* px = x + (size_t)row * ld + k0;
+                if (k0 + 8 <= K && vec) {
+                    a = *reinterpret_cast<const float4*>(px);
+                    b4 = *reinterpret_cast<const float4*>(px + 4);
+                } else {
+                    float t8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t8[j] = (k0 + j < K) ? px[j] : 0.f;
+                    a = make_float4(t8[0], t8[1], t8[2], t8[3]); b4 = make_float4(t8[4], t8[5], t8[6], t8[7]);
+                }
+            }
+            va[tI][q] = a; vb[tI][q] = b4;
         }
-        pkx8 hh, ll;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { pk_t h, l; split2(v[j], scale, h, l); hh[j] = h; ll[j] = l; }
-        const int slot = r * 4 + (c ^ ((r >> 2) & 3));
-        o[slot] = hh; o[512 + slot] = ll;
+    for (int tI = 0; tI < PK_KPB; ++tI) {
+        if (kb0 + tI >= KB) break;
+        pkx8* o = reinterpret_cast<pkx8*>(out) + ((size_t)rb * KB + kb0 + tI) * 2 * 512;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int s = threadIdx.x + q * NT, r = s >> 2, c = s & 3;
+            const float v[8] = {va[tI][q].x, va[tI][q].y, va[tI][q].z, va[tI][q].w, vb[tI][q].x, vb[tI][q].y, vb[tI][q].z, vb[tI][q].w};
+            pkx8 hh, ll;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { pk_t h, l; split2(v[j], scale, h, l); hh[j] = h; ll[j] = l; }
+            const int slot = r * 4 + (c ^ ((r >> 2) & 3));
+            o[slot] = hh; o[512 + slot] = ll;
+        }
     }
 }
 
@@ -614,7 +634,7 @@ int lstc_pack3(const float* src, int64_t rows, int64_t K, int64_t ld, int32_t k_
         hipLaunchKernelGGL(pack3_km_kernel, dim3((unsigned)(RB * KB)), dim3(NT), 0, st, src, (int)rows, (int)K,
                            (long long)ld, (pk_t*)dst, (int)KB, trailer);
     else
-        hipLaunchKernelGGL(pack3_kc_kernel, dim3((unsigned)(RB * KB)), dim3(NT), 0, st, src, (int)rows, (int)K,
+        hipLaunchKernelGGL(pack3_kc_kernel, dim3((unsigned)(RB * ((KB + PK_KPB - 1) / PK_KPB))), dim3(NT), 0, st, src, (int)rows, (int)K,
                            (long long)ld, (pk_t*)dst, (int)KB, trailer);
     return lstc_launch_status();
 }

@@ -132,8 +132,8 @@ static void timeit(int M, int N, int K, int tA, int tB, int variant, int split, 
             if (variant >= 7 && variant <= 9) lstc_pack3(dB, K, N, ldb, 0, pB, nullptr); else lstc_pack3(dB, N, K, ldb, tB ? 0 : 1, pB, nullptr);
             CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
             float msb; CK(hipEventElapsedTime(&msb, e0, e1));
-            if (rep) printf("PACK A [%d x %d]%s %.3f ms (%.2f TB/s)   B [%d x %d]%s %.3f ms\n", M, K, tA ? " k-major" : "", msa,
-                            10.0 * M * K / (msa * 1e-3) / 1e12, N, K, tB ? "" : " k-major", msb);
+            if (rep) printf("PACK A [%d x %d]%s %.3f ms (%.2f TB/s: absmax read + pack read + write)   B [%d x %d]%s %.3f ms\n", M, K, tA ? " k-major" : "", msa,
+                            12.0 * M * K / (msa * 1e-3) / 1e12, N, K, tB ? "" : " k-major", msb);
         }
         d.A = pA; d.B = pB;
         if (variant >= 7 && variant <= 9) { d.transA = 1; d.transB = 0; d.variant = variant == 8 ? 2 : variant == 9 ? 3 : 1; } else { d.transA = 0; d.transB = 1; }
