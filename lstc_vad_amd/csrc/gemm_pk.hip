@@ -544,6 +544,187 @@ __global__ void __launch_bounds__(NT, 2) gemm_pk2s_kernel(const PkParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 256x128 tile, 4 waves x (128x64), three LDS stages of 48 KB, one workgroup per CU.  The 128x128 kernels move 4 B per 64
+// MACs out of L2 and sit at ~10.5 TB/s of L2->LDS traffic; this form moves 3/4 of that and reads 12 fragments per 24 MFMAs
+// instead of 8 per 12.  A wave's 128 rows of A are one packed row block.  Stage = [A block 0][A block 1][B block], 48
+// pieces of 1 KB, piece P = 12 wave + j.  A round = one plane product on one 32-row band = 2 MFMAs + one fragment read
+// (+ one DMA piece in phase 2).  TR form: stage = [A: 8 feature blocks x 2 planes x 2 KB][B: 4 x 2 x 2 KB].
+constexpr int WD_STAGE = 3 * PK_TILE;       // 48 KB
+
+template <bool TR>
+__global__ void __launch_bounds__(NT, 1) gemm_pkw_kernel(const PkParams p) {
+    extern __shared__ __attribute__((aligned(16))) pk_t smem_pk[];
+    pk_t* const smem = smem_pk;
+    int pid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = pid & 7, idx = pid >> 3, q = nwg >> 3, r = nwg & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mb = pid / p.tilesN, nb = pid % p.tilesN;          // 256-row tile, 128-column tile
+    const int kt0 = blockIdx.y * p.ktiles_per_split;
+    const int nkt = min(p.KB, kt0 + p.ktiles_per_split) - kt0;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    // global address (elements) of piece P (0..47) of K step kt.
+    //   NT: region P / 16 = A block 0, A block 1, B block; inside a region the packed tile is contiguous (1 KB per piece).
+    //   TR: pieces 0..31 = A (feature block P / 4, plane (P % 4) / 2, half P % 2), 32..47 = B likewise.
+    auto gaddr = [&](int P, int kt) -> const pk_t* {
+        if (TR) {
+            const int k = kt0 + kt;
+            const bool isb = P >= 32;
+            const int q = isb ? P - 32 : P;
+            const pk_t* base = isb ? p.B + (size_t)nb * 4 * PK_TILE : p.A + (size_t)mb * 8 * PK_TILE;
+            const int fbk = isb ? p.fbB : p.fbA;
+            return base + ((size_t)(k >> 2) * fbk + (q >> 2)) * PK_TILE + ((q & 3) >> 1) * PK_IMG + (size_t)(k & 3) * 1024 + (q & 1) * 512;
+        }
+        const int region = P >> 4, off = P & 15;
+        const pk_t* base = region == 2 ? p.B + ((size_t)nb * p.KB + kt0 + kt) * PK_TILE
+                                       : p.A + (((size_t)mb * 2 + region) * p.KB + kt0 + kt) * PK_TILE;
+        return base + off * 512;
+    };
+#define WD_DMA(j, kt, stage)                                                                                           \
+    do {                                                                                                               \
+        const int P_ = wave * 12 + (j);                                                                                \
+        const pk_t* g_ = gaddr(P_, kt);                                                                                \
+        const uint32_t l_ = (uint32_t)(((stage) * WD_STAGE + P_ * 512) * 2);                                           \
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_off), "s"(g_), "s"(l_) : "memory"); \
+    } while (0)
+#define WD_DMA_TILE(kt, stage)                                                                                         \
+    do {                                                                                                               \
+        WD_DMA(0, kt, stage); WD_DMA(1, kt, stage); WD_DMA(2, kt, stage); WD_DMA(3, kt, stage);                        \
+        WD_DMA(4, kt, stage); WD_DMA(5, kt, stage); WD_DMA(6, kt, stage); WD_DMA(7, kt, stage);                        \
+        WD_DMA(8, kt, stage); WD_DMA(9, kt, stage); WD_DMA(10, kt, stage); WD_DMA(11, kt, stage);                      \
+    } while (0)
+    const int trq = (lane >> 2) & 3, trchunk = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1), trsub = (lane & 1) * 4;
+    auto rd = [&](const pk_t* img, int row, int ks) -> pkx8 {
+        return *reinterpret_cast<const pkx8*>(img + (row * 4 + ((2 * h + ks) ^ ((row >> 2) & 3))) * 8);
+    };
+    auto rd_tr = [&](const pk_t* img, int ks) -> pkx8 {
+        typedef short short4v __attribute__((ext_vector_type(4)));
+        typedef short short8v __attribute__((ext_vector_type(8)));
+        typedef short4v __attribute__((address_space(3))) * lds_ptr;
+        const int t0 = 16 * ks + 8 * h + trq, t1 = t0 + 4;
+        const pk_t* a0 = img + t0 * 32 + ((trchunk ^ ((t0 >> 2) & 3)) * 8) + trsub;
+        const pk_t* a1 = img + t1 * 32 + ((trchunk ^ ((t1 >> 2) & 3)) * 8) + trsub;
+        const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0));
+        const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a1));
+        short8v f;
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        return __builtin_bit_cast(pkx8, f);
+    };
+    pkx8 f0a[2][4], f0b[2][2], f1a[2][4], f1b[2][2];
+    // fragment e (0..11) in order of first use by the rounds (lh x4, hl x4, hh x4): B.h[0,1], A.l[0..3], B.l[0,1], A.h[0..3]
+    auto frag_one = [&](int e, const pk_t* s, int ks, pkx8 (&fa)[2][4], pkx8 (&fb)[2][2]) {
+        const bool isb = e < 2 || (e >= 6 && e < 8);
+        const int pl = isb ? (e < 2 ? 0 : 1) : (e < 6 ? 1 : 0);
+        const int i = isb ? (e & 1) : (e < 6 ? e - 2 : e - 8);
+        if (TR) {
+            if (!isb) fa[pl][i] = rd_tr(s + ((4 * wm + i) * 2 + pl) * 1024, ks);
+            else fb[pl][i] = rd_tr(s + 2 * PK_TILE + ((2 * wn + i) * 2 + pl) * 1024, ks);
+        } else {
+            if (!isb) fa[pl][i] = rd(s + (wm * 2 + pl) * PK_IMG, i * 32 + l31, ks);
+            else fb[pl][i] = rd(s + 2 * PK_TILE + pl * PK_IMG, wn * 64 + i * 32 + l31, ks);
+        }
+    };
+    WD_DMA_TILE(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    WD_DMA_TILE(min(1, nkt - 1), 1);
+    __builtin_amdgcn_sched_barrier(0);
+    WD_DMA_TILE(min(2, nkt - 1), 2);
+    __builtin_amdgcn_s_waitcnt(0x4F78);              // vmcnt(24): tile 0 landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int e = 0; e < 12; ++e) frag_one(e, smem, 0, f0a, f0b);
+
+    auto step = [&](int it, auto tag) {
+        // SMODE 1: tiles t+1..t+3 exist; 4: t+1, t+2 exist (nothing more to request); 2: only t+1; 3: last tile
+        constexpr int SMODE = decltype(tag)::smode;
+        constexpr int CUR = decltype(tag)::cur;              // stage of tile t (0..2)
+        constexpr int NXT = (CUR + 1) % 3;
+        constexpr bool HAS1 = SMODE != 3, HAS3 = SMODE == 1;
+        const pk_t* s_cur = smem + CUR * WD_STAGE;
+        const pk_t* s_nxt = smem + NXT * WD_STAGE;
+#define WD_MMA(FA, FB, q, i)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[pa(q)][i], FB[pb(q)][j], acc[i][j], 0, 0, 0);       \
+    __builtin_amdgcn_sched_barrier(0)
+#define WD_R1(r)                                                                                                \
+    frag_one(r, s_cur, 1, f1a, f1b);                                                                             \
+    WD_MMA(f0a, f0b, 2 - (r) / 4, (r) & 3)
+#define WD_R2(r)                                                                                                \
+    if (HAS3) { WD_DMA(r, it + 3, CUR); }                                                                        \
+    if (HAS1) { frag_one(r, s_nxt, 0, f0a, f0b); }                                                               \
+    WD_MMA(f1a, f1b, 2 - (r) / 4, (r) & 3)
+        WD_R1(0); WD_R1(1); WD_R1(2); WD_R1(3); WD_R1(4); WD_R1(5); WD_R1(6); WD_R1(7); WD_R1(8); WD_R1(9); WD_R1(10); WD_R1(11);
+        if (SMODE == 1 || SMODE == 4) __builtin_amdgcn_s_waitcnt(0x007C);     // vmcnt(12) lgkmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(0x0070);                              // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        WD_R2(0); WD_R2(1); WD_R2(2); WD_R2(3); WD_R2(4); WD_R2(5); WD_R2(6); WD_R2(7); WD_R2(8); WD_R2(9); WD_R2(10); WD_R2(11);
+#undef WD_MMA
+#undef WD_R1
+#undef WD_R2
+    };
+    int it = 0;
+    for (; it + 5 < nkt; it += 3) {
+        step(it, StepTag<1, 0>{});
+        step(it + 1, StepTag<1, 1>{});
+        step(it + 2, StepTag<1, 2>{});
+    }
+    for (; it < nkt; it += 3) {      // tail (it % 3 == 0): 1..5 tiles left
+        const int rem = nkt - it;
+        if (rem >= 4) step(it, StepTag<1, 0>{}); else if (rem == 3) step(it, StepTag<4, 0>{}); else if (rem == 2) step(it, StepTag<2, 0>{}); else step(it, StepTag<3, 0>{});
+        if (rem >= 5) step(it + 1, StepTag<1, 1>{}); else if (rem == 4) step(it + 1, StepTag<4, 1>{}); else if (rem == 3) step(it + 1, StepTag<2, 1>{}); else if (rem == 2) step(it + 1, StepTag<3, 1>{});
+        if (rem >= 6) step(it + 2, StepTag<1, 2>{}); else if (rem == 5) step(it + 2, StepTag<4, 2>{}); else if (rem == 4) step(it + 2, StepTag<2, 2>{}); else if (rem == 3) step(it + 2, StepTag<3, 2>{});
+    }
+#undef WD_DMA
+#undef WD_DMA_TILE
+
+    const int flags = p.flags;
+    const bool atomic = gridDim.y > 1;
+    const float alpha = p.alpha * p.inv_a[0] * p.inv_b[0];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = nb * 128 + wn * 64 + j * 32 + l31;
+        if (col >= p.N) continue;
+        const float bv = (flags & LSTC_EPI_BIAS) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rbase = mb * 256 + wm * 128 + i * 32 + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] * alpha;
+                float* cp = p.C + (size_t)row * p.ldc + col;
+                if (atomic) {
+                    atomicAdd(cp, v);
+                    continue;
+                }
+                v += bv;
+                if (flags & LSTC_EPI_RELU) v = fmaxf(v, 0.f);
+                if (flags & LSTC_EPI_DROPOUT) {
+                    const uint32_t idx = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+                    v = drop_keep(idx, p.dk) ? v * p.dk.scale : 0.f;
+                }
+                if (flags & LSTC_EPI_RESIDUAL) v += p.res[(size_t)row * p.ldr + col];
+                if (flags & LSTC_EPI_RELU_MASK) v = p.relu_src[(size_t)row * p.ld_relu + col] > 0.f ? v : 0.f;
+                if (flags & LSTC_EPI_ACCUM) v += *cp;
+                *cp = v;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // Packed-operand GEMM behind lstc_gemm (dtype LSTC_F32X3): d->A / d->B point to lstc_pack3 outputs for [M, K] / [N, K].
@@ -581,6 +762,23 @@ int lstc_gemm_f32x3_impl(const LstcGemmDesc* d, hipStream_t st) {
     // (A 256x256-tile form - 16 accumulators per wave, half the L2 traffic - was built and measured: correct, but 3.33 /
     // 5.22 ms against 2.57 / 4.48 ms on the K = 2048 / 4096 forward shapes, its two 64-KB stages leaving 1.5 phases between
     // a request and its use, and its 256 accumulators spilling around the K loop; removed.)
+    // 256x128-tile kernel: variant 2, and by default for the weight-gradient form (K = tokens, long loops): 2.01 / 3.68 ms
+    // against 2.19 / 4.17 ms of the two-stage 128x128 kernel on 2048x2048 / 4096x2048 outputs over 100352 tokens; on the
+    // K = 2048 forward shapes it loses (2.61 vs 2.42 ms: one workgroup per CU, nothing overlaps prologue and epilogue)
+    if ((d->variant == 2 && (!tr || (d->M % 256) == 0)) || (d->variant == 0 && tr && (d->M % 256) == 0 && d->K >= 8192)) {
+        const int tM = (d->M + 255) / 256;
+        p.tilesN = (d->N + 127) / 128;
+        constexpr size_t ldsw = (size_t)3 * WD_STAGE * sizeof(pk_t);
+        static bool attrw = false;
+        if (!attrw) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pkw_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pkw_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+            attrw = true;
+        }
+        if (tr) hipLaunchKernelGGL(gemm_pkw_kernel<true>, dim3(tM * p.tilesN, eff_splits), dim3(NT), ldsw, st, p);
+        else hipLaunchKernelGGL(gemm_pkw_kernel<false>, dim3(tM * p.tilesN, eff_splits), dim3(NT), ldsw, st, p);
+        return lstc_launch_status();
+    }
     const int tilesM = (d->M + 127) / 128;
     p.tilesN = (d->N + 127) / 128;
     // default (variant 0 / 3): the two-stage kernel, two workgroups per CU - 2.44 / 4.30 / 4.93 ms against 2.63 / 4.56 /
@@ -613,7 +811,9 @@ extern "C" {
 
 int64_t lstc_pack3_bytes(int64_t rows, int64_t K) {
     if (rows <= 0 || K <= 0) return 0;
-    return ((rows + 127) / 128) * ((K + 31) / 32) * (int64_t)PK_TILE * (int64_t)sizeof(pk_t) + PK_TRAILER;
+    // one spare row block when the count is odd: the 256-row kernel may stream it (its products are never stored)
+    const int64_t rb = (rows + 127) / 128;
+    return (rb + (rb & 1)) * ((K + 31) / 32) * (int64_t)PK_TILE * (int64_t)sizeof(pk_t) + PK_TRAILER;
 }
 
 int lstc_pack3(const float* src, int64_t rows, int64_t K, int64_t ld, int32_t k_major, void* dst, void* stream) {

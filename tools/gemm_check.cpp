@@ -54,7 +54,7 @@ static int check(const Case& c) {
     if (c.dtype == LSTC_F32X3) {     // operands go through lstc_pack3: A as [M, K], B as [N, K]
         CK(hipMalloc(&pA, lstc_pack3_bytes(M, K))); CK(hipMalloc(&pB, lstc_pack3_bytes(N, K)));
         int r1, r2;
-        if (c.variant >= 7 && c.variant <= 9) {            // weight-gradient form (7: three-stage kernel, 9: two-stage kernel): packs of the SOURCES [K, M], [K, N] + transposed reads
+        if (c.variant >= 7 && c.variant <= 9) {            // weight-gradient form (7: three-stage kernel, 8: 256x128-tile kernel, 9: two-stage kernel): packs of the SOURCES [K, M], [K, N] + transposed reads
             r1 = lstc_pack3(dA, K, M, lda, 0, pA, nullptr); r2 = lstc_pack3(dB, K, N, ldb, 0, pB, nullptr);
             d.transA = 1; d.transB = 0; d.variant = c.variant == 8 ? 2 : c.variant == 9 ? 3 : 1;   /* 7 -> three-stage kernel */
         } else {
@@ -215,6 +215,10 @@ int main(int argc, char** argv) {
             fails += check({256, 128, 384, 1, 0, 0, 7, split, LSTC_F32X3});
             fails += check({128, 384, 1152, 1, 0, 0, 7, split + 1, LSTC_F32X3});
             fails += check({256, 384, 640, 1, 0, 0, 9, split, LSTC_F32X3});                  // 2-stage kernel, TR
+            fails += check({512, 256, 640, 1, 0, 0, 8, split, LSTC_F32X3});                  // 256x128-tile kernel, TR
+            fails += check({300, 520, 100 + 32 * split, 0, 1, ALLB, 2, 1, LSTC_F32X3});     // 256x128-tile kernel, ragged NT
+            fails += check({512, 200, 96, 0, 0, LSTC_EPI_RELU_MASK, 2, 1, LSTC_F32X3});
+            fails += check({260, 130, 515, 1, 0, 0, 2, split, LSTC_F32X3});
             fails += check({300, 520, 100 + 32 * split, 0, 1, ALLB, 3, 1, LSTC_F32X3});     // 2-stage kernel, ragged NT
             fails += check({130, 260, 515 + 32 * split, 1, 0, 0, 3, split, LSTC_F32X3});
         }
