@@ -155,7 +155,7 @@ def train(script: str, argv=None):
         ppath += ".npy"                                     # Train/spatio_transformer_MIL_CE.py:142
     real = (not args.synthetic) and bool(getattr(args, "dataset_path", ""))
     if real:
-        data, eval_fn = _real_data(args, mode, part_len, ppath, dev, rank, world)
+        data, eval_fn = _real_data(args, mode, part_len, ppath, dev, rank, enc, head)
     else:
         n_pairs = args.synthetic_pairs or 2 * args.batch_size
         thr = None if mode == "STN" else 0.65
@@ -163,8 +163,6 @@ def train(script: str, argv=None):
         data = SyntheticVideos(n_pairs, args.batch_size, args.part_num, part_len, args.n_patch, d_model, dev,
                                seed=seed + 1000 * rank, sample=args.sample, pseudo_threshold=thr, pseudo_labels=pseudo)
         eval_fn = lambda: evaluate(enc, head, mode, data, part_len, roc_auc)
-    if hasattr(eval_fn, "bind"):
-        eval_fn.bind(enc, head)
     epochs = int(_get(args, "epochs", pre, 1))
     inter = int(getattr(args, "inter_epoch", 10))
     best_auc, it = 0.0, 0
@@ -224,7 +222,7 @@ class _HostPairs:
         self.ds.shuffle_keys()
 
 
-def _real_data(args, mode, part_len, pseudo_path, dev, rank, world):
+def _real_data(args, mode, part_len, pseudo_path, dev, rank, enc, head):
     """Feature-archive training source + evaluation closure for a Train/*.py run.  Dataset class per
     script as upstream (e.g. Train/temporal_transformer_shanghaitech.py:45-51, Train/spatio_transformer_MIL_CE.py:114-149);
     under torchrun every rank seeds ``np.random`` with ``seed + rank`` so the ranks draw different pairs (the reference's
@@ -252,10 +250,8 @@ def _real_data(args, mode, part_len, pseudo_path, dev, rank, world):
     def eval_fn():
         if not getattr(args, "testing_txt", ""):
             return 0.0
-        return evaluate_auc(_eval_models[0].eval(), _eval_models[1].eval(), kind, dataset, test_arc, args.testing_txt, masks,
-                            part_len, args.n_patch, args.segment_len)
-    _eval_models = []
-    eval_fn.bind = lambda enc, head: _eval_models.extend([enc, head])
+        return evaluate_auc(enc.eval(), head.eval(), kind, dataset, test_arc, args.testing_txt, masks, part_len, args.n_patch,
+                            args.segment_len)
     return data, eval_fn
 
 
