@@ -191,6 +191,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     scal = [float(x) for x in sc.cpu()]
+    hbm_peak = torch.cuda.max_memory_allocated(dev)
+    torch.cuda.reset_peak_memory_stats(dev)
     # ---- second pass: the same K steps with the big products on the 16-bit matrix cores (f32-accurate split operands,
     # csrc/gemm_pk.hip).  Reported next to the headline, never as `value`.
     x3 = None
@@ -214,7 +216,7 @@ def main():
             tt = torch.tensor([dt3], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt3 = float(tt.item())
-        x3 = {"dt": dt3, "gp": gp, "pp": pp, "loss": float(sc3.cpu()[0])}
+        x3 = {"dt": dt3, "gp": gp, "pp": pp, "loss": float(sc3.cpu()[0]), "hbm": torch.cuda.max_memory_allocated(dev)}
     pcie = None
     if a.h2d and world == 1 and not mixed:
         from lstc_vad_amd.feed import PinnedFeeder
@@ -289,10 +291,11 @@ def main():
                                       f"{nseq} sequences/GPU/step, dropout={'off' if a.no_dropout else 'reference rates'}, last layer: "
                                       f"{'all tokens (naive)' if a.naive_last_layer else 'CLS token only, K/V projections re-associated (exact)'}",
                           "global_videos": 2 * bs * world * len(names), "parallelism": f"dp{world}"},
-               "loss": scal[0], "roofline": roof}
+               "loss": scal[0], "hbm_peak_GB": round(hbm_peak / 1e9, 2), "roofline": roof}
         if x3 is not None:
             o3 = {"value": round(snippets_per_step * a.steps / x3["dt"], 1), "unit": "snippets/s",
                   "ms_per_step": round(1e3 * x3["dt"] / a.steps, 3), "loss": x3["loss"],
+                  "hbm_peak_GB": round(x3["hbm"] / 1e9, 2),
                   "dtype": "f32 storage and accumulation; products of the large GEMMs on the f16 matrix cores: operands scaled by a "
                            "power of two and split into two f16 planes (x*s = h + l to 2^-24), three plane products hh + hl + lh",
                   "accuracy": "error against f64 <= the exact-f32 MFMA kernel's (tests/test_hip_parity.py::test_f32x3_*, "
