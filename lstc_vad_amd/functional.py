@@ -95,6 +95,7 @@ _pack_prof = None          # list of (bytes_in, start_event, end_event) while be
 _wepoch = 0
 _memo_stack = []           # activation packs made inside one autograd-node body are shared by the GEMMs of that body
 _x3_min = (256, 256, 1 << 30)   # min(M, N), K, M*N*K from which a product goes to the packed kernel
+_DETERMINISTIC_WGRAD = True     # exact-f32 mode: split-K weight gradients through partials + ordered sum instead of atomics
 
 
 def set_x3_threshold(min_mn=256, min_k=256, min_mnk=1 << 30):
@@ -291,6 +292,13 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, x_pack: Optional[Packed] = None) ->
         d.A, d.B, d.C = dev_ptr(ap.buf), dev_ptr(bp.buf), dev_ptr(out)
         _launch_gemm(d, 2.0 * O * I * T)
         return out
+    if s > 1 and _compute_dtype == F32 and _DETERMINISTIC_WGRAD and T % s == 0 and dy.stride(1) == 1 and x.stride(1) == 1:
+        # exact-f32 mode: the s K-chunks are ONE batched launch into [s, O, I] partials, summed in a fixed order by
+        # lstc_colsum - same parallelism as the atomic split-K, but the step is bit-reproducible run to run
+        part = torch.empty((s, O * I), device=dy.device, dtype=torch.float32)
+        Tc = T // s
+        gemm_batched(dy, x, part, O, I, Tc, dy.stride(0), x.stride(0), I, True, False, s, Tc * dy.stride(0), Tc * x.stride(0), O * I)
+        return colsum(part).view(O, I)
     return gemm(dy, x, trans_a=True, trans_b=False, split_k=s)
 
 
