@@ -82,7 +82,9 @@ typedef struct LstcGemmDesc {
     int32_t ldr;                    /* residual leading dimension */
     int32_t ld_relu;                /* relu_src leading dimension */
     int32_t split_k;                /* 0/1 = none; >1: K split over workgroups, partial sums added with f32 atomics
-                                       into C, which the caller must have zeroed (only alpha epilogue allowed) */
+                                       into C, which the caller must have zeroed (only alpha epilogue allowed).
+                                       LSTC_F32X3 with batch_stride_c != 0: split z writes its partial product to
+                                       C + z*batch_stride_c instead (no atomics; the caller sums the partials) */
     int32_t variant;                /* 0 = library default tile; >0 selects a tile variant (tuning / tests) */
     int32_t batch;                  /* 0/1 = single problem; >1: `batch` independent problems of identical shape, problem z
                                        uses A + z*batch_stride_a etc. (elements).  Per-head products of the last layer's

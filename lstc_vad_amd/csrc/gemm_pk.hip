@@ -165,6 +165,7 @@ struct PkParams {
     int tilesN, KB, ktiles_per_split;
     const float* inv_a;  // 1/scale of the A and B packs (their trailers)
     const float* inv_b;
+    long long split_stride;   // elements between the outputs of consecutive K splits (0: add into one C with atomics)
     int fbA, fbB;        // TR mode: 32-feature blocks per token row-block of the A / B packs (= ceil(M/32), ceil(N/32))
 };
 
@@ -334,7 +335,8 @@ __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
 
     // ---- epilogue (semantics of gemm_f32.hip)
     const int flags = p.flags;
-    const bool atomic = gridDim.y > 1;
+    const bool atomic = gridDim.y > 1 && p.split_stride == 0;      // split_stride != 0: split z owns C + z * split_stride
+    float* const Cz = p.C + (size_t)blockIdx.y * p.split_stride;
     const float alpha = p.alpha * p.inv_a[0] * p.inv_b[0];       // undo the operands' power-of-two scales (exact)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -349,7 +351,7 @@ __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 if (row >= p.M) continue;
                 float v = acc[i][j][r] * alpha;
-                float* cp = p.C + (size_t)row * p.ldc + col;
+                float* cp = Cz + (size_t)row * p.ldc + col;
                 if (atomic) {
                     atomicAdd(cp, v);
                     continue;
@@ -509,7 +511,8 @@ __global__ void __launch_bounds__(NT, 2) gemm_pk2s_kernel(const PkParams p) {
 #undef S2_DMA_TILE
 
     const int flags = p.flags;
-    const bool atomic = gridDim.y > 1;
+    const bool atomic = gridDim.y > 1 && p.split_stride == 0;      // split_stride != 0: split z owns C + z * split_stride
+    float* const Cz = p.C + (size_t)blockIdx.y * p.split_stride;
     const float alpha = p.alpha * p.inv_a[0] * p.inv_b[0];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -524,7 +527,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_pk2s_kernel(const PkParams p) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 if (row >= p.M) continue;
                 float v = acc[i][j][r] * alpha;
-                float* cp = p.C + (size_t)row * p.ldc + col;
+                float* cp = Cz + (size_t)row * p.ldc + col;
                 if (atomic) {
                     atomicAdd(cp, v);
                     continue;
@@ -690,7 +693,8 @@ __global__ void __launch_bounds__(NT, 1) gemm_pkw_kernel(const PkParams p) {
 #undef WD_DMA_TILE
 
     const int flags = p.flags;
-    const bool atomic = gridDim.y > 1;
+    const bool atomic = gridDim.y > 1 && p.split_stride == 0;      // split_stride != 0: split z owns C + z * split_stride
+    float* const Cz = p.C + (size_t)blockIdx.y * p.split_stride;
     const float alpha = p.alpha * p.inv_a[0] * p.inv_b[0];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -705,7 +709,7 @@ __global__ void __launch_bounds__(NT, 1) gemm_pkw_kernel(const PkParams p) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 if (row >= p.M) continue;
                 float v = acc[i][j][r] * alpha;
-                float* cp = p.C + (size_t)row * p.ldc + col;
+                float* cp = Cz + (size_t)row * p.ldc + col;
                 if (atomic) {
                     atomicAdd(cp, v);
                     continue;
@@ -740,6 +744,7 @@ int lstc_gemm_f32x3_impl(const LstcGemmDesc* d, hipStream_t st) {
     const int splits = d->split_k > 1 ? d->split_k : 1;
     if (splits > 1 && d->flags != 0) return LSTC_E_UNSUPPORTED;
     PkParams p;
+    p.split_stride = splits > 1 ? d->batch_stride_c : 0;      // K splits into separate partial outputs (no atomics)
     p.A = (const pk_t*)d->A; p.B = (const pk_t*)d->B; p.C = (float*)d->C;
     p.bias = d->bias; p.res = (const float*)d->residual; p.relu_src = (const float*)d->relu_src;
     p.M = d->M; p.N = d->N; p.ldc = d->ldc; p.ldr = d->ldr; p.ld_relu = d->ld_relu; p.flags = d->flags; p.alpha = d->alpha;

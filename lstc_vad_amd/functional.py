@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from contextlib import contextmanager
 from typing import Optional
 
@@ -95,7 +96,7 @@ _pack_prof = None          # list of (bytes_in, start_event, end_event) while be
 _wepoch = 0
 _memo_stack = []           # activation packs made inside one autograd-node body are shared by the GEMMs of that body
 _x3_min = (256, 256, 1 << 30)   # min(M, N), K, M*N*K from which a product goes to the packed kernel
-_DETERMINISTIC_WGRAD = True     # exact-f32 mode: split-K weight gradients through partials + ordered sum instead of atomics
+_DETERMINISTIC_WGRAD = os.environ.get("LSTC_ATOMIC_SPLITK", "0") != "1"   # split-K weight gradients: partials + ordered sum, not atomics
 
 
 def set_x3_threshold(min_mn=256, min_k=256, min_mnk=1 << 30):
@@ -284,14 +285,17 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, x_pack: Optional[Packed] = None) ->
             (x_pack is not None or (min(O, I) >= _x3_min[0] and T >= _x3_min[1] and T * O * I >= _x3_min[2])):
         ap = _packed_operand(dy, False)
         bp = x_pack if x_pack is not None else _packed_operand(x, False)
-        out = torch.zeros((O, I), device=dy.device, dtype=torch.float32) if s > 1 else \
-            torch.empty((O, I), device=dy.device, dtype=torch.float32)
+        # K splits write separate partials that lstc_colsum adds in a fixed order (no atomics: bit-reproducible)
+        det = s > 1 and _DETERMINISTIC_WGRAD
+        out = torch.empty((s, O * I), device=dy.device, dtype=torch.float32) if (det or s == 1) else \
+            torch.zeros((1, O * I), device=dy.device, dtype=torch.float32)
         d = GemmDesc()
         d.M, d.N, d.K, d.lda, d.ldb, d.ldc = O, I, T, O, I, I
         d.transA, d.transB, d.dtype, d.flags, d.alpha, d.split_k = 1, 0, _lib.F32X3, 0, 1.0, s
+        d.batch_stride_c = O * I if (s > 1 and _DETERMINISTIC_WGRAD) else 0
         d.A, d.B, d.C = dev_ptr(ap.buf), dev_ptr(bp.buf), dev_ptr(out)
         _launch_gemm(d, 2.0 * O * I * T)
-        return out
+        return (colsum(out) if det else out).view(O, I)
     if s > 1 and _compute_dtype == F32 and _DETERMINISTIC_WGRAD and T % s == 0 and dy.stride(1) == 1 and x.stride(1) == 1:
         # exact-f32 mode: the s K-chunks are ONE batched launch into [s, O, I] partials, summed in a fixed order by
         # lstc_colsum - same parallelism as the atomic split-K, but the step is bit-reproducible run to run
