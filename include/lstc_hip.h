@@ -140,7 +140,11 @@ typedef struct LstcAttnDesc {
     /* backward only */
     const void* dO;                 /* [N,S,H*dv] */
     void* dQ; void* dK; void* dV;   /* [N,S,H*dk|dv], written (not accumulated) */
-    float* dtable;                  /* [rows,H] accumulated with atomics; caller zeroes; NULL = skip */
+    float* dtable;                  /* dtable_chunks == 0: [rows,H] accumulated with atomics, caller zeroes; NULL = skip.
+                                       dtable_chunks > 0: [chunks][rows][H] partial tables, one per chunk of
+                                       ceil(N/chunks) sequences, written (no atomics; the caller sums them - a
+                                       fixed-order, bit-reproducible gradient) */
+    int32_t dtable_chunks;
 } LstcAttnDesc;
 
 int lstc_attn_fwd(const LstcAttnDesc* d, void* stream);
@@ -206,7 +210,7 @@ int lstc_dropout_mask(uint8_t* mask, int64_t n, float p, uint64_t seed, void* st
  * softmax(x W^T + b) (c=2, models/Classifier.py:10).  x [rows, 32]. */
 int lstc_head_out_fwd(const float* x, const float* W, const float* b, float* out, int64_t rows, int32_t c,
                       void* stream);
-/* dx [rows,32], dW [c,32], db [c] from d(out); dW/db are accumulated with atomics (caller zeroes). */
+/* dx [rows,32], dW [c,32], db [c] from d(out); dW/db are ADDED to (caller zeroes) by one workgroup in a fixed order. */
 int lstc_head_out_bwd(const float* x, const float* W, const float* out, const float* dout,
                       float* dx, float* dW, float* db, int64_t rows, int32_t c, void* stream);
 

@@ -34,6 +34,7 @@ struct AttnParams {
     int has_drop;
     int vec_qk, vec_v;     // float4 operand loads allowed for the dk / dv contractions
     int n_per_wg;
+    int table_partials;     // 1: dtable is [gridDim.x][table_rows][H] partials (plain stores), 0: [rows][H] with atomics
 };
 
 __device__ __forceinline__ void load16(const float* __restrict__ p, int k0, int kdim, bool vec, float (&f)[16]) {
@@ -203,12 +204,15 @@ __global__ void __launch_bounds__(NT, T <= 3 ? 2 : 1) attn_bwd_kernel(const Attn
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Dm = sm;                 // dP~ then dA
     float* Pm = sm + SP * LD;       // dropped probabilities
-    float* tacc = sm + 2 * SP * LD; // [table_rows] bias-table gradient of this head
+    float* tacc = sm + 2 * SP * LD; // [NT/64][table_rows] bias-table gradient of this head, one copy per wave
     const int h = blockIdx.y, S = p.S;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool has_bias = p.index_ld > 0 && p.dtable != nullptr;
     if (has_bias)
-        for (int i = threadIdx.x; i < p.table_rows; i += NT) tacc[i] = 0.f;
+        for (int i = threadIdx.x; i < (NT / 64) * p.table_rows; i += NT) tacc[i] = 0.f;
+    // a wave owns its copy: within one row i the S - 1 columns map to distinct table rows (relative offsets of distinct
+    // positions differ), and a wave walks its rows in order, so plain read-modify-write is race-free and the sum order fixed
+    float* const tw = tacc + wave * p.table_rows;
     const int n_begin = blockIdx.x * p.n_per_wg;
     const int n_end = min(p.N, n_begin + p.n_per_wg);
 #pragma unroll 1
@@ -258,7 +262,7 @@ __global__ void __launch_bounds__(NT, T <= 3 ? 2 : 1) attn_bwd_kernel(const Attn
                     drow[j] = da;
                     prow[j] = pv[jj] * keep[jj];
                     if (has_bias && i >= 1 && j >= 1 && j < S)
-                        atomicAdd(&tacc[p.index[(size_t)(i - 1) * p.index_ld + (j - 1)]], da);
+                        tw[p.index[(size_t)(i - 1) * p.index_ld + (j - 1)]] += da;
                 }
             }
         }
@@ -269,7 +273,13 @@ __global__ void __launch_bounds__(NT, T <= 3 ? 2 : 1) attn_bwd_kernel(const Attn
     }
     if (has_bias) {
         __syncthreads();
-        for (int i = threadIdx.x; i < p.table_rows; i += NT) atomicAdd(&p.dtable[(size_t)i * p.H + h], tacc[i]);
+        for (int i = threadIdx.x; i < p.table_rows; i += NT) {
+            float v = tacc[i];
+#pragma unroll
+            for (int w = 1; w < NT / 64; ++w) v += tacc[w * p.table_rows + i];
+            if (p.table_partials) p.dtable[((size_t)blockIdx.x * p.table_rows + i) * p.H + h] = v;
+            else atomicAdd(&p.dtable[(size_t)i * p.H + h], v);
+        }
     }
 }
 
@@ -338,14 +348,20 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
     const int T = (p.S + 31) / 32;
     p.table_rows = (d->index_ld > 0 && d->dtable) ? d->table_rows : 0;
     if (d->index_ld > 0 && d->dtable && d->table_rows <= 0) return LSTC_E_SHAPE;
-    const size_t lds = ((size_t)2 * (32 * T) * (32 * T + 1) + p.table_rows) * sizeof(float);
+    const size_t lds = ((size_t)2 * (32 * T) * (32 * T + 1) + (size_t)(NT / 64) * p.table_rows) * sizeof(float);
     if (lds > 160 * 1024) return LSTC_E_RANGE;
     // enough workgroups to fill the chip (>= ~2048) while amortising the bias-table flush over a few sequences
     int npw = (int)(((int64_t)p.N * p.H + 4095) / 4096);
     if (npw < 1) npw = 1;
     if (npw > 8) npw = 8;
+    p.table_partials = 0;
+    if (p.table_rows > 0 && d->dtable_chunks > 0) {          // the caller fixes the chunking and gets one partial table per chunk
+        npw = (p.N + d->dtable_chunks - 1) / d->dtable_chunks;
+        p.table_partials = 1;
+    }
     p.n_per_wg = npw;
     dim3 grid((p.N + npw - 1) / npw, p.H);
+    if (p.table_partials && (int)grid.x != d->dtable_chunks) return LSTC_E_SHAPE;
 #define LSTC_BWD(TT)                                                         \
     do {                                                                     \
         static bool once = false;                                            \

@@ -328,20 +328,21 @@ __global__ void __launch_bounds__(NT) head_out_fwd_kernel(const float* __restric
     }
 }
 
+// ONE workgroup walks all rows (a few thousand at most: one row per sequence): every thread keeps its own partial sums of
+// dW / db in registers, then wave shuffles and a wave-ordered LDS sum - a fixed summation order, no atomics.
 __global__ void __launch_bounds__(NT) head_out_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                            const float* __restrict__ out, const float* __restrict__ dout,
                                                            float* __restrict__ dx, float* __restrict__ dW,
                                                            float* __restrict__ db, int64_t rows, int c) {
     __shared__ float w[64];
-    __shared__ float acc[2 * 32 + 2];
+    __shared__ float accw[NT / 64][2 * 32 + 2];
     if (threadIdx.x < c * 32) w[threadIdx.x] = W[threadIdx.x];
-    if (threadIdx.x < 66) acc[threadIdx.x] = 0.f;
     __syncthreads();
-    const int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x;
-    float dz0 = 0.f, dz1 = 0.f;
-    float xv[32];
-    const bool live = r < rows;
-    if (live) {
+    float a0[32], a1[32], b0 = 0.f, b1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) a0[i] = a1[i] = 0.f;
+    for (int64_t r = threadIdx.x; r < rows; r += NT) {
+        float dz0, dz1 = 0.f;
         if (c == 1) {
             const float o = out[r];
             dz0 = dout[r] * o * (1.f - o);
@@ -356,39 +357,35 @@ __global__ void __launch_bounds__(NT) head_out_bwd_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float4 v = xr[i];
-            xv[4 * i] = v.x; xv[4 * i + 1] = v.y; xv[4 * i + 2] = v.z; xv[4 * i + 3] = v.w;
             float4 d4;
             d4.x = dz0 * w[4 * i] + (c == 2 ? dz1 * w[32 + 4 * i] : 0.f);
             d4.y = dz0 * w[4 * i + 1] + (c == 2 ? dz1 * w[32 + 4 * i + 1] : 0.f);
             d4.z = dz0 * w[4 * i + 2] + (c == 2 ? dz1 * w[32 + 4 * i + 2] : 0.f);
             d4.w = dz0 * w[4 * i + 3] + (c == 2 ? dz1 * w[32 + 4 * i + 3] : 0.f);
             dr[i] = d4;
+            a0[4 * i] += dz0 * v.x; a0[4 * i + 1] += dz0 * v.y; a0[4 * i + 2] += dz0 * v.z; a0[4 * i + 3] += dz0 * v.w;
+            a1[4 * i] += dz1 * v.x; a1[4 * i + 1] += dz1 * v.y; a1[4 * i + 2] += dz1 * v.z; a1[4 * i + 3] += dz1 * v.w;
         }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 32; ++i) xv[i] = 0.f;
+        b0 += dz0; b1 += dz1;
     }
-    // workgroup reduction of dW / db: wave shuffles, then LDS atomics, then one global atomic per entry
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
-        const float a = wave_sum(dz0 * xv[i]);
-        if (lane == 0) atomicAdd(&acc[i], a);
-        if (c == 2) {
-            const float bb = wave_sum(dz1 * xv[i]);
-            if (lane == 0) atomicAdd(&acc[32 + i], bb);
-        }
+        const float s0 = wave_sum(a0[i]), s1 = wave_sum(a1[i]);
+        if (lane == 0) { accw[wave][i] = s0; accw[wave][32 + i] = s1; }
     }
     {
-        const float a = wave_sum(dz0), bb = wave_sum(dz1);
-        if (lane == 0) {
-            atomicAdd(&acc[64], a);
-            atomicAdd(&acc[65], bb);
-        }
+        const float s0 = wave_sum(b0), s1 = wave_sum(b1);
+        if (lane == 0) { accw[wave][64] = s0; accw[wave][65] = s1; }
     }
     __syncthreads();
-    if (threadIdx.x < c * 32) atomicAdd(&dW[threadIdx.x], acc[threadIdx.x]);
-    if (threadIdx.x < c) atomicAdd(&db[threadIdx.x], acc[64 + threadIdx.x]);
+    if (threadIdx.x < 66) {
+        float v = accw[0][threadIdx.x];
+#pragma unroll
+        for (int q = 1; q < NT / 64; ++q) v += accw[q][threadIdx.x];
+        if (threadIdx.x < c * 32) dW[threadIdx.x] += v;
+        else if (threadIdx.x >= 64 && threadIdx.x - 64 < c) db[threadIdx.x - 64] += v;
+    }
 }
 
 // --------------------------------------------------------------------------------- Adagrad
@@ -555,8 +552,7 @@ int lstc_head_out_bwd(const float* x, const float* W, const float* out, const fl
     if (!x || !W || !out || !dout || !dx || !dW || !db) return LSTC_E_NULL;
     if (rows <= 0 || (c != 1 && c != 2)) return LSTC_E_SHAPE;
     if (!aligned16(x) || !aligned16(dx)) return LSTC_E_ALIGN;
-    hipLaunchKernelGGL(head_out_bwd_kernel, (unsigned)((rows + NT - 1) / NT), NT, 0, (hipStream_t)stream, x, W, out, dout,
-                       dx, dW, db, rows, c);
+    hipLaunchKernelGGL(head_out_bwd_kernel, 1u, NT, 0, (hipStream_t)stream, x, W, out, dout, dx, dW, db, rows, c);
     return lstc_launch_status();
 }
 

@@ -395,16 +395,22 @@ def attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, p_drop, seed, ou
     d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), do.stride(0)
     assert dq.stride(0) == q.stride(0) and dk_.stride(0) == k.stride(0) and dv_.stride(0) == v.stride(0)
     d.dtype = F32
-    dtable = None
+    dtable = parts = None
     if table is not None:
-        dtable = torch.zeros_like(table)
-        d.index_ld, d.table_rows = index.shape[1], table.shape[0]
-        d.table, d.index, d.dtable = dev_ptr(table), dev_ptr(index), dev_ptr(dtable)
+        # one partial table per chunk of sequences, summed in a fixed order afterwards: no float atomics anywhere
+        npw = min(8, max(1, (N * H + 4095) // 4096))
+        chunks = (N + npw - 1) // npw
+        chunks = (N + ((N + chunks - 1) // chunks) - 1) // ((N + chunks - 1) // chunks)
+        parts = torch.empty((chunks, table.shape[0] * H), device=q.device, dtype=torch.float32)
+        d.index_ld, d.table_rows, d.dtable_chunks = index.shape[1], table.shape[0], chunks
+        d.table, d.index, d.dtable = dev_ptr(table), dev_ptr(index), dev_ptr(parts)
     d.scale = 1.0 / (dk ** 0.5)
     d.dropout_p, d.dropout_seed = float(p_drop), int(seed)
     d.Q, d.K, d.V, d.probs = dev_ptr(q), dev_ptr(k), dev_ptr(v), dev_ptr(probs)
     d.dO, d.dQ, d.dK, d.dV = dev_ptr(do), dev_ptr(dq), dev_ptr(dk_), dev_ptr(dv_)
     check(_lib.load().lstc_attn_bwd(C.byref(d), stream_ptr()), "lstc_attn_bwd")
+    if parts is not None:
+        dtable = colsum(parts).view(table.shape[0], H)
     return dq, dk_, dv_, dtable
 
 

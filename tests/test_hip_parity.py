@@ -692,3 +692,30 @@ def test_f32x3_full_width_step_tracks_exact_f32_step():
         assert float((x - y).abs().max() / x.abs().max()) < 1e-5
     for (_, x), (_, y) in zip(l1[n_fwd:], l3[n_fwd:]):
         assert float((x - y).double().norm() / x.double().norm()) < 5e-3
+
+
+def test_exact_f32_training_step_is_bit_reproducible():
+    """Two runs of the same exact-f32 step (dropout on, same seeds) give bit-identical weights: weight-gradient K splits
+    and bias-table gradients are summed in a fixed order (no float atomics on the default path)."""
+    from lstc_vad_amd import functional as Fn
+    from lstc_vad_amd.engine import TrainStep
+    from lstc_vad_amd.models import Classifier, Encoder
+    ekw = dict(n_layers=3, n_head=4, d_k=64, d_v=64, d_model=256, d_inner=512, MHA_layerNorm=True, FFN_layerNorm=True,
+               relative_pe=True, window_size=4, window_depth=3)
+    bs, pn, L, P, d = 8, 16, 3, 16, 256               # 256 sequences x 49 tokens = 12544 rows: split-K weight gradients
+    g = torch.Generator().manual_seed(2)
+    nf = (0.5 * torch.relu(torch.randn(bs, pn * L, P, d, generator=g))).to(DEV)
+    af = (0.5 * torch.relu(torch.randn(bs, pn * L, P, d, generator=g))).to(DEV)
+    u = torch.rand(bs, pn * L, 1, generator=g); al = torch.where(u > 0.65, u, torch.zeros_like(u)).to(DEV)
+    results = []
+    for run in range(2):
+        torch.manual_seed(11); Fn.reset_rng(0)
+        enc = Encoder(MHA_attn_dropout=0.2, MHA_fc_dropout=0.2, FFN_dropout=0.1, weight_init=True, **ekw).to(DEV).train()
+        head = Classifier(d, 0.6).to(DEV).train()
+        ts = TrainStep(_args("LTN", dict(batch_size=bs, part_num=pn, part_len=L, n_patch=P)), "LTN", enc, head, 1e-4, 1e-2, 1e-3)
+        for _ in range(3):
+            sc = ts.step(nf, af, al)
+        results.append((sc.cpu(), {k: v.detach().cpu().clone() for k, v in enc.state_dict().items()}))
+    assert torch.equal(results[0][0], results[1][0])
+    for k, v in results[0][1].items():
+        assert torch.equal(v, results[1][1][k]), k
