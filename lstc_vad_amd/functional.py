@@ -296,8 +296,8 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, x_pack: Optional[Packed] = None) ->
         d.A, d.B, d.C = dev_ptr(ap.buf), dev_ptr(bp.buf), dev_ptr(out)
         _launch_gemm(d, 2.0 * O * I * T)
         return (colsum(out) if det else out).view(O, I)
-    if s > 1 and _compute_dtype == F32 and _DETERMINISTIC_WGRAD and T % s == 0 and dy.stride(1) == 1 and x.stride(1) == 1:
-        # exact-f32 mode: the s K-chunks are ONE batched launch into [s, O, I] partials, summed in a fixed order by
+    if s > 1 and _compute_dtype in (F32, _lib.F32X3) and _DETERMINISTIC_WGRAD and T % s == 0 and dy.stride(1) == 1 and x.stride(1) == 1:
+        # exact-f32 kernel (also the small products of f32x3 mode): the s K-chunks are ONE batched launch into [s, O, I] partials, summed in a fixed order by
         # lstc_colsum - same parallelism as the atomic split-K, but the step is bit-reproducible run to run
         part = torch.empty((s, O * I), device=dy.device, dtype=torch.float32)
         Tc = T // s

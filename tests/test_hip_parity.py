@@ -694,9 +694,10 @@ def test_f32x3_full_width_step_tracks_exact_f32_step():
         assert float((x - y).double().norm() / x.double().norm()) < 5e-3
 
 
-def test_exact_f32_training_step_is_bit_reproducible():
-    """Two runs of the same exact-f32 step (dropout on, same seeds) give bit-identical weights: weight-gradient K splits
-    and bias-table gradients are summed in a fixed order (no float atomics on the default path)."""
+@pytest.mark.parametrize("gemm_mode", ["fp32", "f32x3"])
+def test_training_step_is_bit_reproducible(gemm_mode):
+    """Two runs of the same training steps (dropout on, same seeds) give bit-identical weights: weight-gradient K splits,
+    bias-table gradients and the head's dW/db are summed in a fixed order (no float atomics on the default path)."""
     from lstc_vad_amd import functional as Fn
     from lstc_vad_amd.engine import TrainStep
     from lstc_vad_amd.models import Classifier, Encoder
@@ -708,6 +709,7 @@ def test_exact_f32_training_step_is_bit_reproducible():
     af = (0.5 * torch.relu(torch.randn(bs, pn * L, P, d, generator=g))).to(DEV)
     u = torch.rand(bs, pn * L, 1, generator=g); al = torch.where(u > 0.65, u, torch.zeros_like(u)).to(DEV)
     results = []
+    Fn.set_compute_dtype(gemm_mode)
     for run in range(2):
         torch.manual_seed(11); Fn.reset_rng(0)
         enc = Encoder(MHA_attn_dropout=0.2, MHA_fc_dropout=0.2, FFN_dropout=0.1, weight_init=True, **ekw).to(DEV).train()
@@ -716,6 +718,7 @@ def test_exact_f32_training_step_is_bit_reproducible():
         for _ in range(3):
             sc = ts.step(nf, af, al)
         results.append((sc.cpu(), {k: v.detach().cpu().clone() for k, v in enc.state_dict().items()}))
+    Fn.set_compute_dtype("fp32")
     assert torch.equal(results[0][0], results[1][0])
     for k, v in results[0][1].items():
         assert torch.equal(v, results[1][1][k]), k
