@@ -205,10 +205,16 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
             pa, pb = dev_ptr(a.buf), dev_ptr(b.buf)
         else:
             dtype = F32
+    parts = None
     if out is None:
-        out = torch.empty((M, N), device=dev, dtype=torch.float32)
-        if split_k > 1:
-            out.zero_()
+        if split_k > 1 and dtype == _lib.F32X3 and _DETERMINISTIC_WGRAD:
+            # K splits of the packed kernel into separate partials, summed in a fixed order afterwards (no atomics)
+            parts = torch.empty((split_k, M * N), device=dev, dtype=torch.float32)
+            out = parts[0].view(M, N)
+        else:
+            out = torch.empty((M, N), device=dev, dtype=torch.float32)
+            if split_k > 1:
+                out.zero_()
     pc, cr, cc, ldc = _mat(out)
     assert (cr, cc) == (M, N)
     d = GemmDesc()
@@ -239,7 +245,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
     d.A, d.B, d.C = pa, pb, pc
     if dtype == _lib.F32X3:
         d.transA, d.transB = 0, 1              # packs of [M, K] and [N, K]
+        if parts is not None:
+            d.batch_stride_c = M * N
     _launch_gemm(d, 2.0 * M * N * K)
+    if parts is not None:
+        return colsum(parts).view(M, N)
     return out
 
 
@@ -296,7 +306,9 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, x_pack: Optional[Packed] = None) ->
         d.A, d.B, d.C = dev_ptr(ap.buf), dev_ptr(bp.buf), dev_ptr(out)
         _launch_gemm(d, 2.0 * O * I * T)
         return (colsum(out) if det else out).view(O, I)
-    if s > 1 and _compute_dtype in (F32, _lib.F32X3) and _DETERMINISTIC_WGRAD and T % s == 0 and dy.stride(1) == 1 and x.stride(1) == 1:
+    x3_big = _compute_dtype == _lib.F32X3 and min(O, I) >= _x3_min[0] and T >= _x3_min[1] and T * O * I >= _x3_min[2]
+    if s > 1 and (_compute_dtype == F32 or (_compute_dtype == _lib.F32X3 and not x3_big)) and _DETERMINISTIC_WGRAD and \
+            T % s == 0 and dy.stride(1) == 1 and x.stride(1) == 1:
         # exact-f32 kernel (also the small products of f32x3 mode): the s K-chunks are ONE batched launch into [s, O, I] partials, summed in a fixed order by
         # lstc_colsum - same parallelism as the atomic split-K, but the step is bit-reproducible run to run
         part = torch.empty((s, O * I), device=dy.device, dtype=torch.float32)
