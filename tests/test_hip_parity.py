@@ -722,3 +722,21 @@ def test_training_step_is_bit_reproducible(gemm_mode):
     assert torch.equal(results[0][0], results[1][0])
     for k, v in results[0][1].items():
         assert torch.equal(v, results[1][1][k]), k
+
+
+def test_f32x3_scale_edge_cases(f32x3_everywhere):
+    """Power-of-two tensor scales at the ends of the f32 range, an all-zero operand, and operands of very different
+    magnitude: same relative accuracy as in the middle of the range, zeros stay zeros."""
+    Fn = f32x3_everywhere
+    g = torch.Generator().manual_seed(4)
+    a = torch.randn(300, 200, generator=g); b = torch.randn(260, 200, generator=g)
+    ref = a.double() @ b.double().t()
+    for sa, sb in ((1.0, 1.0), (1e30, 1e-30), (1e-15, 1e-15), (3e15, 2e15), (1e-20, 1.0)):
+        y = Fn.gemm((a * sa).to(DEV), (b * sb).to(DEV), trans_b=True).cpu().double()
+        want = ref * (float(torch.tensor(sa, dtype=torch.float32)) * float(torch.tensor(sb, dtype=torch.float32)))
+        rel = float((y - want).abs().max() / want.abs().max())
+        assert rel < 2e-6, (sa, sb, rel)
+    z = Fn.gemm(torch.zeros(300, 200, device=DEV), b.to(DEV), trans_b=True)
+    assert float(z.abs().max()) == 0.0
+    w = Fn.wgrad(torch.zeros(256, 128, device=DEV), torch.randn(256, 128, generator=g).to(DEV))
+    assert float(w.abs().max()) == 0.0
