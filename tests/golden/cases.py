@@ -27,3 +27,45 @@ CASES = {
                                dict(batch_size=2, part_num=3, part_len=3, n_patch=16, temporal_only=True,
                                     clip_grad=True)),
 }
+
+
+# Full-width cases: the BASELINE model widths with enough tokens (T >= 4096) that the backward runs the
+# production instantiations - the steady-state K loop of the exact-f32 GEMM in all three layouts, the batched split-K
+# weight gradients, the d_k = 256 attention backward, the scalar-load path of the unaligned n_hidden = 3027.  Weights are
+# 350-400 MB, so the fixtures hold the seed plus SAMPLES of the expected outputs (``sample_index``); both sides regenerate
+# inputs and weights from lstc_vad_amd.synthetic (``fill_params``).
+FULL_CASES = {
+    "ltn_full": ("LTN", dict(d_model=2048, n_head=8, d_k=256, d_v=256, d_inner=4096, MHA_layerNorm=True,
+                             FFN_layerNorm=True, relative_pe=True, window_size=4, window_depth=3),
+                 dict(batch_size=4, part_num=16, part_len=3, n_patch=16), 31),     # 128 sequences, S = 49, 6272 tokens
+    "stn_full": ("STN", dict(d_model=2048, n_head=8, d_k=256, d_v=256, d_inner=3027, FFN_layerNorm=True),
+                 dict(batch_size=2, part_num=16, part_len=4, n_patch=16), 32),     # 256 sequences, S = 17, 4352 tokens
+}
+N_SAMPLE = 256
+
+
+def sample_index(numel, n=N_SAMPLE):
+    """``n`` flat positions spread over a tensor by a multiplicative hash (portable, no RNG): the entries of a gradient
+    / weight tensor that the full-width fixtures keep."""
+    import numpy as np
+    return (np.arange(min(n, numel), dtype=np.int64) * 2654435761 + 12345) % numel
+
+
+def fill_params(module, seed):
+    """Overwrite every parameter of a reference OR build module with portable-generator values (stream = position in
+    ``named_parameters()``, identical on both sides)."""
+    import torch
+    from lstc_vad_amd import synthetic as syn
+    with torch.no_grad():
+        for i, (k, p) in enumerate(module.named_parameters()):
+            if k.endswith("layer_norm.weight"):
+                v = 1.0 + syn.small_uniform(p.shape, seed, 100 + i, 0.2)
+            elif k.endswith("bias") and p.dim() == 1:
+                v = syn.small_uniform(p.shape, seed, 100 + i, 0.1)
+            elif k.endswith("relative_position_bias_table"):
+                v = syn.small_uniform(p.shape, seed, 100 + i, 0.5)
+            elif k in ("cls_token", "position_enc"):
+                v = syn.small_uniform(p.shape, seed, 100 + i, 0.3)
+            else:
+                v = syn.xavier_uniform(p.shape, seed, 100 + i)
+            p.copy_(torch.from_numpy(v))

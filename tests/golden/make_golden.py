@@ -29,49 +29,94 @@ REF = "/root/reference"
 sys.dont_write_bytecode = True
 for name in ("cv2", "h5py"):
     sys.modules.setdefault(name, types.ModuleType(name))
-sys.path.insert(0, REF)
+sys.path.insert(0, HERE)
+from _refimport import assert_reference, bind_reference     # noqa: E402
+
+# The repo's own utils/ models/ Train/ Test/ shims share the reference's top-level names: bind the reference's packages
+# by file location first (a regular package would otherwise shadow the reference's namespace package utils/).
+bind_reference(REF)
 sys.path.insert(1, ROOT)
-sys.path.insert(2, HERE)
 
 from models.Encoder import Encoder as RefEncoder            # noqa: E402  (reference)
 from models.Regressor import Regressor as RefRegressor      # noqa: E402
 from models.Classifier import Classifier as RefClassifier   # noqa: E402
+from models.MultiHeadAttention import MultiHeadAttention as RefMHA   # noqa: E402
 import Train.temporal_transformer_shanghaitech as ref_ltn   # noqa: E402
 import Train.spatio_transformer_shanghaitech as ref_stn     # noqa: E402
 import Train.spatio_transformer_MIL_CE as ref_coteach       # noqa: E402
+import utils.utils as ref_utils                             # noqa: E402
+import utils.eval_utils as ref_eval_utils                   # noqa: E402
 from utils.eval_utils import eval as ref_eval               # noqa: E402
 
+assert_reference(RefEncoder, RefRegressor, RefClassifier, RefMHA, ref_ltn, ref_stn, ref_coteach, ref_utils,
+                 ref_eval_utils, ref_eval)
+
 from lstc_vad_amd import synthetic as syn                   # noqa: E402
+assert os.path.realpath(syn.__file__).startswith(os.path.realpath(ROOT) + os.sep)
 
 torch.set_num_threads(4)
+OUT_DIR = HERE      # ``--out DIR`` writes elsewhere (tests/test_golden_recipes.py regenerates into a temp dir and diffs)
 
 
-def fill_params(module: torch.nn.Module, seed: int):
-    """Overwrite every parameter with portable-generator values (stream = position)."""
-    with torch.no_grad():
-        for i, (k, p) in enumerate(module.named_parameters()):
-            if k.endswith("layer_norm.weight"):
-                v = 1.0 + syn.small_uniform(p.shape, seed, 100 + i, 0.2)
-            elif k.endswith("bias") and p.dim() == 1:
-                v = syn.small_uniform(p.shape, seed, 100 + i, 0.1)
-            elif k.endswith("relative_position_bias_table"):
-                v = syn.small_uniform(p.shape, seed, 100 + i, 0.5)
-            elif k in ("cls_token", "position_enc"):
-                v = syn.small_uniform(p.shape, seed, 100 + i, 0.3)
-            else:
-                v = syn.xavier_uniform(p.shape, seed, 100 + i)
-            p.copy_(torch.from_numpy(v))
+from cases import CASES, FULL_CASES, fill_params, sample_index   # noqa: E402
 
 
-from cases import CASES   # noqa: E402
+def make_args(enc_kw, st_kw):
+    return Namespace(batch_size=st_kw["batch_size"], part_num=st_kw["part_num"], part_len=st_kw["part_len"],
+                     n_patch=st_kw["n_patch"], d_model=enc_kw["d_model"], lambda_1=0.01,
+                     lambda_MIL=1.0, lambda_CE=0.8, lambda_BCE=1.0, lambda_normal=0.2, lambda_abnormal=2.0,
+                     temporal_only=st_kw.get("temporal_only", False), clip_grad=st_kw.get("clip_grad", False))
+
+
+def ref_forward_loss(mode, args, enc, head, tnf, taf, tal):
+    """Forward + loss exactly as the reference train loops spell them, on the reference's own modules and loss functions."""
+    bs, pn, L, P, d = args.batch_size, args.part_num, args.part_len, args.n_patch, args.d_model
+    if mode == "LTN":      # Train/temporal_transformer_shanghaitech.py:103-134
+        norm_labs = torch.zeros([bs, pn, 2]); norm_labs[:, :, 0] += 1
+        ab = tal.view([bs, pn, L]).mean(dim=-1).view([bs, pn, 1])
+        tmp = torch.zeros([bs, pn, 2]); tmp[:, :, 1] = ab[:, :, 0]; tmp[:, :, 0] = 1 - tmp[:, :, 1]
+        clip_labs = torch.cat([norm_labs, tmp], dim=0)
+        feats = torch.cat([tnf.float().view([bs * pn, L * P, d]), taf.float().view([bs * pn, L * P, d])], dim=0)
+        enc_out = enc(feats)
+        cls = enc_out[:, 0, :].float().view([bs * 2, pn, d])
+        outputs = head(cls).view([bs * 2 * pn, -1])
+        score = outputs[:, 1]
+        if not args.temporal_only:
+            aux = ref_ltn.get_CE_loss(args, outputs, clip_labs.view([bs * 2 * pn, -1]))
+        else:
+            aux = torch.zeros(())
+        mil, err, l1 = ref_ltn.get_MIL_loss(args, score)
+        loss = args.lambda_MIL * mil + args.lambda_CE * aux
+    elif mode == "STN":    # Train/spatio_transformer_shanghaitech.py:90-101
+        feats = torch.cat([tnf.float().view([bs * pn * L, P, d]), taf.float().view([bs * pn * L, P, d])], dim=0)
+        enc_out = enc(feats)
+        cls = enc_out[:, 0, :].float().view([bs * 2, pn * L, d])
+        outputs = head(cls).view([bs * 2, pn * L, -1])
+        loss, err, l1 = ref_stn.get_MIL_loss(args, outputs)
+        mil, aux, score = loss, torch.zeros(()), outputs.reshape(-1)
+    else:                  # Train/spatio_transformer_MIL_CE.py:156-181
+        norm_labs = torch.zeros([bs, pn, 2]); norm_labs[:, :, 0] += 1
+        ab = tal.view([bs, pn, L]).mean(dim=-1).view([bs, pn, 1])
+        tmp = torch.zeros([bs, pn, 2]); tmp[:, :, 1] = ab[:, :, 0]; tmp[:, :, 0] = 1 - tmp[:, :, 1]
+        clip_labs = torch.cat([norm_labs, tmp], dim=0)
+        feats = torch.cat([tnf.float().view([bs * pn * L, P, d]), taf.float().view([bs * pn * L, P, d])], dim=0)
+        enc_out = enc(feats)
+        outputs = head(enc_out[:, 0, :])
+        mil, err, l1 = ref_coteach.get_MIL_loss(args, outputs, L)
+        aux = ref_coteach.get_BCE_loss(args, torch.mean(outputs.view([bs * 2, pn, L]), dim=-1), clip_labs)
+        loss = args.lambda_BCE * aux + mil
+        score = outputs.reshape(-1)
+    return enc_out, outputs, score, loss, mil, err, l1, aux
+
+
+def scalars_of(loss, mil, err, l1, aux):
+    return np.array([loss.item(), mil.item(), err.item(), l1.item(), float(aux)], np.float64)
 
 
 def run_case(name, mode, enc_kw, st_kw, seed):
     bs, pn, L, P = st_kw["batch_size"], st_kw["part_num"], st_kw["part_len"], st_kw["n_patch"]
     d = enc_kw["d_model"]
-    args = Namespace(batch_size=bs, part_num=pn, part_len=L, n_patch=P, d_model=d, lambda_1=0.01,
-                     lambda_MIL=1.0, lambda_CE=0.8, lambda_BCE=1.0, lambda_normal=0.2, lambda_abnormal=2.0,
-                     temporal_only=st_kw.get("temporal_only", False), clip_grad=st_kw.get("clip_grad", False))
+    args = make_args(enc_kw, st_kw)
     enc = RefEncoder(n_layers=3, MHA_attn_dropout=0.0, MHA_fc_dropout=0.0, FFN_dropout=0.0, position_dropout=0.0,
                      weight_init=False, **enc_kw)
     head = RefRegressor(d, 0.0, weight_init=False) if mode != "LTN" else RefClassifier(d, 0.0, weight_init=False)
@@ -91,41 +136,7 @@ def run_case(name, mode, enc_kw, st_kw, seed):
                                {"params": head.parameters(), "lr": 1e-2}], weight_decay=1e-3)
     tnf, taf, tal = torch.from_numpy(nf), torch.from_numpy(af), torch.from_numpy(al)
     for step in range(2):
-        if mode == "LTN":      # Train/temporal_transformer_shanghaitech.py:103-134
-            norm_labs = torch.zeros([bs, pn, 2]); norm_labs[:, :, 0] += 1
-            ab = tal.view([bs, pn, L]).mean(dim=-1).view([bs, pn, 1])
-            tmp = torch.zeros([bs, pn, 2]); tmp[:, :, 1] = ab[:, :, 0]; tmp[:, :, 0] = 1 - tmp[:, :, 1]
-            clip_labs = torch.cat([norm_labs, tmp], dim=0)
-            feats = torch.cat([tnf.float().view([bs * pn, L * P, d]), taf.float().view([bs * pn, L * P, d])], dim=0)
-            enc_out = enc(feats)
-            cls = enc_out[:, 0, :].float().view([bs * 2, pn, d])
-            outputs = head(cls).view([bs * 2 * pn, -1])
-            score = outputs[:, 1]
-            if not args.temporal_only:
-                aux = ref_ltn.get_CE_loss(args, outputs, clip_labs.view([bs * 2 * pn, -1]))
-            else:
-                aux = torch.zeros(())
-            mil, err, l1 = ref_ltn.get_MIL_loss(args, score)
-            loss = args.lambda_MIL * mil + args.lambda_CE * aux
-        elif mode == "STN":    # Train/spatio_transformer_shanghaitech.py:90-101
-            feats = torch.cat([tnf.float().view([bs * pn * L, P, d]), taf.float().view([bs * pn * L, P, d])], dim=0)
-            enc_out = enc(feats)
-            cls = enc_out[:, 0, :].float().view([bs * 2, pn * L, d])
-            outputs = head(cls).view([bs * 2, pn * L, -1])
-            loss, err, l1 = ref_stn.get_MIL_loss(args, outputs)
-            mil, aux, score = loss, torch.zeros(()), outputs.reshape(-1)
-        else:                  # Train/spatio_transformer_MIL_CE.py:156-181
-            norm_labs = torch.zeros([bs, pn, 2]); norm_labs[:, :, 0] += 1
-            ab = tal.view([bs, pn, L]).mean(dim=-1).view([bs, pn, 1])
-            tmp = torch.zeros([bs, pn, 2]); tmp[:, :, 1] = ab[:, :, 0]; tmp[:, :, 0] = 1 - tmp[:, :, 1]
-            clip_labs = torch.cat([norm_labs, tmp], dim=0)
-            feats = torch.cat([tnf.float().view([bs * pn * L, P, d]), taf.float().view([bs * pn * L, P, d])], dim=0)
-            enc_out = enc(feats)
-            outputs = head(enc_out[:, 0, :])
-            mil, err, l1 = ref_coteach.get_MIL_loss(args, outputs, L)
-            aux = ref_coteach.get_BCE_loss(args, torch.mean(outputs.view([bs * 2, pn, L]), dim=-1), clip_labs)
-            loss = args.lambda_BCE * aux + mil
-            score = outputs.reshape(-1)
+        enc_out, outputs, score, loss, mil, err, l1, aux = ref_forward_loss(mode, args, enc, head, tnf, taf, tal)
         opt.zero_grad()
         loss.backward()
         if args.clip_grad:
@@ -135,7 +146,7 @@ def run_case(name, mode, enc_kw, st_kw, seed):
             out["enc_out"] = enc_out.detach().numpy().copy()
             out["outputs"] = outputs.detach().numpy().copy()
             out["score"] = score.detach().numpy().copy()
-            out["scalars"] = np.array([loss.item(), mil.item(), err.item(), l1.item(), float(aux)], np.float64)
+            out["scalars"] = scalars_of(loss, mil, err, l1, aux)
             for k, p in enc.named_parameters():
                 if p.grad is not None:
                     out["enc_grad." + k] = p.grad.numpy().copy()
@@ -143,7 +154,7 @@ def run_case(name, mode, enc_kw, st_kw, seed):
                 if p.grad is not None:
                     out["head_grad." + k] = p.grad.numpy().copy()
         else:
-            out["scalars_step2"] = np.array([loss.item(), mil.item(), err.item(), l1.item(), float(aux)], np.float64)
+            out["scalars_step2"] = scalars_of(loss, mil, err, l1, aux)
         opt.step()
     for k, v in enc.state_dict().items():
         out["enc_after2." + k] = v.numpy().copy()
@@ -165,14 +176,61 @@ def run_case(name, mode, enc_kw, st_kw, seed):
         else:
             x = torch.from_numpy(nf).view([bs * pn * L, P, d])[:3]
             out["eval_enc_out"] = enc2(x).numpy().copy()
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, name + ".npz"), **out)
     print(f"{name}: loss {out['scalars'][0]:.6f} -> wrote {name}.npz "
-          f"({os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024:.0f} KiB)")
+          f"({os.path.getsize(os.path.join(OUT_DIR, name + '.npz')) / 1024:.0f} KiB)")
+
+
+def run_full_case(name, mode, enc_kw, st_kw, seed):
+    """Full-width step on the reference: two training steps; keeps samples, norms and scalars only."""
+    bs, pn, L, P = st_kw["batch_size"], st_kw["part_num"], st_kw["part_len"], st_kw["n_patch"]
+    d = enc_kw["d_model"]
+    args = make_args(enc_kw, st_kw)
+    torch.set_num_threads(8)
+    enc = RefEncoder(n_layers=3, MHA_attn_dropout=0.0, MHA_fc_dropout=0.0, FFN_dropout=0.0, position_dropout=0.0,
+                     weight_init=False, **enc_kw)
+    head = RefRegressor(d, 0.0, weight_init=False) if mode != "LTN" else RefClassifier(d, 0.0, weight_init=False)
+    fill_params(enc, seed)
+    fill_params(head, seed + 1)
+    enc.train(); head.train()
+    nf, nl, af, al = syn.training_batch(bs, pn, L, P, d, seed=seed, with_pseudo=True, threshold=0.6)
+    out = {"seed": np.int64(seed)}
+    opt = torch.optim.Adagrad([{"params": enc.parameters(), "lr": 1e-4},
+                               {"params": head.parameters(), "lr": 1e-2}], weight_decay=1e-3)
+    tnf, taf, tal = torch.from_numpy(nf), torch.from_numpy(af), torch.from_numpy(al)
+    for step in range(2):
+        enc_out, outputs, score, loss, mil, err, l1, aux = ref_forward_loss(mode, args, enc, head, tnf, taf, tal)
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            eo = enc_out.detach()
+            out["cls_rows"] = eo[:, 0, :].numpy().copy()[::max(1, eo.shape[0] // 16)][:16]       # 16 sequences' CLS rows
+            out["tok_rows"] = eo[::max(1, eo.shape[0] // 8), eo.shape[1] // 2, :].numpy().copy()[:8]   # 8 mid-sequence rows
+            out["outputs"] = outputs.detach().numpy().copy()
+            out["score"] = score.detach().numpy().copy()
+            out["scalars"] = scalars_of(loss, mil, err, l1, aux)
+            for pre, mod in (("enc", enc), ("head", head)):
+                for k, p in mod.named_parameters():
+                    if p.grad is None:
+                        continue
+                    g = p.grad.detach().double().reshape(-1)
+                    out[f"{pre}_gnorm.{k}"] = np.float64(g.norm().item())
+                    out[f"{pre}_gmax.{k}"] = np.float64(g.abs().max().item())
+                    out[f"{pre}_gs.{k}"] = p.grad.detach().reshape(-1).numpy()[sample_index(g.numel())].copy()
+        else:
+            out["scalars_step2"] = scalars_of(loss, mil, err, l1, aux)
+        opt.step()
+    for pre, mod in (("enc", enc), ("head", head)):
+        for k, p in mod.named_parameters():
+            out[f"{pre}_w2s.{k}"] = p.detach().reshape(-1).numpy()[sample_index(p.numel())].copy()
+    torch.set_num_threads(4)
+    np.savez_compressed(os.path.join(OUT_DIR, name + ".npz"), **out)
+    print(f"{name}: loss {out['scalars'][0]:.6f} -> wrote {name}.npz "
+          f"({os.path.getsize(os.path.join(OUT_DIR, name + '.npz')) / 1024:.0f} KiB)")
 
 
 def misc():
     out = {}
-    from models.MultiHeadAttention import MultiHeadAttention as RefMHA
     for (L, ws) in [(3, 4), (2, 4), (5, 4), (2, 3), (1, 4)]:
         m = RefMHA(2, 8, 4, 4, relative_pe=True, window_size=ws, window_depth=L)
         out[f"relidx3d_L{L}_ws{ws}"] = m.relative_position_index.numpy().copy()
@@ -201,12 +259,21 @@ def misc():
     out["regressor_param_count"] = np.int64(sum(p.numel() for p in RefRegressor(2048).parameters()))
     out["classifier_state_keys"] = np.array(list(RefClassifier(8).state_dict().keys()))
     out["regressor_state_keys"] = np.array(list(RefRegressor(8).state_dict().keys()))
-    np.savez_compressed(os.path.join(HERE, "misc.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "misc.npz"), **out)
     print("misc: auc", out["auc_value"], out["auc2_value"], "ltn params", out["ltn_param_count"],
           "stn params", out["stn_param_count"])
 
 
 if __name__ == "__main__":
+    if "--out" in sys.argv:
+        OUT_DIR = sys.argv[sys.argv.index("--out") + 1]
+    only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None
     for i, (name, (mode, ekw, skw)) in enumerate(CASES.items()):
-        run_case(name, mode, ekw, skw, seed=11 + i)
-    misc()
+        if only is None or name in only:
+            run_case(name, mode, ekw, skw, seed=11 + i)
+    if only is None or "misc" in only:
+        misc()
+    if "--skip-full-width" not in sys.argv:
+        for name, (mode, ekw, skw, seed) in FULL_CASES.items():
+            if only is None or name in only:
+                run_full_case(name, mode, ekw, skw, seed)

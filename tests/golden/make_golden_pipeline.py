@@ -46,9 +46,12 @@ class _H5File:                     # h5py.File stand-in over an .npz archive
 h5 = types.ModuleType("h5py"); h5.File = _H5File
 sys.modules["h5py"] = h5
 sys.modules.setdefault("cv2", types.ModuleType("cv2"))
-sys.path.insert(0, REF)
+sys.path.insert(0, HERE)
+from _refimport import assert_reference, bind_reference              # noqa: E402
+
+# bind the reference's utils/ models/ Train/ Test/ by file location: the repo's same-named shims must not win
+bind_reference(REF)
 sys.path.insert(1, ROOT)
-sys.path.insert(2, HERE)
 torch.Tensor.cuda = lambda self, *a, **k: self
 torch.nn.Module.cuda = lambda self, *a, **k: self
 
@@ -60,6 +63,11 @@ import Test.evaluation_UCF as ref_eval_ucf                           # noqa: E40
 from models.Encoder import Encoder as RefEncoder                     # noqa: E402
 from models.Regressor import Regressor as RefRegressor               # noqa: E402
 from models.Classifier import Classifier as RefClassifier            # noqa: E402
+
+import utils.eval_utils as ref_eval_utils                             # noqa: E402
+
+assert_reference(ref_ds, ref_gen_s, ref_gen_t, ref_eval_sht, ref_eval_ucf, ref_eval_utils, RefEncoder, RefRegressor,
+                 RefClassifier)
 
 import pipeline_world as pw                                          # noqa: E402
 from pipeline_cases import DATASET_CASES, build_dataset              # noqa: E402
@@ -162,8 +170,7 @@ def run_evals(W):
     def capture(scores, labels, logger):
         captured["s"] = np.asarray(scores, np.float32).reshape(-1)
         captured["l"] = np.asarray(labels, np.float64).reshape(-1)
-        from utils.eval_utils import eval as ref_auc
-        captured["auc"] = ref_auc(scores, labels, logger)
+        captured["auc"] = ref_eval_utils.eval(scores, labels, logger)
         return captured["auc"]
 
     ev = dict(segment_len=16, part_len=3, n_patch=16, d_model=32, temporal_n_head=2, temporal_n_hidden=64, temporal_d_k=16,
@@ -193,8 +200,9 @@ def main():
         run_test_loaders(W)
         run_generators(W, tmp)
         run_evals(W)
-    np.savez_compressed(os.path.join(HERE, "pipeline.npz"), **OUT)
-    print("pipeline.npz:", len(OUT), "arrays,", os.path.getsize(os.path.join(HERE, "pipeline.npz")), "bytes")
+    out_dir = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else HERE
+    np.savez_compressed(os.path.join(out_dir, "pipeline.npz"), **OUT)
+    print("pipeline.npz:", len(OUT), "arrays,", os.path.getsize(os.path.join(out_dir, "pipeline.npz")), "bytes")
 
 
 if __name__ == "__main__":

@@ -7,13 +7,15 @@ Bars (written next to each check):
     lr*sign(g): an entry whose gradient is at rounding level may legitimately flip).
 Every call goes through the C ABI (lstc_vad_amd._lib -> liblstc_hip.so); nothing here reads /root/reference.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from cases import CASES
 from oracle import lstc_oracle as orc
-from util import load_case, sub, oracle_cfgs, max_abs_diff
+from util import GOLDEN, load_case, sub, oracle_cfgs, max_abs_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -740,3 +742,79 @@ def test_f32x3_scale_edge_cases(f32x3_everywhere):
     assert float(z.abs().max()) == 0.0
     w = Fn.wgrad(torch.zeros(256, 128, device=DEV), torch.randn(256, 128, generator=g).to(DEV))
     assert float(w.abs().max()) == 0.0
+
+
+def _full_width_models(name):
+    """Build-side models at BASELINE width with the portable-generator weights the full-width fixture was made from."""
+    from cases import FULL_CASES, fill_params
+    mode, ekw, skw, seed = FULL_CASES[name]
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    assert int(z["seed"]) == seed
+    d = ekw["d_model"]
+    enc, head = _models(mode, dict(ekw), d)
+    fill_params(enc, seed)
+    fill_params(head, seed + 1)
+    from lstc_vad_amd import synthetic as syn
+    nf, _, af, al = syn.training_batch(skw["batch_size"], skw["part_num"], skw["part_len"], skw["n_patch"], d, seed=seed,
+                                       with_pseudo=True, threshold=0.6)
+    return z, mode, skw, d, enc, head, nf, af, al
+
+
+@pytest.mark.parametrize("cls_only", [True, False])
+@pytest.mark.parametrize("name", ["ltn_full", "stn_full"])
+def test_full_width_training_step_matches_reference_golden(name, cls_only):
+    """BASELINE widths (d=2048, H=8x256, F=4096 / 3027, 3 layers), T >= 4096 tokens: forward, loss, EVERY parameter
+    gradient and the weights after two Adagrad steps against the real reference's run (tests/golden/make_golden.py
+    ``run_full_case``; sampled entries + norms, weights regenerate from the seed).  This is the oracle check of the
+    production-size backward: PIPE 5 steady loop in NT/NN/TN, batched split-K weight gradients, attn_bwd at d_k = 256,
+    the scalar-load GEMM path of n_hidden = 3027."""
+    from cases import sample_index
+    from lstc_vad_amd.optim import Adagrad
+    z, mode, skw, d, enc, head, nf, af, al = _full_width_models(name)
+    enc, head = enc.to(DEV).train(), head.to(DEV).train()
+    args = _args(mode, skw)
+    nf, af, al = (torch.from_numpy(x).to(DEV) for x in (nf, af, al))
+    opt = Adagrad([{"params": enc.parameters(), "lr": 1e-4}, {"params": head.parameters(), "lr": 1e-2}], weight_decay=1e-3)
+    init = {("enc", k): p.detach().clone() for k, p in enc.named_parameters()}
+    init.update({("head", k): p.detach().clone() for k, p in head.named_parameters()})
+    for step in range(2):
+        enc_out, outputs, loss, sc = _step(enc, head, mode, args, nf, af, al, d, cls_only)
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            n_seq = enc_out.shape[0]
+            cls = enc_out[:, 0, :][::max(1, n_seq // 16)][:16]
+            assert max_abs_diff(cls, z["cls_rows"]) < 5e-4                         # post-LN activations are O(1..5)
+            if not cls_only:
+                tok = enc_out[::max(1, n_seq // 8), enc_out.shape[1] // 2, :][:8]
+                assert max_abs_diff(tok, z["tok_rows"]) < 5e-4
+            assert max_abs_diff(outputs.reshape(z["outputs"].shape), z["outputs"]) < 1e-4      # north_star tolerance
+            assert np.max(np.abs(sc.cpu().double().numpy() - z["scalars"])) < 2e-5
+            for pre, mod in (("enc", enc), ("head", head)):
+                want = {k[len(pre) + 7:] for k in z.files if k.startswith(pre + "_gnorm.")}
+                got = {k for k, p in mod.named_parameters() if p.grad is not None}
+                assert got == want, got ^ want
+                for k, p in mod.named_parameters():
+                    if p.grad is None:
+                        continue
+                    g = p.grad.detach().reshape(-1)
+                    gmax, gnorm = float(z[f"{pre}_gmax.{k}"]), float(z[f"{pre}_gnorm.{k}"])
+                    idx = torch.from_numpy(sample_index(g.numel())).to(DEV)
+                    err = max_abs_diff(g[idx], z[f"{pre}_gs.{k}"])
+                    assert err < 2e-4 * gmax + 1e-7, (pre, k, err, gmax)
+                    assert abs(float(g.double().norm()) - gnorm) < 1e-4 * gnorm + 1e-9, (pre, k, float(g.double().norm()), gnorm)
+                    assert abs(float(g.abs().max()) - gmax) < 2e-4 * gmax + 1e-7, (pre, k)
+        else:
+            assert np.max(np.abs(sc.cpu().double().numpy() - z["scalars_step2"])) < 1e-4
+        opt.step()
+    for pre, mod in (("enc", enc), ("head", head)):
+        lr = 1e-4 if pre == "enc" else 1e-2
+        for k, p in mod.named_parameters():
+            w = p.detach().reshape(-1)
+            idx = torch.from_numpy(sample_index(w.numel())).to(DEV)
+            diff = (w[idx].cpu() - torch.from_numpy(z[f"{pre}_w2s.{k}"])).abs()
+            # an Adagrad step moves an entry by at most lr; an entry whose gradient sits at rounding level may flip sign
+            assert float(diff.max()) <= 2 * 2 * lr + 1e-6, (pre, k, float(diff.max()))
+            assert float((diff > 5e-5).float().mean()) <= (1e-2 if pre == "head" else 4e-3), (pre, k, float(diff.max()))
+            assert float((w - init[(pre, k)].reshape(-1)).abs().max()) > 0 or z[f"{pre}_w2s.{k}"].size == 0 or \
+                np.array_equal(z[f"{pre}_w2s.{k}"], init[(pre, k)].reshape(-1)[idx].cpu().numpy())

@@ -105,3 +105,53 @@ def test_param_shapes_match_reference_counts_and_keys():
     keys = [k for k in z["ltn_state_keys"].tolist() if not k.endswith("relative_position_index")]
     assert sorted(keys) == sorted(orc.encoder_param_shapes(ltn))
     assert sorted(z["stn_state_keys"].tolist()) == sorted(orc.encoder_param_shapes(stn))
+
+
+@pytest.mark.parametrize("name", ["ltn_full", "stn_full"])
+def test_full_width_step_against_reference_samples(name):
+    """The oracle at BASELINE widths (d=2048, 8x256 heads, F=4096 / 3027) against the reference's own full-width run:
+    scores, scalars, sampled gradient entries, gradient norms (tests/golden/make_golden.py ``run_full_case``)."""
+    from cases import FULL_CASES, sample_index
+    mode, ekw, skw, seed = FULL_CASES[name]
+    z = np.load(GOLDEN + f"/{name}.npz", allow_pickle=False)
+    torch.set_num_threads(8)
+    try:
+        ecfg, st = oracle_cfgs(mode, dict(ekw), dict(skw))
+        shapes = orc.encoder_param_shapes(ecfg)
+        kind = "classifier" if mode == "LTN" else "regressor"
+        hshapes = orc.head_param_shapes(ekw["d_model"], kind)
+
+        from lstc_vad_amd.models import Encoder, Classifier, Regressor
+        from cases import fill_params
+        enc = Encoder(n_layers=3, MHA_attn_dropout=0.0, MHA_fc_dropout=0.0, FFN_dropout=0.0, position_dropout=0.0,
+                      weight_init=False, **ekw)
+        head = (Classifier if mode == "LTN" else Regressor)(ekw["d_model"], 0.0, weight_init=False)
+        fill_params(enc, seed); fill_params(head, seed + 1)
+        enc_P = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+        head_P = {k: v.detach().clone() for k, v in head.state_dict().items()}
+        assert set(shapes) <= set(enc_P) and set(hshapes) == set(head_P)
+        del enc, head
+        nf, _, af, al = syn.training_batch(skw["batch_size"], skw["part_num"], skw["part_len"], skw["n_patch"],
+                                           ekw["d_model"], seed=seed, with_pseudo=True, threshold=0.6)
+        nf, af, al = (torch.from_numpy(x) for x in (nf, af, al))
+        enc_S = {k: torch.zeros_like(v) for k, v in enc_P.items() if v.is_floating_point()}
+        head_S = {k: torch.zeros_like(v) for k, v in head_P.items()}
+        out, enc_P1, head_P1, enc_S, head_S, enc_g, head_g = orc.train_step(enc_P, head_P, enc_S, head_S, ecfg, st, nf, af, al)
+    finally:
+        torch.set_num_threads(4)
+    assert max_abs_diff(out["outputs"].reshape(z["outputs"].shape), z["outputs"]) < 5e-6
+    sc = np.array([out["loss"].item(), out["mil"].item(), out["err"].item(), out["l1"].item(), float(out["aux"].detach())])
+    assert np.max(np.abs(sc - z["scalars"])) < 2e-6
+    for pre, G in (("enc", enc_g), ("head", head_g)):
+        want = {k[len(pre) + 7:] for k in z.files if k.startswith(pre + "_gnorm.")}
+        assert {k for k, g in G.items() if g is not None} == want
+        for k in want:
+            g = G[k].detach().reshape(-1)
+            gmax, gnorm = float(z[f"{pre}_gmax.{k}"]), float(z[f"{pre}_gnorm.{k}"])
+            assert max_abs_diff(g[torch.from_numpy(sample_index(g.numel()))], z[f"{pre}_gs.{k}"]) < 2e-4 * gmax + 1e-9, (pre, k)
+            assert abs(float(g.double().norm()) - gnorm) < 1e-4 * gnorm + 1e-12, (pre, k)
+    for pre, Pn in (("enc", enc_P1), ("head", head_P1)):       # after ONE step here; the fixture holds step 2: bound only
+        for k in (enc_g if pre == "enc" else head_g):
+            lr = 1e-4 if pre == "enc" else 1e-2
+            w = Pn[k].reshape(-1)[torch.from_numpy(sample_index(Pn[k].numel()))]
+            assert float((w - torch.from_numpy(z[f"{pre}_w2s.{k}"])).abs().max()) <= 2 * lr + 1e-6, (pre, k)
