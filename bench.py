@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: snippets/sec of one full LSTC_VAD training step on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config ltn_sht|stn_sht|ltn_ucf|ltn_ubnormal]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config ltn_sht|stn_sht|ltn_ucf|ltn_ubnormal|mixed_ubn_sht]
+                    [--scaling strong|weak] [--feed resident|static] [--dtype fp32|bf16|f32x3]
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on): LTN temporal transformer,
-part_len=3, n_head=8, d_k=d_v=256, relative position bias (window 4), d_model=2048, n_hidden=4096, 3 layers,
-MHA + FFN LayerNorm, fp32; B=64 videos (--batch_size 32 pairs), T=32 parts, P=16 patches per GPU;
-reference dropout rates (0.2/0.2/0.1/0.6); synthetic I3D-like features resident in HBM.
-A step = sequence reshape + Encoder + Classifier + MIL/CE loss + backward + [gradient all-reduce] + Adagrad.
-For N>1 launch with ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``: one process
-per GPU over RCCL, every rank gets its own B=64 videos (weak scaling), value = all ranks' snippets / max time.
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): LTN temporal transformer, part_len=3,
+n_head=8, d_k=d_v=256, relative position bias (window 4), d_model=2048, n_hidden=4096, 3 layers, MHA + FFN LayerNorm,
+fp32; GLOBAL batch B=64 videos (--batch_size 32 normal/abnormal pairs), T=32 parts, P=16 patches; reference dropout rates
+(0.2/0.2/0.1/0.6); synthetic I3D-like features resident in HBM.
 
-Prints ONE JSON line (rank 0) with `roofline` (the dominant kernel = the exact-f32 MFMA GEMM; achieved = the
-launches' algorithmic 2MNK FLOPs / their HIP-event durations, measured live on the launch stream) and
-`cpu_baseline` (the oracle = CPU restatement of the reference, timed on the host cores on a bounded sample).
+A step = batch formation (the reference's window sampler on the host + lstc_gather_rows out of the HBM-resident feature
+bank) + sequence reshape + Encoder + Classifier + MIL/CE loss + backward + [gradient all-reduce] + Adagrad.
+
+Multi-GPU: one process per GPU over RCCL.  ``python bench.py --gpus N`` starts the N ranks itself (fresh child processes,
+created before this process touches the GPU); it also runs unchanged under ``python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).
+``--scaling strong`` (default, the split the metric is quoted on): the global batch stays 32 pairs, rank r
+owns pairs [r*32/N, (r+1)*32/N).  ``--scaling weak``: every rank gets its own 32 pairs.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the exact-f32 MFMA GEMM; achieved = the launches'
+algorithmic 2MNK FLOPs / their HIP-event durations, measured live on the launch stream), `cpu_baseline` (the oracle = CPU
+restatement of the reference, timed on the host cores on a bounded sample) and, at N=1, the sub-objects `static_batch`
+(same step on one fixed batch: no batch formation), `stn_headline` (STN, the literal [64,32,16,2048] input), `bf16` and
+`f32x3` (other GEMM compute modes; never `value`).
 """
 import argparse
 import json
@@ -22,23 +31,22 @@ import sys
 import time
 from argparse import Namespace
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CONFIGS = {
-    # name: (mode, encoder kwargs, step kwargs, dropout (attn, fc, ffn, head))
+    # name: (mode, encoder kwargs, step kwargs, dropout (attn, fc, ffn, head), clip-count range of the synthetic videos)
     "ltn_sht": ("LTN", dict(d_model=2048, d_inner=4096, MHA_layerNorm=True, FFN_layerNorm=True, relative_pe=True,
-                            window_size=4, window_depth=3), dict(part_len=3, n_patch=16), (0.2, 0.2, 0.1, 0.6)),
+                            window_size=4, window_depth=3), dict(part_len=3, n_patch=16), (0.2, 0.2, 0.1, 0.6), (24, 160)),
     "stn_sht": ("STN", dict(d_model=2048, d_inner=3027, FFN_layerNorm=True), dict(part_len=1, n_patch=16),
-                (0.1, 0.1, 0.1, 0.6)),
+                (0.1, 0.1, 0.1, 0.6), (24, 160)),
     "ltn_ucf": ("LTN", dict(d_model=2048, d_inner=4096, MHA_layerNorm=True, FFN_layerNorm=True, relative_pe=True,
-                            window_size=4, window_depth=2), dict(part_len=2, n_patch=9), (0.2, 0.2, 0.1, 0.6)),
+                            window_size=4, window_depth=2), dict(part_len=2, n_patch=9), (0.2, 0.2, 0.1, 0.6), (64, 4000)),
     "ltn_ubnormal": ("LTN", dict(d_model=1024, d_inner=4096, MHA_layerNorm=True, FFN_layerNorm=True, relative_pe=True,
-                                 window_size=4, window_depth=5), dict(part_len=5, n_patch=16), (0.2, 0.2, 0.1, 0.6)),
+                                 window_size=4, window_depth=5), dict(part_len=5, n_patch=16), (0.2, 0.2, 0.1, 0.6), (24, 160)),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA
 
 
 def train_flops_per_sequence(S, d, Hd, F, n_layers, c):
@@ -50,8 +58,9 @@ def train_flops_per_sequence(S, d, Hd, F, n_layers, c):
 def cpu_baseline(cfg_name, threads):
     """Time the oracle's full training step (forward, loss, backward, Adagrad) on the host cores on a bounded
     sample of the same workload: same model width, 2+2 videos x 8 parts (32 sequences)."""
+    import torch
     from oracle import lstc_oracle as orc
-    mode, ekw, skw, drops = CONFIGS[cfg_name]
+    mode, ekw, skw, drops, _ = CONFIGS[cfg_name]
     torch.set_num_threads(threads)
     bs, pn, L, P, d = 2, 8, skw["part_len"], skw["n_patch"], ekw["d_model"]
     ecfg = orc.EncoderCfg(n_layers=3, n_head=8, d_k=256, d_v=256, MHA_attn_dropout=drops[0], MHA_fc_dropout=drops[1],
@@ -87,6 +96,136 @@ def cpu_baseline(cfg_name, threads):
                       f"{t:.2f} s/step"}
 
 
+# ---------------------------------------------------------------------------------------------- N-rank launcher
+def launch_ranks(n, argv, script=None):
+    """``python bench.py --gpus N`` without a launcher: start N fresh rank processes (this parent has not touched the GPU and
+    never will), relay rank 0's JSON line, fail if any rank fails.  Replaces the reference's single-process
+    ``nn.DataParallel`` wrap (Train/temporal_transformer_shanghaitech.py:76-78) with one process per GPU."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this pool
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    line = None
+    failed = None
+    out0 = procs[0].stdout
+    import selectors
+    sel = selectors.DefaultSelector()
+    sel.register(out0, selectors.EVENT_READ)
+    open0 = True
+    while True:
+        if open0:
+            for _key, _ in sel.select(timeout=0.5):
+                ln = out0.readline()
+                if ln == "":
+                    open0 = False
+                    sel.unregister(out0)
+                elif ln.lstrip().startswith("{"):
+                    line = ln.strip()
+                else:
+                    sys.stderr.write(ln)
+        else:
+            time.sleep(0.2)
+        codes = [p.poll() for p in procs]
+        bad = [i for i, c in enumerate(codes) if c not in (None, 0)]
+        if bad and failed is None:
+            failed = (bad[0], codes[bad[0]])
+            for p in procs:                                      # exact PIDs we started, nothing by pattern
+                if p.poll() is None:
+                    p.terminate()
+        if all(c is not None for c in codes) and not open0:
+            break
+    if failed is not None:
+        sys.stderr.write(f"[bench] rank {failed[0]} exited with code {failed[1]}; all ranks stopped\n")
+        return 1
+    if line is None:
+        sys.stderr.write("[bench] rank 0 printed no JSON line\n")
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------- synthetic resident feed
+class SyntheticResidentPairs:
+    """A synthetic training set resident in HBM, served like ``lstc_vad_amd.load_dataset.ResidentPairs`` serves a real one:
+    per step the host runs the reference's window sampler (``window_indices``, utils/load_dataset.py:69-88) for every pair
+    of the GLOBAL batch (identical ``np.random`` consumption on every rank), and ``lstc_gather_rows`` forms this rank's
+    shard ``[bs_local, pn*L, P, d]`` x2 out of the bank.  Pair order: a fresh permutation per epoch (``shuffle_keys``)."""
+
+    def __init__(self, cfg_name, bs_global, part_num, dev, rank, world, seed):
+        import numpy as np
+        import torch
+        from lstc_vad_amd.feed import ResidentBank
+        mode, ekw, skw, _, (lo, hi) = CONFIGS[cfg_name]
+        self.np, self.bs, self.pn, self.L = np, bs_global, part_num, skw["part_len"]
+        self.rank, self.world = rank, world
+        P, d = skw["n_patch"], ekw["d_model"]
+        n_vid = max(2 * bs_global, 64)                               # per class
+        rs = np.random.RandomState(seed)
+        self.lengths = rs.randint(max(lo, self.L + 1), hi + 1, size=(2, n_vid))
+        self.offsets = np.concatenate([[0], np.cumsum(self.lengths.reshape(-1))]).astype(np.int64)
+        total = int(self.offsets[-1])
+        g = torch.Generator(device=dev).manual_seed(seed)
+        bank = torch.empty((total, P, d), device=dev, dtype=torch.float32)
+        step = max(1, (1 << 28) // (P * d))
+        for o in range(0, total, step):                              # 0.5 * relu(N(0, 1)): I3D-like post-ReLU features
+            n = min(step, total - o)
+            bank[o:o + n] = 0.5 * torch.relu(torch.randn(n, P, d, device=dev, generator=g))
+        self.feed = ResidentBank(bank)
+        self.bank_GB = total * P * d * 4 / 1e9
+        u = [rs.rand(int(n), 1).astype(np.float32) for n in self.lengths[1]]
+        self.pseudo = [np.where(x > 0.9, x, np.float32(0.0)) for x in u]      # rule of README.md:27
+        self.rng_state = np.random.RandomState(seed + 1).get_state()          # sampler stream (np.random global, saved/restored)
+        self.n_vid, self.pos = n_vid, 0
+        self.order = None
+        self._shuffle()
+
+    def _with_rng(self, fn):
+        np = self.np
+        keep = np.random.get_state()
+        np.random.set_state(self.rng_state)
+        try:
+            return fn()
+        finally:
+            self.rng_state = np.random.get_state()
+            np.random.set_state(keep)
+
+    def _shuffle(self):
+        np = self.np
+        self.order = self._with_rng(lambda: (np.random.permutation(self.n_vid), np.random.permutation(self.n_vid)))
+        self.pos = 0
+
+    def next_batch(self):
+        from lstc_vad_amd.load_dataset import window_indices
+        np = self.np
+        if self.pos + self.bs > self.n_vid:
+            self._shuffle()
+        bl = self.bs // self.world
+        lo = self.rank * bl
+        rows = self.pn * self.L
+        idx = np.empty((2, bl, rows), np.int64)
+        labs = np.zeros((bl, rows, 1), np.float32)
+
+        def draw():
+            for j in range(self.bs):
+                for kind in (0, 1):
+                    vid = int(self.order[kind][self.pos + j])
+                    w = window_indices(int(self.lengths[kind, vid]), self.pn, self.L, "uniform")
+                    if lo <= j < lo + bl:
+                        idx[kind, j - lo] = w + self.offsets[kind * self.n_vid + vid]
+                        if kind == 1:
+                            labs[j - lo] = self.pseudo[vid][w]
+        self._with_rng(draw)
+        self.pos += self.bs
+        out, labs_d = self.feed.gather(idx, labs)
+        return out[0], out[1], labs_d
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,11 +234,19 @@ def main():
     ap.add_argument("--config", default="ltn_sht", choices=list(CONFIGS) + ["mixed_ubn_sht"],
                     help="mixed_ubn_sht = BASELINE config 5: half the videos UBnormal (d=1024, L=5), half SHT (d=2048, L=3), two "
                          "model pairs stepped in one iteration (lstc_vad_amd.engine.MixedStep)")
-    ap.add_argument("--batch_size", type=int, default=32, help="normal/abnormal pairs per GPU (B = 2*batch_size videos)")
+    ap.add_argument("--batch_size", type=int, default=32, help="normal/abnormal pairs of the GLOBAL batch under --scaling strong "
+                    "(B = 2*batch_size videos), per GPU under --scaling weak")
     ap.add_argument("--part_num", type=int, default=32)
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--feed", default="resident", choices=["resident", "static"],
+                    help="resident (default): every step forms a fresh batch (host window sampler + lstc_gather_rows from the "
+                         "HBM-resident bank) inside the timed region; static: one fixed batch")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "f32x3"],
-                    help="GEMM compute type: fp32 = exact-f32 MFMA (headline, parity mode); f32x3 = f32-accurate products on the 16-bit "
-                         "matrix cores (2 scaled f16 planes per operand, 3 plane products, csrc/gemm_pk.hip); bf16 = bf16 MFMA on f32 storage")
+                    help="GEMM compute type of `value`: fp32 = exact-f32 MFMA (headline, parity mode); bf16 = bf16 MFMA, f32 "
+                         "storage/accumulate (BASELINE configs 3/5); f32x3 = f32-accurate products on the f16 matrix cores")
+    ap.add_argument("--lr_scale", type=float, default=1e-3, help="multiplies the reference learning rates (1e-4 / 1e-2): with "
+                    "i.i.d. synthetic features the classifier saturates within two Adagrad steps at the reference rates and the "
+                    "backward then runs on near-zero operands; timing does not depend on it")
     ap.add_argument("--h2d", action="store_true", help="also time the step with the batch arriving from pinned host memory "
                     "every step through lstc_vad_amd.feed.PinnedFeeder (reported as pcie_inclusive, never as value)")
     ap.add_argument("--naive-last-layer", action="store_true", help="evaluate the last encoder layer for every token like the "
@@ -107,16 +254,21 @@ def main():
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
-    ap.add_argument("--no-f32x3", action="store_true", help="skip the second timed pass in f32x3 mode (reported as the \"f32x3\" "
-                    "object of the JSON line; `value` is always the --dtype mode, exact-f32 MFMA by default)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the N=1 sub-objects (static_batch, stn_headline, bf16, f32x3)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))             # before anything initialises the GPU in this process
+
+    import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the LSTC_VAD hot path here is HIP-only (no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: --gpus {world} but only {torch.cuda.device_count()} device(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     force_dist = os.environ.get("LSTC_FORCE_DIST", "0") == "1"      # exercise the RCCL code path on a single GPU
@@ -126,100 +278,185 @@ def main():
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
     if a.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    strong = a.scaling == "strong"
+    bs_global = a.batch_size if strong else a.batch_size * world
+    if bs_global % world:
+        raise SystemExit(f"--batch_size {a.batch_size} pairs cannot be split over {world} ranks (SURVEY.md 8e: rank r owns pairs "
+                         f"[r*bs/N, (r+1)*bs/N))")
+    bs_local = bs_global // world
 
     from lstc_vad_amd import functional as Fn
-    from lstc_vad_amd.engine import TrainStep
+    from lstc_vad_amd.engine import MixedStep, TrainStep
     from lstc_vad_amd.models import Classifier, Encoder, Regressor
-
-    Fn.set_compute_dtype(a.dtype)
-    from lstc_vad_amd.engine import MixedStep
-
-    def make(cfg_name, bs, seed_off=0):
-        mode, ekw, skw, drops = CONFIGS[cfg_name]
-        if a.no_dropout:
-            drops = (0.0, 0.0, 0.0, 0.0)
-        pn, L, P, d = a.part_num, skw["part_len"], skw["n_patch"], ekw["d_model"]
-        args = Namespace(batch_size=bs, part_num=pn, part_len=L, n_patch=P, lambda_1=0.01, lambda_MIL=1.0, lambda_CE=0.8,
-                         lambda_BCE=1.0, lambda_normal=0.2, lambda_abnormal=2.0, temporal_only=False, clip_grad=False)
-        torch.manual_seed(seed_off)       # same replica on every rank
-        enc = Encoder(n_layers=3, n_head=8, d_k=256, d_v=256, MHA_attn_dropout=drops[0], MHA_fc_dropout=drops[1],
-                      FFN_dropout=drops[2], weight_init=(mode != "LTN"), **ekw).to(dev).train()
-        head = (Classifier(d, drops[3]) if mode == "LTN" else Regressor(d, drops[3])).to(dev).train()
-        ts = TrainStep(args, mode, enc, head, lr_encoder=1e-4, lr_head=1e-2, weight_decay=1e-3, cls_only=not a.naive_last_layer)
-        gen = torch.Generator(device=dev).manual_seed(1000 + rank + 97 * seed_off)      # every rank its own videos
-        T = pn * L
-        nf = 0.5 * torch.relu(torch.randn(bs, T, P, d, device=dev, generator=gen))
-        af = 0.5 * torch.relu(torch.randn(bs, T, P, d, device=dev, generator=gen))
-        u = torch.rand(bs, T, 1, device=dev, generator=gen)
-        al = torch.where(u > 0.9, u, torch.zeros_like(u))            # pseudo labels, rule of README.md:27
-        return ts, (nf, af, al)
-
-    mixed = a.config == "mixed_ubn_sht"
-    if mixed:
-        parts = [make("ltn_ubnormal", a.batch_size // 2, 0), make("ltn_sht", a.batch_size // 2, 1)]
-        ms_ = MixedStep([p[0] for p in parts])
-        run_step = lambda: ms_.step([p[1] for p in parts])[-1]
-        names = ["ltn_ubnormal", "ltn_sht"]
-    else:
-        ts, (nf, af, al) = make(a.config, a.batch_size)
-        run_step = lambda: ts.step(nf, af, al)
-        names = [a.config]
-    mode, ekw, skw, drops = CONFIGS[names[-1]]
-    bs, pn, L, P, d = (a.batch_size // 2 if mixed else a.batch_size), a.part_num, skw["part_len"], skw["n_patch"], ekw["d_model"]
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        run_step()
-    sync()
-    prof = None if a.no_gemm_events else []
-    Fn.set_gemm_profiling(prof)
-    pack_prof = [] if (prof is not None and a.dtype == "f32x3") else None
-    Fn._pack_prof = pack_prof
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        sc = run_step()
-    sync()
-    dt = time.perf_counter() - t0
-    Fn.set_gemm_profiling(None)
-    Fn._pack_prof = None
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    scal = [float(x) for x in sc.cpu()]
-    hbm_peak = torch.cuda.max_memory_allocated(dev)
-    torch.cuda.reset_peak_memory_stats(dev)
-    # ---- second pass: the same K steps with the big products on the 16-bit matrix cores (f32-accurate split operands,
-    # csrc/gemm_pk.hip).  Reported next to the headline, never as `value`.
-    x3 = None
-    if a.dtype == "fp32" and not a.no_f32x3:
-        Fn.set_compute_dtype("f32x3")
-        for _ in range(max(1, a.warmup)):
+    def make(cfg_name, bs_l, bs_g, seed_off=0, feed=None):
+        """Fresh model + optimizer state (identical replica on every rank) and the batch source of one config."""
+        mode, ekw, skw, drops, _ = CONFIGS[cfg_name]
+        if a.no_dropout:
+            drops = (0.0, 0.0, 0.0, 0.0)
+        pn, L, P, d = a.part_num, skw["part_len"], skw["n_patch"], ekw["d_model"]
+        args = Namespace(batch_size=bs_l, part_num=pn, part_len=L, n_patch=P, lambda_1=0.01, lambda_MIL=1.0, lambda_CE=0.8,
+                         lambda_BCE=1.0, lambda_normal=0.2, lambda_abnormal=2.0, temporal_only=False, clip_grad=False)
+        torch.manual_seed(seed_off)       # same replica on every rank
+        enc = Encoder(n_layers=3, n_head=8, d_k=256, d_v=256, MHA_attn_dropout=drops[0], MHA_fc_dropout=drops[1],
+                      FFN_dropout=drops[2], weight_init=(mode != "LTN"), **ekw).to(dev).train()
+        head = (Classifier(d, drops[3]) if mode == "LTN" else Regressor(d, drops[3])).to(dev).train()
+        ts = TrainStep(args, mode, enc, head, lr_encoder=1e-4 * a.lr_scale, lr_head=1e-2 * a.lr_scale, weight_decay=1e-3,
+                       cls_only=not a.naive_last_layer)
+        feed = feed or a.feed
+        if feed == "resident":
+            src = SyntheticResidentPairs(cfg_name, bs_g, pn, dev, rank if strong else 0, world if strong else 1,
+                                         seed=1000 + 97 * seed_off + (0 if strong else rank))
+            nxt = src.next_batch
+        else:
+            gen = torch.Generator(device=dev).manual_seed(1000 + rank + 97 * seed_off)
+            T = pn * L
+            nf = 0.5 * torch.relu(torch.randn(bs_l, T, P, d, device=dev, generator=gen))
+            af = 0.5 * torch.relu(torch.randn(bs_l, T, P, d, device=dev, generator=gen))
+            u = torch.rand(bs_l, T, 1, device=dev, generator=gen)
+            al = torch.where(u > 0.9, u, torch.zeros_like(u))            # pseudo labels, rule of README.md:27
+            src, nxt = None, (lambda: (nf, af, al))
+        return ts, nxt, src
+
+    def timed_pass(cfg, dtype, feed=None, steps=None, warmup=None, gemm_events=True):
+        """Fresh weights and optimizer state, W untimed steps, K timed steps between barrier + synchronize; MAX over ranks."""
+        steps = a.steps if steps is None else steps
+        warmup = a.warmup if warmup is None else warmup
+        Fn.set_compute_dtype(dtype)
+        Fn.reset_rng(0)
+        torch.cuda.reset_peak_memory_stats(dev)
+        mixed = cfg == "mixed_ubn_sht"
+        if mixed:
+            if bs_local % 2:
+                raise SystemExit("mixed_ubn_sht needs an even number of pairs per rank")
+            parts = [make("ltn_ubnormal", bs_local // 2, bs_global // 2, 0, feed), make("ltn_sht", bs_local // 2, bs_global // 2, 1, feed)]
+            ms_ = MixedStep([p[0] for p in parts])
+            run_step = lambda: ms_.step([p[1]() for p in parts])[-1]
+            tss = [p[0] for p in parts]
+        else:
+            ts, nxt, src = make(cfg, bs_local, bs_global, 0, feed)
+            run_step = lambda: ts.step(*nxt())
+            tss = [ts]
+        for _ in range(warmup):
             run_step()
         sync()
-        gp, pp = ([], []) if prof is not None else (None, None)
-        Fn.set_gemm_profiling(gp)
-        Fn._pack_prof = pp
-        t3 = time.perf_counter()
-        for _ in range(a.steps):
-            sc3 = run_step()
+        prof = [] if (gemm_events and not a.no_gemm_events) else None
+        pprof = [] if (prof is not None and dtype != "fp32") else None
+        Fn.set_gemm_profiling(prof)
+        Fn._pack_prof = pprof
+        scs = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            scs.append(run_step())
         sync()
-        dt3 = time.perf_counter() - t3
+        dt = time.perf_counter() - t0
         Fn.set_gemm_profiling(None)
         Fn._pack_prof = None
         Fn.set_compute_dtype("fp32")
         if world > 1:
-            tt = torch.tensor([dt3], device=dev, dtype=torch.float64)
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt3 = float(tt.item())
-        x3 = {"dt": dt3, "gp": gp, "pp": pp, "loss": float(sc3.cpu()[0]), "hbm": torch.cuda.max_memory_allocated(dev)}
+            dt = float(tt.item())
+        first, last = torch.stack([scs[0], scs[-1]]).clone()
+        if world > 1:                      # scalars are rank-local contributions: their sum is the global loss
+            both = torch.stack([first, last]); dist.all_reduce(both); first, last = both
+        res = {"dt": dt, "steps": steps, "prof": prof, "pprof": pprof, "loss_first": float(first[0]), "loss_last": float(last[0]),
+               "hbm": torch.cuda.max_memory_allocated(dev),
+               "allreduce_MB": round(sum(t.reducer.payload_bytes() for t in tss if t.reducer is not None) / 1e6, 1),
+               "bank_GB": None if mixed or src is None else round(src.bank_GB, 2)}
+        del tss, run_step
+        if mixed:
+            del parts, ms_
+        else:
+            del ts, nxt, src
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        return res
+
+    def snippets_per_step(cfg):
+        names = ["ltn_ubnormal", "ltn_sht"] if cfg == "mixed_ubn_sht" else [cfg]
+        b = bs_global // 2 if cfg == "mixed_ubn_sht" else bs_global
+        return sum(2 * b * a.part_num * CONFIGS[n][2]["part_len"] for n in names)
+
+    def roofline_of(res, dtype, cfg):
+        prof = res["prof"]
+        if not prof:
+            return None
+        fl = sum(p[0] for p in prof)
+        ms = sum(p[1].elapsed_time(p[2]) for p in prof)
+        ach = fl / (ms * 1e-3) / 1e12
+        # f32x3: three f16 MFMA products per f32 product -> the f32-equivalent ceiling is the 16-bit peak / 3
+        peak = {"fp32": FP32_MFMA_PEAK_TFLOPS, "f32x3": round(BF16_MFMA_PEAK_TFLOPS / 3, 1), "bf16": BF16_MFMA_PEAK_TFLOPS}[dtype]
+        kname = {"fp32": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+                 "f32x3": "gemm_pk2s_kernel (3 x v_mfma_f32_32x32x16_f16 per f32 product, packed 2-plane operands; small products "
+                          "on gemm_f32_kernel)",
+                 "bf16": "gemm_bf16c_kernel (v_mfma_f32_32x32x16_bf16, f32 operands in HBM converted while staged)"}[dtype]
+        k = res["steps"]
+        roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": len(prof) // k,
+                "gemm_ms_per_step": round(ms / k, 3), "step_executed_gemm_tflop": round(fl / k / 1e12, 3),
+                "step_frac_of_peak_executed": round(fl / k / (res["dt"] / k) / 1e12 / peak, 4)}
+        if res["pprof"]:
+            pms = sum(q[1].elapsed_time(q[2]) for q in res["pprof"])
+            roof["pack_ms_per_step"] = round(pms / k, 3)
+            roof["pack_launches_per_step"] = len(res["pprof"]) // k
+            roof["pack_input_GBps"] = round(sum(q[0] for q in res["pprof"]) / (pms * 1e-3) / 1e9, 1)
+        return roof
+
+    def alg_tflop(cfg):
+        names = ["ltn_ubnormal", "ltn_sht"] if cfg == "mixed_ubn_sht" else [cfg]
+        b = bs_global // 2 if cfg == "mixed_ubn_sht" else bs_global
+        tot = 0.0
+        for n in names:
+            m_, e_, s_, _, _ = CONFIGS[n]
+            S_ = 1 + (s_["part_len"] * s_["n_patch"] if m_ == "LTN" else s_["n_patch"])
+            tot += train_flops_per_sequence(S_, e_["d_model"], 2048, e_["d_inner"], 3, 2 if m_ == "LTN" else 1) * \
+                2 * b * a.part_num * (1 if m_ == "LTN" else s_["part_len"])
+        return tot / 1e12
+
+    def sub_object(res, cfg, dtype):
+        o = {"value": round(snippets_per_step(cfg) * res["steps"] / res["dt"], 1), "unit": "snippets/s",
+             "ms_per_step": round(1e3 * res["dt"] / res["steps"], 3), "loss_first_timed_step": res["loss_first"],
+             "loss_last_timed_step": res["loss_last"], "hbm_peak_GB": round(res["hbm"] / 1e9, 2)}
+        r = roofline_of(res, dtype, cfg)
+        if r:
+            o["roofline"] = r
+        return o
+
+    # ---- the headline pass -------------------------------------------------------------------------------------------
+    head_res = timed_pass(a.config, a.dtype)
+    value = snippets_per_step(a.config) * a.steps / head_res["dt"]
+
+    extras = {}
+    solo = world == 1 and not force_dist and not a.no_extras and a.config != "mixed_ubn_sht"
+    if solo:
+        if a.feed == "resident":
+            extras["static_batch"] = dict(sub_object(timed_pass(a.config, a.dtype, feed="static", gemm_events=False), a.config, a.dtype),
+                                          note="same step on ONE fixed HBM batch: no window sampling, no lstc_gather_rows")
+        if a.config == "ltn_sht":
+            extras["stn_headline"] = dict(sub_object(timed_pass("stn_sht", a.dtype), "stn_sht", a.dtype),
+                                          workload="stn_sht: STN full training step on the literal [64,32,16,2048] input (L=1, S=17, "
+                                                   "n_hidden=3027, 2048 sequences/step), MIL loss, resident feed",
+                                          step_algorithmic_tflop=round(alg_tflop("stn_sht"), 3))
+        if a.dtype == "fp32":
+            extras["bf16"] = dict(sub_object(timed_pass(a.config, "bf16"), a.config, "bf16"),
+                                  dtype="bf16 MFMA (operands rounded to bf16 RNE), f32 accumulate, f32 master weights / activations "
+                                        "/ attention / LayerNorm / loss / Adagrad (BASELINE configs 3 and 5)")
+            extras["f32x3"] = dict(sub_object(timed_pass(a.config, "f32x3"), a.config, "f32x3"),
+                                   dtype="f32 storage and accumulation; products of the large GEMMs on the f16 matrix cores (two scaled "
+                                         "f16 planes per operand, hh + hl + lh); narrower than IEEE f32 products, reported as an extra")
     pcie = None
-    if a.h2d and world == 1 and not mixed:
+    if a.h2d and world == 1 and a.config != "mixed_ubn_sht":
         from lstc_vad_amd.feed import PinnedFeeder
+        Fn.set_compute_dtype(a.dtype)
+        ts, nxt, _ = make(a.config, bs_local, bs_global, 0, "static")
+        nf, af, al = nxt()
         host = tuple(t.cpu() for t in (nf, torch.zeros_like(al), af, al))
         feeder = PinnedFeeder((host for _ in range(a.steps + 2)), dev)
         t1 = None
@@ -229,94 +466,61 @@ def main():
             ts.step(hnf, haf, hal)
         torch.cuda.synchronize()
         dth = (time.perf_counter() - t1) / a.steps
-        pcie = {"value": round(2 * bs * pn * L / dth, 1), "unit": "snippets/s", "ms_per_step": round(1e3 * dth, 3),
+        Fn.set_compute_dtype("fp32")
+        pcie = {"value": round(snippets_per_step(a.config) / dth, 1), "unit": "snippets/s", "ms_per_step": round(1e3 * dth, 3),
                 "batch_MB": round(sum(t.numel() * 4 for t in host) / 1e6, 1),
                 "note": "batch copied pageable->pinned->HBM every step on a side stream, overlapped with the previous step"}
+        del ts, nxt, feeder
 
-    snippets_per_step = sum(2 * bs * pn * CONFIGS[n][2]["part_len"] for n in names) * world
-    value = snippets_per_step * a.steps / dt
     if rank == 0:
+        mixed = a.config == "mixed_ubn_sht"
+        last = "ltn_sht" if mixed else a.config
+        mode, ekw, skw, drops, _ = CONFIGS[last]
+        pn, L, P, d = a.part_num, skw["part_len"], skw["n_patch"], ekw["d_model"]
         S = 1 + (L * P if mode == "LTN" else P)
-        nseq = 2 * bs * pn * (1 if mode == "LTN" else L)
-        f_seq = train_flops_per_sequence(S, d, 2048, ekw["d_inner"], 3, 2 if mode == "LTN" else 1)
-        alg_flops = 0.0
-        for n in names:
-            m_, e_, s_, _ = CONFIGS[n]
-            S_ = 1 + (s_["part_len"] * s_["n_patch"] if m_ == "LTN" else s_["n_patch"])
-            alg_flops += train_flops_per_sequence(S_, e_["d_model"], 2048, e_["d_inner"], 3, 2 if m_ == "LTN" else 1) * \
-                2 * bs * pn * (1 if m_ == "LTN" else s_["part_len"])
-        roof = None
-        if prof:
-            fl = sum(p[0] for p in prof)
-            ms = sum(p[1].elapsed_time(p[2]) for p in prof)
-            ach = fl / (ms * 1e-3) / 1e12
-            traffic = None
+        b_l = bs_local // 2 if mixed else bs_local
+        nseq = 2 * b_l * pn * (1 if mode == "LTN" else L)
+        roof = roofline_of(head_res, a.dtype, a.config)
+        if roof is not None:
             pmc = os.path.join(ROOT, "profiles", "gemm_pmc_traffic.json")
-            if os.path.exists(pmc):
+            if os.path.exists(pmc) and not mixed and a.dtype == "fp32" and world == 1:
                 try:
-                    traffic = None if mixed else json.load(open(pmc)).get(a.config)
+                    roof["traffic"] = json.load(open(pmc)).get(a.config)
                 except Exception:
-                    traffic = None
-            # f32x3: three f16 MFMA products per f32 product -> the f32-equivalent ceiling is the 16-bit peak / 3
-            peak = FP32_MFMA_PEAK_TFLOPS if a.dtype == "fp32" else (round(2500.0 / 3, 1) if a.dtype == "f32x3" else 2500.0)
-            kname = {"fp32": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
-                     "f32x3": "gemm_pk_kernel (3 x v_mfma_f32_32x32x16_f16 per f32 product, packed 2-plane operands; small "
-                              "products on gemm_f32_kernel)",
-                     "bf16": "gemm_bf16c_kernel (v_mfma_f32_32x32x16_bf16, f32 operands in HBM)"}[a.dtype]
-            roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2),
-                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "launches_per_step": len(prof) // a.steps,
-                    "gemm_ms_per_step": round(ms / a.steps, 3),
-                    "gemm_flops_per_step": fl / a.steps,
-                    # SURVEY 8(d) counts the full last layer; the step skips its dead rows (only the CLS token of the
-                    # last layer is read), so executed GEMM FLOPs < algorithmic FLOPs.  frac is on EXECUTED work.
-                    "step_algorithmic_tflop": round(alg_flops / 1e12, 3),
-                    "step_executed_gemm_tflop": round(fl / a.steps / 1e12, 3),
-                    "step_frac_of_peak_executed": round(fl / a.steps / (dt / a.steps) / 1e12 / peak, 4)}
-            if pack_prof:
-                pms = sum(q[1].elapsed_time(q[2]) for q in pack_prof)
-                roof["pack_ms_per_step"] = round(pms / a.steps, 3)
-                roof["pack_launches_per_step"] = len(pack_prof) // a.steps
-                roof["pack_input_GBps"] = round(sum(q[0] for q in pack_prof) / (pms * 1e-3) / 1e9, 1)
+                    roof["traffic"] = None
+            # SURVEY 8(d) counts the full last layer; the step skips its dead rows (only the CLS token of the last layer is
+            # read) and re-associates its K/V projections, so executed GEMM FLOPs < algorithmic FLOPs.  frac is on EXECUTED
+            # work; on the algorithmic count the same step would read frac_on_algorithmic_flops (can exceed 1).
+            roof["step_algorithmic_tflop"] = round(alg_tflop(a.config) / world, 3)          # per rank
+            roof["frac_on_algorithmic_flops"] = round(alg_tflop(a.config) / world / (head_res["dt"] / a.steps) / roof["peak"], 4)
+        feed_txt = ("batch formed every step inside the timed region: host window sampler (utils/load_dataset.py:69-88 rule) + "
+                    "lstc_gather_rows from an HBM-resident bank of %s GB" % head_res["bank_GB"]) if a.feed == "resident" else \
+            "one fixed HBM-resident batch (no batch formation in the timed region)"
         out = {"metric": "snippets/sec training step (B=64,T=32,P=16,d=2048)", "value": round(value, 1),
                "unit": "snippets/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(1e3 * head_res["dt"] / a.steps, 3), "higher_is_better": True, "scaling": a.scaling,
                "vs_baseline": None, "dtype": {"fp32": "f32", "f32x3": "f32 (operands split into 2 scaled f16 planes, 3 f16-MFMA products, f32 accumulate)",
-                         "bf16": "bf16 (f32 storage/accumulate)"}[a.dtype], "data": "synthetic",
-               "config": {"workload": ("mixed batch (BASELINE config 5): per GPU 32 UBnormal videos (d=1024, L=5, S=81) + 32 SHT "
-                                       "videos (d=2048, L=3, S=49), two model pairs, one iteration; second model: " if mixed else "") +
-                                      f"{names[-1]}: {mode} full training step (fwd+loss+bwd+"
-                                      f"{'allreduce+' if world > 1 else ''}Adagrad), per GPU B={2 * bs} videos x T={pn} parts x "
+                                              "bf16": "bf16 (f32 storage/accumulate)"}[a.dtype], "data": "synthetic",
+               "config": {"workload": ("mixed batch (BASELINE config 5): UBnormal videos (d=1024, L=5, S=81) + SHT videos (d=2048, L=3, "
+                                       "S=49) in equal numbers, two model pairs, one iteration; second model: " if mixed else "") +
+                                      f"{last}: {mode} full training step (batch formation+fwd+loss+bwd+"
+                                      f"{'allreduce+' if world > 1 else ''}Adagrad), GLOBAL batch B={2 * bs_global} videos x T={pn} parts x "
                                       f"L={L} snippets x P={P} patches, d_model={d}, n_hidden={ekw['d_inner']}, S={S}, "
-                                      f"{nseq} sequences/GPU/step, dropout={'off' if a.no_dropout else 'reference rates'}, last layer: "
-                                      f"{'all tokens (naive)' if a.naive_last_layer else 'CLS token only, K/V projections re-associated (exact)'}",
-                          "global_videos": 2 * bs * world * len(names), "parallelism": f"dp{world}"},
-               "loss": scal[0], "hbm_peak_GB": round(hbm_peak / 1e9, 2), "roofline": roof}
-        if x3 is not None:
-            o3 = {"value": round(snippets_per_step * a.steps / x3["dt"], 1), "unit": "snippets/s",
-                  "ms_per_step": round(1e3 * x3["dt"] / a.steps, 3), "loss": x3["loss"],
-                  "hbm_peak_GB": round(x3["hbm"] / 1e9, 2),
-                  "dtype": "f32 storage and accumulation; products of the large GEMMs on the f16 matrix cores: operands scaled by a "
-                           "power of two and split into two f16 planes (x*s = h + l to 2^-24), three plane products hh + hl + lh",
-                  "accuracy": "error against f64 <= the exact-f32 MFMA kernel's (tests/test_hip_parity.py::test_f32x3_*, "
-                              "tools/x3_probe.hip: rms 0.82e-7 vs 0.92e-7 for an f32 fma chain); golden training parity at the f32 tolerances"}
-            if x3["gp"]:
-                fl3 = sum(q[0] for q in x3["gp"])
-                ms3 = sum(q[1].elapsed_time(q[2]) for q in x3["gp"])
-                pk3 = round(2500.0 / 3, 1)
-                o3["roofline"] = {"bound": "mfma", "kernel": "gemm_pk2s_kernel (3 x v_mfma_f32_32x32x16_f16 per f32 product)",
-                                  "achieved": round(fl3 / (ms3 * 1e-3) / 1e12, 2), "peak": pk3, "unit": "TFLOP/s (f32-equivalent)",
-                                  "frac": round(fl3 / (ms3 * 1e-3) / 1e12 / pk3, 4), "gemm_ms_per_step": round(ms3 / a.steps, 3)}
-                if x3["pp"]:
-                    pms = sum(q[1].elapsed_time(q[2]) for q in x3["pp"])
-                    o3["roofline"]["pack_ms_per_step"] = round(pms / a.steps, 3)
-            out["f32x3"] = o3
+                                      f"dropout={'off' if a.no_dropout else 'reference rates'}, lr = reference x {a.lr_scale:g}, last layer: "
+                                      f"{'all tokens (naive)' if a.naive_last_layer else 'CLS token only, K/V projections re-associated (exact)'}; "
+                                      f"fresh weights and Adagrad state for the timed pass",
+                          "feed": feed_txt, "global_videos": 2 * bs_global, "parallelism": f"dp{world}",
+                          "per_rank_pairs": bs_local, "per_rank_sequences": nseq, "allreduce_MB": head_res["allreduce_MB"],
+                          "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1},
+               "loss_first_timed_step": head_res["loss_first"], "loss_last_timed_step": head_res["loss_last"],
+               "hbm_peak_GB": round(head_res["hbm"] / 1e9, 2), "roofline": roof}
+        out.update(extras)
         if pcie:
             out["pcie_inclusive"] = pcie
         if world == 1 and not a.no_cpu_baseline and not mixed:
             # torch-CPU sgemm on the GPU box's host peaks at 16-32 threads (tools/cpu_threads_scan.py: 1.3 TFLOP/s
             # at 16-32, 0.5 at 128 of 256 hardware threads), so the baseline uses min(32, available) threads
-            out["cpu_baseline"] = cpu_baseline(names[-1], min(32, len(os.sched_getaffinity(0))))
+            out["cpu_baseline"] = cpu_baseline(last, min(32, len(os.sched_getaffinity(0))))
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()

@@ -141,7 +141,10 @@ def train(script: str, argv=None):
         head.load_state_dict(strip(torch.load(args.load_classifier_model_path, map_location="cpu")), False)
     enc, head = enc.to(dev).train(), head.to(dev).train()
 
-    step_args = Namespace(batch_size=args.batch_size, part_num=args.part_num, part_len=part_len, n_patch=args.n_patch,
+    if args.batch_size % world:
+        raise SystemExit(f"--batch_size {args.batch_size} (pairs of the global batch) does not split over {world} ranks")
+    # --batch_size keeps the reference's meaning (pairs per optimizer step, globally); each rank owns batch_size/world of them
+    step_args = Namespace(batch_size=args.batch_size // world, part_num=args.part_num, part_len=part_len, n_patch=args.n_patch,
                           lambda_1=args.lambda_1, lambda_MIL=getattr(args, "lambda_MIL", 1.0),
                           lambda_CE=getattr(args, "lambda_CE", 0.0), lambda_BCE=getattr(args, "lambda_BCE", 1.0),
                           lambda_normal=getattr(args, "lambda_normal", 0.2), lambda_abnormal=getattr(args, "lambda_abnormal", 2.0),
@@ -155,13 +158,13 @@ def train(script: str, argv=None):
         ppath += ".npy"                                     # Train/spatio_transformer_MIL_CE.py:142
     real = (not args.synthetic) and bool(getattr(args, "dataset_path", ""))
     if real:
-        data, eval_fn = _real_data(args, mode, part_len, ppath, dev, rank, enc, head)
+        data, eval_fn = _real_data(args, mode, part_len, ppath, dev, rank, world, enc, head)
     else:
         n_pairs = args.synthetic_pairs or 2 * args.batch_size
         thr = None if mode == "STN" else 0.65
         pseudo = np.load(ppath, allow_pickle=True).tolist() if ppath and os.path.exists(ppath) else None
         data = SyntheticVideos(n_pairs, args.batch_size, args.part_num, part_len, args.n_patch, d_model, dev,
-                               seed=seed + 1000 * rank, sample=args.sample, pseudo_threshold=thr, pseudo_labels=pseudo)
+                               seed=seed, sample=args.sample, pseudo_threshold=thr, pseudo_labels=pseudo, rank=rank, world=world)
         eval_fn = lambda: evaluate(enc, head, mode, data, part_len, roc_auc)
     epochs = int(_get(args, "epochs", pre, 1))
     inter = int(getattr(args, "inter_epoch", 10))
@@ -206,32 +209,39 @@ class _HostPairs:
     """Batches of a lazy / ten-crop dataset: items collated on the host (``DataLoader(batch_size, drop_last=True,
     num_workers=0)`` order), staged through pinned memory, copied to the device."""
 
-    def __init__(self, dataset, batch_size, device):
-        self.ds, self.bs, self.device = dataset, batch_size, device
+    def __init__(self, dataset, batch_size, device, rank=0, world=1):
+        """``batch_size`` = pairs of the global batch; rank ``r`` keeps items ``[r*bs/world, (r+1)*bs/world)`` of each.  Every
+        rank draws ALL items (the samplers consume ``np.random`` / ``random`` per item), so the union of the shards is the
+        single-process batch; the price is ``world`` times the host reads of a lazy dataset."""
+        if batch_size % world:
+            raise ValueError(f"--batch_size {batch_size} pairs do not split over {world} ranks")
+        self.ds, self.bs, self.device, self.rank, self.world = dataset, batch_size, device, rank, world
 
     def __len__(self):
         return len(self.ds) // self.bs
 
     def __iter__(self):
         import torch
+        bl = self.bs // self.world
         for b in range(len(self)):
-            items = [self.ds[b * self.bs + j] for j in range(self.bs)]
+            items = [self.ds[b * self.bs + j] for j in range(self.bs)][self.rank * bl:(self.rank + 1) * bl]
             yield tuple(torch.stack([it[k] for it in items]).pin_memory().to(self.device, non_blocking=True) for k in range(4))
 
     def shuffle_keys(self):
         self.ds.shuffle_keys()
 
 
-def _real_data(args, mode, part_len, pseudo_path, dev, rank, enc, head):
+def _real_data(args, mode, part_len, pseudo_path, dev, rank, world, enc, head):
     """Feature-archive training source + evaluation closure for a Train/*.py run.  Dataset class per
-    script as upstream (e.g. Train/temporal_transformer_shanghaitech.py:45-51, Train/spatio_transformer_MIL_CE.py:114-149);
-    under torchrun every rank seeds ``np.random`` with ``seed + rank`` so the ranks draw different pairs (the reference's
-    DataLoader workers do the same with ``seed + worker_id``, :39-41)."""
+    script as upstream (e.g. Train/temporal_transformer_shanghaitech.py:45-51, Train/spatio_transformer_MIL_CE.py:114-149).
+    Under data parallelism every rank seeds ``np.random`` IDENTICALLY and walks the same permutation / window draws; rank
+    ``r`` keeps pairs ``[r*bs/world, (r+1)*bs/world)`` of each global batch, so shards are disjoint and the global batch is
+    the one a single process would have formed."""
     import numpy as np
     from . import load_dataset as lds
     from .pipeline import evaluate_auc
     dataset = str(getattr(args, "dataset", "SHT"))
-    np.random.seed(int(getattr(args, "seed", 0)) + rank)
+    np.random.seed(int(getattr(args, "seed", 0)))
     common = dict(part_num=args.part_num, part_len=part_len, h5_path=args.dataset_path, train_txt=args.training_txt,
                   n_patch=args.n_patch, sample=args.sample, pseudo_labels_path=pseudo_path if mode != "STN" else None)
     if dataset == "UCF":
@@ -242,7 +252,7 @@ def _real_data(args, mode, part_len, pseudo_path, dev, rank, enc, head):
         ds = lds.SH_Train_Origin_Dataset_MutualTraining(**common)
     else:
         ds = lds.SH_Train_Origin_Dataset(**common)
-    data = _HostPairs(ds, args.batch_size, dev) if ds.lazy else lds.ResidentPairs(ds, args.batch_size, dev)
+    data = (_HostPairs if ds.lazy else lds.ResidentPairs)(ds, args.batch_size, dev, rank, world)
     masks = getattr(args, "test_mask_path", "") if dataset == "UCF" else getattr(args, "test_mask_dir", "")
     test_arc = getattr(args, "test_dataset_path", "") or args.dataset_path
     kind = "LTN" if mode == "LTN" else "STN"

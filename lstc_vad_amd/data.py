@@ -35,7 +35,10 @@ class SyntheticVideos:
     abnorm_labs) exactly shaped like the reference loader's batches, already on ``device``."""
 
     def __init__(self, n_pairs, batch_size, part_num, part_len, n_patch, d_model, device, seed=0, sample="uniform",
-                 pseudo_threshold=None, min_clips=24, max_clips=160, pseudo_labels=None):
+                 pseudo_threshold=None, min_clips=24, max_clips=160, pseudo_labels=None, rank=0, world=1):
+        if batch_size % world:
+            raise ValueError(f"batch_size {batch_size} pairs do not split over {world} ranks")
+        self.rank, self.world = rank, world          # rank r serves pairs [r*bs/world, (r+1)*bs/world) of each global batch
         self.bs, self.pn, self.L, self.P, self.d = batch_size, part_num, part_len, n_patch, d_model
         self.device, self.seed, self.sample, self.thr = device, seed, sample, pseudo_threshold
         rs = np.random.RandomState(seed)
@@ -69,10 +72,15 @@ class SyntheticVideos:
         for b in range(len(self)):
             ids = self.order[b * self.bs:(b + 1) * self.bs]
             out = [[], [], [], []]
-            for vid in ids:
+            bl = self.bs // self.world
+            for j, vid in enumerate(ids):
                 for kind in (0, 1):
+                    n = int(self.lengths[kind, int(vid)])
+                    w = sample_windows(n, self.pn, self.L, self.sample, self.rng)     # every rank draws every window
+                    if not (self.rank * bl <= j < (self.rank + 1) * bl):
+                        continue
                     feats, labs = self._video(kind, int(vid))
-                    idx = torch.from_numpy(sample_windows(feats.shape[0], self.pn, self.L, self.sample, self.rng)).to(self.device)
+                    idx = torch.from_numpy(w).to(self.device)
                     f = feats[idx]
                     if kind == 0:
                         l = torch.zeros(idx.numel(), 1, device=self.device)

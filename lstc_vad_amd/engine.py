@@ -20,10 +20,13 @@ from .optim import Adagrad, clip_grad_norm_
 
 class TrainStep:
     def __init__(self, args, mode: str, encoder, head, lr_encoder: float, lr_head: float, weight_decay: float,
-                 group=None, cls_only: bool = True):
+                 group=None, cls_only: bool = True, loss_rank=None, loss_exchange=None):
         # cls_only=False evaluates the last encoder layer for every token like the reference does (its extra rows are
         # never read); kept for A/B measurements — results are identical (tests/test_hip_parity.py)
         self.cls_only = cls_only
+        # (rank, world) + bag exchange override for the loss: lets a test run the shards of several ranks on one device
+        # through this very object (tests/test_hip_parity.py::test_two_emulated_ranks_through_trainstep)
+        self.loss_rank, self.loss_exchange = loss_rank, loss_exchange
         self.args, self.mode, self.encoder, self.head, self.group = args, mode, encoder, head, group
         # MultiHeadAttention.fuse_qkv_() (one projection / dW / dX GEMM per layer instead of three) is available but
         # not applied: measured 304.0 vs 301.3 ms per LTN step — the 128x128-tile GEMMs gain nothing from being wider.
@@ -50,7 +53,8 @@ class TrainStep:
         else:
             cls = self.encoder(self.sequences(norm_feats, abnorm_feats))[:, 0, :]
         outputs = self.head(cls)
-        loss, scalars = training_loss(self.args, self.mode, outputs, abnorm_labs, group=self.group)
+        loss, scalars = training_loss(self.args, self.mode, outputs, abnorm_labs, group=self.group,
+                                      distributed=self.loss_rank, exchange=self.loss_exchange)
         return loss, scalars, outputs
 
     def step(self, norm_feats, abnorm_feats, abnorm_labs):

@@ -62,3 +62,45 @@ class PinnedFeeder:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             self._consumed[cur] = ev
+
+
+class ResidentBank:
+    """Features resident in HBM as ONE ``[total_clips, ...row]`` tensor; a training batch is formed on the device by
+    ``lstc_gather_rows`` from clip indices the host sampler produced (MI355X-first data feed: a whole training set fits in
+    288 GB, so no feature bytes cross PCIe per step).
+
+    The index / label arrays of a step (a few tens of KB) travel through a ring of pinned host slabs with truly
+    asynchronous copies on the compute stream, so the host keeps running ahead of the GPU (a pageable ``.to(device)`` would
+    block the host until the previous step has drained)."""
+
+    def __init__(self, bank: torch.Tensor, depth: int = 4):
+        from . import functional as F
+        self.F, self.bank, self.depth = F, bank, depth
+        self._slot = 0
+        self._pinned = [None] * depth
+        self._done = [None] * depth
+
+    def _stage(self, arrays):
+        import numpy as np
+        s = self._slot
+        self._slot = (s + 1) % self.depth
+        if self._done[s] is not None:
+            self._done[s].synchronize()                 # the copies issued from this slab `depth` steps ago have completed
+        slabs = self._pinned[s]
+        if slabs is None or any(p.shape != tuple(a.shape) or p.numpy().dtype != a.dtype for p, a in zip(slabs, arrays)):
+            slabs = self._pinned[s] = [torch.from_numpy(np.empty(a.shape, a.dtype)).pin_memory() for a in arrays]
+        outs = []
+        for p, a in zip(slabs, arrays):
+            p.numpy()[...] = a
+            outs.append(p.to(self.bank.device, non_blocking=True))
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.bank.device))
+        self._done[s] = ev
+        return outs
+
+    def gather(self, idx, *extras):
+        """``idx``: int64 numpy array of clip rows (any shape); returns ``bank[idx]`` with shape ``idx.shape + row`` plus the
+        ``extras`` (small numpy arrays, e.g. labels) as device tensors."""
+        dev = self._stage([idx.reshape(-1)] + list(extras))
+        out = self.F.gather_rows(self.bank, dev[0]).reshape(tuple(idx.shape) + tuple(self.bank.shape[1:]))
+        return (out, *dev[1:])

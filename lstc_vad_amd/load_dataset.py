@@ -277,6 +277,29 @@ UCF_test_tenCrop = UCF_test        # utils/load_dataset.py:494-510 is the same f
 
 # -- HBM-resident serving of the same items --------------------------------------------------------------------------
 
+def shard_plan(ds, offsets, n_norm, b, bs, rank=0, world=1):
+    """Window indices + labels of global batch ``b`` (``bs`` pairs) for rank ``rank`` of ``world``: pairs
+    ``[rank*bs/world, (rank+1)*bs/world)``.  The sampler runs for EVERY pair (same ``np.random`` consumption on every rank
+    as in the single-process run), so the ranks' shards are disjoint and their union is the single-process batch."""
+    rows = ds.part_num * ds.part_len
+    bl = bs // world
+    lo = rank * bl
+    idx = np.empty((2, bl, rows), np.int64)
+    labs = np.empty((2, bl, rows, 1), np.float32)
+    for j in range(bs):
+        item = b * bs + j
+        ni, ai = ds.norm_iters[item], ds.abnorm_iters[item]
+        for kind, vid in ((0, ni), (1, ai)):
+            feats = (ds.norm_feats if kind == 0 else ds.abnorm_feats)[vid]
+            keys = ds.norm_keys if kind == 0 else ds.abnorm_keys
+            l = ds._labels_for(feats.shape[0], ds._pseudo(keys[vid]), "Normal" if kind == 0 else "Abnormal")
+            w = window_indices(feats.shape[0], ds.part_num, ds.part_len, ds.sample)     # consumes np.random on every rank
+            if lo <= j < lo + bl:
+                idx[kind, j - lo] = w + offsets[vid + (n_norm if kind else 0)]
+                labs[kind, j - lo] = np.asarray(l, np.float32).reshape(-1, 1)[w] if np.ndim(l) == 1 else l[w]
+    return idx, labs
+
+
 class ResidentPairs:
     """Serve a ``_PairSource``'s batches from HBM.
 
@@ -286,11 +309,17 @@ class ResidentPairs:
     num_workers=0, shuffle=False)``), so the batches are bit-identical to the host path while no feature bytes cross
     PCIe per step.  Labels are tiny and travel with the indices."""
 
-    def __init__(self, dataset: _PairSource, batch_size: int, device):
-        from . import functional as F
+    def __init__(self, dataset: _PairSource, batch_size: int, device, rank: int = 0, world: int = 1):
+        """``batch_size`` = pairs of the GLOBAL batch (the reference's ``--batch_size``); under data parallelism rank ``r``
+        of ``world`` serves pairs ``[r*bs/world, (r+1)*bs/world)`` of every global batch.  Every rank runs the
+        sampler for the whole global batch - same ``np.random`` consumption as the single-process run - so the ranks'
+        shards are disjoint and their union IS the single-process batch."""
+        from .feed import ResidentBank
         if dataset.lazy or dataset.ten_crop:
             raise ValueError("ResidentPairs serves the eager single-crop datasets (SH / UBnormal)")
-        self.F, self.ds, self.bs, self.device = F, dataset, batch_size, device
+        if batch_size % world:
+            raise ValueError(f"--batch_size {batch_size} pairs do not split over {world} ranks")
+        self.ds, self.bs, self.device, self.rank, self.world = dataset, batch_size, device, rank, world
         P = dataset.n_patch
         vids = dataset.norm_feats + dataset.abnorm_feats
         cut = (lambda f: f) if P == 1 else (lambda f: f[:, :P, :])
@@ -300,29 +329,20 @@ class ResidentPairs:
         self.bank = torch.empty((int(self.offsets[-1]),) + self.row_shape, dtype=torch.float32, device=device)
         for o, v in zip(self.offsets[:-1], vids):            # one staged copy per video, then everything is resident
             self.bank[o:o + v.shape[0]].copy_(torch.from_numpy(np.ascontiguousarray(cut(v), dtype=np.float32)))
+        self.feed = ResidentBank(self.bank)
 
     def __len__(self):
         return len(self.ds) // self.bs
 
+    def plan(self, b):
+        """Host side of batch ``b``: (clip rows into the bank ``[2, bs_local, pn*L]`` int64, labels ``[2, bs_local, pn*L, 1]``)
+        of THIS rank's shard.  Draws the windows of every pair of the global batch, in the dataset's own order."""
+        return shard_plan(self.ds, self.offsets, self.n_norm, b, self.bs, self.rank, self.world)
+
     def __iter__(self):
-        ds = self.ds
-        rows = ds.part_num * ds.part_len
         for b in range(len(self)):
-            idx = np.empty((2, self.bs, rows), np.int64)
-            labs = np.empty((2, self.bs, rows, 1), np.float32)
-            for j in range(self.bs):
-                item = b * self.bs + j
-                ni, ai = ds.norm_iters[item], ds.abnorm_iters[item]
-                for kind, vid in ((0, ni), (1, ai)):
-                    feats = (ds.norm_feats if kind == 0 else ds.abnorm_feats)[vid]
-                    keys = ds.norm_keys if kind == 0 else ds.abnorm_keys
-                    l = ds._labels_for(feats.shape[0], ds._pseudo(keys[vid]), "Normal" if kind == 0 else "Abnormal")
-                    w = window_indices(feats.shape[0], ds.part_num, ds.part_len, ds.sample)
-                    idx[kind, j] = w + self.offsets[vid + (self.n_norm if kind else 0)]
-                    labs[kind, j] = np.asarray(l, np.float32).reshape(-1, 1)[w] if np.ndim(l) == 1 else l[w]
-            idx_d = torch.from_numpy(idx).to(self.device, non_blocking=True)
-            labs_d = torch.from_numpy(labs).to(self.device, non_blocking=True)
-            out = self.F.gather_rows(self.bank, idx_d.reshape(-1)).reshape((2, self.bs, rows) + self.row_shape)
+            idx, labs = self.plan(b)
+            out, labs_d = self.feed.gather(idx, labs)
             yield out[0], labs_d[0], out[1], labs_d[1]
 
     def shuffle_keys(self):

@@ -21,7 +21,7 @@ def _dist_info(group=None):
     return 0, 1
 
 
-def training_loss(args, mode: str, head_out: torch.Tensor, abnorm_labs=None, group=None, distributed=None):
+def training_loss(args, mode: str, head_out: torch.Tensor, abnorm_labs=None, group=None, distributed=None, exchange=None):
     """Loss of one training step from the head output of THIS rank's sequences.
 
     mode "LTN": Train/temporal_transformer_shanghaitech.py:103-134 (MIL on out[:,1] + lambda_CE * CE unless
@@ -29,12 +29,14 @@ def training_loss(args, mode: str, head_out: torch.Tensor, abnorm_labs=None, gro
                 "STN_MIL_CE": Train/spatio_transformer_MIL_CE.py:176-181.
     ``args.batch_size`` is this rank's number of normal/abnormal pairs; under data parallelism the global
     batch is ``world_size * args.batch_size`` pairs and the hinge couples all of them.
-    Returns ``(loss, scalars)`` with scalars = [loss, MIL, err, l1, aux] (rank-local contributions)."""
+    ``distributed=(rank, world)`` overrides the process-group lookup and ``exchange(bag)`` the bag all-reduce (tests that
+    emulate ranks on one device).  Returns ``(loss, scalars)`` with scalars = [loss, MIL, err, l1, aux] (rank-local
+    contributions: summing them over ranks gives the single-process values)."""
     rank, world = _dist_info(group) if distributed is None else distributed
     bs_l, pn, L = args.batch_size, args.part_num, args.part_len
     bs_g = bs_l * world
     cfg = dict(bs_global=bs_g, bs_local=bs_l, rank_off=rank * bs_l, part_num=pn, label_len=L,
-               lambda_1=float(args.lambda_1), lambda_normal=0.0, lambda_abnormal=0.0, group=group)
+               lambda_1=float(args.lambda_1), lambda_normal=0.0, lambda_abnormal=0.0, group=group, exchange=exchange)
     if mode == "LTN":
         use_ce = not getattr(args, "temporal_only", False)
         cfg.update(mode=MODE_LTN, score_len=1, l1_skip=bs_g, lambda_MIL=float(args.lambda_MIL),

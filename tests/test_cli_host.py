@@ -73,3 +73,36 @@ def test_models_import_shim():
     from models.Classifier import Classifier
     from lstc_vad_amd.models import Encoder as E2
     assert Encoder is E2 and PositionwiseFeedForward.__name__ == "PositionwiseFeedForward" and Classifier
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """``python bench.py --gpus N`` without a launcher: N fresh rank processes with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*,
+    rank 0's JSON line relayed, a failing rank fails the run (bench.launch_ranks; no GPU needed for the mechanism)."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lstc_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ok = tmp_path / "rank_ok.py"
+    ok.write_text("import os, json, sys\n"
+                  "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+                  "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+                  "print('noise from rank', r)\n"
+                  "if r == 0: print(json.dumps({'n_gpus': w, 'argv': sys.argv[1:]}))\n")
+    bad = tmp_path / "rank_bad.py"
+    bad.write_text("import os, sys, time\n"
+                   "if os.environ['RANK'] == '1': sys.exit(3)\n"
+                   "time.sleep(30)\n")
+    import contextlib
+    import io
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rc = bench.launch_ranks(3, ["--gpus", "3", "--steps", "2"], script=str(ok))
+    assert rc == 0
+    out = json.loads(buf.getvalue().strip().splitlines()[-1])
+    assert out == {"n_gpus": 3, "argv": ["--gpus", "3", "--steps", "2"]}
+    import time
+    t0 = time.time()
+    assert bench.launch_ranks(2, [], script=str(bad)) == 1         # rank 1 fails -> rank 0 is stopped, run fails
+    assert time.time() - t0 < 20

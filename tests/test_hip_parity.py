@@ -818,3 +818,52 @@ def test_full_width_training_step_matches_reference_golden(name, cls_only):
             assert float((diff > 5e-5).float().mean()) <= (1e-2 if pre == "head" else 4e-3), (pre, k, float(diff.max()))
             assert float((w - init[(pre, k)].reshape(-1)).abs().max()) > 0 or z[f"{pre}_w2s.{k}"].size == 0 or \
                 np.array_equal(z[f"{pre}_w2s.{k}"], init[(pre, k)].reshape(-1)[idx].cpu().numpy())
+
+
+@pytest.mark.parametrize("name", ["ltn_sht", "stn_sht", "stn_mil_ce"])
+def test_two_emulated_ranks_through_trainstep(name):
+    """The data-parallel composition the N-GPU run executes - TrainStep.forward_loss -> VadLossFunction phase 0 -> bag
+    exchange -> phase 1 -> backward - for the shards of two ranks on ONE device: the other rank's bag is injected through
+    the ``exchange`` hook (what dist.all_reduce delivers), gradients are summed by hand (what the gradient all-reduce
+    delivers).  Sum of the ranks' scalars == the reference's loss; summed gradients == the reference's gradients."""
+    from lstc_vad_amd.engine import TrainStep
+    z, mode, ekw, skw = load_case(name)
+    d, bs = ekw["d_model"], skw["batch_size"]
+    assert bs % 2 == 0
+    nf, af, al = (torch.from_numpy(z[k]).to(DEV) for k in ("norm_feats", "abnorm_feats", "abnorm_labs"))
+    h = bs // 2
+    lskw = dict(skw, batch_size=h)                   # args.batch_size is the rank-local pair count
+    bags, steps = {}, []
+    for r in range(2):
+        enc, head = _models(mode, ekw, d)
+        enc.load_state_dict(sub(z, "enc_init."), strict=True); head.load_state_dict(sub(z, "head_init."), strict=True)
+        enc, head = enc.to(DEV).train(), head.to(DEV).train()
+
+        def exchange(bag, r=r):
+            if r not in bags:                        # first pass: publish this rank's slots
+                bags[r] = bag.clone()
+            else:                                    # second pass: the sum over ranks, as the all-reduce would leave it
+                bag.add_(bags[1 - r])
+        steps.append(TrainStep(_args(mode, lskw), mode, enc, head, 1e-4, 1e-2, 1e-3, loss_rank=(r, 2), loss_exchange=exchange))
+    shard = lambda r: (nf[r * h:(r + 1) * h], af[r * h:(r + 1) * h], al[r * h:(r + 1) * h])
+    with torch.no_grad():
+        for r in range(2):                           # pass 1 only collects the bags
+            steps[r].forward_loss(*shard(r))
+    assert set(bags) == {0, 1} and float((bags[0] * bags[1]).abs().max()) == 0.0     # disjoint slots
+    tot = torch.zeros(5, device=DEV)
+    for r in range(2):
+        loss, sc, _ = steps[r].forward_loss(*shard(r))
+        loss.backward()
+        tot += sc
+    assert np.max(np.abs(tot.cpu().double().numpy() - z["scalars"])) < 2e-5
+    ref_g = dict(sub(z, "enc_grad."))
+    ref_h = sub(z, "head_grad.")
+    for (k, p0), (_, p1) in zip(steps[0].encoder.named_parameters(), steps[1].encoder.named_parameters()):
+        if k in ref_g:
+            g = ref_g[k]
+            assert max_abs_diff(p0.grad + p1.grad, g) < 2e-4 * float(g.abs().max()) + 1e-7, k
+        else:
+            assert p0.grad is None and p1.grad is None
+    for (k, p0), (_, p1) in zip(steps[0].head.named_parameters(), steps[1].head.named_parameters()):
+        g = ref_h[k]
+        assert max_abs_diff(p0.grad + p1.grad, g) < 2e-4 * float(g.abs().max()) + 1e-7, k

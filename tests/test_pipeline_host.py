@@ -181,3 +181,42 @@ def test_utils_import_shim(world):
     assert ul.SH_Train_Origin_Dataset is ds_mod.SH_Train_Origin_Dataset and ul.UCF_test is ds_mod.UCF_test
     assert ue.eval([0.1, 0.9, 0.3], [0, 1, 0], None) == 1.0
     assert uu.get_video_names(world["sht_test"], abnormal=True, normal=False) == [n for n, l, _ in pw.SHT_TEST if l]
+
+
+@pytest.mark.parametrize("name", ["sh_uniform", "sh_random_pseudo", "ubn_uniform"])
+def test_rank_shards_are_disjoint_and_union_is_the_single_process_batch(world, name):
+    """Data parallelism over videos: every rank seeds np.random identically and walks the same permutation
+    and window draws; rank r keeps pairs [r*bs/G, (r+1)*bs/G).  The shards' union must equal the batch one process forms,
+    which in turn is what iterating the dataset item by item gives (the reference's DataLoader order)."""
+    spec = DATASET_CASES[name]
+    bs = 2
+
+    def plans(rank, world_size):
+        np.random.seed(spec["seed"]); random.seed(spec["seed"])
+        ds = build_dataset(ds_mod, spec, world)
+        offs = np.concatenate([[0], np.cumsum([v.shape[0] for v in ds.norm_feats + ds.abnorm_feats])]).astype(np.int64)
+        out = []
+        for epoch in range(2):
+            for b in range(len(ds) // bs):
+                out.append(ds_mod.shard_plan(ds, offs, len(ds.norm_feats), b, bs, rank, world_size))
+            ds.shuffle_keys()
+        return out, ds, offs
+
+    single, ds, offs = plans(0, 1)
+    r0, _, _ = plans(0, 2)
+    r1, _, _ = plans(1, 2)
+    assert len(single) >= 2
+    for (i1, l1), (ia, la), (ib, lb) in zip(single, r0, r1):
+        assert np.array_equal(np.concatenate([ia, ib], 1), i1) and np.array_equal(np.concatenate([la, lb], 1), l1)
+        assert ia.shape[1] == ib.shape[1] == bs // 2
+    # and the single-process plan addresses exactly the clips that __getitem__ returns
+    np.random.seed(spec["seed"]); random.seed(spec["seed"])
+    ds2 = build_dataset(ds_mod, spec, world)
+    bank = np.concatenate([v[:, :ds2.n_patch] if ds2.n_patch != 1 else v for v in ds2.norm_feats + ds2.abnorm_feats], 0)
+    idx, labs = single[0]
+    for j in range(bs):
+        item = ds2[j]
+        assert np.array_equal(bank[idx[0, j]], item[0].numpy()) and np.array_equal(bank[idx[1, j]], item[2].numpy())
+        assert np.array_equal(labs[1, j].reshape(item[3].shape), item[3].numpy())
+    with pytest.raises(ValueError):
+        ds_mod.ResidentPairs(ds2, 3, "cpu", 0, 2)            # 3 pairs do not split over 2 ranks
