@@ -6,7 +6,7 @@ CSRC  := lstc_vad_amd/csrc
 SRCS  := $(wildcard $(CSRC)/*.hip)
 OBJS  := $(SRCS:.hip=.o)
 LIB   := lstc_vad_amd/liblstc_hip.so
-HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -ffp-contract=off
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Werror=return-type -Wno-unused-function -ffp-contract=off $(EXTRA_HIPFLAGS)
 
 all: $(LIB)
 

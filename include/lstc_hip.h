@@ -85,7 +85,9 @@ typedef struct LstcGemmDesc {
                                        into C, which the caller must have zeroed (only alpha epilogue allowed).
                                        LSTC_F32X3 with batch_stride_c != 0: split z writes its partial product to
                                        C + z*batch_stride_c instead (no atomics; the caller sums the partials) */
-    int32_t variant;                /* 0 = library default tile; >0 selects a tile variant (tuning / tests) */
+    int32_t variant;                /* 0 = library default tile; 1..11 select a documented tile variant (tuning / tests);
+                                       anything else -> LSTC_E_UNSUPPORTED.  Timing-only ablation variants exist only in
+                                       -DLSTC_TUNING builds (tools/gemm_check), never in the production library */
     int32_t batch;                  /* 0/1 = single problem; >1: `batch` independent problems of identical shape, problem z
                                        uses A + z*batch_stride_a etc. (elements).  Per-head products of the last layer's
                                        CLS attention (q_h W_k,h etc.).  Only alpha / ACCUM epilogues. */
@@ -99,6 +101,11 @@ typedef struct LstcGemmDesc {
 } LstcGemmDesc;
 
 int lstc_gemm(const LstcGemmDesc* d, void* stream);
+
+/* Number of K slices lstc_gemm actually launches for (dtype, K, split_k): ceil(kt / ceil(kt / split_k)) with kt = K tiles
+ * of that dtype's kernel.  It can be SMALLER than split_k (e.g. 132 K tiles, split_k 16 -> 15 slices of 9 tiles), so a
+ * caller that gives each slice its own partial output (batch_stride_c) must size and sum exactly this many. */
+int32_t lstc_gemm_splits(int32_t dtype, int32_t K, int32_t split_k);
 
 /* Operand packing for LSTC_F32X3.  The tensor is scaled by the power of two s that puts its largest magnitude in
  * [2^14, 2^15) and written as 128-row x 32-k tiles (row = an output row of A's side or an output column of B's side, K = the

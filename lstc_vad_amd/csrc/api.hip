@@ -16,6 +16,15 @@ int lstc_gemm(const LstcGemmDesc* d, void* stream) {
     return LSTC_E_UNSUPPORTED;
 }
 
+int32_t lstc_gemm_splits(int32_t dtype, int32_t K, int32_t split_k) {
+    if (K <= 0) return 0;
+    const int bk = dtype == LSTC_BF16 ? 64 : 32;           // K tile of gemm_bf16c / gemm_f32, gemm_pk (csrc/*.hip: BK, PK tiles)
+    const int s = split_k > 1 ? split_k : 1;
+    const int kt = (K + bk - 1) / bk;
+    const int per = (kt + s - 1) / s;
+    return (kt + per - 1) / per;
+}
+
 int lstc_version(void) { return LSTC_VERSION; }
 
 const char* lstc_strerror(int code) {

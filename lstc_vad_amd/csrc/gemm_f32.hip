@@ -725,11 +725,13 @@ int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipS
                 return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // buffer path: aligned, < 4 GiB operands
         case 10: case 11: if (va && vb && p.K % BK == 0) return launch_cfg<128, 128, 2, 2, 4, A_KC, B_KC>(p, true, true, splits, st);
                  return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // LDS-DMA needs aligned rows, full K tiles
-        case 12: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 1, A_KC, B_KC>(p, va, vb, splits, st); break;
-        case 13: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 3, A_KC, B_KC>(p, va, vb, splits, st); break;
-        case 14: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 7, A_KC, B_KC>(p, va, vb, splits, st); break;
-        case 15: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 4, A_KC, B_KC>(p, va, vb, splits, st); break;
-        default: return launch_cfg<128, 128, 2, 2, 2, A_KC, B_KC>(p, va, vb, splits, st);
+#ifdef LSTC_TUNING      // timing-only ablations: products are WRONG by construction; never in the production library
+        case 12: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 1, A_KC, B_KC>(p, va, vb, splits, st); return LSTC_E_UNSUPPORTED;
+        case 13: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 3, A_KC, B_KC>(p, va, vb, splits, st); return LSTC_E_UNSUPPORTED;
+        case 14: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 7, A_KC, B_KC>(p, va, vb, splits, st); return LSTC_E_UNSUPPORTED;
+        case 15: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 4, A_KC, B_KC>(p, va, vb, splits, st); return LSTC_E_UNSUPPORTED;
+#endif
+        default: return LSTC_E_UNSUPPORTED;
     }
 }
 
@@ -759,7 +761,14 @@ int lstc_gemm_f32_impl(const LstcGemmDesc* d, hipStream_t st) {
     if (p.batch > 65535) return LSTC_E_RANGE;
     p.ktiles = (d->K + BK - 1) / BK;
     p.ktiles_per_split = (p.ktiles + splits - 1) / splits;
-    p.debug = d->variant >> 4;
+#ifdef LSTC_TUNING
+    p.debug = d->variant >> 4;          // tools/gemm_check ablations (no loads / no LDS writes / no barrier): wrong products
+#else
+    // the production library accepts the documented tile variants only: garbage in this public field must not select a
+    // timing ablation or an undefined tile (LstcGemmDesc.variant, include/lstc_hip.h)
+    if (d->variant < 0 || d->variant > 11) return LSTC_E_UNSUPPORTED;
+    p.debug = 0;
+#endif
     const size_t a_ext = ((size_t)((d->transA ? d->K : d->M) - 1) * d->lda + (d->transA ? d->M : d->K)) * sizeof(float) + p.batch_stride_a * sizeof(float) * (size_t)(p.batch - 1) * 0;
     const size_t b_ext = ((size_t)((d->transB ? d->N : d->K) - 1) * d->ldb + (d->transB ? d->K : d->N)) * sizeof(float);
     const bool fits32 = a_ext < 0xffffffffull && b_ext < 0xffffffffull;

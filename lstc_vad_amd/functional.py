@@ -208,7 +208,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
     parts = None
     if out is None:
         if split_k > 1 and dtype == _lib.F32X3 and _DETERMINISTIC_WGRAD:
-            # K splits of the packed kernel into separate partials, summed in a fixed order afterwards (no atomics)
+            # K splits of the packed kernel into separate partials, summed in a fixed order afterwards (no atomics).  The
+            # library launches lstc_gemm_splits() slices, possibly fewer than asked for: size and sum exactly that many
+            split_k = int(_lib.load().lstc_gemm_splits(dtype, K, split_k))
             parts = torch.empty((split_k, M * N), device=dev, dtype=torch.float32)
             out = parts[0].view(M, N)
         else:
@@ -295,7 +297,10 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, x_pack: Optional[Packed] = None) ->
             (x_pack is not None or (min(O, I) >= _x3_min[0] and T >= _x3_min[1] and T * O * I >= _x3_min[2])):
         ap = _packed_operand(dy, False)
         bp = x_pack if x_pack is not None else _packed_operand(x, False)
-        # K splits write separate partials that lstc_colsum adds in a fixed order (no atomics: bit-reproducible)
+        # K splits write separate partials that lstc_colsum adds in a fixed order (no atomics: bit-reproducible).  The
+        # library may launch fewer slices than asked for (132 K tiles / 16 -> 15 slices): allocate and sum exactly those,
+        # an extra row would add uninitialised memory into the gradient
+        s = int(_lib.load().lstc_gemm_splits(_lib.F32X3, T, s))
         det = s > 1 and _DETERMINISTIC_WGRAD
         out = torch.empty((s, O * I), device=dy.device, dtype=torch.float32) if (det or s == 1) else \
             torch.zeros((1, O * I), device=dy.device, dtype=torch.float32)
