@@ -19,7 +19,18 @@ $(LIB): $(OBJS)
 tools/gemm_check: tools/gemm_check.cpp $(LIB)
 	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude $< -o $@ -Llstc_vad_amd -llstc_hip -Wl,-rpath,'$$ORIGIN/../lstc_vad_amd'
 
+# tuning build (timing ablations compiled in; NEVER the product): tools/tuning/liblstc_hip.so + tools/tuning/gemm_check
+TOBJS := $(patsubst $(CSRC)/%.hip,tools/tuning/%.o,$(SRCS))
+tools/tuning/%.o: $(CSRC)/%.hip $(CSRC)/lstc_common.h include/lstc_hip.h
+	@mkdir -p tools/tuning
+	$(HIPCC) $(HIPFLAGS) -DLSTC_TUNING -c $< -o $@
+tools/tuning/liblstc_hip.so: $(TOBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(TOBJS)
+tools/tuning/gemm_check: tools/gemm_check.cpp tools/tuning/liblstc_hip.so
+	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude $< -o $@ -Ltools/tuning -llstc_hip -Wl,-rpath,'$$ORIGIN'
+tuning: tools/tuning/gemm_check
+
 clean:
 	rm -f $(OBJS) $(LIB) tools/gemm_check
 
-.PHONY: all clean
+.PHONY: all clean tuning

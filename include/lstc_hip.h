@@ -38,7 +38,7 @@ enum {
     LSTC_E_RANGE = -5               /* size exceeds a documented limit (e.g. sequence length, 32-bit indexing) */
 };
 
-enum { LSTC_F32 = 0, LSTC_BF16 = 1, LSTC_F32X3 = 2 };
+enum { LSTC_F32 = 0, LSTC_BF16 = 1, LSTC_F32X3 = 2, LSTC_BF16P = 3 };
 
 /* ----------------------------------------------------------------------------- GEMM
  * C[M,N] = epilogue( alpha * op(A)[M,K] * op(B)[K,N] )
@@ -64,6 +64,10 @@ enum { LSTC_F32 = 0, LSTC_BF16 = 1, LSTC_F32X3 = 2 };
  *   sources on the way).  (1, 0): packs of the k-major SOURCES [K,M] and [K,N] themselves - the weight-gradient product
  *   dY^T X reuses the packs the forward / input-gradient products made of X and dY; needs M, N, K multiples of 128.
  *   C, bias, residual, relu_src and the epilogue are f32 exactly as for LSTC_F32; no batch.
+ * dtype LSTC_BF16P: the LSTC_BF16 arithmetic (operands rounded to bf16 RNE, f32 accumulate, f32 C / epilogue) on PACKED bf16
+ *   operands produced by lstc_pack1 (lda/ldb ignored): 2 B per element through L2/LDS instead of 4, streamed by LDS-DMA into
+ *   a 256x256x64-tile kernel (csrc/gemm_bf16p.hip).  (0, 1): packs of [M,K] and [N,K];  (1, 0): packs of the k-major SOURCES
+ *   [K,M] and [K,N] (weight gradient dY^T X reusing the packs of dY and X; K must be a multiple of 128).  No batch.
  */
 enum {
     LSTC_EPI_BIAS = 1, LSTC_EPI_RELU = 2, LSTC_EPI_DROPOUT = 4, LSTC_EPI_RESIDUAL = 8,
@@ -118,6 +122,13 @@ int32_t lstc_gemm_splits(int32_t dtype, int32_t K, int32_t split_k);
  * dst needs lstc_pack3_bytes(rows, K) bytes, 16-B aligned.  The same nn.Linear products as lstc_gemm (see above). */
 int64_t lstc_pack3_bytes(int64_t rows, int64_t K);
 int lstc_pack3(const float* src, int64_t rows, int64_t K, int64_t ld, int32_t k_major, void* dst, void* stream);
+
+/* Operand packing for LSTC_BF16P: the logical [rows, K] operand rounded to bf16 (RNE) and stored as 128-row x 32-k tiles,
+ * each tile the 8-KB LDS image the GEMM reads (64-B rows, 16-B chunk index XOR (row >> 2) & 3); rows and K are zero-padded
+ * to an EVEN number of tiles each way.  k_major as for lstc_pack3.  One launch.  dst needs lstc_pack1_bytes(rows, K) bytes,
+ * 16-B aligned.  Same nn.Linear products as lstc_gemm (models/MultiHeadAttention.py:97-99,123; models/FFN.py:17). */
+int64_t lstc_pack1_bytes(int64_t rows, int64_t K);
+int lstc_pack1(const float* src, int64_t rows, int64_t K, int64_t ld, int32_t k_major, void* dst, void* stream);
 
 /* ------------------------------------------------------------------------ attention
  * Fused core of models/MultiHeadAttention.py:103-122 for one layer, all sequences, heads:

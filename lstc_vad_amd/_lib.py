@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported first so its libamdhip64.so.7 is t
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblstc_hip.so")
 
-F32, BF16, F32X3 = 0, 1, 2
+F32, BF16, F32X3, BF16P = 0, 1, 2, 3
 EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_RESIDUAL, EPI_RELU_MASK, EPI_ACCUM, EPI_OUT_F32 = 1, 2, 4, 8, 16, 32, 64
 
 EXPORTS = (
@@ -22,7 +22,7 @@ EXPORTS = (
     "lstc_cls_outer", "lstc_layernorm_fwd", "lstc_layernorm_bwd",
     "lstc_cls_concat_fwd", "lstc_cls_concat_bwd", "lstc_colsum", "lstc_dropout_apply", "lstc_dropout_mask",
     "lstc_head_out_fwd", "lstc_head_out_bwd", "lstc_vad_loss", "lstc_adagrad_step", "lstc_sqnorm_accum", "lstc_scale",
-    "lstc_gather_rows", "lstc_pack3", "lstc_pack3_bytes", "lstc_gemm_splits",
+    "lstc_gather_rows", "lstc_pack3", "lstc_pack3_bytes", "lstc_pack1", "lstc_pack1_bytes", "lstc_gemm_splits",
     "lstc_version", "lstc_strerror",
 )
 
@@ -98,6 +98,8 @@ def load():
         "lstc_gather_rows": [vp, i64, vp, vp, i64, i64, vp],
         "lstc_pack3": [vp, i64, i64, i64, C.c_int32, vp, vp],
         "lstc_pack3_bytes": [i64, i64],
+        "lstc_pack1": [vp, i64, i64, i64, C.c_int32, vp, vp],
+        "lstc_pack1_bytes": [i64, i64],
         "lstc_gemm_splits": [i32, i32, i32],
         "lstc_version": [],
     }
@@ -106,6 +108,7 @@ def load():
         fn.argtypes = args
         fn.restype = C.c_int
     lib.lstc_pack3_bytes.restype = C.c_int64
+    lib.lstc_pack1_bytes.restype = C.c_int64
     lib.lstc_strerror.argtypes = [C.c_int]
     lib.lstc_strerror.restype = C.c_char_p
     _lib = lib

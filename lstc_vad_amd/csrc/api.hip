@@ -4,6 +4,7 @@
 int lstc_gemm_f32_impl(const LstcGemmDesc* d, hipStream_t st);
 int lstc_gemm_bf16_impl(const LstcGemmDesc* d, hipStream_t st) __attribute__((weak));
 int lstc_gemm_f32x3_impl(const LstcGemmDesc* d, hipStream_t st);
+int lstc_gemm_bf16p_impl(const LstcGemmDesc* d, hipStream_t st);
 
 extern "C" {
 
@@ -13,12 +14,13 @@ int lstc_gemm(const LstcGemmDesc* d, void* stream) {
     if (d->dtype == LSTC_F32) return lstc_gemm_f32_impl(d, st);
     if (d->dtype == LSTC_BF16 && lstc_gemm_bf16_impl) return lstc_gemm_bf16_impl(d, st);
     if (d->dtype == LSTC_F32X3) return lstc_gemm_f32x3_impl(d, st);
+    if (d->dtype == LSTC_BF16P) return lstc_gemm_bf16p_impl(d, st);
     return LSTC_E_UNSUPPORTED;
 }
 
 int32_t lstc_gemm_splits(int32_t dtype, int32_t K, int32_t split_k) {
     if (K <= 0) return 0;
-    const int bk = dtype == LSTC_BF16 ? 64 : 32;           // K tile of gemm_bf16c / gemm_f32, gemm_pk (csrc/*.hip: BK, PK tiles)
+    const int bk = (dtype == LSTC_BF16 || dtype == LSTC_BF16P) ? 64 : 32;   // K tile of gemm_bf16c, gemm_bf16p / gemm_f32, gemm_pk
     const int s = split_k > 1 ? split_k : 1;
     const int kt = (K + bk - 1) / bk;
     const int per = (kt + s - 1) / s;

@@ -66,8 +66,10 @@ _compute_dtype = F32      # LstcGemmDesc.dtype used by every GEMM: F32 = exact f
 def set_compute_dtype(name: str):
     """"fp32" (default; exact-f32 MFMA, the parity mode), "f32x3" (f32-accurate products on the 16-bit matrix cores: every
     operand scaled by a power of two and split into two f16 planes, three plane products, f32 accumulation -
-    csrc/gemm_pk.hip; small GEMMs stay on the exact-f32 kernel) or "bf16" (operands rounded to bf16 inside the GEMM, f32 accumulate and f32 storage everywhere:
-    BASELINE.json configs 3 / 5).  Attention, LayerNorm, loss and Adagrad stay f32."""
+    csrc/gemm_pk.hip; small GEMMs stay on the exact-f32 kernel) or "bf16" (operands rounded to bf16 RNE, f32 accumulate and
+    f32 storage everywhere: BASELINE.json configs 3 / 5; large products run on packed bf16 tiles - lstc_pack1 +
+    csrc/gemm_bf16p.hip - small or batched ones convert while staging, csrc/gemm_bf16c.hip).  Attention, LayerNorm, loss and
+    Adagrad stay f32."""
     global _compute_dtype
     if name in ("fp32", "f32", "float32"):
         _compute_dtype = F32
@@ -85,11 +87,21 @@ def get_compute_dtype() -> str:
 
 # ---- packed operands of the f32x3 GEMM (csrc/gemm_pk.hip) ------------------------------------------------------------
 class Packed:
-    """An operand as lstc_pack3 leaves it: logical [rows, K], two f16 planes in the GEMM's LDS-image tiling + scale."""
-    __slots__ = ("buf", "rows", "K")
+    """An operand as lstc_pack3 / lstc_pack1 leave it: logical [rows, K] in the GEMM's LDS-image tiling (``kind`` F32X3: two
+    scaled f16 planes + scale trailer; BF16P: one bf16 plane)."""
+    __slots__ = ("buf", "rows", "K", "kind")
 
-    def __init__(self, buf, rows, K):
-        self.buf, self.rows, self.K = buf, rows, K
+    def __init__(self, buf, rows, K, kind):
+        self.buf, self.rows, self.K, self.kind = buf, rows, K, kind
+
+
+def _packed_kind():
+    """GEMM dtype code of the packed-operand kernel of the current compute mode (None in exact-f32 mode)."""
+    if _compute_dtype == _lib.F32X3:
+        return _lib.F32X3
+    if _compute_dtype == _lib.BF16:
+        return _lib.BF16P
+    return None
 
 
 _pack_prof = None          # list of (bytes_in, start_event, end_event) while bench.py profiles
@@ -124,21 +136,25 @@ class pack_memo:
         return False
 
 
-def pack3(t: torch.Tensor, k_major: bool = False) -> Packed:
-    """Pack a 2-D f32 operand for the f32x3 GEMM.  ``k_major`` = the contraction runs along dim 0 of ``t``."""
+def pack3(t: torch.Tensor, k_major: bool = False, kind=None) -> Packed:
+    """Pack a 2-D f32 operand for the packed-operand GEMM of the current mode (f32x3: lstc_pack3, bf16: lstc_pack1).
+    ``k_major`` = the contraction runs along dim 0 of ``t``."""
+    kind = _packed_kind() if kind is None else kind
     pt, r, c, ld = _mat(t)
     rows, K = (c, r) if k_major else (r, c)
     lib = _lib.load()
-    buf = torch.empty((int(lib.lstc_pack3_bytes(rows, K)),), device=t.device, dtype=torch.uint8)
+    nbytes, fn, name = (lib.lstc_pack3_bytes, lib.lstc_pack3, "lstc_pack3") if kind == _lib.F32X3 else \
+        (lib.lstc_pack1_bytes, lib.lstc_pack1, "lstc_pack1")
+    buf = torch.empty((int(nbytes(rows, K)),), device=t.device, dtype=torch.uint8)
     if _pack_prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(lib.lstc_pack3(pt, rows, K, ld, int(k_major), dev_ptr(buf), stream_ptr()), "lstc_pack3")
+        check(fn(pt, rows, K, ld, int(k_major), dev_ptr(buf), stream_ptr()), name)
         e1.record()
         _pack_prof.append((4.0 * rows * K, e0, e1))
     else:
-        check(lib.lstc_pack3(pt, rows, K, ld, int(k_major), dev_ptr(buf), stream_ptr()), "lstc_pack3")
-    return Packed(buf, rows, K)
+        check(fn(pt, rows, K, ld, int(k_major), dev_ptr(buf), stream_ptr()), name)
+    return Packed(buf, rows, K, kind)
 
 
 def _packed_operand(t, k_major):
@@ -148,14 +164,15 @@ def _packed_operand(t, k_major):
         # cached ON the parameter object (a key built from data_ptr would outlive the tensor and hand a stale pack to the
         # next model that lands on the same address); autograd returns the same object from ctx.saved_tensors for leaves
         cache = t.__dict__.setdefault("_lstc_packs", {})
-        hit = cache.get(k_major)
+        ck = (k_major, _packed_kind())
+        hit = cache.get(ck)
         if hit is not None and hit[0] == _wepoch and hit[1] == t._version and hit[3] == t.data_ptr():
             return hit[2]
         pk = pack3(t.detach(), k_major)
-        cache[k_major] = (_wepoch, t._version, pk, t.data_ptr())
+        cache[ck] = (_wepoch, t._version, pk, t.data_ptr())
         return pk
     if _memo_stack:
-        key = (t.data_ptr(), tuple(t.shape), t.stride(), k_major)
+        key = (t.data_ptr(), tuple(t.shape), t.stride(), k_major, _packed_kind())
         hit = _memo_stack[-1].get(key)
         if hit is None:
             hit = _memo_stack[-1][key] = pack3(t, k_major)
@@ -197,17 +214,21 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
     if K != Kb:
         raise RuntimeError(f"gemm inner dims differ: {K} vs {Kb}")
     dtype = _compute_dtype
-    if dtype == _lib.F32X3:
-        # small products (heads of 512 / 32 columns, the CLS-only last layer) stay on the exact-f32 kernel
+    pkind = _packed_kind()
+    packed = False
+    if pkind is not None:
+        # small products (heads of 512 / 32 columns, the CLS-only last layer) stay on the exact-f32 kernel (f32x3 mode) or on
+        # the convert-while-staging bf16 kernel (bf16 mode)
         if isinstance(a, Packed) or isinstance(b, Packed) or (min(M, N) >= _x3_min[0] and K >= _x3_min[1] and M * N * K >= _x3_min[2]):
             a = _packed_operand(a, trans_a)
             b = _packed_operand(b, not trans_b)
             pa, pb = dev_ptr(a.buf), dev_ptr(b.buf)
-        else:
+            dtype, packed = pkind, True
+        elif dtype == _lib.F32X3:
             dtype = F32
     parts = None
     if out is None:
-        if split_k > 1 and dtype == _lib.F32X3 and _DETERMINISTIC_WGRAD:
+        if split_k > 1 and packed and _DETERMINISTIC_WGRAD:
             # K splits of the packed kernel into separate partials, summed in a fixed order afterwards (no atomics).  The
             # library launches lstc_gemm_splits() slices, possibly fewer than asked for: size and sum exactly that many
             split_k = int(_lib.load().lstc_gemm_splits(dtype, K, split_k))
@@ -245,7 +266,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
         flags |= EPI_ACCUM
     d.flags, d.alpha, d.split_k, d.variant = flags, float(alpha), int(split_k), int(variant)
     d.A, d.B, d.C = pa, pb, pc
-    if dtype == _lib.F32X3:
+    if packed:
         d.transA, d.transB = 0, 1              # packs of [M, K] and [N, K]
         if parts is not None:
             d.batch_stride_c = M * N
@@ -269,17 +290,17 @@ def _launch_gemm(d, flops):
 def maybe_pack(t: torch.Tensor):
     """Packed form of an activation [rows, K] when f32x3 mode would route its products to the packed kernel, else None.
     Lets a forward body pack X once, feed several GEMMs and keep the pack for the weight gradient of the backward."""
-    if _compute_dtype != _lib.F32X3 or t.shape[0] < max(_x3_min[0], 1) or t.shape[1] < _x3_min[1]:
+    if _packed_kind() is None or t.shape[0] < max(_x3_min[0], 1) or t.shape[1] < _x3_min[1]:
         return None
     if t.shape[0] * t.shape[1] * max(_x3_min[0], 1) < _x3_min[2]:
         return None
     return _packed_operand(t, False)
 
 
-def _wgrad_split(m_out: int, n_out: int) -> int:
+def _wgrad_split(m_out: int, n_out: int, tile: int = 128) -> int:
     """Split-K factor for weight gradients: K = token count is huge and the output small, so the K range is
-    split until the grid has >= ~2 workgroups per CU (256 CUs, 128x128 tiles)."""
-    tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
+    split until the grid has >= ~2 workgroups per CU (256 CUs; 128x128 tiles, 256x256 for the packed bf16 kernel)."""
+    tiles = ((m_out + tile - 1) // tile) * ((n_out + tile - 1) // tile)
     s = 1
     while tiles * s < 512 and s < 16:
         s *= 2
@@ -292,26 +313,31 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, x_pack: Optional[Packed] = None) ->
     packs are reused through the transposed-read form of the packed kernel (``x_pack`` = the forward's pack of ``x``)."""
     T, O = dy.shape
     I = x.shape[1]
-    s = _wgrad_split(O, I) if T >= 4096 else 1
-    if _compute_dtype == _lib.F32X3 and T % 128 == 0 and O % 128 == 0 and I % 128 == 0 and \
+    pkind = _packed_kind()
+    # split-K factor: 256x256 output tiles on the packed bf16 kernel, 128x128 everywhere else
+    s = _wgrad_split(O, I, 256 if pkind == _lib.BF16P else 128) if T >= 4096 else 1
+    tr_ok = T % 128 == 0 and (pkind == _lib.BF16P or (O % 128 == 0 and I % 128 == 0))
+    if pkind is not None and tr_ok and \
             (x_pack is not None or (min(O, I) >= _x3_min[0] and T >= _x3_min[1] and T * O * I >= _x3_min[2])):
         ap = _packed_operand(dy, False)
         bp = x_pack if x_pack is not None else _packed_operand(x, False)
         # K splits write separate partials that lstc_colsum adds in a fixed order (no atomics: bit-reproducible).  The
         # library may launch fewer slices than asked for (132 K tiles / 16 -> 15 slices): allocate and sum exactly those,
         # an extra row would add uninitialised memory into the gradient
-        s = int(_lib.load().lstc_gemm_splits(_lib.F32X3, T, s))
+        s = int(_lib.load().lstc_gemm_splits(pkind, T, s))
         det = s > 1 and _DETERMINISTIC_WGRAD
         out = torch.empty((s, O * I), device=dy.device, dtype=torch.float32) if (det or s == 1) else \
             torch.zeros((1, O * I), device=dy.device, dtype=torch.float32)
         d = GemmDesc()
         d.M, d.N, d.K, d.lda, d.ldb, d.ldc = O, I, T, O, I, I
-        d.transA, d.transB, d.dtype, d.flags, d.alpha, d.split_k = 1, 0, _lib.F32X3, 0, 1.0, s
+        d.transA, d.transB, d.dtype, d.flags, d.alpha, d.split_k = 1, 0, pkind, 0, 1.0, s
         d.batch_stride_c = O * I if (s > 1 and _DETERMINISTIC_WGRAD) else 0
         d.A, d.B, d.C = dev_ptr(ap.buf), dev_ptr(bp.buf), dev_ptr(out)
         _launch_gemm(d, 2.0 * O * I * T)
         return (colsum(out) if det else out).view(O, I)
-    x3_big = _compute_dtype == _lib.F32X3 and min(O, I) >= _x3_min[0] and T >= _x3_min[1] and T * O * I >= _x3_min[2]
+    x3_big = pkind is not None and min(O, I) >= _x3_min[0] and T >= _x3_min[1] and T * O * I >= _x3_min[2]
+    if pkind == _lib.BF16P and not x3_big:
+        s = _wgrad_split(O, I, 128) if T >= 4096 else 1       # not a packed product after all: 128x128-tile kernel
     if s > 1 and (_compute_dtype == F32 or (_compute_dtype == _lib.F32X3 and not x3_big)) and _DETERMINISTIC_WGRAD and \
             T % s == 0 and dy.stride(1) == 1 and x.stride(1) == 1:
         # exact-f32 kernel (also the small products of f32x3 mode): the s K-chunks are ONE batched launch into [s, O, I] partials, summed in a fixed order by

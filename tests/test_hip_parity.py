@@ -867,3 +867,102 @@ def test_two_emulated_ranks_through_trainstep(name):
     for (k, p0), (_, p1) in zip(steps[0].head.named_parameters(), steps[1].head.named_parameters()):
         g = ref_h[k]
         assert max_abs_diff(p0.grad + p1.grad, g) < 2e-4 * float(g.abs().max()) + 1e-7, k
+
+
+def test_gemm_check_tool_shape_list_against_f64_host_products():
+    """tools/gemm_check (standalone C++ harness over the C ABI, no torch): every GEMM kernel family - exact f32 in all tile
+    variants and layouts, bf16c, f32x3 (NT / TR / split-K), bf16p (NT / TR / ragged / split-K) - on odd shapes, every
+    epilogue flag, against a double-precision host product; C padding columns must stay untouched."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gemm_check")
+    if not os.path.exists(exe):
+        pytest.fail("tools/gemm_check is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([exe, "check"], capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith(("PASS", "FAIL"))]
+    assert len(lines) > 100 and not [l for l in lines if l.startswith("FAIL")], "\n".join(l for l in lines if l.startswith("FAIL"))
+    assert "ALL PASS" in r.stdout and r.returncode == 0, r.stdout[-2000:]
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("shape", [(4224, 512, 512), (1000, 300, 260), (6272, 2048, 2048)])
+def test_bf16p_gemm_forms_match_bf16_rounded_reference(shape):
+    """The packed bf16 GEMM (lstc_pack1 + gemm_bf16p_kernel) through functional.gemm / wgrad in bf16 mode: forward X W^T with
+    bias+ReLU, input gradient dY W, weight gradient dY^T X (TR form with split-K partials; T = 4224 gives 66 K steps that
+    do not divide by 16 - the partial-row case of ADVICE r1) against f64 products of the bf16-rounded operands."""
+    from lstc_vad_amd import functional as Fn
+    T, O, I = shape
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(T, I, device=DEV, generator=g)
+    w = torch.randn(O, I, device=DEV, generator=g) * 0.05
+    b = torch.randn(O, device=DEV, generator=g)
+    dy = torch.randn(T, O, device=DEV, generator=g)
+    xr, wr, dyr = _bf16_round(x).double(), _bf16_round(w).double(), _bf16_round(dy).double()
+    Fn.set_compute_dtype("bf16"); Fn.set_x3_threshold(0, 0, 0)
+    try:
+        with Fn.pack_memo():
+            y = Fn.gemm(x, w, trans_b=True, bias=b, relu=True)
+            dx = Fn.gemm(dy, w)
+            dw = Fn.wgrad(dy, x)
+        torch.cuda.synchronize()
+    finally:
+        Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
+    tol = 3e-5 * (I ** 0.5)
+    assert max_abs_diff(y, torch.relu(xr @ wr.T + b.double())) < tol
+    assert max_abs_diff(dx, dyr @ wr) < 3e-5 * (O ** 0.5) * 0.2
+    ref_dw = dyr.T @ xr
+    assert max_abs_diff(dw, ref_dw) < 3e-5 * (T ** 0.5) * 4
+
+
+@pytest.mark.parametrize("T", [4224, 4736])
+def test_f32x3_wgrad_with_uneven_k_splits(T):
+    """T = 4224 tokens (132 K tiles) with split 16 launches 15 slices; the partial buffer must hold exactly the
+    launched slices (lstc_gemm_splits), not the requested count."""
+    from lstc_vad_amd import functional as Fn
+    g = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.randn(T, 512, device=DEV, generator=g)
+    dy = torch.randn(T, 512, device=DEV, generator=g)
+    junk = torch.full((64, 512 * 512), float("nan"), device=DEV)      # poison the allocator's free list
+    del junk
+    Fn.set_compute_dtype("f32x3"); Fn.set_x3_threshold(0, 0, 0)
+    try:
+        with Fn.pack_memo():
+            dw = Fn.wgrad(dy, x)
+        torch.cuda.synchronize()
+    finally:
+        Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
+    ref = dy.double().T @ x.double()
+    assert torch.isfinite(dw).all()
+    assert max_abs_diff(dw, ref) < 2e-4 * (T ** 0.5) * 0.05
+
+
+@pytest.mark.parametrize("name", ["ltn_full", "stn_full"])
+def test_full_width_bf16_step_tracks_reference(name):
+    """bf16 GEMM mode (packed bf16 kernel on every large product incl. TR weight gradients, bf16c on the heads) at BASELINE
+    widths against the reference's fp32 run: scores within 2e-2, loss within 2e-2, every large gradient tensor's direction
+    (cosine on the sampled entries) > 0.98."""
+    from cases import sample_index
+    from lstc_vad_amd import functional as Fn
+    z, mode, skw, d, enc, head, nf, af, al = _full_width_models(name)
+    enc, head = enc.to(DEV).train(), head.to(DEV).train()
+    args = _args(mode, skw)
+    nf, af, al = (torch.from_numpy(x).to(DEV) for x in (nf, af, al))
+    Fn.set_compute_dtype("bf16")
+    try:
+        enc_out, outputs, loss, sc = _step(enc, head, mode, args, nf, af, al, d, cls_only=True)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        Fn.set_compute_dtype("fp32")
+    assert max_abs_diff(outputs.reshape(z["outputs"].shape), z["outputs"]) < 2e-2
+    assert abs(float(sc[0]) - float(z["scalars"][0])) < 2e-2
+    for k, p in enc.named_parameters():
+        if p.grad is None or p.numel() < 4096 or float(z[f"enc_gnorm.{k}"]) == 0.0:
+            continue
+        gs = torch.from_numpy(z[f"enc_gs.{k}"]).double()
+        got = p.grad.detach().reshape(-1)[torch.from_numpy(sample_index(p.numel())).to(DEV)].cpu().double()
+        cos = float((got * gs).sum() / (got.norm() * gs.norm() + 1e-30))
+        assert cos > 0.98, (k, cos)
+        assert abs(float(p.grad.double().norm()) / float(z[f"enc_gnorm.{k}"]) - 1.0) < 0.05, k

@@ -1,6 +1,7 @@
 // Standalone check + timing harness for lstc_gemm (links liblstc_hip.so, no torch).
 //   tools/gemm_check            correctness on odd shapes (vs a double-precision host reference) + timing table
 //   tools/gemm_check time       timing only
+//   tools/gemm_check check      correctness only (tests/test_hip_parity.py runs this as a -m gpu test)
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -51,17 +52,23 @@ static int check(const Case& c) {
     d.dtype = c.dtype; d.flags = c.flags; d.alpha = 0.75f; d.dropout_p = 0.f; d.ldr = ldr; d.ld_relu = ldm;
     d.split_k = c.split; d.variant = c.variant; d.A = dA; d.B = dB; d.C = dC; d.bias = dbias; d.residual = dres; d.relu_src = dmask;
     void *pA = nullptr, *pB = nullptr;
-    if (c.dtype == LSTC_F32X3) {     // operands go through lstc_pack3: A as [M, K], B as [N, K]
-        CK(hipMalloc(&pA, lstc_pack3_bytes(M, K))); CK(hipMalloc(&pB, lstc_pack3_bytes(N, K)));
+    const bool p1 = c.dtype == LSTC_BF16P;
+    auto packf = [&](const float* s_, int64_t r_, int64_t k_, int64_t ld_, int km_, void* d_) {
+        return p1 ? lstc_pack1(s_, r_, k_, ld_, km_, d_, nullptr) : lstc_pack3(s_, r_, k_, ld_, km_, d_, nullptr); };
+    auto packb = [&](int64_t r_, int64_t k_) { return p1 ? lstc_pack1_bytes(r_, k_) : lstc_pack3_bytes(r_, k_); };
+    if (c.dtype == LSTC_F32X3 || p1) {     // operands go through lstc_pack3 / lstc_pack1: A as [M, K], B as [N, K]
+        const bool trc = c.variant >= 7 && c.variant <= 9;
+        CK(hipMalloc(&pA, trc ? packb(K, M) : packb(M, K))); CK(hipMalloc(&pB, trc ? packb(K, N) : packb(N, K)));
+        CK(hipMemset(pA, 0xff, trc ? packb(K, M) : packb(M, K))); CK(hipMemset(pB, 0xff, trc ? packb(K, N) : packb(N, K)));   // NaN-fill: padding must be written by the pack
         int r1, r2;
         if (c.variant >= 7 && c.variant <= 9) {            // weight-gradient form (7: three-stage kernel, 8: 256x128-tile kernel, 9: two-stage kernel): packs of the SOURCES [K, M], [K, N] + transposed reads
-            r1 = lstc_pack3(dA, K, M, lda, 0, pA, nullptr); r2 = lstc_pack3(dB, K, N, ldb, 0, pB, nullptr);
-            d.transA = 1; d.transB = 0; d.variant = c.variant == 8 ? 2 : c.variant == 9 ? 3 : 1;   /* 7 -> three-stage kernel */
+            r1 = packf(dA, K, M, lda, 0, pA); r2 = packf(dB, K, N, ldb, 0, pB);
+            d.transA = 1; d.transB = 0; d.variant = p1 ? 0 : c.variant == 8 ? 2 : c.variant == 9 ? 3 : 1;   /* 7 -> three-stage kernel */
         } else {
-            r1 = lstc_pack3(dA, M, K, lda, c.tA ? 1 : 0, pA, nullptr); r2 = lstc_pack3(dB, N, K, ldb, c.tB ? 0 : 1, pB, nullptr);
-            d.transA = 0; d.transB = 1;
+            r1 = packf(dA, M, K, lda, c.tA ? 1 : 0, pA); r2 = packf(dB, N, K, ldb, c.tB ? 0 : 1, pB);
+            d.transA = 0; d.transB = 1; if (p1) d.variant = 0;
         }
-        if (r1 || r2) { printf("lstc_pack3 rc=%d/%d\n", r1, r2); return 1; }
+        if (r1 || r2) { printf("lstc_pack rc=%d/%d\n", r1, r2); return 1; }
         d.A = pA; d.B = pB;
     }
     int rc = lstc_gemm(&d, nullptr);
@@ -76,7 +83,7 @@ static int check(const Case& c) {
             for (int k = 0; k < K; ++k) {
                 float af = c.tA ? hA[(size_t)k * lda + m] : hA[(size_t)m * lda + k];
                 float bf = c.tB ? hB[(size_t)n * ldb + k] : hB[(size_t)k * ldb + n];
-                if (c.dtype == LSTC_BF16) { af = bf16_round(af); bf = bf16_round(bf); }
+                if (c.dtype == LSTC_BF16 || c.dtype == LSTC_BF16P) { af = bf16_round(af); bf = bf16_round(bf); }
                 s += (double)af * (double)bf;
             }
             double v = s * 0.75;
@@ -98,7 +105,7 @@ static int check(const Case& c) {
     if (pA) hipFree(pA);
     if (pB) hipFree(pB);
     printf("%s %s M=%d N=%d K=%d tA=%d tB=%d flags=%d var=%d split=%d maxerr=%.3g pad_ok=%d\n", ok ? "PASS" : "FAIL",
-           c.dtype == LSTC_F32X3 ? "f32x3" : c.dtype ? "bf16c" : "f32", M, N, K, c.tA, c.tB, c.flags, c.variant, c.split, maxerr, (int)pad_ok);
+           c.dtype == LSTC_F32X3 ? "f32x3" : c.dtype == LSTC_BF16P ? "bf16p" : c.dtype ? "bf16c" : "f32", M, N, K, c.tA, c.tB, c.flags, c.variant, c.split, maxerr, (int)pad_ok);
     hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dbias); hipFree(dres); hipFree(dmask);
     return ok ? 0 : 1;
 }
@@ -121,22 +128,27 @@ static void timeit(int M, int N, int K, int tA, int tB, int variant, int split, 
     d.residual = dC; d.ldr = N; d.dropout_p = 0.1f; d.dropout_seed = 5;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     void *pA = nullptr, *pB = nullptr;
-    if (dtype == LSTC_F32X3) {
-        CK(hipMalloc(&pA, lstc_pack3_bytes(M, K))); CK(hipMalloc(&pB, lstc_pack3_bytes(N, K)));
+    const bool p1 = dtype == LSTC_BF16P;
+    auto packf = [&](const float* s_, int64_t r_, int64_t k_, int64_t ld_, int km_, void* d_) {
+        return p1 ? lstc_pack1(s_, r_, k_, ld_, km_, d_, nullptr) : lstc_pack3(s_, r_, k_, ld_, km_, d_, nullptr); };
+    if (dtype == LSTC_F32X3 || p1) {
+        const bool trc = variant >= 7 && variant <= 9;
+        CK(hipMalloc(&pA, p1 ? (trc ? lstc_pack1_bytes(K, M) : lstc_pack1_bytes(M, K)) : lstc_pack3_bytes(M, K)));
+        CK(hipMalloc(&pB, p1 ? (trc ? lstc_pack1_bytes(K, N) : lstc_pack1_bytes(N, K)) : lstc_pack3_bytes(N, K)));
         for (int rep = 0; rep < 2; ++rep) {
             CK(hipEventRecord(e0, nullptr));
-            if (variant >= 7 && variant <= 9) lstc_pack3(dA, K, M, lda, 0, pA, nullptr); else lstc_pack3(dA, M, K, lda, tA ? 1 : 0, pA, nullptr);
+            if (variant >= 7 && variant <= 9) packf(dA, K, M, lda, 0, pA); else packf(dA, M, K, lda, tA ? 1 : 0, pA);
             CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
             float msa; CK(hipEventElapsedTime(&msa, e0, e1));
             CK(hipEventRecord(e0, nullptr));
-            if (variant >= 7 && variant <= 9) lstc_pack3(dB, K, N, ldb, 0, pB, nullptr); else lstc_pack3(dB, N, K, ldb, tB ? 0 : 1, pB, nullptr);
+            if (variant >= 7 && variant <= 9) packf(dB, K, N, ldb, 0, pB); else packf(dB, N, K, ldb, tB ? 0 : 1, pB);
             CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
             float msb; CK(hipEventElapsedTime(&msb, e0, e1));
-            if (rep) printf("PACK A [%d x %d]%s %.3f ms (%.2f TB/s: absmax read + pack read + write)   B [%d x %d]%s %.3f ms\n", M, K, tA ? " k-major" : "", msa,
-                            12.0 * M * K / (msa * 1e-3) / 1e12, N, K, tB ? "" : " k-major", msb);
+            if (rep) printf("PACK A [%d x %d]%s %.3f ms (%.2f TB/s read + write)   B [%d x %d]%s %.3f ms\n", M, K, tA ? " k-major" : "", msa,
+                            (p1 ? 6.0 : 12.0) * M * K / (msa * 1e-3) / 1e12, N, K, tB ? "" : " k-major", msb);
         }
         d.A = pA; d.B = pB;
-        if (variant >= 7 && variant <= 9) { d.transA = 1; d.transB = 0; d.variant = variant == 8 ? 2 : variant == 9 ? 3 : 1; } else { d.transA = 0; d.transB = 1; }
+        if (variant >= 7 && variant <= 9) { d.transA = 1; d.transB = 0; d.variant = p1 ? 0 : variant == 8 ? 2 : variant == 9 ? 3 : 1; } else { d.transA = 0; d.transB = 1; if (p1) d.variant = variant & ~15; }
     }
     for (int i = 0; i < 6; ++i) { int rc = lstc_gemm(&d, nullptr); if (rc) { printf("rc=%d\n", rc); return; } }   // clock ramp
     CK(hipDeviceSynchronize());
@@ -145,8 +157,9 @@ static void timeit(int M, int N, int K, int tA, int tB, int variant, int split, 
     CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
     const double tf = 2.0 * M * N * (double)K / (ms * 1e-3) / 1e12;
-    printf("TIME %s M=%6d N=%5d K=%6d tA=%d tB=%d var=%d split=%d flags=%2d pad=%d,%d : %8.3f ms  %7.2f TFLOP/s (%.1f%% of 157.3)\n", dtype == LSTC_F32X3 ? "f32x3" : dtype ? "bf16c" : "f32", M, N, K, tA, tB,
-           variant, split, flags, pad_a, pad_b, ms, tf, 100.0 * tf / 157.3);
+    const double peak = (dtype == LSTC_BF16 || dtype == LSTC_BF16P) ? 2500.0 : 157.3;
+    printf("TIME %s M=%6d N=%5d K=%6d tA=%d tB=%d var=%d split=%d flags=%2d pad=%d,%d : %8.3f ms  %7.2f TFLOP/s (%.1f%% of %.1f)\n", dtype == LSTC_F32X3 ? "f32x3" : dtype == LSTC_BF16P ? "bf16p" : dtype ? "bf16c" : "f32", M, N, K, tA, tB,
+           variant, split, flags, pad_a, pad_b, ms, tf, 100.0 * tf / peak, peak);
     if (pA) hipFree(pA);
     if (pB) hipFree(pB);
     fflush(stdout);
@@ -160,6 +173,7 @@ int main(int argc, char** argv) {
         return 0;
     }
     const bool time_only = argc > 1 && !strcmp(argv[1], "time");
+    const bool check_only = argc > 1 && !strcmp(argv[1], "check");
     int fails = 0;
     if (!time_only) {
         const int ALL = LSTC_EPI_BIAS | LSTC_EPI_RELU | LSTC_EPI_RESIDUAL | LSTC_EPI_RELU_MASK | LSTC_EPI_ACCUM;
@@ -222,8 +236,24 @@ int main(int argc, char** argv) {
             fails += check({300, 520, 100 + 32 * split, 0, 1, ALLB, 3, 1, LSTC_F32X3});     // 2-stage kernel, ragged NT
             fails += check({130, 260, 515 + 32 * split, 1, 0, 0, 3, split, LSTC_F32X3});
         }
+        for (int split : {1, 3}) {             // packed bf16 kernel (256x256x64 tiles, 8 waves): every layout goes through lstc_pack1
+            fails += check({300, 200, 100, 0, 1, 0, 0, 1, LSTC_BF16P});
+            fails += check({257, 131, 67, 0, 1, ALLB, 1, 1, LSTC_BF16P});
+            fails += check({300, 200, 132, 0, 0, LSTC_EPI_RELU_MASK, 0, 1, LSTC_BF16P});
+            fails += check({130, 260, 515, 1, 0, 0, 1, split, LSTC_BF16P});
+            fails += check({64, 1, 32, 0, 1, LSTC_EPI_BIAS, 0, 1, LSTC_BF16P});
+            fails += check({256, 384, 64 * (3 + split), 0, 1, 0, 1, 1, LSTC_BF16P});
+            fails += check({512, 512, 64, 0, 1, 0, 1, 1, LSTC_BF16P});
+            fails += check({600, 520, 1000, 0, 1, ALLB, 1, 1, LSTC_BF16P});
+            fails += check({500, 260, 1000, 1, 0, 0, 1, split + 1, LSTC_BF16P});
+            fails += check({256, 256, 384, 1, 0, 0, 7, split, LSTC_BF16P});                 // TR form (weight gradient)
+            fails += check({512, 256, 1152, 1, 0, 0, 7, split + 1, LSTC_BF16P});
+            fails += check({300, 523, 640, 1, 0, 0, 7, split, LSTC_BF16P});                 // TR, ragged feature counts
+            fails += check({96, 40, 128, 1, 0, 0, 7, 1, LSTC_BF16P});
+        }
         printf("%s: %d failing cases\n", fails ? "FAILED" : "ALL PASS", fails);
     }
+    if (check_only) return fails;
     // LTN headline shapes: tokens M = 2048*49 = 100352, d = 2048, Hd = 2048, F = 4096.  A smaller M (25088)
     // is timed first to keep the table quick; TFLOP/s is what matters.
     const int Mtok = 100352;
