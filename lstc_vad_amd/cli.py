@@ -9,8 +9,10 @@ utils/utils.py:152-173).  ``--gpu`` selects the device through ``HIP_VISIBLE_DEV
 ``CUDA_VISIBLE_DEVICES``, e.g. Train/temporal_transformer_shanghaitech.py:328).
 
 Loop structure follows the reference: epochs over a pair loader, one step per batch, the same log line formats, an
-evaluation every ``--inter_epoch`` epochs, best-AUC checkpoints named like upstream
-(Train/temporal_transformer_shanghaitech.py:240-248).  Under ``torchrun`` every process takes its own shard of pairs.
+evaluation every ``--inter_epoch`` epochs over the test videos AND (where the script does) the training videos, and the
+script's own checkpoint rule (``SELECTION``: e.g. Train/temporal_transformer_shanghaitech.py:186-252 saves when the
+TRAIN-set AUC improves and exceeds ``--save_threshold``, file name ``<prefix>temporal_model_oneCrop_<type>_<str(auc)>``).
+Under ``torchrun`` ``--batch_size`` stays the global pair count; rank r owns pairs [r*bs/N, (r+1)*bs/N) of every batch.
 """
 from __future__ import annotations
 
@@ -35,6 +37,72 @@ SCRIPTS = {
     "temporal_transformer_UBnormal": ("LTN", "classifier", ""),
     "spatio_transformer_MIL_CE": ("STN_MIL_CE", "regressor", "spatio_"),
 }
+
+
+SELECTION = {
+    # script -> how it picks checkpoints (file:line of the rule).  train: flag naming the archive the TRAINING videos are
+    # scored from (None: the script never computes a train AUC / sets it to 0); on: which AUC gates the save; thr: the save
+    # also needs AUC > --save_threshold; prefix / typ: --saved_prefix and --type appear in the file name; join: os.path.join
+    # instead of string concatenation; head: file-name stem of the head's checkpoint.
+    "spatio_transformer_shanghaitech": dict(train="train_dataset", on="train", thr=True, enc="spatio", head="regression",
+                                            prefix=True, typ=True, join=False),        # :145-190
+    "temporal_transformer_shanghaitech": dict(train="dataset_path", on="train", thr=True, enc="temporal", head="classifier",
+                                              prefix=True, typ=True, join=False),      # :186-252
+    "spatio_transformer_UBnormal": dict(train=None, on="train", thr=True, enc="spatio", head="regression",
+                                        prefix=False, typ=True, join=True),            # :128-149 (auc_train = 0: never saves)
+    "temporal_transformer_UBnormal": dict(train="dataset_path", on="train", thr=True, enc="temporal", head="classifier",
+                                          prefix=False, typ=True, join=False),         # :193-254
+    "spatio_transformer_UCF": dict(train=None, on="test", thr=True, enc="spatio", head="regression",
+                                   prefix=False, typ=False, join=False),               # :137-150
+    "temporal_transformer_UCF": dict(train=None, on="test", thr=True, enc="temporal", head="classifier",
+                                     prefix=False, typ=True, join=False),              # :173-186
+    "spatio_transformer_MIL_CE": dict(train="dataset_path", on="train", thr=False, enc="spatio", head="regression",
+                                      prefix=True, typ=True, join=False),              # :343-365 (UCF / UBnormal: auc_train = 0)
+}
+
+
+def checkpoint_names(script, args, auc):
+    """(encoder path, head path) exactly as the script spells them, e.g. Train/temporal_transformer_shanghaitech.py:242-247:
+    ``model_save_dir + saved_prefix + "temporal_model_oneCrop_" + type + "_" + str(auc_train)``."""
+    rule = SELECTION[script]
+    tail = (str(args.type) + "_" if rule["typ"] else "") + str(auc)
+    pre = (getattr(args, "saved_prefix", None) or "") if rule["prefix"] else ""
+    d = getattr(args, "model_save_dir", "") or ""
+    cat = (lambda n: os.path.join(d, n)) if rule["join"] else (lambda n: d + n)
+    return cat(pre + rule["enc"] + "_model_oneCrop_" + tail), cat(pre + rule["head"] + "_model_oneCrop_" + tail)
+
+
+class Selector:
+    """Best-AUC bookkeeping + save decision of one Train script."""
+
+    def __init__(self, script, args):
+        self.script, self.args, self.rule = script, args, SELECTION[script]
+        thr = float(getattr(args, "save_threshold", 0.0) or 0.0)
+        self.best_test = thr if script == "spatio_transformer_MIL_CE" else 0.0      # MIL_CE.py:104
+        self.best_train, self.best_test_epoch, self.best_train_epoch, self.thr = 0.0, 0, 0, thr
+
+    def update(self, epoch, auc_test, auc_train):
+        """Returns the AUC to save under (or None) and the log lines upstream prints."""
+        r, save = self.rule, None
+        if self.script == "spatio_transformer_MIL_CE":
+            if auc_train > self.best_train:
+                self.best_train, self.best_train_epoch, save = auc_train, epoch, auc_train
+            if auc_test > self.best_test:
+                self.best_test, self.best_test_epoch = auc_test, epoch
+            return save, ['best_train_AUC {} at epoch {} now train_AUC is {}'.format(self.best_train, self.best_train_epoch, auc_train),
+                          'best_test_AUC {} at epoch {} now test_AUC is {}'.format(self.best_test, self.best_test_epoch, auc_test)]
+        if auc_test > self.best_test:
+            self.best_test, self.best_test_epoch = auc_test, epoch
+            if r["on"] == "test" and auc_test > self.thr:
+                save = auc_test
+        if r["on"] == "train" and auc_train > self.best_train:
+            self.best_train, self.best_train_epoch = auc_train, epoch
+            if auc_train > self.thr:
+                save = auc_train
+        if r["on"] == "test":
+            return save, ['best_test_AUC {} at epoch {} now test_AUC is {}'.format(self.best_test, self.best_test_epoch, auc_test)]
+        return save, ['best_test_AUC {} at epoch {} now test_AUC is {} \nbest_train_AUC {} at epoch {} now train_AUC is {}'.format(
+            self.best_test, self.best_test_epoch, auc_test, self.best_train, self.best_train_epoch, auc_train)]
 
 
 def build_parser(script: str) -> argparse.ArgumentParser:
@@ -158,17 +226,19 @@ def train(script: str, argv=None):
         ppath += ".npy"                                     # Train/spatio_transformer_MIL_CE.py:142
     real = (not args.synthetic) and bool(getattr(args, "dataset_path", ""))
     if real:
-        data, eval_fn = _real_data(args, mode, part_len, ppath, dev, rank, world, enc, head)
+        data, eval_fn = _real_data(script, args, mode, part_len, ppath, dev, rank, world, enc, head)
     else:
         n_pairs = args.synthetic_pairs or 2 * args.batch_size
         thr = None if mode == "STN" else 0.65
         pseudo = np.load(ppath, allow_pickle=True).tolist() if ppath and os.path.exists(ppath) else None
         data = SyntheticVideos(n_pairs, args.batch_size, args.part_num, part_len, args.n_patch, d_model, dev,
                                seed=seed, sample=args.sample, pseudo_threshold=thr, pseudo_labels=pseudo, rank=rank, world=world)
-        eval_fn = lambda: evaluate(enc, head, mode, data, part_len, roc_auc)
+        eval_fn = lambda: (evaluate(enc, head, mode, data, part_len, roc_auc),
+                           evaluate(enc, head, mode, data, part_len, roc_auc, train=True) if SELECTION[script]["train"] else 0)
     epochs = int(_get(args, "epochs", pre, 1))
     inter = int(getattr(args, "inter_epoch", 10))
-    best_auc, it = 0.0, 0
+    sel = Selector(script, args)
+    it = 0
     for epoch in range(epochs):
         for norm_feats, norm_labs, abnorm_feats, abnorm_labs in data:
             sc = ts.step(norm_feats, abnorm_feats, abnorm_labs)
@@ -186,23 +256,26 @@ def train(script: str, argv=None):
                 break
         data.shuffle_keys()
         if rank == 0 and epoch % inter == 0:
-            auc = eval_fn()
+            auc_test, auc_train = eval_fn()
             enc.train(); head.train()
-            logger.info('epoch {} test AUC {:.4f} (best {:.4f})'.format(epoch, auc, best_auc))
-            if auc > best_auc:
-                best_auc = auc
-                tag = "temporal" if mode == "LTN" else "spatio"
-                prefix = getattr(args, "saved_prefix", None) or ""
-                save_dir = getattr(args, "model_save_dir", "") or log_dir
-                os.makedirs(save_dir, exist_ok=True)
-                name = "{}{}_model_{}_{}_{:.4f}".format(prefix, tag, args.data_crop, args.type, auc)
-                torch.save(enc.state_dict(), os.path.join(save_dir, name))
-                torch.save(head.state_dict(), os.path.join(save_dir, name.replace(tag + "_model", head_kind + "_model")))
+            save_auc, lines = sel.update(epoch, auc_test, auc_train)
+            if save_auc is not None:
+                logger.info("saving model......")
+                enc_path, head_path = checkpoint_names(script, args, save_auc)
+                if not (getattr(args, "model_save_dir", "") or ""):                   # no directory given: next to the log
+                    enc_path, head_path = os.path.join(log_dir, enc_path), os.path.join(log_dir, head_path)
+                os.makedirs(os.path.dirname(enc_path) or ".", exist_ok=True)
+                torch.save(enc.state_dict(), enc_path)
+                torch.save(head.state_dict(), head_path)
+                logger.info("save complete.")
+            for ln in lines:
+                logger.info(ln)
+            logger.info('======================================================================================')
         if args.steps and it >= args.steps:
             break
     if world > 1:
         dist.destroy_process_group()
-    return best_auc
+    return sel.best_test if sel.rule["on"] == "test" else sel.best_train
 
 
 class _HostPairs:
@@ -231,7 +304,7 @@ class _HostPairs:
         self.ds.shuffle_keys()
 
 
-def _real_data(args, mode, part_len, pseudo_path, dev, rank, world, enc, head):
+def _real_data(script, args, mode, part_len, pseudo_path, dev, rank, world, enc, head):
     """Feature-archive training source + evaluation closure for a Train/*.py run.  Dataset class per
     script as upstream (e.g. Train/temporal_transformer_shanghaitech.py:45-51, Train/spatio_transformer_MIL_CE.py:114-149).
     Under data parallelism every rank seeds ``np.random`` IDENTICALLY and walks the same permutation / window draws; rank
@@ -239,7 +312,7 @@ def _real_data(args, mode, part_len, pseudo_path, dev, rank, world, enc, head):
     the one a single process would have formed."""
     import numpy as np
     from . import load_dataset as lds
-    from .pipeline import evaluate_auc
+    from .pipeline import evaluate_auc, evaluate_train_auc
     dataset = str(getattr(args, "dataset", "SHT"))
     np.random.seed(int(getattr(args, "seed", 0)))
     common = dict(part_num=args.part_num, part_len=part_len, h5_path=args.dataset_path, train_txt=args.training_txt,
@@ -257,15 +330,25 @@ def _real_data(args, mode, part_len, pseudo_path, dev, rank, world, enc, head):
     test_arc = getattr(args, "test_dataset_path", "") or args.dataset_path
     kind = "LTN" if mode == "LTN" else "STN"
 
+    train_flag = SELECTION[script]["train"]
+    if script == "spatio_transformer_MIL_CE" and dataset in ("UCF", "UBnormal"):
+        train_flag = None                                        # Train/spatio_transformer_MIL_CE.py:344-345: auc_train = 0
+    train_arc = getattr(args, train_flag, "") if train_flag else ""
+
     def eval_fn():
-        if not getattr(args, "testing_txt", ""):
-            return 0.0
-        return evaluate_auc(enc.eval(), head.eval(), kind, dataset, test_arc, args.testing_txt, masks, part_len, args.n_patch,
-                            args.segment_len)
+        """(test AUC, train AUC) as the script's in-loop evaluation computes them (0 where it does not)."""
+        auc_test = auc_train = 0.0
+        if getattr(args, "testing_txt", ""):
+            auc_test = evaluate_auc(enc.eval(), head.eval(), kind, dataset, test_arc, args.testing_txt, masks, part_len,
+                                    args.n_patch, args.segment_len)
+        if train_arc and dataset != "UCF":
+            auc_train = evaluate_train_auc(enc.eval(), head.eval(), kind, dataset, train_arc, args.training_txt,
+                                           getattr(args, "test_mask_dir", ""), part_len, args.n_patch, args.segment_len)
+        return auc_test, auc_train
     return data, eval_fn
 
 
-def evaluate(enc, head, mode, data, part_len, roc_auc, segment_len=16):
+def evaluate(enc, head, mode, data, part_len, roc_auc, segment_len=16, train=False):
     """Frame-level AUC as the reference's in-loop evaluation (Train/temporal_transformer_shanghaitech.py:151-229):
     LTN scores every part of ``part_len`` clips (the last part may be shorter: shorter sequence, same model),
     STN scores every clip; scores are repeated to frame level (x segment_len)."""
@@ -274,7 +357,7 @@ def evaluate(enc, head, mode, data, part_len, roc_auc, segment_len=16):
     enc.eval(); head.eval()
     scores, labels = [], []
     with torch.no_grad():
-        for feats, labs in data.test_videos():
+        for feats, labs in (data.train_videos_labelled() if train else data.test_videos()):
             sc = score_video(enc, head, mode, feats, part_len)
             scores.append(np.repeat(sc.cpu().numpy(), segment_len))
             labels.append(np.repeat(labs.reshape(-1).cpu().numpy(), segment_len))

@@ -109,6 +109,12 @@ class SyntheticVideos:
             for kind in (0, 1):
                 yield self.key(kind, vid), self._video(kind, vid)[0]
 
+    def train_videos_labelled(self):
+        """(features, per-clip 0/1 labels) of every training video - the train-AUC pass of the SHT / UBnormal scripts."""
+        for vid in range(self.n_pairs):
+            for kind in (0, 1):
+                yield self._video(kind, vid)
+
     def test_videos(self, n_videos=8):
         """(features [n_clips, P, d], per-clip 0/1 labels) for evaluation."""
         rs = np.random.RandomState(self.seed + 7)

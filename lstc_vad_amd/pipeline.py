@@ -134,3 +134,58 @@ def evaluate_auc(enc, head, mode, dataset, dataset_path, testing_txt, masks, par
     s, l = np.concatenate(scores), np.concatenate(labels)
     auc = roc_auc(s, l)
     return (auc, s, l) if return_frames else auc
+
+
+@torch.no_grad()
+def evaluate_train_auc(enc, head, mode, dataset, train_archive, training_txt, mask_dir, part_len, n_patch, segment_len=16,
+                       return_frames=False, pool_sequences=2048):
+    """Frame-level AUC over the TRAINING videos, the quantity the SHT / UBnormal train scripts select checkpoints on
+    (Train/temporal_transformer_shanghaitech.py:186-229, Train/spatio_transformer_shanghaitech.py:145-172,
+    Train/temporal_transformer_UBnormal.py:193-232): every training video is scored like a test video; a normal video's
+    frames are labelled 0, an abnormal video's labels are the first frames of ``mask_dir + key + ".npy"`` (the upstream
+    string concatenation - ``--test_mask_dir`` holds the masks of the training videos too).  Video class: second list
+    field (SHT ``name,label``) or the ``abnormal`` / ``normal`` name prefix (UBnormal)."""
+    device = next(enc.parameters()).device
+    scores, labels, pool = [], [], []
+
+    def flush():
+        if not pool:
+            return
+        sc = scoring.ltn_sequence_scores(enc, head, [q for _, seqs, _ in pool for q in seqs]).cpu().numpy()
+        off = 0
+        for slot, seqs, expand in pool:
+            scores[slot], labels[slot] = expand(sc[off:off + len(seqs)]); off += len(seqs)
+        pool.clear()
+
+    def frame_labels(abnormal, key, n):
+        if not abnormal:
+            return np.zeros(n)
+        return np.asarray(np.load(mask_dir + key + ".npy", allow_pickle=True))[:n]
+
+    with FeatureArchive(train_archive) as arc:
+        for line in open(training_txt, "r").readlines():
+            fields = line.strip().split(",")
+            key = fields[0]
+            if dataset in ("SHT", "MT_SHT"):
+                abnormal = int(fields[1]) == 1
+            else:
+                abnormal = not key.startswith("normal")
+            f = _dev(arc[key + ".npy"], device, n_patch)
+            if mode != "LTN":
+                sc = scoring.stn_clip_scores(enc, head, f).reshape(-1).cpu().numpy()
+                s = np.repeat(sc, segment_len)
+                scores.append(s); labels.append(frame_labels(abnormal, key, s.shape[0]))
+                continue
+            seqs, ranges = scoring.ltn_part_sequences(f, part_len, tail="rewindow")
+            scores.append(None); labels.append(None)
+
+            def expand(v, ranges=ranges, abnormal=abnormal, key=key):
+                sfr = np.concatenate([np.full((e - b) * segment_len, float(x), np.float32) for x, (b, e) in zip(v, ranges)])
+                return sfr, frame_labels(abnormal, key, sfr.shape[0])
+            pool.append((len(scores) - 1, seqs, expand))
+            if sum(len(q[1]) for q in pool) >= pool_sequences:
+                flush()
+        flush()
+    s, l = np.concatenate(scores), np.concatenate(labels)
+    auc = roc_auc(s, l)
+    return (auc, s, l) if return_frames else auc

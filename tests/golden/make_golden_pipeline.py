@@ -60,6 +60,8 @@ import Train.pseudo_labels_generator_spatio as ref_gen_s             # noqa: E40
 import Train.pseudo_labels_generator_temporal as ref_gen_t           # noqa: E402
 import Test.evaluation_shanghaitech_ubnormal as ref_eval_sht         # noqa: E402
 import Test.evaluation_UCF as ref_eval_ucf                           # noqa: E402
+import Train.temporal_transformer_shanghaitech as ref_train_ltn      # noqa: E402
+import Train.spatio_transformer_shanghaitech as ref_train_stn        # noqa: E402
 from models.Encoder import Encoder as RefEncoder                     # noqa: E402
 from models.Regressor import Regressor as RefRegressor               # noqa: E402
 from models.Classifier import Classifier as RefClassifier            # noqa: E402
@@ -67,7 +69,7 @@ from models.Classifier import Classifier as RefClassifier            # noqa: E40
 import utils.eval_utils as ref_eval_utils                             # noqa: E402
 
 assert_reference(ref_ds, ref_gen_s, ref_gen_t, ref_eval_sht, ref_eval_ucf, ref_eval_utils, RefEncoder, RefRegressor,
-                 RefClassifier)
+                 RefClassifier, ref_train_ltn, ref_train_stn)
 
 import pipeline_world as pw                                          # noqa: E402
 from pipeline_cases import DATASET_CASES, build_dataset              # noqa: E402
@@ -193,6 +195,70 @@ def run_evals(W):
     OUT["ev/ucf/scores"], OUT["ev/ucf/labels"], OUT["ev/ucf/auc"] = captured["s"], captured["l"], np.array([captured["auc"]])
 
 
+def run_train_loops(W, tmp):
+    """The reference's own ``train(args)`` (Train/temporal_transformer_shanghaitech.py:38-254,
+    Train/spatio_transformer_shanghaitech.py:35-198) for ONE epoch on the world with both learning rates 0 - Adagrad then
+    leaves the loaded weights untouched, so the in-loop evaluation block (test AND train videos), the best-AUC bookkeeping,
+    the save rule and the checkpoint file names run on known weights.  Environment supplied here: a logger instead of
+    ``log_setting`` (hard-coded /data/ssy/... directories), in-process DataLoader workers."""
+    import logging
+    from torch.utils.data import DataLoader as TorchLoader
+
+    def strip_ckpt(src, dst):                       # train() loads with strict=False and does not strip "module."
+        sd = torch.load(src)
+        torch.save({(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}, dst)
+        return dst
+
+    for tag, mod, extra in (
+        ("ltn_sht", ref_train_ltn, ["--part_len", "3", "--n_hidden", "64", "--MHA_layerNorm", "--relative_position_encoding",
+                                    "--load_temporal_model_path", strip_ckpt(W["ltn_sht_enc.ckpt"], os.path.join(tmp, "enc_l.ckpt")),
+                                    "--load_classifier_model_path", strip_ckpt(W["ltn_sht_cls.ckpt"], os.path.join(tmp, "cls_l.ckpt")),
+                                    "--lr_classifier", "0", "--saved_prefix", "pre_", "--save_threshold", "0.05"]),
+        ("stn_sht", ref_train_stn, ["--part_len", "2", "--n_hidden", "47", "--train_dataset", W["sht_feats"],
+                                    "--load_spatio_model_path", W["stn_sht_enc.ckpt"], "--load_classifier_model_path", W["stn_sht_reg.ckpt"],
+                                    "--lr_regressor", "0", "--num_workers", "0", "--saved_prefix", "", "--save_threshold", "0.05"])):
+        save_dir = os.path.join(tmp, "save_" + tag) + os.sep
+        os.makedirs(save_dir)
+        argv = ["x", "--dataset_path", W["sht_feats"], "--training_txt", W["sht_train"], "--testing_txt", W["sht_test"],
+                "--test_mask_dir", W["sht_masks"], "--model_save_dir", save_dir, "--batch_size", "2", "--part_num", "3",
+                "--n_patch", "16", "--n_head", "2", "--d_model", "32", "--d_k", "16", "--d_v", "16", "--FFN_layerNorm",
+                "--load_model", "--lr_encoder", "0", "--epochs", "1", "--inter_epoch", "1", "--seed", "3"] + extra
+        keep = sys.argv
+        sys.argv = argv
+        try:
+            args = mod.parser_arg()
+        finally:
+            sys.argv = keep
+        lines, calls = [], []
+
+        class _H(logging.Handler):
+            def emit(self, rec):
+                lines.append(rec.getMessage())
+        lg = logging.getLogger("golden_" + tag); lg.handlers.clear(); lg.addHandler(_H()); lg.setLevel(logging.INFO); lg.propagate = False
+        mod.log_setting = lambda a, lg=lg: lg
+        mod.DataLoader = lambda ds, batch_size, num_workers=0, worker_init_fn=None, drop_last=False: \
+            TorchLoader(ds, batch_size=batch_size, num_workers=0, drop_last=drop_last)
+
+        def capture(scores, labels, logger, calls=calls):
+            calls.append((np.asarray(scores, np.float32).reshape(-1), np.asarray(labels, np.float64).reshape(-1)))
+            return ref_eval_utils.eval(scores, labels, logger)
+        mod.eval = capture
+        np.random.seed(3); random.seed(3); torch.manual_seed(3)
+        mod.train(args)
+        assert len(calls) == 2, len(calls)
+        OUT[f"tl_eval/{tag}/test_scores"], OUT[f"tl_eval/{tag}/test_labels"] = calls[0]
+        OUT[f"tl_eval/{tag}/train_scores"], OUT[f"tl_eval/{tag}/train_labels"] = calls[1]
+        OUT[f"tl_eval/{tag}/auc"] = np.array([ref_eval_utils.eval(list(calls[0][0]), list(calls[0][1]), None),
+                                              ref_eval_utils.eval(list(calls[1][0]), list(calls[1][1]), None)])
+        OUT[f"tl_eval/{tag}/saved"] = np.array(sorted(os.listdir(save_dir)))
+        OUT[f"tl_eval/{tag}/log"] = np.array([l for l in lines if l.startswith("best_") or l.startswith("sav")])
+        # the checkpoints train() wrote must hold the loaded weights (learning rates 0)
+        enc_file = [f for f in os.listdir(save_dir) if "temporal_model" in f or "spatio_model" in f][0]
+        sd = torch.load(os.path.join(save_dir, enc_file))
+        ref_sd = torch.load(extra[extra.index("--load_temporal_model_path" if tag == "ltn_sht" else "--load_spatio_model_path") + 1])
+        assert all(torch.equal(sd[k], ref_sd[k]) for k in ref_sd), "lr = 0 run changed the weights"
+
+
 def main():
     with tempfile.TemporaryDirectory() as tmp:
         W = pw.build(os.path.join(tmp, "world"), RefEncoder, RefRegressor, RefClassifier)
@@ -200,6 +266,7 @@ def main():
         run_test_loaders(W)
         run_generators(W, tmp)
         run_evals(W)
+        run_train_loops(W, tmp)
     out_dir = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else HERE
     np.savez_compressed(os.path.join(out_dir, "pipeline.npz"), **OUT)
     print("pipeline.npz:", len(OUT), "arrays,", os.path.getsize(os.path.join(out_dir, "pipeline.npz")), "bytes")

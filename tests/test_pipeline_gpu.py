@@ -141,13 +141,14 @@ def test_reference_command_lines_on_feature_archives(world, tmp_path):
         "--pseudo_labels_path", pl, "--threshold", "0.45"])
     assert r.returncode == 0, r.stderr[-2000:]
     _check_pseudo(np.load(pl, allow_pickle=True).tolist(), "pl/t_sht/", 0.45)
-    save = str(tmp_path / "ckpt")
+    save = str(tmp_path / "ckpt") + os.sep            # upstream concatenates strings: the directory flag ends with a separator
     r = _run("Train", "temporal_transformer_shanghaitech.py", model + [
         "--dataset_path", world["sht_feats"], "--training_txt", world["sht_train"], "--testing_txt", world["sht_test"],
         "--test_mask_dir", world["sht_masks"], "--pseudo_labels_path", pl, "--batch_size", "2", "--part_num", "3",
-        "--epochs", "2", "--inter_epoch", "1", "--model_save_dir", save, "--log_dir", str(tmp_path / "log")])
+        "--epochs", "2", "--inter_epoch", "1", "--model_save_dir", save, "--saved_prefix", "", "--save_threshold", "0",
+        "--log_dir", str(tmp_path / "log")])
     assert r.returncode == 0, r.stderr[-2000:]
-    assert "test AUC" in r.stderr and "MIL_loss" in r.stderr
+    assert "best_test_AUC" in r.stderr and "best_train_AUC" in r.stderr and "MIL_loss" in r.stderr
     saved = sorted(os.listdir(save))
     enc_ckpt = [f for f in saved if f.startswith("temporal_model")][-1]
     cls_ckpt = [f for f in saved if f.startswith("classifier_model")][-1]
@@ -159,7 +160,50 @@ def test_reference_command_lines_on_feature_archives(world, tmp_path):
         os.path.join(save, cls_ckpt)])
     assert r.returncode == 0, r.stderr[-2000:]
     auc = float(r.stdout.strip().split("auc = ")[-1])
-    assert abs(auc - float(enc_ckpt.rsplit("_", 1)[-1])) < 1e-3        # the file name carries the AUC to 4 decimals
+    # the file name carries str(train AUC) (Train/temporal_transformer_shanghaitech.py:242-247); the TEST AUC of the epoch
+    # that wrote the last checkpoint is in the log line printed right after the save
+    train_auc = enc_ckpt.rsplit("_", 1)[-1]
+    line = [l for l in r.stderr.splitlines() if "now test_AUC is" in l and ("now train_AUC is " + train_auc) in
+            r.stderr[r.stderr.index(l):r.stderr.index(l) + len(l) + 200]]
+    assert line, r.stderr[-1500:]
+    assert abs(auc - float(line[-1].split("now test_AUC is ")[1].split()[0])) < 1e-3
+
+
+@pytest.mark.parametrize("tag", ["ltn_sht", "stn_sht"])
+def test_train_cli_evaluation_block_matches_reference_train(world, tmp_path, tag):
+    """Train/temporal_transformer_shanghaitech.py / Train/spatio_transformer_shanghaitech.py through the HIP path, one epoch
+    with both learning rates 0 from the world's checkpoints - the run the reference's own train() made for the fixture
+    (tests/golden/make_golden_pipeline.py run_train_loops): same AUCs over the test and the training videos, same
+    best-AUC log line, same save decision, same checkpoint file names up to the AUC's last digits."""
+    save = str(tmp_path / "ck") + os.sep
+    common = ["--dataset_path", world["sht_feats"], "--training_txt", world["sht_train"], "--testing_txt", world["sht_test"],
+              "--test_mask_dir", world["sht_masks"], "--model_save_dir", save, "--batch_size", "2", "--part_num", "3",
+              "--n_patch", "16", "--n_head", "2", "--d_model", "32", "--d_k", "16", "--d_v", "16", "--FFN_layerNorm",
+              "--load_model", "--lr_encoder", "0", "--epochs", "1", "--inter_epoch", "1", "--seed", "3", "--save_threshold", "0.05",
+              "--log_dir", str(tmp_path / "log")]
+    if tag == "ltn_sht":
+        script = "temporal_transformer_shanghaitech.py"
+        extra = ["--part_len", "3", "--n_hidden", "64", "--MHA_layerNorm", "--relative_position_encoding", "--load_temporal_model_path",
+                 world["ltn_sht_enc.ckpt"], "--load_classifier_model_path", world["ltn_sht_cls.ckpt"], "--lr_classifier", "0",
+                 "--saved_prefix", "pre_"]
+    else:
+        script = "spatio_transformer_shanghaitech.py"
+        extra = ["--part_len", "2", "--n_hidden", "47", "--train_dataset", world["sht_feats"], "--load_spatio_model_path",
+                 world["stn_sht_enc.ckpt"], "--load_classifier_model_path", world["stn_sht_reg.ckpt"], "--lr_regressor", "0",
+                 "--saved_prefix", ""]
+    r = _run("Train", script, common + extra)
+    assert r.returncode == 0, r.stderr[-2500:]
+    ref_auc = G[f"tl_eval/{tag}/auc"]
+    line = [l for l in r.stderr.splitlines() if "best_test_AUC" in l][-1]
+    nxt = r.stderr[r.stderr.index(line):].splitlines()[1]
+    got_test = float(line.split("now test_AUC is ")[1].split()[0])
+    got_train = float(nxt.split("now train_AUC is ")[1].split()[0])
+    assert abs(got_test - ref_auc[0]) < 1e-4 and abs(got_train - ref_auc[1]) < 1e-4
+    want = G[f"tl_eval/{tag}/saved"].tolist()
+    got = sorted(os.listdir(save))
+    assert [g.rsplit("_", 1)[0] for g in got] == [w.rsplit("_", 1)[0] for w in want]
+    assert all(abs(float(g.rsplit("_", 1)[1]) - float(w.rsplit("_", 1)[1])) < 1e-4 for g, w in zip(got, want))
+    assert "saving model......" in r.stderr and "save complete." in r.stderr
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f32x3"])

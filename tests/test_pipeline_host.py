@@ -220,3 +220,50 @@ def test_rank_shards_are_disjoint_and_union_is_the_single_process_batch(world, n
         assert np.array_equal(labs[1, j].reshape(item[3].shape), item[3].numpy())
     with pytest.raises(ValueError):
         ds_mod.ResidentPairs(ds2, 3, "cpu", 0, 2)            # 3 pairs do not split over 2 ranks
+
+
+def test_train_loop_evaluation_and_checkpoint_rule_like_the_reference_train(world):
+    """The in-loop evaluation + selection of the SHT train scripts, pinned to the reference's own ``train(args)`` run on the
+    world with learning rates 0 (tests/golden/make_golden_pipeline.py ``run_train_loops``): frame scores / labels of the
+    test AND the training videos, both AUCs, the best-AUC log line, the save decision and the checkpoint file names
+    (``<prefix>temporal_model_oneCrop_<type>_<str(auc_train)>``).  Host logic here (oracle as the model)."""
+    from argparse import Namespace
+    from lstc_vad_amd import cli
+    for tag, script, enc_ck, head_ck, kw, kind, mode, L, prefix in (
+            ("ltn_sht", "temporal_transformer_shanghaitech", "ltn_sht_enc.ckpt", "ltn_sht_cls.ckpt", pw.LTN_SHT, "classifier", "LTN", 3, "pre_"),
+            ("stn_sht", "spatio_transformer_shanghaitech", "stn_sht_enc.ckpt", "stn_sht_reg.ckpt", pw.STN_SHT, "regressor", "STN", 2, "")):
+        enc, head = _OracleEncoder(world[enc_ck], kw), _OracleHead(world[head_ck], kind)
+        at, st, lt = pipeline.evaluate_auc(enc, head, mode, "SHT", world["sht_feats"], world["sht_test"], world["sht_masks"], L, 16,
+                                           return_frames=True)
+        ar, sr, lr = pipeline.evaluate_train_auc(enc, head, mode, "SHT", world["sht_feats"], world["sht_train"], world["sht_masks"],
+                                                 L, 16, return_frames=True)
+        for got, key in ((st, "test_scores"), (sr, "train_scores")):
+            assert got.shape == G[f"tl_eval/{tag}/{key}"].shape and np.max(np.abs(got - G[f"tl_eval/{tag}/{key}"])) < 2e-6
+        assert np.array_equal(lt, G[f"tl_eval/{tag}/test_labels"]) and np.array_equal(lr, G[f"tl_eval/{tag}/train_labels"])
+        ref_auc = G[f"tl_eval/{tag}/auc"]
+        assert abs(at - ref_auc[0]) < 1e-9 and abs(ar - ref_auc[1]) < 1e-9
+        # selection rule + file names, fed with the reference's AUC values
+        args = Namespace(save_threshold=0.05, saved_prefix=prefix, type="I3D_RGB", model_save_dir="")
+        sel = cli.Selector(script, args)
+        save, lines = sel.update(0, float(ref_auc[0]), float(ref_auc[1]))
+        assert save == float(ref_auc[1])
+        names = sorted(os.path.basename(p) for p in cli.checkpoint_names(script, args, save))
+        assert names == G[f"tl_eval/{tag}/saved"].tolist()
+        assert lines[0] == [l for l in G[f"tl_eval/{tag}/log"].tolist() if l.startswith("best_")][0]
+        # second evaluation: no improvement -> no save; better train AUC under the threshold -> no save either
+        assert sel.update(10, 0.9, float(ref_auc[1]))[0] is None and sel.best_test == 0.9 and sel.best_test_epoch == 10
+        sel2 = cli.Selector(script, Namespace(save_threshold=0.99, saved_prefix=None, type="I3D_RGB", model_save_dir="/m/"))
+        assert sel2.update(0, 0.5, 0.6)[0] is None and sel2.best_train == 0.6
+    # the other scripts' rules (file:line in cli.SELECTION)
+    a = Namespace(save_threshold=0.8, saved_prefix="p_", type="I3D_RGB", model_save_dir="/m/")
+    s = cli.Selector("spatio_transformer_UCF", a)
+    assert s.update(0, 0.7, 0.0)[0] is None and s.update(5, 0.85, 0.0)[0] == 0.85          # test AUC gates, threshold applies
+    assert cli.checkpoint_names("spatio_transformer_UCF", a, 0.85) == ("/m/spatio_model_oneCrop_0.85", "/m/regression_model_oneCrop_0.85")
+    assert cli.checkpoint_names("temporal_transformer_UCF", a, 0.85)[0] == "/m/temporal_model_oneCrop_I3D_RGB_0.85"
+    assert cli.checkpoint_names("temporal_transformer_UBnormal", a, 0.5)[1] == "/m/classifier_model_oneCrop_I3D_RGB_0.5"
+    assert cli.checkpoint_names("spatio_transformer_UBnormal", Namespace(type="T", model_save_dir="/m"), 0.5)[0] == "/m/spatio_model_oneCrop_T_0.5"
+    s = cli.Selector("spatio_transformer_UBnormal", a)
+    assert s.update(0, 0.9, 0.0)[0] is None                                               # auc_train = 0 upstream: never saves
+    s = cli.Selector("spatio_transformer_MIL_CE", a)
+    assert s.best_test == 0.8 and s.update(0, 0.5, 0.3)[0] == 0.3 and s.best_test == 0.8   # no threshold on the save, best_test starts at it
+    assert cli.checkpoint_names("spatio_transformer_MIL_CE", a, 0.3)[0] == "/m/p_spatio_model_oneCrop_I3D_RGB_0.3"
