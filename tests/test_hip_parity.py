@@ -966,3 +966,64 @@ def test_full_width_bf16_step_tracks_reference(name):
         cos = float((got * gs).sum() / (got.norm() * gs.norm() + 1e-30))
         assert cos > 0.98, (k, cos)
         assert abs(float(p.grad.double().norm()) / float(z[f"enc_gnorm.{k}"]) - 1.0) < 0.05, k
+
+
+def test_mixed_step_bf16_vs_fp32_auc_on_the_mixed_pair():
+    """BASELINE config 5 ("UBnormal config (d_model=1024, part_len=5) mixed with SHT in one batch, bf16 + fp32 AUC parity
+    check"), reduced width: the SAME mixed training run - engine.MixedStep over a UBnormal-shaped pair (L=5, S=81) and an
+    SHT-shaped pair (L=3, S=49), 6 steps, dropout off, identical initial weights and batches - once in fp32 and once in bf16
+    mode (packed bf16 GEMMs forced on every product); then both pairs score held-out videos in the mode they were trained
+    in.  Frame-level AUC of each dataset must agree to 1e-2 between the modes and the scores to 5e-2."""
+    from argparse import Namespace
+    from lstc_vad_amd import functional as Fn
+    from lstc_vad_amd.engine import MixedStep, TrainStep
+    from lstc_vad_amd.metrics import roc_auc
+    from lstc_vad_amd.models import Classifier, Encoder
+    cfgs = [dict(d_model=128, L=5), dict(d_model=256, L=3)]
+    bs, pn, P = 4, 8, 16
+
+    def run(mode):
+        Fn.set_compute_dtype(mode)
+        if mode == "bf16":
+            Fn.set_x3_threshold(0, 0, 0)
+        try:
+            steps, batches, tests = [], [], []
+            for ci, c in enumerate(cfgs):
+                d, L = c["d_model"], c["L"]
+                torch.manual_seed(100 + ci)
+                enc = Encoder(n_layers=3, n_head=4, d_k=32, d_v=32, d_model=d, d_inner=2 * d, MHA_attn_dropout=0.0, MHA_fc_dropout=0.0,
+                              FFN_dropout=0.0, MHA_layerNorm=True, FFN_layerNorm=True, relative_pe=True, window_size=4,
+                              window_depth=L, weight_init=True).to(DEV).train()
+                head = Classifier(d, 0.0).to(DEV).train()
+                args = Namespace(batch_size=bs, part_num=pn, part_len=L, n_patch=P, lambda_1=0.01, lambda_MIL=1.0, lambda_CE=0.8,
+                                 temporal_only=False, clip_grad=False)
+                steps.append(TrainStep(args, "LTN", enc, head, 1e-4, 1e-3, 1e-3))
+                g = torch.Generator(device=DEV).manual_seed(7 + ci)
+                nf = 0.5 * torch.relu(torch.randn(bs, pn * L, P, d, device=DEV, generator=g))
+                af = 0.5 * torch.relu(torch.randn(bs, pn * L, P, d, device=DEV, generator=g))
+                af[:, :, :, : d // 8] += 0.4                                    # the anomaly signature
+                al = torch.ones(bs, pn * L, 1, device=DEV)
+                batches.append((nf, af, al))
+                xt = 0.5 * torch.relu(torch.randn(128, L * P, d, device=DEV, generator=g))
+                xt[64:, :, : d // 8] += 0.4
+                tests.append(xt)
+            mixed = MixedStep(steps)
+            for _ in range(6):
+                sc = mixed.step(batches)
+            scores = []
+            with torch.no_grad():
+                for ts, xt in zip(steps, tests):
+                    ts.encoder.eval(); ts.head.eval()
+                    scores.append(ts.head(ts.encoder.forward_cls(xt))[:, 1].cpu().numpy())
+            return [float(s[0]) for s in sc], scores
+        finally:
+            Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
+
+    loss32, s32 = run("fp32")
+    loss16, s16 = run("bf16")
+    labels = np.r_[np.zeros(64), np.ones(64)]
+    for a, b, l32, l16 in zip(s32, s16, loss32, loss16):
+        assert np.isfinite(a).all() and np.isfinite(b).all()
+        assert np.max(np.abs(a - b)) > 0 and np.max(np.abs(a - b)) < 5e-2
+        assert abs(roc_auc(a, labels) - roc_auc(b, labels)) < 1e-2
+        assert abs(l32 - l16) < 5e-2

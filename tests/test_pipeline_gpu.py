@@ -149,6 +149,7 @@ def test_reference_command_lines_on_feature_archives(world, tmp_path):
         "--log_dir", str(tmp_path / "log")])
     assert r.returncode == 0, r.stderr[-2000:]
     assert "best_test_AUC" in r.stderr and "best_train_AUC" in r.stderr and "MIL_loss" in r.stderr
+    train_log = r.stderr
     saved = sorted(os.listdir(save))
     enc_ckpt = [f for f in saved if f.startswith("temporal_model")][-1]
     cls_ckpt = [f for f in saved if f.startswith("classifier_model")][-1]
@@ -163,9 +164,9 @@ def test_reference_command_lines_on_feature_archives(world, tmp_path):
     # the file name carries str(train AUC) (Train/temporal_transformer_shanghaitech.py:242-247); the TEST AUC of the epoch
     # that wrote the last checkpoint is in the log line printed right after the save
     train_auc = enc_ckpt.rsplit("_", 1)[-1]
-    line = [l for l in r.stderr.splitlines() if "now test_AUC is" in l and ("now train_AUC is " + train_auc) in
-            r.stderr[r.stderr.index(l):r.stderr.index(l) + len(l) + 200]]
-    assert line, r.stderr[-1500:]
+    line = [l for l in train_log.splitlines() if "now test_AUC is" in l and ("now train_AUC is " + train_auc) in
+            train_log[train_log.index(l):train_log.index(l) + len(l) + 200]]
+    assert line, train_log[-1500:]
     assert abs(auc - float(line[-1].split("now test_AUC is ")[1].split()[0])) < 1e-3
 
 
