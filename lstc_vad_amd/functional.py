@@ -301,8 +301,9 @@ def _wgrad_split(m_out: int, n_out: int, tile: int = 128) -> int:
     """Split-K factor for weight gradients: K = token count is huge and the output small, so the K range is
     split until the grid has >= ~2 workgroups per CU (256 CUs; 128x128 tiles, 256x256 for the packed bf16 kernel)."""
     tiles = ((m_out + tile - 1) // tile) * ((n_out + tile - 1) // tile)
+    want = 256 if tile == 256 else 512      # the 256x256 kernel holds one workgroup per CU (128 KB of LDS), the others two
     s = 1
-    while tiles * s < 512 and s < 16:
+    while tiles * s < want and s < 16:
         s *= 2
     return s
 
