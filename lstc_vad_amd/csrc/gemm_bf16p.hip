@@ -32,6 +32,7 @@ namespace {
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx4v __attribute__((ext_vector_type(4)));
 
 constexpr int NT8 = 512;                 // 8 waves
 constexpr int P1_TILE = 4096;            // bf16 elements of one packed tile (128 rows x 32 k = 8 KB)
@@ -112,33 +113,40 @@ struct P1Params {
     float alpha;
     DropKey dk;
     int tilesN, nsteps, steps_per_split;     // K steps of 64
+    int splits, total_items;                 // K splits launched; work items = tiles x splits
     int KBa, KBb;                            // 32-k tiles per 128-row block of the A / B pack (even)
     long long split_stride;                  // elements between the outputs of consecutive K splits (0: atomics into one C)
-    int debug;                               // -DLSTC_TUNING builds only: 1 = skip the epilogue (timing ablation)
+    int debug;                               // -DLSTC_TUNING builds only: 1 = skip the epilogue (timing ablation), 2 = narrow epilogue
+    int vec_epi;                             // 16-B epilogue accesses allowed (N, ld's multiples of 4, pointers 16-B aligned)
 };
 
+constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
+
+// PERSISTENT: gridDim.x workgroups (one per CU) walk the work items (output tile x K split) round by round; in a round the
+// 32 workgroups of an XCD (blockIdx % 8) take 32 consecutive tiles (N fastest), so their A panels are shared in that XCD's
+// L2.  Between two items the LDS-DMA of the NEXT item's first two K steps is issued BEFORE the epilogue of the current one:
+// the 822 MB of f32 output per forward GEMM are then in flight while the next tile's first K steps compute.  vmcnt is one
+// in-order counter for DMA and stores, so the waits of those first K steps count the epilogue's stores in: the wide epilogue
+// issues EXACTLY 32 global_store_dwordx4 per wave through inline asm (full tiles only), which makes "prologue DMA landed"
+// = vmcnt(32 + younger DMA) a compile-time constant.  Every other epilogue drains (vmcnt(0)) and starts the next item cold.
 template <bool TR>
 __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_p1[];
     bf16_t* const smem = smem_p1;
-    int pid = blockIdx.x;
-    {   // XCD-aware bijective remap: each XCD works on a contiguous run of tiles (N fastest) and keeps their A panel in its L2
-        const int nwg = gridDim.x, xcd = pid & 7, idx = pid >> 3, q = nwg >> 3, r = nwg & 7;
-        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int mb = pid / p.tilesN, nb = pid % p.tilesN;
-    const int kt0 = blockIdx.y * p.steps_per_split;
-    const int nkt = min(p.nsteps, kt0 + p.steps_per_split) - kt0;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int l31 = lane & 31, h = lane >> 5;
-    floatx16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // work item -> (tile, split); per round the XCD's workgroups own a contiguous run of items
+    const int G = gridDim.x, per_xcd = G >> 3;
+    const int first = (G & 7) ? (int)blockIdx.x : ((int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3));
+    int item = first;
+    int mb = 0, nb = 0, kt0 = 0, nkt = 0;
+    auto set_item = [&](int w) {
+        const int tile = w / p.splits, sp = w - tile * p.splits;
+        mb = tile / p.tilesN; nb = tile - mb * p.tilesN;
+        kt0 = sp * p.steps_per_split;
+        nkt = min(p.nsteps, kt0 + p.steps_per_split) - kt0;
+    };
 
     // ---- LDS-DMA: per unit one wave-uniform global base (SGPRs) + LDS byte address; pieces j = 0, 1 are consecutive KBs
     // (the instruction's immediate offset applies to both sides).  Element offsets.
@@ -167,7 +175,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
         const int slot_ = unit_slot(u), pc_ = unit_piece(u);                                                           \
         const bf16_t* g_ = slot_gaddr(slot_, kt0 + (ktl)) + pc_ * 512;                                                 \
         const uint32_t l_ = (uint32_t)(((buf) * P1_BUF + slot_ * P1_SLOT + pc_ * 512) * 2);                            \
-        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" \
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" \
                      :: "v"(lane_off), "s"(g_), "s"(l_) : "memory");                                                   \
     } while (0)
 
@@ -199,17 +207,13 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
         return *reinterpret_cast<const bf16x8*>(s + ((q & 1) ? nt_off1 : nt_off0));
     };
     bf16x8 fa[4][2], fb[2][4];            // A: [k16 step][row tile of the current half]; B: [column tile][k16 step]
+    floatx16 acc[4][2];
 
-    // ---- prologue: tile 0 complete + U0, U1 of tile 1 (the in-flight state every tile starts from)
-    P1_DMA_UNIT(0, 0, 0); P1_DMA_UNIT(1, 0, 0); P1_DMA_UNIT(2, 0, 0); P1_DMA_UNIT(3, 0, 0);
-    if (nkt > 1) {
-        P1_DMA_UNIT(0, 1, 1); P1_DMA_UNIT(1, 1, 1);
-        __builtin_amdgcn_s_waitcnt(0x0F74);          // vmcnt(4): this wave's 8 pieces of tile 0 have landed
-    } else {
-        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
-    }
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();       // waves 4-7 run one barrier behind: their LOAD beside the partner's COMPUTE
+    // K steps 0 and 1 of the current item (mb, nb, kt0, nkt) -> buffers 0 and 1, all four units each: 8 (+8) DMA per wave
+    auto issue_head = [&]() {
+        P1_DMA_UNIT(0, 0, 0); P1_DMA_UNIT(1, 0, 0); P1_DMA_UNIT(2, 0, 0); P1_DMA_UNIT(3, 0, 0);
+        if (nkt > 1) { P1_DMA_UNIT(0, 1, 1); P1_DMA_UNIT(1, 1, 1); P1_DMA_UNIT(2, 1, 1); P1_DMA_UNIT(3, 1, 1); }
+    };
 
 #define P1_MMA(ih, jj)                                                                                                 \
     do {                                                                                                               \
@@ -230,8 +234,12 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     } while (0)
 
-    auto tile = [&](int tl, auto bufc) {
+    // One K step.  HEAD = K step 0 of an item: K step 1 is already in flight whole (issue_head), and PEND stores of the
+    // previous item's epilogue (0 or 32, younger than that DMA) may still be outstanding.
+    auto tile = [&](int tl, auto bufc, auto headc, auto pendc) {
         constexpr int CUR = decltype(bufc)::value;
+        constexpr bool HEAD = decltype(headc)::value;
+        constexpr int PEND = decltype(pendc)::value;
         const bf16_t* cur = smem + CUR * P1_BUF;
         const bool has1 = tl + 1 < nkt, has2 = tl + 2 < nkt;
         // ---- phase 0: quadrant (rows first 64, cols first 32)
@@ -240,87 +248,197 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) { fa[q][0] = rd_a(cur, 0, q); fa[q][1] = rd_a(cur, 1, q); }
-        if (has1) P1_DMA_UNIT(2, tl + 1, CUR ^ 1);
+        if (!HEAD && has1) P1_DMA_UNIT(2, tl + 1, CUR ^ 1);
         P1_SYNC_COMPUTE(0, 0);
         // ---- phase 1: (first 64 rows, second 32 cols)
 #pragma unroll
         for (int q = 0; q < 4; ++q) fb[1][q] = rd_b(cur, 1, q);
-        if (has1) P1_DMA_UNIT(3, tl + 1, CUR ^ 1);
+        if (!HEAD && has1) P1_DMA_UNIT(3, tl + 1, CUR ^ 1);
         P1_SYNC_COMPUTE(0, 1);
         // ---- phase 2: (second 64 rows, second 32 cols)
 #pragma unroll
         for (int q = 0; q < 4; ++q) { fa[q][0] = rd_a(cur, 2, q); fa[q][1] = rd_a(cur, 3, q); }
         if (has2) P1_DMA_UNIT(0, tl + 2, CUR);
         P1_SYNC_COMPUTE(1, 1);
-        // ---- phase 3: (second 64 rows, first 32 cols): no fragment reads; tile t+1 must have landed before the next read
+        // ---- phase 3: (second 64 rows, first 32 cols): no fragment reads; K step t+1 must have landed before the next read
         if (has2) {
             P1_DMA_UNIT(1, tl + 2, CUR);
-            __builtin_amdgcn_s_waitcnt(0x0F74);      // vmcnt(4): everything but U0, U1 of tile t+2
+            __builtin_amdgcn_s_waitcnt(vmcnt_imm(4 + (HEAD ? PEND : 0)));   // everything but U0, U1 of step t+2 (and the stores)
         } else {
-            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+            __builtin_amdgcn_s_waitcnt(vmcnt_imm(HEAD ? PEND : 0));
         }
         P1_SYNC_COMPUTE(1, 0);
     };
-    int tl = 0;
-    for (; tl + 1 < nkt; tl += 2) {
-        tile(tl, std::integral_constant<int, 0>{});
-        tile(tl + 1, std::integral_constant<int, 1>{});
-    }
-    if (tl < nkt) tile(tl, std::integral_constant<int, 0>{});
-    if (wr == 0) __builtin_amdgcn_s_barrier();       // balance the stagger
-#undef P1_DMA_UNIT
-#undef P1_MMA
-#undef P1_SYNC_COMPUTE
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 32> I32;
+    typedef std::integral_constant<bool, true> BT;
+    typedef std::integral_constant<bool, false> BF;
 
-    // ---- epilogue (semantics of gemm_f32.hip)
-#ifdef LSTC_TUNING
-    if (p.debug & 1) {       // timing ablation: keep the accumulators live, store nothing
-        float s = 0.f;
+    const int total = p.total_items;
+    if (item >= total) return;
+    // (Tried: staggering the workgroups' start per XCD or inside an XCD so that their epilogues do not collide - no gain
+    // per XCD, 2-14 % slower inside an XCD: the 64 MB of a round's output drain at the HBM write rate either way.)
+    set_item(item);
+    issue_head();
+    bool pending = false;                 // 32 epilogue stores of the previous item younger than the head DMA
+    while (true) {
+        // ---- K step 0 landed?  younger ops: K step 1 (8) and the pending stores (32)
+        if (nkt > 1) { if (pending) __builtin_amdgcn_s_waitcnt(vmcnt_imm(40)); else __builtin_amdgcn_s_waitcnt(vmcnt_imm(8)); }
+        else { if (pending) __builtin_amdgcn_s_waitcnt(vmcnt_imm(32)); else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0)); }
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();       // waves 4-7 run one barrier behind: their LOAD beside the partner's COMPUTE
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
-        if (s == 1.2345e-30f) p.C[0] = s;
-        return;
-    }
-#endif
-    const int flags = p.flags;
-    const bool atomic = gridDim.y > 1 && p.split_stride == 0;
-    float* const Cz = p.C + (size_t)blockIdx.y * p.split_stride;
-    const float alpha = p.alpha;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = nb * 256 + wc * 64 + j * 32 + l31;
-        if (col >= p.N) continue;
-        const float bv = (flags & LSTC_EPI_BIAS) ? p.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rbase = mb * 256 + wr * 128 + i * 32 + 4 * h;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] * alpha;
-                float* cp = Cz + (size_t)row * p.ldc + col;
-                if (atomic) {
-                    atomicAdd(cp, v);
-                    continue;
-                }
-                v += bv;
-                if (flags & LSTC_EPI_RELU) v = fmaxf(v, 0.f);
-                if (flags & LSTC_EPI_DROPOUT) {
-                    const uint32_t idx = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
-                    v = drop_keep(idx, p.dk) ? v * p.dk.scale : 0.f;
-                }
-                if (flags & LSTC_EPI_RESIDUAL) v += p.res[(size_t)row * p.ldr + col];
-                if (flags & LSTC_EPI_RELU_MASK) v = p.relu_src[(size_t)row * p.ld_relu + col] > 0.f ? v : 0.f;
-                if (flags & LSTC_EPI_ACCUM) v += *cp;
-                *cp = v;
-            }
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        if (pending) tile(0, I0{}, BT{}, I32{}); else tile(0, I0{}, BT{}, I0{});
+        int tl = 1;
+        if (tl < nkt) { tile(tl, I1{}, BF{}, I0{}); ++tl; }
+        for (; tl + 1 < nkt; tl += 2) {
+            tile(tl, I0{}, BF{}, I0{});
+            tile(tl + 1, I1{}, BF{}, I0{});
         }
+        if (tl < nkt) tile(tl, I0{}, BF{}, I0{});
+        if (wr == 0) __builtin_amdgcn_s_barrier();       // balance the stagger: every LDS read of the item is complete
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- next item: request its first two K steps before this item's epilogue
+        const int cmb = mb, cnb = nb, csplit = kt0 / p.steps_per_split;
+        const int next = item + G;
+        const bool has_next = next < total;
+        if (has_next) { set_item(next); issue_head(); }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- epilogue of (cmb, cnb, csplit) (semantics of gemm_f32.hip)
+        bool done = false;
+#ifdef LSTC_TUNING
+        if (p.debug & 1) {       // timing ablation: keep the accumulators live, store nothing
+            float sacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+            if (sacc == 1.2345e-30f) p.C[0] = sacc;
+            done = true; pending = false;
+            __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+        }
+#endif
+        const int flags = p.flags;
+        const bool atomic = p.splits > 1 && p.split_stride == 0;
+        float* const Cz = p.C + (size_t)csplit * p.split_stride;
+        const float alpha = p.alpha;
+        if (!done && p.vec_epi && !atomic) {
+            // wide epilogue: a 32x32 accumulator holds, per lane, ONE column and 16 rows (4 consecutive rows per register
+            // group); a 4x4 transpose inside each quad of lanes (DPP quad_perm, no LDS) turns a register group into 4
+            // consecutive columns of one row, so every lane moves 16 B and a wave-instruction covers 8 rows x 128 B full lines
+            // instead of 2 rows x 128 B with four times the instructions (cdna_hip_programming.md T21).
+            const bool full = (cmb + 1) * 256 <= p.M && (cnb + 1) * 256 <= p.N;       // wave-uniform
+            const int c4 = lane & 3, q8 = l31 >> 2;
+            auto xpose = [&](float& v0, float& v1, float& v2, float& v3) {
+                const bool b1 = (c4 & 2) != 0, b0 = (c4 & 1) != 0;
+                int s0 = __float_as_int(b1 ? v0 : v2), s1 = __float_as_int(b1 ? v1 : v3);
+                float r0 = __int_as_float(__builtin_amdgcn_mov_dpp(s0, 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+                float r1 = __int_as_float(__builtin_amdgcn_mov_dpp(s1, 0x4E, 0xF, 0xF, true));
+                if (b1) { v0 = r0; v1 = r1; } else { v2 = r0; v3 = r1; }
+                s0 = __float_as_int(b0 ? v0 : v1); s1 = __float_as_int(b0 ? v2 : v3);
+                r0 = __int_as_float(__builtin_amdgcn_mov_dpp(s0, 0xB1, 0xF, 0xF, true));            // quad_perm [1,0,3,2]
+                r1 = __int_as_float(__builtin_amdgcn_mov_dpp(s1, 0xB1, 0xF, 0xF, true));
+                if (b0) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
+            };
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = cnb * 256 + wc * 64 + j * 32 + 4 * q8;
+                const bool cok = col < p.N;                                   // N % 4 == 0: all four columns or none
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((flags & LSTC_EPI_BIAS) && cok) bv = *reinterpret_cast<const float4*>(p.bias + col);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+                        xpose(v0, v1, v2, v3);
+                        const int row = cmb * 256 + wr * 128 + i * 32 + 4 * h + 8 * g + c4;
+                        if (!full && (!cok || row >= p.M)) continue;
+                        float4 v = make_float4(v0 * alpha + bv.x, v1 * alpha + bv.y, v2 * alpha + bv.z, v3 * alpha + bv.w);
+                        if (flags & LSTC_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        if (flags & LSTC_EPI_DROPOUT) {
+                            const uint32_t idx = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+                            v.x = drop_keep(idx, p.dk) ? v.x * p.dk.scale : 0.f;
+                            v.y = drop_keep(idx + 1, p.dk) ? v.y * p.dk.scale : 0.f;
+                            v.z = drop_keep(idx + 2, p.dk) ? v.z * p.dk.scale : 0.f;
+                            v.w = drop_keep(idx + 3, p.dk) ? v.w * p.dk.scale : 0.f;
+                        }
+                        if (flags & LSTC_EPI_RESIDUAL) {
+                            const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)row * p.ldr + col);
+                            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                        }
+                        if (flags & LSTC_EPI_RELU_MASK) {
+                            const float4 m = *reinterpret_cast<const float4*>(p.relu_src + (size_t)row * p.ld_relu + col);
+                            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                        }
+                        float* cp = Cz + (size_t)row * p.ldc + col;
+                        if (flags & LSTC_EPI_ACCUM) { const float4 o = *reinterpret_cast<const float4*>(cp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                        if (full) {      // exactly one store instruction per (j, i, g): 32 per wave, counted by the next item's waits
+                            const floatx4v sv = {v.x, v.y, v.z, v.w};
+                            // s_nop 1: the store reads its 16 B of data registers after issue (cdna_hip_programming.md 5.7 item 1)
+                            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(cp), "v"(sv) : "memory");
+                        } else {
+                            *reinterpret_cast<float4*>(cp) = v;
+                        }
+                    }
+                }
+            }
+            done = true;
+            if (full && has_next) pending = true;
+            else { pending = false; __builtin_amdgcn_s_waitcnt(vmcnt_imm(0)); }
+        }
+        if (!done) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = cnb * 256 + wc * 64 + j * 32 + l31;
+                if (col >= p.N) continue;
+                const float bv = (flags & LSTC_EPI_BIAS) ? p.bias[col] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int rbase = cmb * 256 + wr * 128 + i * 32 + 4 * h;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + (r & 3) + 8 * (r >> 2);
+                        if (row >= p.M) continue;
+                        float v = acc[i][j][r] * alpha;
+                        float* cp = Cz + (size_t)row * p.ldc + col;
+                        if (atomic) {
+                            atomicAdd(cp, v);
+                            continue;
+                        }
+                        v += bv;
+                        if (flags & LSTC_EPI_RELU) v = fmaxf(v, 0.f);
+                        if (flags & LSTC_EPI_DROPOUT) {
+                            const uint32_t idx = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+                            v = drop_keep(idx, p.dk) ? v * p.dk.scale : 0.f;
+                        }
+                        if (flags & LSTC_EPI_RESIDUAL) v += p.res[(size_t)row * p.ldr + col];
+                        if (flags & LSTC_EPI_RELU_MASK) v = p.relu_src[(size_t)row * p.ld_relu + col] > 0.f ? v : 0.f;
+                        if (flags & LSTC_EPI_ACCUM) v += *cp;
+                        *cp = v;
+                    }
+                }
+            }
+            pending = false;
+            __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!has_next) break;
+        item = next;
     }
+#undef P1_DMA_UNIT
+#undef P1_MMA
+#undef P1_SYNC_COMPUTE
 }
 
 inline int64_t p1_rbp(int64_t rows) { const int64_t rb = (rows + 127) / 128; return rb + (rb & 1); }
@@ -356,6 +474,13 @@ int lstc_gemm_bf16p_impl(const LstcGemmDesc* d, hipStream_t st) {
     p.debug = 0;
     if (d->variant != 0) return LSTC_E_UNSUPPORTED;
 #endif
+    p.vec_epi = (d->N % 4 == 0) && (d->ldc % 4 == 0) && aligned16(d->C) && (p.split_stride % 4 == 0) &&
+                (!(d->flags & LSTC_EPI_BIAS) || aligned16(d->bias)) &&
+                (!(d->flags & LSTC_EPI_RESIDUAL) || (aligned16(d->residual) && d->ldr % 4 == 0)) &&
+                (!(d->flags & LSTC_EPI_RELU_MASK) || (aligned16(d->relu_src) && d->ld_relu % 4 == 0));
+#ifdef LSTC_TUNING
+    if (p.debug & 2) p.vec_epi = 0;
+#endif
     p.KBa = (int)p1_kbp(tr ? d->M : d->K);
     p.KBb = (int)p1_kbp(tr ? d->N : d->K);
     p.nsteps = (d->K + 63) / 64;
@@ -363,15 +488,21 @@ int lstc_gemm_bf16p_impl(const LstcGemmDesc* d, hipStream_t st) {
     const int eff_splits = (p.nsteps + p.steps_per_split - 1) / p.steps_per_split;
     const int tilesM = (d->M + 255) / 256;
     p.tilesN = (d->N + 255) / 256;
+    p.splits = eff_splits;
+    p.total_items = tilesM * p.tilesN * eff_splits;
     constexpr size_t lds = (size_t)2 * P1_BUF * sizeof(bf16_t);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
     }
-    if (tr) hipLaunchKernelGGL(gemm_bf16p_kernel<true>, dim3(tilesM * p.tilesN, eff_splits), dim3(NT8), lds, st, p);
-    else hipLaunchKernelGGL(gemm_bf16p_kernel<false>, dim3(tilesM * p.tilesN, eff_splits), dim3(NT8), lds, st, p);
+    const int grid = p.total_items < n_cu ? p.total_items : n_cu;       // persistent: one workgroup per CU (128 KB of LDS each)
+    if (tr) hipLaunchKernelGGL(gemm_bf16p_kernel<true>, dim3(grid), dim3(NT8), lds, st, p);
+    else hipLaunchKernelGGL(gemm_bf16p_kernel<false>, dim3(grid), dim3(NT8), lds, st, p);
     return lstc_launch_status();
 }
 

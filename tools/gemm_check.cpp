@@ -21,7 +21,7 @@ static std::vector<float> rnd(size_t n, unsigned seed) {
     return v;
 }
 
-struct Case { int M, N, K, tA, tB, flags, variant, split, dtype = 0; };
+struct Case { int M, N, K, tA, tB, flags, variant, split, dtype = 0, alignc = 0; };   // alignc: C / residual / mask leading dims multiples of 4 (16-B epilogue path)
 
 static float bf16_round(float x) {   // RNE to bfloat16, back to float (host model of the kernel's operand rounding)
     uint32_t u; memcpy(&u, &x, 4);
@@ -34,7 +34,7 @@ static int check(const Case& c) {
     const bool pad = (c.variant % 2 == 0) && c.variant != 4;     // padded lds exercise the scalar-load path
     const int lda = (c.tA ? M : K) + (pad ? 3 : 0);
     const int ldb = (c.tB ? K : N) + (pad ? 1 : 0);
-    const int ldc = N + 2, ldr = N + 1, ldm = N;
+    const int ldc = c.alignc ? N + 4 : N + 2, ldr = c.alignc ? N + 8 : N + 1, ldm = N;
     const size_t na = (size_t)(c.tA ? K : M) * lda, nb = (size_t)(c.tB ? N : K) * ldb;
     auto hA = rnd(na, 1), hB = rnd(nb, 2), hbias = rnd(N, 3), hres = rnd((size_t)M * ldr, 4), hmask = rnd((size_t)M * ldm, 5);
     std::vector<float> hC((size_t)M * ldc, 0.5f);
@@ -250,6 +250,10 @@ int main(int argc, char** argv) {
             fails += check({512, 256, 1152, 1, 0, 0, 7, split + 1, LSTC_BF16P});
             fails += check({300, 523, 640, 1, 0, 0, 7, split, LSTC_BF16P});                 // TR, ragged feature counts
             fails += check({96, 40, 128, 1, 0, 0, 7, 1, LSTC_BF16P});
+            fails += check({600, 520, 1000, 0, 1, ALLB, 1, 1, LSTC_BF16P, 1});              // 16-B (quad-transposed) epilogue, every flag
+            fails += check({257, 132, 67, 0, 1, LSTC_EPI_BIAS | LSTC_EPI_RELU, 1, 1, LSTC_BF16P, 1});
+            fails += check({300, 200, 132, 0, 0, LSTC_EPI_RELU_MASK | LSTC_EPI_ACCUM, 0, 1, LSTC_BF16P, 1});
+            fails += check({512, 256, 1152, 1, 0, 0, 7, 1, LSTC_BF16P, 1});
         }
         printf("%s: %d failing cases\n", fails ? "FAILED" : "ALL PASS", fails);
     }
