@@ -33,13 +33,46 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.lstc_version() == 100
 
 
-def test_descriptor_layouts_match_header(lib):
-    """ctypes mirrors must have the C struct sizes (natural alignment, 64-bit pointers)."""
+def test_descriptor_layouts_match_header(lib, tmp_path):
+    """The ctypes mirrors against the C compiler's own layout of include/lstc_hip.h: sizeof and the offset of every field of
+    the three descriptors (a C program built with gcc prints them)."""
+    import subprocess
     from lstc_vad_amd._lib import GemmDesc, AttnDesc, LossDesc
-    assert C.sizeof(GemmDesc) == 17 * 4 + 4 + 8 + 6 * 8 - 4 or C.sizeof(GemmDesc) % 8 == 0
-    assert GemmDesc.dropout_seed.offset % 8 == 0 and GemmDesc.A.offset % 8 == 0
-    assert AttnDesc.dropout_seed.offset % 8 == 0 and AttnDesc.Q.offset % 8 == 0
-    assert LossDesc.out.offset % 8 == 0 and LossDesc.phase.offset == LossDesc.scalars.offset + 8
+    structs = {"LstcGemmDesc": GemmDesc, "LstcAttnDesc": AttnDesc, "LstcLossDesc": LossDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "lstc_hip.h"', 'int main(void) {']
+    for cname, ct in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, ct in structs.items():
+        assert int(got[cname]) == C.sizeof(ct), (cname, got[cname], C.sizeof(ct))
+        for fname, _ in ct._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, (cname, fname)
+
+
+def test_production_library_refuses_tuning_variants(lib):
+    """LstcGemmDesc.variant is a public field: values outside the documented tile variants (and the timing-only ablation
+    bits of -DLSTC_TUNING builds) must be refused before any launch, for every GEMM dtype."""
+    from lstc_vad_amd._lib import GemmDesc
+    d = GemmDesc()
+    d.A = d.B = d.C = 16
+    d.M = d.N = d.K = 128
+    d.lda = d.ldb = d.ldc = 128
+    d.transB = 1
+    for dtype, bad in ((0, (12, 13, 14, 15, 16, 4 + 16, 1 << 20, -1)), (3, (1, 16, 32))):
+        d.dtype = dtype
+        for v in bad:
+            d.variant = v
+            assert lib.lstc_gemm(C.byref(d), None) == -4, (dtype, v)
+    assert lib.lstc_gemm_splits(0, 4224, 16) == 15 and lib.lstc_gemm_splits(2, 4224, 16) == 15       # 132 K tiles -> 15 slices of 9
+    assert lib.lstc_gemm_splits(3, 100352, 8) == 8 and lib.lstc_gemm_splits(1, 130, 4) == 3 and lib.lstc_gemm_splits(0, 64, 1) == 1
 
 
 def test_host_side_validation_error_codes(lib):

@@ -105,6 +105,10 @@ def test_training_step_matches_reference_golden(name, cls_only):
             frac_bad = float((diff > 5e-5).float().mean())
             lim = 1e-3 if prefix.startswith("enc") else 1e-2
             assert frac_bad <= lim, (k, frac_bad, float(diff.max()))
+            # and no entry may be off by more than what two sign-flipped Adagrad steps can move it (2 * 2 * lr): an
+            # unwritten partial or a corrupted slice would show up here whatever its share of the tensor
+            lr = 1e-4 if prefix.startswith("enc") else 1e-2
+            assert float(diff.max()) <= 4 * lr + 1e-6, (k, float(diff.max()))
 
 
 @pytest.mark.parametrize("name", ["ltn_sht", "stn_sht", "ltn_ubnormal"])
@@ -350,7 +354,7 @@ def test_rccl_gradient_bucket_path_single_rank():
         dist.destroy_process_group()
         os.environ["LSTC_FORCE_DIST"] = "0"
     sc0, w0 = run(False)
-    # not bitwise: the split-K weight-gradient GEMMs add their partial sums with f32 atomics (order varies run to run)
+    # (the two paths differ only in where the gradients live - flat buckets vs per-parameter tensors)
     assert max_abs_diff(sc0, sc1) < 1e-6
     for k in w0:
         assert max_abs_diff(w0[k], w1[k]) < 1e-6, k
