@@ -163,6 +163,9 @@ typedef struct LstcAttnDesc {
                                        ceil(N/chunks) sequences, written (no atomics; the caller sums them - a
                                        fixed-order, bit-reproducible gradient) */
     int32_t dtable_chunks;
+    int32_t variant;                /* 0 = default kernels; 1 = first-generation kernels (operands straight from global in
+                                       MFMA lane layout) - kept for A/B measurements and as the fallback for shapes the
+                                       staged kernels do not take (d_k or d_v not a multiple of 32, unaligned operands, S > 96) */
 } LstcAttnDesc;
 
 int lstc_attn_fwd(const LstcAttnDesc* d, void* stream);

@@ -283,6 +283,262 @@ __global__ void __launch_bounds__(NT, T <= 3 ? 2 : 1) attn_bwd_kernel(const Attn
     }
 }
 
+// =====================================================================================================
+// Second-generation backward (T <= 3, d_k and d_v multiples of 32, 16-B aligned operands): same math, same LDS score tiles,
+// same bias-table accumulation as attn_bwd_kernel, but the operands reach the MFMAs differently.
+//   * dP = dO V^T contracts over FEATURES, so the MFMA lane layout (lane = row, 16 consecutive floats per lane) makes a
+//     direct global load touch 32 different 128-B lines per instruction.  Here dO and V are staged through LDS in 32-feature
+//     chunks by LDS-DMA (global_load_lds_dwordx4: 8 rows x 128 B per wave-instruction, whole lines, no staging registers),
+//     double buffered, chunk c+1 in flight under the 16 MFMAs of chunk c.  Rows are 128 B in LDS; the 16-B chunk index is
+//     XOR-ed with (row >> 1) & 7 on the SOURCE side of the DMA and on the read side, which puts the 16 lanes of every
+//     ds_read_b128 lane group on 16 distinct 16-B slots.
+//   * dV = Pd^T dO, dQ = dA K, dK = dA^T Q contract over the S tokens: lane = output column, so global loads are coalesced
+//     already; each wave walks a list of (product, 32-column tile) jobs, holds ALL S rows of the job's B operand in
+//     registers (SP/2 floats per lane) and requests the next job's rows before the 32 T MFMAs of the current one.
+// First version (attn_bwd_kernel): every K chunk exposed one global-load latency; 22 % MFMA-busy, 2.8 ms per LTN layer.
+// Phase 3 of the backward as ONE software pipeline over (product, 32-column tile) jobs.  Every product is
+// Out[S, cols] = scale * A^T B with A^T read from an LDS tile laid out [k][i] (the caller keeps dA both ways), B = rows of a
+// global matrix.  Per job a lane keeps the SP / 2 values of its column that its MFMA lane-half consumes (rows 16 b + 8 h2 + s)
+// in registers; the rows of the wave's NEXT job - possibly of the next product - are requested before the 32 T MFMAs of the
+// current one (two register sets, loop unrolled by two so no set is ever copied).
+//   * buffer loads / stores: ONE per-lane offset register (column + the lane-half's row shift), the row rides in the scalar
+//     offset, and rows >= S fall outside the descriptors' S * ld * 4 bytes: they read 0 and their stores are dropped - no
+//     clamps, no 64-bit per-access addresses (plain pointers: 2 address registers per value, 682 spilled registers);
+//   * macros, not lambdas taking the register arrays by reference (those sent both sets to scratch).
+struct RtlJob {
+    const float* A;                    // LDS tile, [k][i] with row stride LD
+    __amdgpu_buffer_rsrc_t b, o;       // B rows, output rows (S rows each)
+    uint32_t brow, orow;               // row pitches in bytes
+    float scale;
+    int ct;                            // 32-column tile
+};
+#define RTL_LOAD(J, bv_)                                                                                      \
+    do {                                                                                                      \
+        const uint32_t vo_ = (uint32_t)c31 * 4u + (uint32_t)(8 * h2) * J.brow + (uint32_t)(128 * J.ct);       \
+        _Pragma("unroll") for (int b_ = 0; b_ < SP / 16; ++b_)                                                  \
+            _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_)                                                    \
+                bv_[8 * b_ + s_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(             \
+                    J.b, vo_, (uint32_t)(16 * b_ + s_) * J.brow, 0));                                         \
+    } while (0)
+#define RTL_COMPUTE(J, bv_)                                                                                   \
+    do {                                                                                                      \
+        floatx16 o_[T];                                                                                       \
+        _Pragma("unroll") for (int t_ = 0; t_ < T; ++t_)                                                        \
+            _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) o_[t_][i_] = 0.f;                                 \
+        _Pragma("unroll") for (int b_ = 0; b_ < SP / 16; ++b_) {                                                \
+            _Pragma("unroll") for (int t_ = 0; t_ < T; ++t_) {                                                  \
+                float av_[8];                                                                                 \
+                _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_)                                                \
+                    av_[s_] = J.A[(16 * b_ + 8 * h2 + s_) * LD + 32 * t_ + c31];                              \
+                _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_)                                                \
+                    o_[t_] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[s_], bv_[8 * b_ + s_], o_[t_], 0, 0, 0); \
+            }                                                                                                 \
+        }                                                                                                     \
+        const uint32_t wo_ = (uint32_t)c31 * 4u + (uint32_t)(4 * h2) * J.orow + (uint32_t)(128 * J.ct);       \
+        _Pragma("unroll") for (int t_ = 0; t_ < T; ++t_)                                                        \
+            _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_)                                                   \
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o_[t_][r_] * J.scale), J.o, wo_, \
+                    (uint32_t)(32 * t_ + (r_ & 3) + 8 * (r_ >> 2)) * J.orow, 0);                              \
+    } while (0)
+
+#undef RTL_PLACEHOLDER
+struct StageDma {
+    // one DMA piece = 8 rows x 32 floats (1 KB); lane -> (row in piece, 16-B position); the source chunk is swizzled
+    __device__ static __forceinline__ void issue(const float* __restrict__ base, int ld, int S, int row0, int kc, uint32_t lds_bytes) {
+        const int lane = threadIdx.x & 63;
+        const int r = min(row0 + (lane >> 3), S - 1), c = lane & 7;
+        const float* g = base + (size_t)r * ld + kc * 32 + ((c ^ ((r >> 1) & 7)) << 2);
+        const uint32_t lb = __builtin_amdgcn_readfirstlane(lds_bytes);        // wave-uniform by construction; make it provable
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(lb) : "memory");
+    }
+};
+
+template <int T>
+__global__ void __launch_bounds__(NT, 2) attn_bwd2_kernel(const AttnParams p) {
+    constexpr int SP = 32 * T, LD = SP + 1, NJ = (SP + 63) / 64;
+    constexpr int CH = SP * 32;                  // floats of one staged operand chunk (SP rows x 32 features)
+    constexpr int NPW = 2 * T;                   // DMA pieces per wave and chunk: 2 operands x SP/8 pieces / 4 waves
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Dm = sm;                              // dP~ then dA
+    float* Pm = sm + SP * LD;                    // dropped probabilities
+    constexpr int ST0 = (2 * SP * LD + 3) & ~3;  // staging ring: [buf][operand][SP][32], 16-B aligned
+    float* stage = sm + ST0;
+    float* DmT = stage;                          // dA^T (phase 2 / 3): the staging ring is idle after phase 1 (SP * LD <= 4 * CH)
+    float* tacc = stage + 4 * CH;                // [NT/64][table_rows]
+    const int h = blockIdx.y, S = p.S;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, h2 = lane >> 5;
+    const bool has_bias = p.index_ld > 0 && p.dtable != nullptr;
+    if (has_bias)
+        for (int i = threadIdx.x; i < (NT / 64) * p.table_rows; i += NT) tacc[i] = 0.f;
+    float* const tw = tacc + wave * p.table_rows;
+    const int n_begin = blockIdx.x * p.n_per_wg;
+    const int n_end = min(p.N, n_begin + p.n_per_wg);
+    const uint32_t stage_b = (uint32_t)(ST0 * 4);       // dynamic LDS starts at byte 0 of the workgroup's allocation
+    const int nchunks = p.dv >> 5;
+#pragma unroll 1
+    for (int n = n_begin; n < n_end; ++n) {
+        const float* Qb = p.Q + (size_t)n * S * p.ldq + (size_t)h * p.dk;
+        const float* Kb = p.K + (size_t)n * S * p.ldk + (size_t)h * p.dk;
+        const float* Vb = p.V + (size_t)n * S * p.ldv + (size_t)h * p.dv;
+        const float* dOb = p.dO + (size_t)n * S * p.ldo + (size_t)h * p.dv;
+        __syncthreads();   // previous sequence's LDS readers are done (plain barrier: no DMA is in flight here)
+        // ---- phase 1: dP~ = dO V^T, operands staged per 32-feature chunk
+        auto issue_chunk = [&](int kc, int buf) {
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) {
+                const int piece = wave + 4 * j;                  // 0 .. 2*SP/8-1: first half dO, second half V
+                const int op = piece >= SP / 8 ? 1 : 0, pj = piece - op * (SP / 8);
+                StageDma::issue(op ? Vb : dOb, op ? p.ldv : p.ldo, S, 8 * pj, kc, stage_b + (uint32_t)(((buf * 2 + op) * CH + pj * 256) * 4));
+            }
+        };
+        floatx16 acc[(T * T + 3) / 4];
+#pragma unroll
+        for (int t = 0; t < (T * T + 3) / 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        issue_chunk(0, 0);
+        // the probabilities of this wave's rows (phase 2) are requested now and land under phase 1 (first version: one exposed
+        // global-load latency per row, 16 rows per wave)
+        const float* pr_base = p.probs + ((size_t)n * p.H + h) * S * S;
+        float pvr[SP / 4][NJ];
+#pragma unroll
+        for (int ii = 0; ii < SP / 4; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int i = wave + 4 * ii, j = lane + 64 * jj;
+                pvr[ii][jj] = (i < S && j < S) ? pr_base[(size_t)i * S + j] : 0.f;
+            }
+#pragma unroll 1
+        for (int kc = 0; kc < nchunks; ++kc) {
+            const int buf = kc & 1;
+            if (kc + 1 < nchunks) {
+                issue_chunk(kc + 1, buf ^ 1);
+                __builtin_amdgcn_s_waitcnt((NPW & 15) | (7 << 4) | (15 << 8) | ((NPW >> 4) << 14));    // vmcnt(NPW): chunk kc landed
+            } else {
+                __builtin_amdgcn_s_waitcnt(0x0F70);                                                    // vmcnt(0)
+            }
+            __builtin_amdgcn_s_barrier();                        // every wave's pieces of chunk kc are in LDS
+            const float* sA = stage + (buf * 2 + 0) * CH;
+            const float* sB = stage + (buf * 2 + 1) * CH;
+#pragma unroll
+            for (int tt = 0; tt < (T * T + 3) / 4; ++tt) {
+                const int t = wave + 4 * tt;
+                if (t < T * T) {
+                    const int ra = 32 * (t / T) + l31, rb = 32 * (t % T) + l31;
+                    float a[16], b[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 va = *reinterpret_cast<const float4*>(sA + ra * 32 + (((4 * h2 + q) ^ ((ra >> 1) & 7)) << 2));
+                        const float4 vb = *reinterpret_cast<const float4*>(sB + rb * 32 + (((4 * h2 + q) ^ ((rb >> 1) & 7)) << 2));
+                        a[4 * q] = va.x; a[4 * q + 1] = va.y; a[4 * q + 2] = va.z; a[4 * q + 3] = va.w;
+                        b[4 * q] = vb.x; b[4 * q + 1] = vb.y; b[4 * q + 2] = vb.z; b[4 * q + 3] = vb.w;
+                    }
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc[tt], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): this chunk's fragments are in registers
+            __builtin_amdgcn_s_barrier();                        // buffer kc & 1 may be refilled (chunk kc + 2)
+        }
+#pragma unroll
+        for (int tt = 0; tt < (T * T + 3) / 4; ++tt) {
+            const int t = wave + 4 * tt;
+            if (t < T * T) store_tile_lds<LD>(Dm, t / T, t % T, acc[tt]);
+        }
+        __syncthreads();
+        // ---- phase 2: dA = P (dP - rowsum(dP P)), bias-table gradient (as attn_bwd_kernel)
+        const uint32_t flat0 = ((uint32_t)n * p.H + h) * (uint32_t)(S * S);
+#pragma unroll
+        for (int ii = 0; ii < SP / 4; ++ii) {
+            const int i = wave + 4 * ii;
+            float* drow = Dm + i * LD;
+            float* prow = Pm + i * LD;
+            if (i >= S) {
+                for (int j = lane; j < SP; j += 64) { drow[j] = prow[j] = 0.f; DmT[j * LD + i] = 0.f; }
+                continue;
+            }
+            float pv[NJ], dp[NJ], keep[NJ];
+            float s = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int j = lane + 64 * jj;
+                pv[jj] = dp[jj] = keep[jj] = 0.f;
+                if (j < S) {
+                    pv[jj] = pvr[ii][jj];
+                    keep[jj] = p.has_drop ? (drop_keep(flat0 + (uint32_t)(i * S + j), p.dkey) ? p.dkey.scale : 0.f) : 1.f;
+                    dp[jj] = drow[j] * keep[jj];
+                    s += dp[jj] * pv[jj];
+                }
+            }
+            s = wave_sum(s);
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int j = lane + 64 * jj;
+                if (j < SP) {
+                    const float da = pv[jj] * (dp[jj] - s);      // zero for j >= S
+                    drow[j] = da;
+                    DmT[j * LD + i] = da;
+                    prow[j] = pv[jj] * keep[jj];
+                    if (has_bias && i >= 1 && j >= 1 && j < S)
+                        tw[p.index[(size_t)(i - 1) * p.index_ld + (j - 1)]] += da;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 3: dV = Pd^T dO, dQ = scale (dA^T)^T K, dK = scale dA^T Q: one pipeline over this wave's (product, column
+        // tile) jobs; dV's tiles first, then dQ's, then dK's
+        {
+            const int jv = ((p.dv >> 5) - wave + 3) >> 2, jk = ((p.dk >> 5) - wave + 3) >> 2;      // tiles of this wave
+            const int njobs = jv + 2 * jk;
+            const uint32_t bytes_v = (uint32_t)S * (uint32_t)p.ldv * 4u, bytes_o = (uint32_t)S * (uint32_t)p.ldo * 4u;
+            const uint32_t bytes_q = (uint32_t)S * (uint32_t)p.ldq * 4u, bytes_k = (uint32_t)S * (uint32_t)p.ldk * 4u;
+            const __amdgpu_buffer_rsrc_t r_dO = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dOb), 0, (int)bytes_o, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_K = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Kb), 0, (int)bytes_k, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_Q = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Qb), 0, (int)bytes_q, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_dV = __builtin_amdgcn_make_buffer_rsrc(p.dV + (size_t)n * S * p.ldv + (size_t)h * p.dv, 0, (int)bytes_v, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_dQ = __builtin_amdgcn_make_buffer_rsrc(p.dQ + (size_t)n * S * p.ldq + (size_t)h * p.dk, 0, (int)bytes_q, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_dK = __builtin_amdgcn_make_buffer_rsrc(p.dK + (size_t)n * S * p.ldk + (size_t)h * p.dk, 0, (int)bytes_k, 0x00020000);
+            auto job = [&](int kj) -> RtlJob {
+                RtlJob J;
+                if (kj < jv) { J.A = Pm; J.b = r_dO; J.brow = (uint32_t)p.ldo * 4u; J.o = r_dV; J.orow = (uint32_t)p.ldv * 4u; J.scale = 1.f; J.ct = wave + 4 * kj; }
+                else if (kj < jv + jk) { J.A = DmT; J.b = r_K; J.brow = (uint32_t)p.ldk * 4u; J.o = r_dQ; J.orow = (uint32_t)p.ldq * 4u; J.scale = p.scale; J.ct = wave + 4 * (kj - jv); }
+                else { J.A = Dm; J.b = r_Q; J.brow = (uint32_t)p.ldq * 4u; J.o = r_dK; J.orow = (uint32_t)p.ldk * 4u; J.scale = p.scale; J.ct = wave + 4 * (kj - jv - jk); }
+                return J;
+            };
+            constexpr int RB = SP / 2;
+            const int c31 = l31;
+            float b0[RB], b1[RB];
+            RtlJob J0 = job(0), J1 = job(1);
+            if (njobs > 0) RTL_LOAD(J0, b0);
+#pragma unroll 1
+            for (int kj = 0; kj < njobs; kj += 2) {
+                if (kj + 1 < njobs) RTL_LOAD(J1, b1);
+                RTL_COMPUTE(J0, b0);
+                if (kj + 1 < njobs) {
+                    J0 = job(kj + 2);
+                    if (kj + 2 < njobs) RTL_LOAD(J0, b0);
+                    RTL_COMPUTE(J1, b1);
+                    J1 = job(kj + 3);
+                }
+            }
+        }
+    }
+    if (has_bias) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < p.table_rows; i += NT) {
+            float v = tacc[i];
+#pragma unroll
+            for (int w = 1; w < NT / 64; ++w) v += tacc[w * p.table_rows + i];
+            if (p.table_partials) p.dtable[((size_t)blockIdx.x * p.table_rows + i) * p.H + h] = v;
+            else atomicAdd(&p.dtable[(size_t)i * p.H + h], v);
+        }
+    }
+}
+
+#undef RTL_LOAD
+#undef RTL_COMPUTE
+
 int fill_params(const LstcAttnDesc* d, AttnParams& p, bool bwd) {
     if (!d) return LSTC_E_NULL;
     if (d->dtype != LSTC_F32) return LSTC_E_UNSUPPORTED;
@@ -362,6 +618,23 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
     p.n_per_wg = npw;
     dim3 grid((p.N + npw - 1) / npw, p.H);
     if (p.table_partials && (int)grid.x != d->dtable_chunks) return LSTC_E_SHAPE;
+    // second-generation kernel (LDS-DMA staged dP, register-resident B rows): d_k, d_v multiples of 32, aligned operands
+    const bool v2 = T <= 3 && p.vec_qk && p.vec_v && (p.dk % 32) == 0 && (p.dv % 32) == 0 && d->variant == 0;
+    if (v2) {
+        const int SP = 32 * T;
+        const size_t lds2 = ((size_t)((2 * SP * (SP + 1) + 3) & ~3) + (size_t)4 * SP * 32 + (size_t)(NT / 64) * p.table_rows) * sizeof(float);
+        if (lds2 <= 160 * 1024) {
+#define LSTC_BWD2(TT)                                                          \
+    do {                                                                       \
+        static bool once2 = false;                                             \
+        if (!once2) { set_lds(attn_bwd2_kernel<TT>, 160 * 1024); once2 = true; } \
+        hipLaunchKernelGGL(attn_bwd2_kernel<TT>, grid, NT, lds2, st, p);       \
+    } while (0)
+            if (T == 1) LSTC_BWD2(1); else if (T == 2) LSTC_BWD2(2); else LSTC_BWD2(3);
+#undef LSTC_BWD2
+            return lstc_launch_status();
+        }
+    }
 #define LSTC_BWD(TT)                                                         \
     do {                                                                     \
         static bool once = false;                                            \

@@ -108,6 +108,7 @@ _pack_prof = None          # list of (bytes_in, start_event, end_event) while be
 _wepoch = 0
 _memo_stack = []           # activation packs made inside one autograd-node body are shared by the GEMMs of that body
 _x3_min = (256, 256, 1 << 30)   # min(M, N), K, M*N*K from which a product goes to the packed kernel
+_ATTN_VARIANT = int(os.environ.get("LSTC_ATTN_VARIANT", "0"))     # 1: first-generation attention kernels (A/B measurements)
 _DETERMINISTIC_WGRAD = os.environ.get("LSTC_ATOMIC_SPLITK", "0") != "1"   # split-K weight gradients: partials + ordered sum, not atomics
 
 
@@ -427,6 +428,7 @@ def attn_fwd(q, k, v, N, S, H, dk, dv, table, index, p_drop, seed):
         d.table, d.index = dev_ptr(table), dev_ptr(index)
     d.scale = 1.0 / (dk ** 0.5)
     d.dropout_p, d.dropout_seed = float(p_drop), int(seed)
+    d.variant = _ATTN_VARIANT
     d.Q, d.K, d.V, d.O, d.probs = dev_ptr(q), dev_ptr(k), dev_ptr(v), dev_ptr(o), dev_ptr(probs)
     check(_lib.load().lstc_attn_fwd(C.byref(d), stream_ptr()), "lstc_attn_fwd")
     return o, probs
@@ -452,6 +454,7 @@ def attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, p_drop, seed, ou
     d.dropout_p, d.dropout_seed = float(p_drop), int(seed)
     d.Q, d.K, d.V, d.probs = dev_ptr(q), dev_ptr(k), dev_ptr(v), dev_ptr(probs)
     d.dO, d.dQ, d.dK, d.dV = dev_ptr(do), dev_ptr(dq), dev_ptr(dk_), dev_ptr(dv_)
+    d.variant = _ATTN_VARIANT
     check(_lib.load().lstc_attn_bwd(C.byref(d), stream_ptr()), "lstc_attn_bwd")
     if parts is not None:
         dtable = colsum(parts).view(table.shape[0], H)

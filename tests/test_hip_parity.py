@@ -1031,3 +1031,52 @@ def test_mixed_step_bf16_vs_fp32_auc_on_the_mixed_pair():
         assert np.max(np.abs(a - b)) > 0 and np.max(np.abs(a - b)) < 5e-2
         assert abs(roc_auc(a, labels) - roc_auc(b, labels)) < 1e-2
         assert abs(l32 - l16) < 5e-2
+
+
+@pytest.mark.parametrize("S,L,dk", [(17, 1, 64), (49, 3, 64), (33, 2, 32), (81, 5, 64), (64, 3, 96), (49, 3, 256)])
+def test_attention_backward_staged_kernel_matches_first_generation_and_f64(S, L, dk):
+    """lstc_attn_bwd's second-generation kernels (LDS-DMA staged dP, register-resident B rows, one job pipeline; T = 1, 2, 3)
+    against the first-generation kernel (LstcAttnDesc.variant = 1) and against an f64 autograd reference that replays the
+    dropout mask: dQ, dK, dV and the bias-table gradient, with relative bias and attention dropout on."""
+    from lstc_vad_amd import functional as Fn
+    from lstc_vad_amd.models.MultiHeadAttention import relative_position_index_3d
+    N, H, p_drop, seed = 5, 3, 0.25, 77
+    g = torch.Generator(device=DEV).manual_seed(S * 131 + dk)
+    M = N * S
+    q, k, v, do = (torch.randn(M, H * dk, device=DEV, generator=g) for _ in range(4))
+    use_bias = (S - 1) % 16 == 0
+    idx = relative_position_index_3d(L, 4).to(DEV) if use_bias else None
+    tab = torch.randn((2 * L - 1) * 49, H, device=DEV, generator=g) * 0.3 if use_bias else None
+    o, probs = Fn.attn_fwd(q, k, v, N, S, H, dk, dk, tab, idx, p_drop, seed)
+    keep = os.environ.pop("LSTC_ATTN_VARIANT", None)
+
+    def run(variant):
+        old = Fn._ATTN_VARIANT
+        Fn._ATTN_VARIANT = variant
+        try:
+            return Fn.attn_bwd(do, q, k, v, probs, N, S, H, dk, dk, tab, idx, p_drop, seed)
+        finally:
+            Fn._ATTN_VARIANT = old
+    dq2, dk2, dv2, dt2 = run(0)
+    dq1, dk1, dv1, dt1 = run(1)
+    torch.cuda.synchronize()
+    if keep is not None:
+        os.environ["LSTC_ATTN_VARIANT"] = keep
+    # f64 reference through torch autograd on the CPU
+    mask = Fn.dropout_mask((N, H, S, S), p_drop, seed, DEV).cpu().double() / (1.0 - p_drop)
+    qd, kd, vd = (t.cpu().double().view(N, S, H, dk).transpose(1, 2).requires_grad_(True) for t in (q, k, v))
+    td = tab.cpu().double().requires_grad_(True) if use_bias else None
+    a = (qd / dk ** 0.5) @ kd.transpose(-1, -2)
+    if use_bias:
+        bias = td[idx.cpu()[: S - 1, : S - 1].reshape(-1)].view(S - 1, S - 1, H).permute(2, 0, 1)
+        a = a + torch.nn.functional.pad(bias, (1, 0, 1, 0)).unsqueeze(0)
+    out = (torch.softmax(a, -1) * mask) @ vd
+    out.backward(do.cpu().double().view(N, S, H, dk).transpose(1, 2))
+    ref = [t.grad.transpose(1, 2).reshape(M, H * dk) for t in (qd, kd, vd)]
+    for got2, got1, r, name in zip((dq2, dk2, dv2), (dq1, dk1, dv1), ref, "QKV"):
+        tol = 2e-5 * float(r.abs().max()) + 1e-6
+        assert max_abs_diff(got2, r) < tol, (name, "v2", max_abs_diff(got2, r), tol)
+        assert max_abs_diff(got1, r) < tol, (name, "v1", max_abs_diff(got1, r), tol)
+    if use_bias:
+        assert max_abs_diff(dt2, td.grad) < 2e-5 * float(td.grad.abs().max()) + 1e-6
+        assert max_abs_diff(dt1, dt2) < 1e-5 * float(td.grad.abs().max()) + 1e-6
