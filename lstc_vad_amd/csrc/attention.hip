@@ -402,12 +402,14 @@ __global__ void __launch_bounds__(NT, 2) attn_bwd2_kernel(const AttnParams p) {
         // global-load latency per row, 16 rows per wave)
         const float* pr_base = p.probs + ((size_t)n * p.H + h) * S * S;
         float pvr[SP / 4][NJ];
+        int idxr[SP / 4][NJ];                 // bias-table row of (i, j), -1 where no bias applies
 #pragma unroll
         for (int ii = 0; ii < SP / 4; ++ii)
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) {
                 const int i = wave + 4 * ii, j = lane + 64 * jj;
                 pvr[ii][jj] = (i < S && j < S) ? pr_base[(size_t)i * S + j] : 0.f;
+                idxr[ii][jj] = (has_bias && i >= 1 && j >= 1 && i < S && j < S) ? (int)p.index[(size_t)(i - 1) * p.index_ld + (j - 1)] : -1;
             }
 #pragma unroll 1
         for (int kc = 0; kc < nchunks; ++kc) {
@@ -480,8 +482,7 @@ __global__ void __launch_bounds__(NT, 2) attn_bwd2_kernel(const AttnParams p) {
                     drow[j] = da;
                     DmT[j * LD + i] = da;
                     prow[j] = pv[jj] * keep[jj];
-                    if (has_bias && i >= 1 && j >= 1 && j < S)
-                        tw[p.index[(size_t)(i - 1) * p.index_ld + (j - 1)]] += da;
+                    if (idxr[ii][jj] >= 0) tw[idxr[ii][jj]] += da;
                 }
             }
         }
@@ -536,6 +537,164 @@ __global__ void __launch_bounds__(NT, 2) attn_bwd2_kernel(const AttnParams p) {
     }
 }
 
+// Second-generation forward: Q K^T with both operands staged by LDS-DMA (as dO V^T in the backward), softmax as in
+// attn_fwd_kernel but writing the dropped probabilities BOTH ways (row-major for nothing but symmetry with the backward is not
+// needed: only the [k][i] copy feeds P V), then O = Pd V as the job pipeline of the backward (A = Pd^T tile, B = V rows).
+template <int T>
+__global__ void __launch_bounds__(NT, 2) attn_fwd2_kernel(const AttnParams p) {
+    constexpr int SP = 32 * T, LD = SP + 1, NJ = (SP + 63) / 64;
+    constexpr int CH = SP * 32;
+    constexpr int NPW = 2 * T;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Am = sm;                              // logits, then probabilities (row-major)
+    constexpr int ST0 = (SP * LD + 3) & ~3;
+    float* stage = sm + ST0;                     // staging ring [buf][operand][SP][32]; after phase 1: Pd^T ([k][i])
+    float* PT = stage;
+    const int n = blockIdx.x, h = blockIdx.y, S = p.S;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, h2 = lane >> 5;
+    const float* Qb = p.Q + (size_t)n * S * p.ldq + (size_t)h * p.dk;
+    const float* Kb = p.K + (size_t)n * S * p.ldk + (size_t)h * p.dk;
+    const float* Vb = p.V + (size_t)n * S * p.ldv + (size_t)h * p.dv;
+    const uint32_t stage_b = (uint32_t)(ST0 * 4);
+    const int nchunks = p.dk >> 5;
+    auto issue_chunk = [&](int kc, int buf) {
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+            const int piece = wave + 4 * j;
+            const int op = piece >= SP / 8 ? 1 : 0, pj = piece - op * (SP / 8);
+            StageDma::issue(op ? Kb : Qb, op ? p.ldk : p.ldq, S, 8 * pj, kc, stage_b + (uint32_t)(((buf * 2 + op) * CH + pj * 256) * 4));
+        }
+    };
+    floatx16 acc[(T * T + 3) / 4];
+#pragma unroll
+    for (int t = 0; t < (T * T + 3) / 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    issue_chunk(0, 0);
+    // relative-position bias of this wave's softmax rows: table[index[i-1, j-1], h] is two DEPENDENT global loads per element;
+    // requested here they land under the Q K^T phase (first version: in the row loop, one exposed double latency per row)
+    float biasr[SP / 4][NJ];
+#pragma unroll
+    for (int ii = 0; ii < SP / 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int i = wave + 4 * ii, j = lane + 64 * jj;
+            biasr[ii][jj] = (p.index_ld > 0 && i >= 1 && j >= 1 && i < S && j < S)
+                                ? p.table[(size_t)p.index[(size_t)(i - 1) * p.index_ld + (j - 1)] * p.H + h] : 0.f;
+        }
+#pragma unroll 1
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nchunks) {
+            issue_chunk(kc + 1, buf ^ 1);
+            __builtin_amdgcn_s_waitcnt((NPW & 15) | (7 << 4) | (15 << 8) | ((NPW >> 4) << 14));
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        __builtin_amdgcn_s_barrier();
+        const float* sA = stage + (buf * 2 + 0) * CH;
+        const float* sB = stage + (buf * 2 + 1) * CH;
+#pragma unroll
+        for (int tt = 0; tt < (T * T + 3) / 4; ++tt) {
+            const int t = wave + 4 * tt;
+            if (t < T * T) {
+                const int ra = 32 * (t / T) + l31, rb = 32 * (t % T) + l31;
+                float a[16], b[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 va = *reinterpret_cast<const float4*>(sA + ra * 32 + (((4 * h2 + q) ^ ((ra >> 1) & 7)) << 2));
+                    const float4 vb = *reinterpret_cast<const float4*>(sB + rb * 32 + (((4 * h2 + q) ^ ((rb >> 1) & 7)) << 2));
+                    a[4 * q] = va.x; a[4 * q + 1] = va.y; a[4 * q + 2] = va.z; a[4 * q + 3] = va.w;
+                    b[4 * q] = vb.x; b[4 * q + 1] = vb.y; b[4 * q + 2] = vb.z; b[4 * q + 3] = vb.w;
+                }
+#pragma unroll
+                for (int s = 0; s < 16; ++s) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s] * p.scale, b[s], acc[tt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int tt = 0; tt < (T * T + 3) / 4; ++tt) {
+        const int t = wave + 4 * tt;
+        if (t < T * T) store_tile_lds<LD>(Am, t / T, t % T, acc[tt]);
+    }
+    __syncthreads();
+    // ---- softmax rows (as attn_fwd_kernel); the dropped probabilities go to PT[j][i] for the P V product
+    float* pr_base = p.probs + ((size_t)n * p.H + h) * S * S;
+    const uint32_t flat0 = ((uint32_t)n * p.H + h) * (uint32_t)(S * S);
+#pragma unroll
+    for (int ii = 0; ii < SP / 4; ++ii) {
+        const int i = wave + 4 * ii;
+        float* row = Am + i * LD;
+        if (i >= S) {
+            for (int j = lane; j < SP; j += 64) PT[j * LD + i] = 0.f;
+            continue;
+        }
+        float v[NJ];
+        float m = -INFINITY;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int j = lane + 64 * jj;
+            float x = -INFINITY;
+            if (j < S) x = row[j] + biasr[ii][jj];
+            v[jj] = x;
+            m = fmaxf(m, x);
+        }
+        m = wave_max(m);
+        float s = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            v[jj] = (lane + 64 * jj < S) ? expf(v[jj] - m) : 0.f;
+            s += v[jj];
+        }
+        s = wave_sum(s);
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int j = lane + 64 * jj;
+            if (j < SP) {
+                float pv = 0.f;
+                if (j < S) {
+                    pv = v[jj] / s;
+                    pr_base[(size_t)i * S + j] = pv;
+                    if (p.has_drop) pv = drop_keep(flat0 + (uint32_t)(i * S + j), p.dkey) ? pv * p.dkey.scale : 0.f;
+                }
+                PT[j * LD + i] = pv;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- O = Pd V: job pipeline over this wave's 32-column tiles
+    {
+        const int njobs = ((p.dv >> 5) - wave + 3) >> 2;
+        const uint32_t bytes_v = (uint32_t)S * (uint32_t)p.ldv * 4u, bytes_o = (uint32_t)S * (uint32_t)p.ldo * 4u;
+        const __amdgpu_buffer_rsrc_t r_V = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vb), 0, (int)bytes_v, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_O = __builtin_amdgcn_make_buffer_rsrc(p.O + (size_t)n * S * p.ldo + (size_t)h * p.dv, 0, (int)bytes_o, 0x00020000);
+        auto job = [&](int kj) -> RtlJob {
+            RtlJob J;
+            J.A = PT; J.b = r_V; J.brow = (uint32_t)p.ldv * 4u; J.o = r_O; J.orow = (uint32_t)p.ldo * 4u; J.scale = 1.f; J.ct = wave + 4 * kj;
+            return J;
+        };
+        constexpr int RB = SP / 2;
+        const int c31 = l31;
+        float b0[RB], b1[RB];
+        RtlJob J0 = job(0), J1 = job(1);
+        if (njobs > 0) RTL_LOAD(J0, b0);
+#pragma unroll 1
+        for (int kj = 0; kj < njobs; kj += 2) {
+            if (kj + 1 < njobs) RTL_LOAD(J1, b1);
+            RTL_COMPUTE(J0, b0);
+            if (kj + 1 < njobs) {
+                J0 = job(kj + 2);
+                if (kj + 2 < njobs) RTL_LOAD(J0, b0);
+                RTL_COMPUTE(J1, b1);
+                J1 = job(kj + 3);
+            }
+        }
+    }
+}
+
 #undef RTL_LOAD
 #undef RTL_COMPUTE
 
@@ -582,6 +741,23 @@ int lstc_attn_fwd(const LstcAttnDesc* d, void* stream) {
     const int T = (p.S + 31) / 32;
     const size_t lds = (size_t)(32 * T) * (32 * T + 1) * sizeof(float);
     dim3 grid(p.N, p.H);
+    if (T == 1 && p.vec_qk && p.vec_v && (p.dk % 32) == 0 && (p.dv % 32) == 0 && d->variant == 0) {
+        // second-generation kernel (LDS-DMA staged Q K^T, register-resident V rows): S <= 32 only.  Interleaved A/B on one
+        // MI355X (tools/attn_time.py): S = 17 0.283 vs 0.350 ms; S = 49 1.10 vs 1.02 ms (the first generation's 4 waves per
+        // SIMD hide more latency than this kernel's 2); S = 81 needs 86 KB of LDS (one workgroup per CU) - both stay on
+        // the first generation.  
+        const int SP = 32 * T;
+        const size_t lds2 = ((size_t)((SP * (SP + 1) + 3) & ~3) + (size_t)4 * SP * 32) * sizeof(float);
+#define LSTC_FWD2(TT)                                                          \
+    do {                                                                       \
+        static bool once2 = false;                                             \
+        if (!once2) { set_lds(attn_fwd2_kernel<TT>, 160 * 1024); once2 = true; } \
+        hipLaunchKernelGGL(attn_fwd2_kernel<TT>, grid, NT, lds2, st, p);       \
+    } while (0)
+        LSTC_FWD2(1);
+#undef LSTC_FWD2
+        return lstc_launch_status();
+    }
     switch (T) {
         case 1: hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, NT, lds, st, p); break;
         case 2: hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, NT, lds, st, p); break;
@@ -619,7 +795,9 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
     dim3 grid((p.N + npw - 1) / npw, p.H);
     if (p.table_partials && (int)grid.x != d->dtable_chunks) return LSTC_E_SHAPE;
     // second-generation kernel (LDS-DMA staged dP, register-resident B rows): d_k, d_v multiples of 32, aligned operands
-    const bool v2 = T <= 3 && p.vec_qk && p.vec_v && (p.dk % 32) == 0 && (p.dv % 32) == 0 && d->variant == 0;
+    // S = 49: 1.63 vs 2.75 ms, S = 17: 0.53 vs 1.19 ms per LTN / STN layer (interleaved A/B); S = 81 (T = 3): 193 spilled
+    // registers, no faster than the first generation (7.3 vs 7.1 ms) - stays there
+    const bool v2 = T <= 2 && p.vec_qk && p.vec_v && (p.dk % 32) == 0 && (p.dv % 32) == 0 && d->variant == 0;
     if (v2) {
         const int SP = 32 * T;
         const size_t lds2 = ((size_t)((2 * SP * (SP + 1) + 3) & ~3) + (size_t)4 * SP * 32 + (size_t)(NT / 64) * p.table_rows) * sizeof(float);
@@ -630,7 +808,7 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
         if (!once2) { set_lds(attn_bwd2_kernel<TT>, 160 * 1024); once2 = true; } \
         hipLaunchKernelGGL(attn_bwd2_kernel<TT>, grid, NT, lds2, st, p);       \
     } while (0)
-            if (T == 1) LSTC_BWD2(1); else if (T == 2) LSTC_BWD2(2); else LSTC_BWD2(3);
+            if (T == 1) LSTC_BWD2(1); else LSTC_BWD2(2);
 #undef LSTC_BWD2
             return lstc_launch_status();
         }

@@ -1035,7 +1035,8 @@ def test_mixed_step_bf16_vs_fp32_auc_on_the_mixed_pair():
 
 @pytest.mark.parametrize("S,L,dk", [(17, 1, 64), (49, 3, 64), (33, 2, 32), (81, 5, 64), (64, 3, 96), (49, 3, 256)])
 def test_attention_backward_staged_kernel_matches_first_generation_and_f64(S, L, dk):
-    """lstc_attn_bwd's second-generation kernels (LDS-DMA staged dP, register-resident B rows, one job pipeline; T = 1, 2, 3)
+    """lstc_attn_fwd / lstc_attn_bwd's second-generation kernels (LDS-DMA staged operands, register-resident B rows, one job
+    pipeline; forward for S <= 32, backward for S <= 64; larger S runs the first generation in both arms)
     against the first-generation kernel (LstcAttnDesc.variant = 1) and against an f64 autograd reference that replays the
     dropout mask: dQ, dK, dV and the bias-table gradient, with relative bias and attention dropout on."""
     from lstc_vad_amd import functional as Fn
@@ -1049,6 +1050,11 @@ def test_attention_backward_staged_kernel_matches_first_generation_and_f64(S, L,
     tab = torch.randn((2 * L - 1) * 49, H, device=DEV, generator=g) * 0.3 if use_bias else None
     o, probs = Fn.attn_fwd(q, k, v, N, S, H, dk, dk, tab, idx, p_drop, seed)
     keep = os.environ.pop("LSTC_ATTN_VARIANT", None)
+    Fn._ATTN_VARIANT, old_variant = 1, Fn._ATTN_VARIANT
+    try:
+        o1, probs1 = Fn.attn_fwd(q, k, v, N, S, H, dk, dk, tab, idx, p_drop, seed)      # first-generation forward
+    finally:
+        Fn._ATTN_VARIANT = old_variant
 
     def run(variant):
         old = Fn._ATTN_VARIANT
@@ -1070,7 +1076,11 @@ def test_attention_backward_staged_kernel_matches_first_generation_and_f64(S, L,
     if use_bias:
         bias = td[idx.cpu()[: S - 1, : S - 1].reshape(-1)].view(S - 1, S - 1, H).permute(2, 0, 1)
         a = a + torch.nn.functional.pad(bias, (1, 0, 1, 0)).unsqueeze(0)
-    out = (torch.softmax(a, -1) * mask) @ vd
+    pr = torch.softmax(a, -1)
+    out = (pr * mask) @ vd
+    for got_o, got_p in ((o, probs), (o1, probs1)):              # forward of both generations
+        assert max_abs_diff(got_p, pr.detach()) < 2e-6
+        assert max_abs_diff(got_o, out.detach().transpose(1, 2).reshape(M, H * dk)) < 2e-5 * float(out.detach().abs().max()) + 1e-6
     out.backward(do.cpu().double().view(N, S, H, dk).transpose(1, 2))
     ref = [t.grad.transpose(1, 2).reshape(M, H * dk) for t in (qd, kd, vd)]
     for got2, got1, r, name in zip((dq2, dk2, dv2), (dq1, dk1, dv1), ref, "QKV"):
