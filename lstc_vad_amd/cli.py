@@ -282,13 +282,15 @@ class _HostPairs:
     """Batches of a lazy / ten-crop dataset: items collated on the host (``DataLoader(batch_size, drop_last=True,
     num_workers=0)`` order), staged through pinned memory, copied to the device."""
 
-    def __init__(self, dataset, batch_size, device, rank=0, world=1):
+    def __init__(self, dataset, batch_size, device, rank=0, world=1, streams=None):
         """``batch_size`` = pairs of the global batch; rank ``r`` keeps items ``[r*bs/world, (r+1)*bs/world)`` of each.  Every
         rank draws ALL items (the samplers consume ``np.random`` / ``random`` per item), so the union of the shards is the
         single-process batch; the price is ``world`` times the host reads of a lazy dataset."""
         if batch_size % world:
             raise ValueError(f"--batch_size {batch_size} pairs do not split over {world} ranks")
         self.ds, self.bs, self.device, self.rank, self.world = dataset, batch_size, device, rank, world
+        from .load_dataset import WorkerStreams
+        self.streams = streams or WorkerStreams(0, 0)
 
     def __len__(self):
         return len(self.ds) // self.bs
@@ -296,8 +298,10 @@ class _HostPairs:
     def __iter__(self):
         import torch
         bl = self.bs // self.world
+        self.streams.begin_epoch()
         for b in range(len(self)):
-            items = [self.ds[b * self.bs + j] for j in range(self.bs)][self.rank * bl:(self.rank + 1) * bl]
+            with self.streams.batch(b):
+                items = [self.ds[b * self.bs + j] for j in range(self.bs)][self.rank * bl:(self.rank + 1) * bl]
             yield tuple(torch.stack([it[k] for it in items]).pin_memory().to(self.device, non_blocking=True) for k in range(4))
 
     def shuffle_keys(self):
@@ -309,7 +313,9 @@ def _real_data(script, args, mode, part_len, pseudo_path, dev, rank, world, enc,
     script as upstream (e.g. Train/temporal_transformer_shanghaitech.py:45-51, Train/spatio_transformer_MIL_CE.py:114-149).
     Under data parallelism every rank seeds ``np.random`` IDENTICALLY and walks the same permutation / window draws; rank
     ``r`` keeps pairs ``[r*bs/world, (r+1)*bs/world)`` of each global batch, so shards are disjoint and the global batch is
-    the one a single process would have formed."""
+    the one a single process would have formed.  Window / crop draws come from the per-worker streams of the
+    script's DataLoader (``load_dataset.WorkerStreams``: batch b from worker b % k, seeded ``seed + worker`` every epoch),
+    pair order from the parent's generator, exactly as upstream."""
     import numpy as np
     from . import load_dataset as lds
     from .pipeline import evaluate_auc, evaluate_train_auc
@@ -325,7 +331,12 @@ def _real_data(script, args, mode, part_len, pseudo_path, dev, rank, world, enc,
         ds = lds.SH_Train_Origin_Dataset_MutualTraining(**common)
     else:
         ds = lds.SH_Train_Origin_Dataset(**common)
-    data = (_HostPairs if ds.lazy else lds.ResidentPairs)(ds, args.batch_size, dev, rank, world)
+    # the loader workers' RNG streams: the count each script gives its DataLoader (temporal SHT / UBnormal hard-code 4,
+    # temporal UCF 1, the spatio scripts and MIL_CE read --num_workers)
+    k = {"temporal_transformer_shanghaitech": 4, "temporal_transformer_UBnormal": 4, "temporal_transformer_UCF": 1}.get(
+        script, int(getattr(args, "num_workers", 0) or 0))
+    streams = lds.WorkerStreams(k, int(getattr(args, "seed", 0)))
+    data = (_HostPairs if ds.lazy else lds.ResidentPairs)(ds, args.batch_size, dev, rank, world, streams)
     masks = getattr(args, "test_mask_path", "") if dataset == "UCF" else getattr(args, "test_mask_dir", "")
     test_arc = getattr(args, "test_dataset_path", "") or args.dataset_path
     kind = "LTN" if mode == "LTN" else "STN"

@@ -277,6 +277,52 @@ UCF_test_tenCrop = UCF_test        # utils/load_dataset.py:494-510 is the same f
 
 # -- HBM-resident serving of the same items --------------------------------------------------------------------------
 
+class WorkerStreams:
+    """The RNG streams of the reference's ``DataLoader(num_workers=k, worker_init_fn=worker_init)``.
+
+    Upstream samples windows (and ten-crop indices) INSIDE the loader's worker processes: worker ``w`` produces batches
+    ``w, w + k, w + 2k, ...`` of an epoch and its ``np.random`` / ``random`` generators are seeded ``seed + w`` by
+    ``worker_init`` (Train/temporal_transformer_shanghaitech.py:39-41).  The workers are re-forked by every ``for ... in
+    dataloader``, i.e. re-seeded at every epoch, and the parent's generators - which ``shuffle_keys`` consumes - never see a
+    sampling draw.  ``with streams.batch(b):`` installs the stream of the worker that owns batch ``b`` of the current epoch
+    and puts the parent's generators back afterwards; ``begin_epoch()`` re-seeds.  ``k = 0`` (``num_workers=0``) leaves
+    everything on the caller's generators, the order the dataset fixtures pin."""
+
+    def __init__(self, k: int, seed: int):
+        self.k, self.seed = int(k), int(seed)
+        self._np, self._py = [None] * self.k, [None] * self.k
+        self.begin_epoch()
+
+    def begin_epoch(self):
+        if self.k <= 0:
+            return
+        keep_np, keep_py = np.random.get_state(), random.getstate()
+        for w in range(self.k):
+            np.random.seed(self.seed + w); random.seed(self.seed + w)
+            self._np[w], self._py[w] = np.random.get_state(), random.getstate()
+        np.random.set_state(keep_np); random.setstate(keep_py)
+
+    def batch(self, b: int):
+        return _WorkerScope(self, b % self.k if self.k > 0 else -1)
+
+
+class _WorkerScope:
+    def __init__(self, streams, w):
+        self.s, self.w = streams, w
+
+    def __enter__(self):
+        if self.w >= 0:
+            self.keep = (np.random.get_state(), random.getstate())
+            np.random.set_state(self.s._np[self.w]); random.setstate(self.s._py[self.w])
+        return self
+
+    def __exit__(self, *exc):
+        if self.w >= 0:
+            self.s._np[self.w], self.s._py[self.w] = np.random.get_state(), random.getstate()
+            np.random.set_state(self.keep[0]); random.setstate(self.keep[1])
+        return False
+
+
 def shard_plan(ds, offsets, n_norm, b, bs, rank=0, world=1):
     """Window indices + labels of global batch ``b`` (``bs`` pairs) for rank ``rank`` of ``world``: pairs
     ``[rank*bs/world, (rank+1)*bs/world)``.  The sampler runs for EVERY pair (same ``np.random`` consumption on every rank
@@ -309,7 +355,7 @@ class ResidentPairs:
     num_workers=0, shuffle=False)``), so the batches are bit-identical to the host path while no feature bytes cross
     PCIe per step.  Labels are tiny and travel with the indices."""
 
-    def __init__(self, dataset: _PairSource, batch_size: int, device, rank: int = 0, world: int = 1):
+    def __init__(self, dataset: _PairSource, batch_size: int, device, rank: int = 0, world: int = 1, streams: "WorkerStreams" = None):
         """``batch_size`` = pairs of the GLOBAL batch (the reference's ``--batch_size``); under data parallelism rank ``r``
         of ``world`` serves pairs ``[r*bs/world, (r+1)*bs/world)`` of every global batch.  Every rank runs the
         sampler for the whole global batch - same ``np.random`` consumption as the single-process run - so the ranks'
@@ -320,6 +366,7 @@ class ResidentPairs:
         if batch_size % world:
             raise ValueError(f"--batch_size {batch_size} pairs do not split over {world} ranks")
         self.ds, self.bs, self.device, self.rank, self.world = dataset, batch_size, device, rank, world
+        self.streams = streams or WorkerStreams(0, 0)
         P = dataset.n_patch
         vids = dataset.norm_feats + dataset.abnorm_feats
         cut = (lambda f: f) if P == 1 else (lambda f: f[:, :P, :])
@@ -340,8 +387,10 @@ class ResidentPairs:
         return shard_plan(self.ds, self.offsets, self.n_norm, b, self.bs, self.rank, self.world)
 
     def __iter__(self):
+        self.streams.begin_epoch()                       # upstream re-forks (re-seeds) the loader's workers every epoch
         for b in range(len(self)):
-            idx, labs = self.plan(b)
+            with self.streams.batch(b):
+                idx, labs = self.plan(b)
             out, labs_d = self.feed.gather(idx, labs)
             yield out[0], labs_d[0], out[1], labs_d[1]
 

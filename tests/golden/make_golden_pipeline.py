@@ -259,6 +259,38 @@ def run_train_loops(W, tmp):
         assert all(torch.equal(sd[k], ref_sd[k]) for k in ref_sd), "lr = 0 run changed the weights"
 
 
+def run_loader_workers(W):
+    """The reference's dataset classes behind a REAL ``torch.utils.data.DataLoader`` with worker processes and the scripts'
+    ``worker_init`` (``np.random.seed(seed + worker_id)``, Train/temporal_transformer_shanghaitech.py:39-41,49): which clips
+    each batch holds over two epochs (workers are re-forked, i.e. re-seeded, by every epoch's iteration; ``shuffle_keys``
+    runs in the parent).  Pins ``lstc_vad_amd.load_dataset.WorkerStreams``."""
+    from torch.utils.data import DataLoader
+    for name, k, bs in (("sh_uniform", 2, 2), ("sh_random_pseudo", 3, 1), ("ucf_uniform", 2, 1), ("sh_tencrop_uniform", 2, 1)):
+        spec = DATASET_CASES[name]
+        seed = spec["seed"]
+        np.random.seed(seed); random.seed(seed); torch.manual_seed(seed)
+        ds = build_dataset(ref_ds, spec, W)
+
+        def worker_init(worker_id, seed=seed):
+            np.random.seed(seed + worker_id)
+            random.seed(seed + worker_id)
+        dl = DataLoader(ds, batch_size=bs, num_workers=k, worker_init_fn=worker_init, drop_last=True)
+        firsts, labs, crops = [], [], []
+        for epoch in range(2):
+            for batch in dl:
+                for j in (0, 2):
+                    a = batch[j].numpy()
+                    firsts.append(a.reshape(a.shape[0] * a.shape[1], -1)[:, 0].copy())
+                    labs.append(batch[j + 1].numpy().reshape(-1))
+                if len(batch) == 5:
+                    crops.extend(int(c) for c in batch[4])
+            ds.shuffle_keys()
+        OUT[f"dlw/{name}/first"] = np.concatenate(firsts)
+        OUT[f"dlw/{name}/labs"] = np.concatenate(labs)
+        OUT[f"dlw/{name}/crops"] = np.array(crops, np.int64)
+        OUT[f"dlw/{name}/cfg"] = np.array([k, bs])
+
+
 def main():
     with tempfile.TemporaryDirectory() as tmp:
         W = pw.build(os.path.join(tmp, "world"), RefEncoder, RefRegressor, RefClassifier)
@@ -267,6 +299,7 @@ def main():
         run_generators(W, tmp)
         run_evals(W)
         run_train_loops(W, tmp)
+        run_loader_workers(W)
     out_dir = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else HERE
     np.savez_compressed(os.path.join(out_dir, "pipeline.npz"), **OUT)
     print("pipeline.npz:", len(OUT), "arrays,", os.path.getsize(os.path.join(out_dir, "pipeline.npz")), "bytes")

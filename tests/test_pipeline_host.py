@@ -267,3 +267,55 @@ def test_train_loop_evaluation_and_checkpoint_rule_like_the_reference_train(worl
     s = cli.Selector("spatio_transformer_MIL_CE", a)
     assert s.best_test == 0.8 and s.update(0, 0.5, 0.3)[0] == 0.3 and s.best_test == 0.8   # no threshold on the save, best_test starts at it
     assert cli.checkpoint_names("spatio_transformer_MIL_CE", a, 0.3)[0] == "/m/p_spatio_model_oneCrop_I3D_RGB_0.3"
+
+
+@pytest.mark.parametrize("name", ["sh_uniform", "sh_random_pseudo", "ucf_uniform", "sh_tencrop_uniform"])
+def test_loader_worker_rng_streams_like_the_reference_dataloader(world, name):
+    """``load_dataset.WorkerStreams`` against the reference's dataset classes behind a REAL torch DataLoader with k worker
+    processes and the scripts' ``worker_init`` (fixture ``dlw/*``): batch b comes from worker b % k, whose generators are
+    seeded ``seed + worker`` at the start of EVERY epoch; ``shuffle_keys`` draws from the parent's generator."""
+    spec = DATASET_CASES[name]
+    k, bs = (int(x) for x in G[f"dlw/{name}/cfg"])
+    seed = spec["seed"]
+    np.random.seed(seed); random.seed(seed)
+    ds = build_dataset(ds_mod, spec, world)
+    streams = ds_mod.WorkerStreams(k, seed)
+    firsts, labs, crops = [], [], []
+    for epoch in range(2):
+        streams.begin_epoch()
+        for b in range(len(ds) // bs):
+            with streams.batch(b):
+                items = [ds[b * bs + j] for j in range(bs)]
+            for j in (0, 2):
+                a = torch.stack([it[j] for it in items]).numpy()
+                firsts.append(a.reshape(a.shape[0] * a.shape[1], -1)[:, 0].copy())
+                labs.append(torch.stack([it[j + 1] for it in items]).numpy().reshape(-1))
+            if len(items[0]) == 5:
+                crops.extend(int(it[4]) for it in items)
+        ds.shuffle_keys()
+    assert np.array_equal(np.concatenate(firsts), G[f"dlw/{name}/first"])
+    assert np.array_equal(np.concatenate(labs), G[f"dlw/{name}/labs"])
+    assert np.array_equal(np.array(crops, np.int64), G[f"dlw/{name}/crops"])
+    if not ds.lazy and not ds.ten_crop:
+        # the HBM-resident source plans the same clips: shard_plan under the same streams (ranks 0 and 1 of 2 when bs splits)
+        np.random.seed(seed); random.seed(seed)
+        ds2 = build_dataset(ds_mod, spec, world)
+        st2 = ds_mod.WorkerStreams(k, seed)
+        offs = np.concatenate([[0], np.cumsum([v.shape[0] for v in ds2.norm_feats + ds2.abnorm_feats])]).astype(np.int64)
+        bank = np.concatenate([v[:, :ds2.n_patch] if ds2.n_patch != 1 else v for v in ds2.norm_feats + ds2.abnorm_feats], 0)
+        got = []
+        for epoch in range(2):
+            st2.begin_epoch()
+            for b in range(len(ds2) // bs):
+                with st2.batch(b):
+                    idx, _ = ds_mod.shard_plan(ds2, offs, len(ds2.norm_feats), b, bs)
+                for kind in (0, 1):
+                    a = bank[idx[kind].reshape(-1)]
+                    got.append(a.reshape(a.shape[0], -1)[:, 0].copy())
+            ds2.shuffle_keys()
+        assert np.array_equal(np.concatenate(got), G[f"dlw/{name}/first"])
+    # num_workers = 0 keeps the caller's generators (the order the ds/* fixtures pin)
+    np.random.seed(seed); a0 = np.random.get_state()[1].copy()
+    with ds_mod.WorkerStreams(0, seed).batch(3):
+        pass
+    assert np.array_equal(np.random.get_state()[1], a0)
