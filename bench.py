@@ -251,6 +251,8 @@ def main():
                     "every step through lstc_vad_amd.feed.PinnedFeeder (reported as pcie_inclusive, never as value)")
     ap.add_argument("--naive-last-layer", action="store_true", help="evaluate the last encoder layer for every token like the "
                     "reference (A/B only: the default skips rows/projections nobody reads, with identical results)")
+    ap.add_argument("--fuse_qkv", default="auto", choices=["auto", "on", "off"], help="Q/K/V projections as one GEMM per layer (auto: when "
+                    "the rank's token count leaves the three separate products with badly filled tile rounds, engine.TrainStep)")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
@@ -307,7 +309,7 @@ def main():
                       FFN_dropout=drops[2], weight_init=(mode != "LTN"), **ekw).to(dev).train()
         head = (Classifier(d, drops[3]) if mode == "LTN" else Regressor(d, drops[3])).to(dev).train()
         ts = TrainStep(args, mode, enc, head, lr_encoder=1e-4 * a.lr_scale, lr_head=1e-2 * a.lr_scale, weight_decay=1e-3,
-                       cls_only=not a.naive_last_layer)
+                       cls_only=not a.naive_last_layer, fuse_qkv=a.fuse_qkv)
         feed = feed or a.feed
         if feed == "resident":
             src = SyntheticResidentPairs(cfg_name, bs_g, pn, dev, rank if strong else 0, world if strong else 1,

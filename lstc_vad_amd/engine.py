@@ -20,7 +20,7 @@ from .optim import Adagrad, clip_grad_norm_
 
 class TrainStep:
     def __init__(self, args, mode: str, encoder, head, lr_encoder: float, lr_head: float, weight_decay: float,
-                 group=None, cls_only: bool = True, loss_rank=None, loss_exchange=None):
+                 group=None, cls_only: bool = True, loss_rank=None, loss_exchange=None, fuse_qkv="auto"):
         # cls_only=False evaluates the last encoder layer for every token like the reference does (its extra rows are
         # never read); kept for A/B measurements — results are identical (tests/test_hip_parity.py)
         self.cls_only = cls_only
@@ -28,14 +28,38 @@ class TrainStep:
         # through this very object (tests/test_hip_parity.py::test_two_emulated_ranks_through_trainstep)
         self.loss_rank, self.loss_exchange = loss_rank, loss_exchange
         self.args, self.mode, self.encoder, self.head, self.group = args, mode, encoder, head, group
-        # MultiHeadAttention.fuse_qkv_() (one projection / dW / dX GEMM per layer instead of three) is available but
-        # not applied: measured 304.0 vs 301.3 ms per LTN step — the 128x128-tile GEMMs gain nothing from being wider.
+        # MultiHeadAttention.fuse_qkv_() (one projection / dW / dX GEMM per layer instead of three).  At the full headline batch
+        # the 128x128-tile GEMMs gain nothing from being wider (304.0 vs 301.3 ms per LTN step), but a rank of a strong-scaled
+        # job holds few tokens: at 8 GPUs 12 544 tokens = 1568 tiles per projection = 3.06 rounds of the chip's 512 workgroup
+        # slots, i.e. 4 rounds at 77 % occupancy, where the fused 4704-tile product runs 9.2 -> 10 rounds at 92 %.  "auto"
+        # fuses when that tile-round arithmetic gains more than 3 %.
+        if fuse_qkv == "auto":
+            fuse_qkv = self._qkv_fusion_pays(args, mode, encoder)
+        if fuse_qkv is True or fuse_qkv == "on":
+            for layer in list(encoder.layer_stack)[:-1] if cls_only else list(encoder.layer_stack):
+                layer.slf_attn.fuse_qkv_()
+        self.fused_qkv = bool(fuse_qkv is True or fuse_qkv == "on")
         self.optimizer = Adagrad([{"params": encoder.parameters(), "lr": lr_encoder},
                                   {"params": head.parameters(), "lr": lr_head}], weight_decay=weight_decay)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         force = os.environ.get("LSTC_FORCE_DIST", "0") == "1" and dist.is_available() and dist.is_initialized()
         self.reducer = (GradAllReducer(encoder_head_buckets(encoder, head), group, force=force)
                         if (self.world > 1 or force) else None)
+
+    @staticmethod
+    def _qkv_fusion_pays(args, mode, encoder) -> bool:
+        from . import functional as Fn
+        try:
+            attn = encoder.layer_stack[0].slf_attn
+            tokens = args.part_len * args.n_patch if mode == "LTN" else args.n_patch
+            n_seq = 2 * args.batch_size * args.part_num * (1 if mode == "LTN" else args.part_len)
+            M, Hd = n_seq * (1 + tokens), attn.n_head * attn.d_k
+        except Exception:
+            return False
+        tile, slots = (256, 256) if Fn.get_compute_dtype() == "bf16" else (128, 512)
+        tiles = -(-M // tile) * -(-Hd // tile)
+        eff = lambda t: (t / slots) / -(-t // slots)
+        return eff(3 * tiles) > eff(tiles) + 0.03
 
     def sequences(self, norm_feats, abnorm_feats):
         """A1: [bs, pn*L, P, d] x2 -> [N, S-1, d], normal sequences first (the loss relies on this order)."""
