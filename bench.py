@@ -422,12 +422,23 @@ def main():
                 2 * b * a.part_num * (1 if m_ == "LTN" else s_["part_len"])
         return tot / 1e12
 
+    def pmc_traffic(cfg, dtype):
+        """HBM-side bytes per launch of the dominant GEMM shape from the committed PMC passes (profiles/gemm_pmc_traffic.json)."""
+        pmc = os.path.join(ROOT, "profiles", "gemm_pmc_traffic.json")
+        if not os.path.exists(pmc) or world != 1:
+            return None
+        try:
+            return json.load(open(pmc)).get(cfg if dtype == "fp32" else f"{cfg}_{dtype}")
+        except Exception:
+            return None
+
     def sub_object(res, cfg, dtype):
         o = {"value": round(snippets_per_step(cfg) * res["steps"] / res["dt"], 1), "unit": "snippets/s",
              "ms_per_step": round(1e3 * res["dt"] / res["steps"], 3), "loss_first_timed_step": res["loss_first"],
              "loss_last_timed_step": res["loss_last"], "hbm_peak_GB": round(res["hbm"] / 1e9, 2)}
         r = roofline_of(res, dtype, cfg)
         if r:
+            r["traffic"] = pmc_traffic(cfg, dtype)
             o["roofline"] = r
         return o
 
@@ -484,12 +495,8 @@ def main():
         nseq = 2 * b_l * pn * (1 if mode == "LTN" else L)
         roof = roofline_of(head_res, a.dtype, a.config)
         if roof is not None:
-            pmc = os.path.join(ROOT, "profiles", "gemm_pmc_traffic.json")
-            if os.path.exists(pmc) and not mixed and a.dtype == "fp32" and world == 1:
-                try:
-                    roof["traffic"] = json.load(open(pmc)).get(a.config)
-                except Exception:
-                    roof["traffic"] = None
+            if not mixed:
+                roof["traffic"] = pmc_traffic(a.config, a.dtype)
             # SURVEY 8(d) counts the full last layer; the step skips its dead rows (only the CLS token of the last layer is
             # read) and re-associates its K/V projections, so executed GEMM FLOPs < algorithmic FLOPs.  frac is on EXECUTED
             # work; on the algorithmic count the same step would read frac_on_algorithmic_flops (can exceed 1).
