@@ -1090,3 +1090,29 @@ def test_attention_backward_staged_kernel_matches_first_generation_and_f64(S, L,
     if use_bias:
         assert max_abs_diff(dt2, td.grad) < 2e-5 * float(td.grad.abs().max()) + 1e-6
         assert max_abs_diff(dt1, dt2) < 1e-5 * float(td.grad.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("epi", ["plain", "bias_relu", "dropout_residual"])
+def test_bf16p_persistent_items_match_f32_kernel_on_rounded_operands(epi):
+    """The persistent packed-bf16 kernel with SEVERAL work items per workgroup (25 152 x 2048 output = 792 tiles on 256
+    workgroups: the next item's LDS-DMA is issued before the current epilogue and the epilogue's stores are counted in the
+    next item's waits; the ragged last row tile takes the draining path in between) against the exact-f32 GEMM kernel on
+    bf16-rounded operands: same products, f32 accumulation in a different order."""
+    from lstc_vad_amd import functional as Fn
+    M, N, K = 25088 + 64, 2048, 1024
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = torch.randn(N, K, device=DEV, generator=g) * 0.05
+    b = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g)
+    kw = {"plain": {}, "bias_relu": dict(bias=b, relu=True), "dropout_residual": dict(bias=b, dropout=(0.1, 1234), residual=res)}[epi]
+    xr, wr = _bf16_round(x), _bf16_round(w)
+    ref = Fn.gemm(xr, wr, trans_b=True, **kw)                       # exact-f32 kernel (fp32 mode)
+    Fn.set_compute_dtype("bf16")
+    try:
+        for _ in range(2):                                          # twice: a stale LDS / wait-count bug shows run to run
+            got = Fn.gemm(x, w, trans_b=True, **kw)
+            torch.cuda.synchronize()
+            assert max_abs_diff(got, ref) < 2e-5 * (K ** 0.5) + 1e-5
+    finally:
+        Fn.set_compute_dtype("fp32")
