@@ -253,6 +253,8 @@ def main():
                     "reference (A/B only: the default skips rows/projections nobody reads, with identical results)")
     ap.add_argument("--fuse_qkv", default="auto", choices=["auto", "on", "off"], help="Q/K/V projections as one GEMM per layer (auto: when "
                     "the rank's token count leaves the three separate products with badly filled tile rounds, engine.TrainStep)")
+    ap.add_argument("--grad_reduce_dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient all-reduce "
+                    "(bf16: buckets rounded by lstc_cast_f32_bf16, half the xGMI bytes; default fp32 = the reference's numerics)")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
@@ -261,6 +263,12 @@ def main():
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))             # before anything initialises the GPU in this process
+
+    # The JSON line must be the only thing on stdout: RCCL prints a version banner through C stdio when a communicator is
+    # created (flushed at exit, i.e. AFTER our line).  Keep the real stdout aside and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -309,7 +317,7 @@ def main():
                       FFN_dropout=drops[2], weight_init=(mode != "LTN"), **ekw).to(dev).train()
         head = (Classifier(d, drops[3]) if mode == "LTN" else Regressor(d, drops[3])).to(dev).train()
         ts = TrainStep(args, mode, enc, head, lr_encoder=1e-4 * a.lr_scale, lr_head=1e-2 * a.lr_scale, weight_decay=1e-3,
-                       cls_only=not a.naive_last_layer, fuse_qkv=a.fuse_qkv)
+                       cls_only=not a.naive_last_layer, fuse_qkv=a.fuse_qkv, grad_reduce_dtype=a.grad_reduce_dtype)
         feed = feed or a.feed
         if feed == "resident":
             src = SyntheticResidentPairs(cfg_name, bs_g, pn, dev, rank if strong else 0, world if strong else 1,
@@ -545,7 +553,7 @@ def main():
             # torch-CPU sgemm on the GPU box's host peaks at 16-32 threads (tools/cpu_threads_scan.py: 1.3 TFLOP/s
             # at 16-32, 0.5 at 128 of 256 hardware threads), so the baseline uses min(32, available) threads
             out["cpu_baseline"] = cpu_baseline(last, min(32, len(os.sched_getaffinity(0))))
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or force_dist:
         dist.destroy_process_group()
 

@@ -286,6 +286,12 @@ int lstc_sqnorm_accum(const float* x, int64_t n, float* out, void* stream);
 /* x *= alpha in place: applies the clip_grad_norm_ coefficient to a gradient tensor. */
 int lstc_scale(float* x, int64_t n, float alpha, void* stream);
 
+/* f32 -> bf16 (round to nearest even) and back, n elements: the optional half-width gradient all-reduce of the data-parallel
+ * path (replaces nothing upstream - nn.DataParallel reduces fp32, Train/temporal_transformer_shanghaitech.py:76-78 - and is
+ * off by default: lstc_vad_amd/dist.py, reduce_dtype). */
+int lstc_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
+int lstc_cast_bf16_f32(const void* x, float* y, int64_t n, void* stream);
+
 /* ------------------------------------------------------------------------- data feed
  * dst[r, :] = src[idx[r], :] for r < n_rows, rows of `row_floats` contiguous floats (multiple of 4, 16-byte aligned
  * bases).  Forms the [B, part_num*part_len, n_patch, d] training batch out of an HBM-resident feature bank from the

@@ -22,7 +22,7 @@ EXPORTS = (
     "lstc_cls_outer", "lstc_layernorm_fwd", "lstc_layernorm_bwd",
     "lstc_cls_concat_fwd", "lstc_cls_concat_bwd", "lstc_colsum", "lstc_dropout_apply", "lstc_dropout_mask",
     "lstc_head_out_fwd", "lstc_head_out_bwd", "lstc_vad_loss", "lstc_adagrad_step", "lstc_sqnorm_accum", "lstc_scale",
-    "lstc_gather_rows", "lstc_pack3", "lstc_pack3_bytes", "lstc_pack1", "lstc_pack1_bytes", "lstc_gemm_splits",
+    "lstc_gather_rows", "lstc_cast_f32_bf16", "lstc_cast_bf16_f32", "lstc_pack3", "lstc_pack3_bytes", "lstc_pack1", "lstc_pack1_bytes", "lstc_gemm_splits",
     "lstc_version", "lstc_strerror",
 )
 
@@ -96,6 +96,8 @@ def load():
         "lstc_sqnorm_accum": [vp, i64, vp, vp],
         "lstc_scale": [vp, i64, f32, vp],
         "lstc_gather_rows": [vp, i64, vp, vp, i64, i64, vp],
+        "lstc_cast_f32_bf16": [vp, vp, i64, vp],
+        "lstc_cast_bf16_f32": [vp, vp, i64, vp],
         "lstc_pack3": [vp, i64, i64, i64, C.c_int32, vp, vp],
         "lstc_pack3_bytes": [i64, i64],
         "lstc_pack1": [vp, i64, i64, i64, C.c_int32, vp, vp],

@@ -432,6 +432,16 @@ __global__ void __launch_bounds__(NT) scale_kernel(float* __restrict__ x, int64_
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) x[i] *= alpha;
 }
 
+// f32 <-> bf16 (RNE) streams for a half-width gradient all-reduce (lstc_vad_amd/dist.py, reduce_dtype="bf16")
+__global__ void __launch_bounds__(NT) cast_f32_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) y[i] = (__bf16)x[i];
+}
+__global__ void __launch_bounds__(NT) cast_bf16_f32_kernel(const __bf16* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) y[i] = (float)x[i];
+}
+
 // dst row r <- src row idx[r].  grid.x = row, grid.y = chunk of the row; float4 streaming copy (HBM-bound, 2 x bytes).
 __global__ void __launch_bounds__(NT) gather_rows_kernel(const float4* __restrict__ src, int64_t src_rows,
                                                          const int64_t* __restrict__ idx, float4* __restrict__ dst,
@@ -569,6 +579,20 @@ int lstc_scale(float* x, int64_t n, float alpha, void* stream) {
     if (!x) return LSTC_E_NULL;
     if (n <= 0) return LSTC_E_SHAPE;
     hipLaunchKernelGGL(scale_kernel, grid_for(n, NT * 4), NT, 0, (hipStream_t)stream, x, n, alpha);
+    return lstc_launch_status();
+}
+
+int lstc_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream) {
+    if (!x || !y) return LSTC_E_NULL;
+    if (n <= 0) return LSTC_E_SHAPE;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, grid_for(n, NT * 4), NT, 0, (hipStream_t)stream, x, (__bf16*)y, n);
+    return lstc_launch_status();
+}
+
+int lstc_cast_bf16_f32(const void* x, float* y, int64_t n, void* stream) {
+    if (!x || !y) return LSTC_E_NULL;
+    if (n <= 0) return LSTC_E_SHAPE;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, grid_for(n, NT * 4), NT, 0, (hipStream_t)stream, (const __bf16*)x, y, n);
     return lstc_launch_status();
 }
 

@@ -20,7 +20,8 @@ from .optim import Adagrad, clip_grad_norm_
 
 class TrainStep:
     def __init__(self, args, mode: str, encoder, head, lr_encoder: float, lr_head: float, weight_decay: float,
-                 group=None, cls_only: bool = True, loss_rank=None, loss_exchange=None, fuse_qkv="auto"):
+                 group=None, cls_only: bool = True, loss_rank=None, loss_exchange=None, fuse_qkv="auto",
+                 grad_reduce_dtype: str = "fp32"):
         # cls_only=False evaluates the last encoder layer for every token like the reference does (its extra rows are
         # never read); kept for A/B measurements — results are identical (tests/test_hip_parity.py)
         self.cls_only = cls_only
@@ -43,7 +44,7 @@ class TrainStep:
                                   {"params": head.parameters(), "lr": lr_head}], weight_decay=weight_decay)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         force = os.environ.get("LSTC_FORCE_DIST", "0") == "1" and dist.is_available() and dist.is_initialized()
-        self.reducer = (GradAllReducer(encoder_head_buckets(encoder, head), group, force=force)
+        self.reducer = (GradAllReducer(encoder_head_buckets(encoder, head), group, force=force, reduce_dtype=grad_reduce_dtype)
                         if (self.world > 1 or force) else None)
 
     @staticmethod

@@ -1116,3 +1116,33 @@ def test_bf16p_persistent_items_match_f32_kernel_on_rounded_operands(epi):
             assert max_abs_diff(got, ref) < 2e-5 * (K ** 0.5) + 1e-5
     finally:
         Fn.set_compute_dtype("fp32")
+
+
+def test_bf16_gradient_allreduce_wire_format_single_rank():
+    """GradAllReducer(reduce_dtype="bf16") over RCCL with one rank: every reduced gradient equals the bf16 rounding (RNE,
+    lstc_cast_f32_bf16 / lstc_cast_bf16_f32) of the gradient the plain path produces; the default fp32 format is bit-exact."""
+    import socket
+    import torch.distributed as dist
+    from lstc_vad_amd.dist import GradAllReducer
+    g = torch.Generator(device=DEV).manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(s, device=DEV, generator=g)) for s in ((300, 70), (41,), (128, 128))]
+    xs = [torch.randn_like(p) for p in ps]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for fmt in ("fp32", "bf16"):
+            for p in ps:
+                p.grad = None
+            red = GradAllReducer([ps[:2], ps[2:]], force=True, reduce_dtype=fmt)
+            red.zero_grad()
+            loss = sum((p * x).sum() for p, x in zip(ps, xs))
+            loss.backward()
+            red.finish()
+            torch.cuda.synchronize()
+            for p, x in zip(ps, xs):
+                want = x if fmt == "fp32" else x.to(torch.bfloat16).to(torch.float32)
+                assert torch.equal(p.grad, want), fmt
+            assert red.payload_bytes() == sum(p.numel() for p in ps) * (4 if fmt == "fp32" else 2)
+    finally:
+        dist.destroy_process_group()
