@@ -205,6 +205,23 @@ int lstc_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 /* dx, and per-workgroup partial dgamma/dbeta in `partial` [2, n_partial, d] (reduce with lstc_colsum). */
 int lstc_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        float* dx, float* partial, int32_t n_partial, int64_t rows, int32_t d, void* stream);
+/* bf16 mode: the same two kernels also emit the packed bf16 operand (lstc_pack1 layout, [rows, d]) of the GEMMs that read
+ * their result, from the registers that hold the row - the separate lstc_pack1 pass (4 B read + 2 B written per element)
+ * and, in the backward, the lstc_dropout_apply pass disappear.
+ *   lstc_layernorm_fwd_pack:      `packed` = pack of y: the A operand of the next block's first product (the Q/K/V
+ *                                 projections after models/FFN.py:20-21, W1 after models/MultiHeadAttention.py:125-126).
+ *   lstc_layernorm_bwd_drop_pack: `packed` = pack of df = dropout-replay(dx) (keep iff the hash of the flat index row*d+col
+ *                                 passes, scaled by 1/(1-p) - exactly lstc_dropout_apply(dx, p, seed)): the operand of the
+ *                                 weight gradient and the input gradient of the Linear in front of the dropout
+ *                                 (fc: MultiHeadAttention.py:123, w_2: FFN.py:17-18); `partial` is [3, n_partial, d], the
+ *                                 third plane = column sums of df (that Linear's bias gradient).  dx stays f32 (residual).
+ * Both need rows % 256 == 0, d % 64 == 0, d <= 2048 (the rows fill the pack's even tile grid exactly; LSTC_E_UNSUPPORTED
+ * otherwise - the caller then packs with lstc_pack1) and `packed` of lstc_pack1_bytes(rows, d) bytes. */
+int lstc_layernorm_fwd_pack(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                            int64_t rows, int32_t d, float eps, void* packed, void* stream);
+int lstc_layernorm_bwd_drop_pack(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                 float* dx, float* partial, int32_t n_partial, int64_t rows, int32_t d, float dropout_p,
+                                 uint64_t dropout_seed, void* packed, void* stream);
 
 /* CLS = mean over tokens (or `cls_token` if not NULL), prepended; optional `pos` [S, d] added to every
  * sequence — models/Encoder.py:51-58.  x [N, S-1, d] -> y [N, S, d].  When `x_hi` is not NULL, sequences

@@ -67,6 +67,15 @@ __device__ inline float block_sum(float v, float* red) {
     return t;
 }
 
+// ---------------------------------------------------------------------------------- packed bf16 operands (lstc_pack1)
+// Element offset of (row, k) inside an lstc_pack1 buffer whose row blocks hold KBp 32-k tiles: 128-row x 32-k tiles of 4096
+// elements, 64-B rows, 16-B chunk index XOR (row >> 2) & 3 (csrc/gemm_bf16p.hip).  k must be a multiple of 4 for the 8-B
+// (4-element) stores of the row-wise producers.
+__host__ __device__ static inline size_t p1_offset(int64_t row, int k, int KBp) {
+    const int rr = (int)(row & 127), kb = k >> 5, ch = (k & 31) >> 3;
+    return ((size_t)(row >> 7) * KBp + kb) * 4096 + (size_t)rr * 32 + (size_t)((ch ^ ((rr >> 2) & 3)) << 3) + (k & 7);
+}
+
 static inline int lstc_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

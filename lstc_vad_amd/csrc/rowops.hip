@@ -11,11 +11,13 @@ constexpr int NT = 256;
 // ------------------------------------------------------------------------------- LayerNorm
 // One wave per row; the row lives in registers (NV float4 per lane, d <= 256*NV) so x is read once.
 // Two-pass statistics (mean, then centred variance) like ATen's CPU kernel for parity.
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+
 template <int NV>
 __global__ void __launch_bounds__(NT) ln_fwd_vec(const float* __restrict__ x, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, float* __restrict__ y,
                                                   float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
-                                                  int d, float eps) {
+                                                  int d, float eps, __bf16* __restrict__ packed, int KBp) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (NT / 64);
@@ -61,6 +63,11 @@ __global__ void __launch_bounds__(NT) ln_fwd_vec(const float* __restrict__ x, co
                 o.z = (v[i].z - mu) * rs * g[i].z + b[i].z;
                 o.w = (v[i].w - mu) * rs * g[i].w + b[i].w;
                 yr[c] = o;
+                if (packed) {       // the same row in the packed bf16 layout of the next GEMM's A operand: 8 B per lane,
+                    bf16x4v h;      // 8 lanes = one tile row's 64 contiguous bytes
+                    h[0] = (__bf16)o.x; h[1] = (__bf16)o.y; h[2] = (__bf16)o.z; h[3] = (__bf16)o.w;
+                    *reinterpret_cast<bf16x4v*>(packed + p1_offset(r, 4 * c, KBp)) = h;
+                }
             }
         }
         if (lane == 0) {
@@ -99,35 +106,140 @@ __global__ void __launch_bounds__(NT) ln_fwd_generic(const float* __restrict__ x
 
 // dx = rstd * (g*dy - mean_d(g*dy) - xhat * mean_d(g*dy*xhat)); per-workgroup partial dgamma = sum dy*xhat,
 // dbeta = sum dy written to partial[0][blockIdx.x][:] / partial[1][blockIdx.x][:].
-template <int NV>
-__global__ void __launch_bounds__(NT) ln_bwd_vec(const float* __restrict__ dy, const float* __restrict__ x,
+// PACK: the kernel also emits what the two GEMMs behind the residual branch consume - df = dropout-replay(dx) rounded to
+// bf16 in the lstc_pack1 layout (dropout index = flat row * d + col, as lstc_dropout_apply) - and a third partial, the
+// column sums of df (the bias gradient of the Linear in front of the dropout).
+template <int NV, bool PACK>
+__global__ void __launch_bounds__(NT, NV == 8 ? 2 : 1) ln_bwd_vec(const float* __restrict__ dy, const float* __restrict__ x,
                                                   const float* __restrict__ gamma, const float* __restrict__ mean,
                                                   const float* __restrict__ rstd, float* __restrict__ dx,
-                                                  float* __restrict__ partial, int64_t rows, int d) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // [NT/64][2][d]
+                                                  float* __restrict__ partial, int64_t rows, int d,
+                                                  __bf16* __restrict__ packed, int KBp, DropKey key) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [NT/64][d], reused per partial kind
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave0 = (int64_t)blockIdx.x * (NT / 64) + wv;
     const int64_t nwaves = (int64_t)gridDim.x * (NT / 64);
     const int nv4 = d >> 2;
-    float4 g[NV], ag[NV], ab[NV];
+    // PACK carries a third accumulator row: gamma is then re-read per row (8 KB, L1-resident) instead of held in registers
+    float4 g[PACK ? 1 : NV], ag[NV], ab[NV], ad[PACK ? NV : 1];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
-        g[i] = c < nv4 ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!PACK) g[i] = c < nv4 ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PACK) ad[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (int64_t r = wave0; r < rows; r += nwaves) {
         const float4* xr = reinterpret_cast<const float4*>(x + r * d);
         const float4* dr = reinterpret_cast<const float4*>(dy + r * d);
         const float mu = mean[r], rs = rstd[r];
         float4 xh[NV], gd[NV];
-        float s1 = 0.f, s2 = 0.f;
+        // per-lane sums in two halves (i < NVa, i >= NVa), added before the butterfly: the order ln_bwd_pack2's wave pair
+        // reproduces, so both kernels give the same dx bit for bit
+        constexpr int NVa = (NV + 1) / 2;
+        float s1 = 0.f, s2 = 0.f, s1b = 0.f, s2b = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
             if (c < nv4) {
                 const float4 xv = xr[c], dv = dr[c];
+                const float4 gi = PACK ? reinterpret_cast<const float4*>(gamma)[c] : g[PACK ? 0 : i];
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                gd[i] = make_float4(dv.x * gi.x, dv.y * gi.y, dv.z * gi.z, dv.w * gi.w);
+                const float t1 = (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
+                const float t2 = (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
+                if (i < NVa) { s1 += t1; s2 += t2; } else { s1b += t1; s2b += t2; }
+                ag[i].x += dv.x * xh[i].x; ag[i].y += dv.y * xh[i].y; ag[i].z += dv.z * xh[i].z; ag[i].w += dv.w * xh[i].w;
+                ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
+            } else {
+                xh[i] = gd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        const float m1 = wave_sum(s1 + s1b) / (float)d, m2 = wave_sum(s2 + s2b) / (float)d;
+        float4* o = reinterpret_cast<float4*>(dx + r * d);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv4) {
+                const float4 ov = make_float4(rs * (gd[i].x - m1 - xh[i].x * m2), rs * (gd[i].y - m1 - xh[i].y * m2),
+                                              rs * (gd[i].z - m1 - xh[i].z * m2), rs * (gd[i].w - m1 - xh[i].w * m2));
+                o[c] = ov;
+                if (PACK) {
+                    const uint32_t fi = (uint32_t)(r * d) + 4u * (uint32_t)c;
+                    float4 f;
+                    f.x = drop_keep(fi + 0, key) ? ov.x * key.scale : 0.f;
+                    f.y = drop_keep(fi + 1, key) ? ov.y * key.scale : 0.f;
+                    f.z = drop_keep(fi + 2, key) ? ov.z * key.scale : 0.f;
+                    f.w = drop_keep(fi + 3, key) ? ov.w * key.scale : 0.f;
+                    ad[i].x += f.x; ad[i].y += f.y; ad[i].z += f.z; ad[i].w += f.w;
+                    bf16x4v h;
+                    h[0] = (__bf16)f.x; h[1] = (__bf16)f.y; h[2] = (__bf16)f.z; h[3] = (__bf16)f.w;
+                    *reinterpret_cast<bf16x4v*>(packed + p1_offset(r, 4 * c, KBp)) = h;
+                }
+            }
+        }
+    }
+    // combine the workgroup's 4 waves through LDS, one partial row per workgroup and kind
+    float4* s4 = reinterpret_cast<float4*>(sm);
+#pragma unroll
+    for (int which = 0; which < (PACK ? 3 : 2); ++which) {
+        if (which) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv4) s4[wv * nv4 + c] = which == 0 ? ag[i] : which == 1 ? ab[i] : ad[PACK ? i : 0];
+        }
+        __syncthreads();
+        for (int cc = threadIdx.x; cc < nv4; cc += NT) {
+            float4 t = s4[cc];
+#pragma unroll
+            for (int w = 1; w < NT / 64; ++w) {
+                const float4 u = s4[w * nv4 + cc];
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            reinterpret_cast<float4*>(partial + ((size_t)which * gridDim.x + blockIdx.x) * d)[cc] = t;
+        }
+    }
+}
+
+// Two waves per row (each NVH float4 per lane of its half of the columns): half the live registers of ln_bwd_vec<.., true>,
+// so three accumulator rows (dgamma, dbeta, column sums of df) fit at 3 waves/SIMD.  The row statistics cross the wave pair
+// through LDS (double-buffered by iteration parity: one barrier per row pair).
+template <int NVH, bool PACK>
+__global__ void __launch_bounds__(NT) ln_bwd_pack2(const float* __restrict__ dy, const float* __restrict__ x,
+                                                    const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                    const float* __restrict__ rstd, float* __restrict__ dx,
+                                                    float* __restrict__ partial, int64_t rows, int d,
+                                                    __bf16* __restrict__ packed, int KBp, DropKey key) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][d] combine buffer, then [2][4][64][2] per-lane row sums
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, slot = wv >> 1, half = wv & 1;
+    const int nv4 = d >> 2, hv4 = nv4 >> 1;
+    float* red = sm + 2 * d;
+    float4 g[NVH], ag[NVH], ab[NVH], ad[PACK ? NVH : 1];
+#pragma unroll
+    for (int i = 0; i < NVH; ++i) {
+        const int cl = lane + 64 * i;
+        g[i] = cl < hv4 ? reinterpret_cast<const float4*>(gamma)[half * hv4 + cl] : make_float4(0.f, 0.f, 0.f, 0.f);
+        ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PACK) ad[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int64_t stride = (int64_t)gridDim.x * 2;
+    const int64_t iters = (rows + stride - 1) / stride;
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t r = it * stride + (int64_t)blockIdx.x * 2 + slot;
+        const bool live = r < rows;
+        const int64_t rr = live ? r : 0;
+        const float4* xr = reinterpret_cast<const float4*>(x + rr * d) + half * hv4;
+        const float4* dr = reinterpret_cast<const float4*>(dy + rr * d) + half * hv4;
+        const float mu = mean[rr], rs = rstd[rr];
+        float4 xh[NVH], gd[NVH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NVH; ++i) {
+            const int cl = lane + 64 * i;
+            if (cl < hv4 && live) {
+                const float4 xv = xr[cl], dv = dr[cl];
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 gd[i] = make_float4(dv.x * g[i].x, dv.y * g[i].y, dv.z * g[i].z, dv.w * g[i].w);
                 s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
@@ -138,36 +250,53 @@ __global__ void __launch_bounds__(NT) ln_bwd_vec(const float* __restrict__ dy, c
                 xh[i] = gd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d;
-        float4* o = reinterpret_cast<float4*>(dx + r * d);
+        float2* rb = reinterpret_cast<float2*>(red) + (it & 1) * 256;
+        rb[wv * 64 + lane] = make_float2(s1, s2);
+        __syncthreads();
+        // lane l of both waves adds the pair's per-lane halves in the same order (columns below d/2 first), then the same
+        // butterfly: the pair agrees bit for bit, and with ln_bwd_vec's two-half order
+        const float2 pa = rb[(slot * 2) * 64 + lane], pb = rb[(slot * 2 + 1) * 64 + lane];
+        const float m1 = wave_sum(pa.x + pb.x) / (float)d, m2 = wave_sum(pa.y + pb.y) / (float)d;
+        if (!live) continue;
+        float4* o = reinterpret_cast<float4*>(dx + r * d) + half * hv4;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nv4)
-                o[c] = make_float4(rs * (gd[i].x - m1 - xh[i].x * m2), rs * (gd[i].y - m1 - xh[i].y * m2),
-                                   rs * (gd[i].z - m1 - xh[i].z * m2), rs * (gd[i].w - m1 - xh[i].w * m2));
+        for (int i = 0; i < NVH; ++i) {
+            const int cl = lane + 64 * i;
+            if (cl < hv4) {
+                const float4 ov = make_float4(rs * (gd[i].x - m1 - xh[i].x * m2), rs * (gd[i].y - m1 - xh[i].y * m2),
+                                              rs * (gd[i].z - m1 - xh[i].z * m2), rs * (gd[i].w - m1 - xh[i].w * m2));
+                o[cl] = ov;
+                if (!PACK) continue;
+                const int c = half * hv4 + cl;
+                const uint32_t fi = (uint32_t)(r * d) + 4u * (uint32_t)c;
+                float4 f;
+                f.x = drop_keep(fi + 0, key) ? ov.x * key.scale : 0.f;
+                f.y = drop_keep(fi + 1, key) ? ov.y * key.scale : 0.f;
+                f.z = drop_keep(fi + 2, key) ? ov.z * key.scale : 0.f;
+                f.w = drop_keep(fi + 3, key) ? ov.w * key.scale : 0.f;
+                ad[i].x += f.x; ad[i].y += f.y; ad[i].z += f.z; ad[i].w += f.w;
+                bf16x4v h;
+                h[0] = (__bf16)f.x; h[1] = (__bf16)f.y; h[2] = (__bf16)f.z; h[3] = (__bf16)f.w;
+                *reinterpret_cast<bf16x4v*>(packed + p1_offset(r, 4 * c, KBp)) = h;
+            }
         }
     }
-    // combine the workgroup's 4 waves through LDS, one partial row per workgroup
+    // combine the two row slots through LDS, one partial row per workgroup and kind
     float4* s4 = reinterpret_cast<float4*>(sm);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv4) {
-            s4[(wv * 2 + 0) * nv4 + c] = ag[i];
-            s4[(wv * 2 + 1) * nv4 + c] = ab[i];
-        }
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < 2 * nv4; c += NT) {
-        const int which = c / nv4, cc = c % nv4;
-        float4 t = s4[(0 * 2 + which) * nv4 + cc];
+    for (int which = 0; which < (PACK ? 3 : 2); ++which) {
+        __syncthreads();
 #pragma unroll
-        for (int w = 1; w < NT / 64; ++w) {
-            const float4 u = s4[(w * 2 + which) * nv4 + cc];
-            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        for (int i = 0; i < NVH; ++i) {
+            const int cl = lane + 64 * i;
+            if (cl < hv4) s4[slot * nv4 + half * hv4 + cl] = which == 0 ? ag[i] : which == 1 ? ab[i] : ad[PACK ? i : 0];
         }
-        reinterpret_cast<float4*>(partial + ((size_t)which * gridDim.x + blockIdx.x) * d)[cc] = t;
+        __syncthreads();
+        for (int cc = threadIdx.x; cc < nv4; cc += NT) {
+            const float4 t = s4[cc], u = s4[nv4 + cc];
+            reinterpret_cast<float4*>(partial + ((size_t)which * gridDim.x + blockIdx.x) * d)[cc] =
+                make_float4(t.x + u.x, t.y + u.y, t.z + u.z, t.w + u.w);
+        }
     }
 }
 
@@ -466,22 +595,40 @@ inline int grid_for(int64_t work_items, int per_block, int cap = 2048) {
 
 extern "C" {
 
-int lstc_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                       int64_t rows, int32_t d, float eps, void* stream) {
+static int ln_fwd_launch(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                         int64_t rows, int32_t d, float eps, void* packed, int KBp, void* stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd) return LSTC_E_NULL;
     if (rows <= 0 || d <= 0) return LSTC_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int grid = grid_for(rows, NT / 64, 4096);
     const bool vec = d % 4 == 0 && d <= 2048 && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta);
     if (vec) {
-        if (d <= 256) hipLaunchKernelGGL(ln_fwd_vec<1>, grid, NT, 0, st, x, gamma, beta, y, mean, rstd, rows, d, eps);
-        else if (d <= 512) hipLaunchKernelGGL(ln_fwd_vec<2>, grid, NT, 0, st, x, gamma, beta, y, mean, rstd, rows, d, eps);
-        else if (d <= 1024) hipLaunchKernelGGL(ln_fwd_vec<4>, grid, NT, 0, st, x, gamma, beta, y, mean, rstd, rows, d, eps);
-        else hipLaunchKernelGGL(ln_fwd_vec<8>, grid, NT, 0, st, x, gamma, beta, y, mean, rstd, rows, d, eps);
+        if (d <= 256) hipLaunchKernelGGL(ln_fwd_vec<1>, grid, NT, 0, st, x, gamma, beta, y, mean, rstd, rows, d, eps, (__bf16*)packed, KBp);
+        else if (d <= 512) hipLaunchKernelGGL(ln_fwd_vec<2>, grid, NT, 0, st, x, gamma, beta, y, mean, rstd, rows, d, eps, (__bf16*)packed, KBp);
+        else if (d <= 1024) hipLaunchKernelGGL(ln_fwd_vec<4>, grid, NT, 0, st, x, gamma, beta, y, mean, rstd, rows, d, eps, (__bf16*)packed, KBp);
+        else hipLaunchKernelGGL(ln_fwd_vec<8>, grid, NT, 0, st, x, gamma, beta, y, mean, rstd, rows, d, eps, (__bf16*)packed, KBp);
     } else {
+        if (packed) return LSTC_E_UNSUPPORTED;
         hipLaunchKernelGGL(ln_fwd_generic, grid, NT, 0, st, x, gamma, beta, y, mean, rstd, rows, d, eps);
     }
     return lstc_launch_status();
+}
+
+// The row-wise producers write whole 128-row x 32-k tiles only when the matrix fills the even-by-even tile grid of
+// lstc_pack1 exactly (the GEMM streams tile pairs and would add the garbage of an unwritten tile into real outputs).
+static bool pack_fused_ok(int64_t rows, int32_t d) { return rows % 256 == 0 && d % 64 == 0 && d <= 2048; }
+
+int lstc_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                       int64_t rows, int32_t d, float eps, void* stream) {
+    return ln_fwd_launch(x, gamma, beta, y, mean, rstd, rows, d, eps, nullptr, 0, stream);
+}
+
+int lstc_layernorm_fwd_pack(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                            int64_t rows, int32_t d, float eps, void* packed, void* stream) {
+    if (!packed) return LSTC_E_NULL;
+    if (rows > 0 && d > 0 && !pack_fused_ok(rows, d)) return LSTC_E_UNSUPPORTED;
+    if (!aligned16(packed)) return LSTC_E_ALIGN;
+    return ln_fwd_launch(x, gamma, beta, y, mean, rstd, rows, d, eps, packed, d / 32, stream);
 }
 
 int lstc_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
@@ -492,16 +639,48 @@ int lstc_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
     const bool vec = d % 4 == 0 && d <= 2048 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) &&
                      aligned16(partial);
     if (vec) {
-        const size_t lds = (size_t)(NT / 64) * 2 * d * sizeof(float);
-        if (d <= 256) hipLaunchKernelGGL(ln_bwd_vec<1>, n_partial, NT, lds, st, dy, x, gamma, mean, rstd, dx, partial, rows, d);
-        else if (d <= 512) hipLaunchKernelGGL(ln_bwd_vec<2>, n_partial, NT, lds, st, dy, x, gamma, mean, rstd, dx, partial, rows, d);
-        else if (d <= 1024) hipLaunchKernelGGL(ln_bwd_vec<4>, n_partial, NT, lds, st, dy, x, gamma, mean, rstd, dx, partial, rows, d);
-        else hipLaunchKernelGGL(ln_bwd_vec<8>, n_partial, NT, lds, st, dy, x, gamma, mean, rstd, dx, partial, rows, d);
+        // model widths: two waves per row (ln_bwd_pack2, 3 waves/SIMD); other widths: one wave per row
+        const size_t lds = (size_t)(NT / 64) * d * sizeof(float), lds2 = (size_t)(2 * d + 1024) * sizeof(float);
+        const DropKey k0 = make_drop_key(0.f, 0);
+        __bf16* np = nullptr;
+        if (d == 512) hipLaunchKernelGGL((ln_bwd_pack2<1, false>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, np, 0, k0);
+        else if (d == 1024) hipLaunchKernelGGL((ln_bwd_pack2<2, false>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, np, 0, k0);
+        else if (d == 2048) hipLaunchKernelGGL((ln_bwd_pack2<4, false>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, np, 0, k0);
+        else if (d <= 256) hipLaunchKernelGGL((ln_bwd_vec<1, false>), n_partial, NT, lds, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, np, 0, k0);
+        else if (d <= 512) hipLaunchKernelGGL((ln_bwd_vec<2, false>), n_partial, NT, lds, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, np, 0, k0);
+        else if (d <= 1024) hipLaunchKernelGGL((ln_bwd_vec<4, false>), n_partial, NT, lds, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, np, 0, k0);
+        else hipLaunchKernelGGL((ln_bwd_vec<8, false>), n_partial, NT, lds, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, np, 0, k0);
     } else {
         if ((size_t)2 * d * sizeof(float) > 64 * 1024) return LSTC_E_RANGE;
         hipLaunchKernelGGL(ln_bwd_generic, n_partial, NT, (size_t)2 * d * sizeof(float), st, dy, x, gamma, mean, rstd, dx,
                            partial, rows, d);
     }
+    return lstc_launch_status();
+}
+
+int lstc_layernorm_bwd_drop_pack(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                 float* dx, float* partial, int32_t n_partial, int64_t rows, int32_t d, float dropout_p,
+                                 uint64_t dropout_seed, void* packed, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !partial || !packed) return LSTC_E_NULL;
+    if (rows <= 0 || d <= 0 || n_partial <= 0 || !(dropout_p >= 0.f && dropout_p < 1.f)) return LSTC_E_SHAPE;
+    if (!pack_fused_ok(rows, d)) return LSTC_E_UNSUPPORTED;
+    if ((uint64_t)rows * (uint64_t)d > 0xffffffffull) return LSTC_E_RANGE;      // 32-bit dropout counter
+    if (!(aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) && aligned16(partial) && aligned16(packed)))
+        return LSTC_E_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const DropKey key = make_drop_key(dropout_p, dropout_seed);
+    __bf16* pk = (__bf16*)packed;
+    const int KBp = d / 32;
+    // d = 512 / 1024 / 2048 (the model widths): two waves per row at 3 waves/SIMD; its column-to-lane map and summation
+    // order equal ln_bwd_vec's exactly at these widths.  Other widths: one wave per row.
+    const size_t lds2 = (size_t)(2 * d + 1024) * sizeof(float), lds1 = (size_t)(NT / 64) * d * sizeof(float);
+    if (d == 512) hipLaunchKernelGGL((ln_bwd_pack2<1, true>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, pk, KBp, key);
+    else if (d == 1024) hipLaunchKernelGGL((ln_bwd_pack2<2, true>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, pk, KBp, key);
+    else if (d == 2048) hipLaunchKernelGGL((ln_bwd_pack2<4, true>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, pk, KBp, key);
+    else if (d <= 256) hipLaunchKernelGGL((ln_bwd_vec<1, true>), n_partial, NT, lds1, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, pk, KBp, key);
+    else if (d <= 512) hipLaunchKernelGGL((ln_bwd_vec<2, true>), n_partial, NT, lds1, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, pk, KBp, key);
+    else if (d <= 1024) hipLaunchKernelGGL((ln_bwd_vec<4, true>), n_partial, NT, lds1, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, pk, KBp, key);
+    else hipLaunchKernelGGL((ln_bwd_vec<8, true>), n_partial, NT, lds1, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, pk, KBp, key);
     return lstc_launch_status();
 }
 

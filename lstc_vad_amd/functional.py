@@ -122,6 +122,38 @@ def bump_weight_epoch():
     """Invalidate the packed-weight cache (the optimizer rewrote the weights through raw pointers)."""
     global _wepoch
     _wepoch += 1
+    _producer_packs.clear()
+
+
+# Packs that a row-wise kernel emitted next to its f32 result (lstc_layernorm_fwd_pack): the next block finds the pack of its
+# input here instead of running lstc_pack1.  Entries hold the producing tensor (so its address cannot be recycled while the
+# entry lives) and its version counter (an in-place write invalidates the pack); consumed on first use, two entries at most.
+_producer_packs = {}
+_FUSE_PACKS = os.environ.get("LSTC_NO_FUSED_PACKS", "0") != "1"
+
+
+def _pack_key(t):
+    return (t.data_ptr(), tuple(t.shape), t.stride())
+
+
+def _register_pack(t: torch.Tensor, pk: "Packed"):
+    while len(_producer_packs) >= 2:
+        _producer_packs.pop(next(iter(_producer_packs)))
+    _producer_packs[_pack_key(t)] = (t, t._version, pk)
+
+
+def _producer_pack(t: torch.Tensor, kind):
+    hit = _producer_packs.pop(_pack_key(t), None)
+    if hit is None or hit[1] != t._version or hit[0]._version != hit[1] or hit[2].kind != kind:
+        return None
+    return hit[2]
+
+
+def _fused_pack_shape(rows: int, d: int) -> bool:
+    """A [rows, d] activation whose products go to the packed bf16 kernel and whose rows fill the pack's tile grid exactly
+    (include/lstc_hip.h, lstc_layernorm_fwd_pack): the row-wise producer may emit its pack."""
+    return (_FUSE_PACKS and _packed_kind() == _lib.BF16P and rows % 256 == 0 and d % 64 == 0 and d <= 2048 and
+            rows >= max(_x3_min[0], 1) and d >= max(_x3_min[1], 256) and rows * d * max(_x3_min[0], 256) >= _x3_min[2])
 
 
 class pack_memo:
@@ -172,6 +204,12 @@ def _packed_operand(t, k_major):
         pk = pack3(t.detach(), k_major)
         cache[ck] = (_wepoch, t._version, pk, t.data_ptr())
         return pk
+    if not k_major and _producer_packs:
+        hit = _producer_pack(t, _packed_kind())
+        if hit is not None:
+            if _memo_stack:
+                _memo_stack[-1][(t.data_ptr(), tuple(t.shape), t.stride(), k_major, _packed_kind())] = hit
+            return hit
     if _memo_stack:
         key = (t.data_ptr(), tuple(t.shape), t.stride(), k_major, _packed_kind())
         hit = _memo_stack[-1].get(key)
@@ -313,7 +351,7 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, x_pack: Optional[Packed] = None) ->
     """dW[out, in] = dy[T, out]^T @ x[T, in]  (autograd of nn.Linear's weight).  f32x3 mode: the contraction runs over the
     tokens, i.e. along the ROWS of the packs that the forward (X) and input-gradient (dY) products already made, so those
     packs are reused through the transposed-read form of the packed kernel (``x_pack`` = the forward's pack of ``x``)."""
-    T, O = dy.shape
+    T, O = (dy.rows, dy.K) if isinstance(dy, Packed) else dy.shape
     I = x.shape[1]
     pkind = _packed_kind()
     # split-K factor: 256x256 output tiles on the packed bf16 kernel, 128x128 everywhere else
@@ -323,13 +361,14 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, x_pack: Optional[Packed] = None) ->
             (x_pack is not None or (min(O, I) >= _x3_min[0] and T >= _x3_min[1] and T * O * I >= _x3_min[2])):
         ap = _packed_operand(dy, False)
         bp = x_pack if x_pack is not None else _packed_operand(x, False)
+        dev = ap.buf.device
         # K splits write separate partials that lstc_colsum adds in a fixed order (no atomics: bit-reproducible).  The
         # library may launch fewer slices than asked for (132 K tiles / 16 -> 15 slices): allocate and sum exactly those,
         # an extra row would add uninitialised memory into the gradient
         s = int(_lib.load().lstc_gemm_splits(pkind, T, s))
         det = s > 1 and _DETERMINISTIC_WGRAD
-        out = torch.empty((s, O * I), device=dy.device, dtype=torch.float32) if (det or s == 1) else \
-            torch.zeros((1, O * I), device=dy.device, dtype=torch.float32)
+        out = torch.empty((s, O * I), device=dev, dtype=torch.float32) if (det or s == 1) else \
+            torch.zeros((1, O * I), device=dev, dtype=torch.float32)
         d = GemmDesc()
         d.M, d.N, d.K, d.lda, d.ldb, d.ldc = O, I, T, O, I, I
         d.transA, d.transB, d.dtype, d.flags, d.alpha, d.split_k = 1, 0, pkind, 0, 1.0, s
@@ -337,6 +376,8 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, x_pack: Optional[Packed] = None) ->
         d.A, d.B, d.C = dev_ptr(ap.buf), dev_ptr(bp.buf), dev_ptr(out)
         _launch_gemm(d, 2.0 * O * I * T)
         return (colsum(out) if det else out).view(O, I)
+    if isinstance(dy, Packed):
+        raise RuntimeError(f"wgrad: packed gradient [{T}, {O}] x [{T}, {I}] does not qualify for the packed kernel")
     x3_big = pkind is not None and min(O, I) >= _x3_min[0] and T >= _x3_min[1] and T * O * I >= _x3_min[2]
     if pkind == _lib.BF16P and not x3_big:
         s = _wgrad_split(O, I, 128) if T >= 4096 else 1       # not a packed product after all: 128x128-tile kernel
@@ -391,13 +432,22 @@ def dropout_mask(shape, p: float, seed: int, device) -> torch.Tensor:
     return m
 
 
-def layernorm_fwd(x2: torch.Tensor, gamma, beta, eps=1e-6):
+def layernorm_fwd(x2: torch.Tensor, gamma, beta, eps=1e-6, pack=False):
+    """``pack``: the result is the input of another encoder block - in bf16 mode the kernel also writes its packed bf16 form,
+    which the block's first GEMM picks up (``_producer_pack``) instead of packing the f32 rows again."""
     rows, d = x2.shape
     y = torch.empty_like(x2)
     mean = torch.empty((rows,), device=x2.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
-    check(_lib.load().lstc_layernorm_fwd(dev_ptr(x2), dev_ptr(gamma), dev_ptr(beta), dev_ptr(y), dev_ptr(mean),
-                                         dev_ptr(rstd), rows, d, float(eps), stream_ptr()), "lstc_layernorm_fwd")
+    lib = _lib.load()
+    if pack and _fused_pack_shape(rows, d):
+        buf = torch.empty((int(lib.lstc_pack1_bytes(rows, d)),), device=x2.device, dtype=torch.uint8)
+        check(lib.lstc_layernorm_fwd_pack(dev_ptr(x2), dev_ptr(gamma), dev_ptr(beta), dev_ptr(y), dev_ptr(mean), dev_ptr(rstd),
+                                          rows, d, float(eps), dev_ptr(buf), stream_ptr()), "lstc_layernorm_fwd_pack")
+        _register_pack(y, Packed(buf, rows, d, _lib.BF16P))
+        return y, mean, rstd
+    check(lib.lstc_layernorm_fwd(dev_ptr(x2), dev_ptr(gamma), dev_ptr(beta), dev_ptr(y), dev_ptr(mean),
+                                 dev_ptr(rstd), rows, d, float(eps), stream_ptr()), "lstc_layernorm_fwd")
     return y, mean, rstd
 
 
@@ -405,7 +455,8 @@ def layernorm_bwd(dy2, x2, gamma, mean, rstd):
     rows, d = x2.shape
     dy2 = dy2.contiguous()
     dx = torch.empty_like(x2)
-    n_partial = int(min(max(rows // 4, 1), 512))
+    # one partial row per workgroup: 4 resident workgroups per CU at the model widths (two waves per row, csrc/rowops.hip), 2 else
+    n_partial = int(min(max(rows // 4, 1), 1024 if d in (512, 1024, 2048) else 512))
     partial = torch.empty((2, n_partial, d), device=x2.device, dtype=torch.float32)
     check(_lib.load().lstc_layernorm_bwd(dev_ptr(dy2), dev_ptr(x2), dev_ptr(gamma), dev_ptr(mean), dev_ptr(rstd),
                                          dev_ptr(dx), dev_ptr(partial), n_partial, rows, d, stream_ptr()),
@@ -413,6 +464,35 @@ def layernorm_bwd(dy2, x2, gamma, mean, rstd):
     dgamma = colsum(partial[0])
     dbeta = colsum(partial[1])
     return dx, dgamma, dbeta
+
+
+def layernorm_bwd_branch(dz2, y, gamma, mean, rstd, p: float, seed: int, layer_norm: bool, want_bias: bool):
+    """Backward of ``z = [LayerNorm](dropout(f) + x)`` up to the two things its callers consume: ``dy`` (gradient of the
+    residual sum, f32: it flows on into x) and ``df`` (gradient of the dropout's input f: operand of the weight / input
+    gradient GEMMs of the Linear that produced f).  Returns (dy, df, dgamma, dbeta, dbias) with dbias = column sums of df when
+    ``want_bias``.  bf16 mode with LayerNorm on a tile-filling shape: ONE kernel writes dy, the packed bf16 df (dropout
+    replayed in registers) and the partial sums - ``df`` is then a ``Packed``; otherwise lstc_layernorm_bwd +
+    lstc_dropout_apply (+ lstc_colsum)."""
+    rows, d = dz2.shape
+    if layer_norm and _fused_pack_shape(rows, d) and rows * d <= 0xffffffff:
+        lib = _lib.load()
+        dz2 = dz2.contiguous()
+        dy = torch.empty_like(y)
+        n_partial = int(min(max(rows // 4, 1), 768))        # 3 workgroups per CU resident (csrc/rowops.hip, ln_bwd_pack2)
+        partial = torch.empty((3, n_partial, d), device=y.device, dtype=torch.float32)
+        buf = torch.empty((int(lib.lstc_pack1_bytes(rows, d)),), device=y.device, dtype=torch.uint8)
+        check(lib.lstc_layernorm_bwd_drop_pack(dev_ptr(dz2), dev_ptr(y), dev_ptr(gamma), dev_ptr(mean), dev_ptr(rstd),
+                                               dev_ptr(dy), dev_ptr(partial), n_partial, rows, d, float(p), int(seed),
+                                               dev_ptr(buf), stream_ptr()), "lstc_layernorm_bwd_drop_pack")
+        return (dy, Packed(buf, rows, d, _lib.BF16P), colsum(partial[0]), colsum(partial[1]),
+                colsum(partial[2]) if want_bias else None)
+    dgamma = dbeta = None
+    if layer_norm:
+        dy, dgamma, dbeta = layernorm_bwd(dz2, y, gamma, mean, rstd)
+    else:
+        dy = dz2
+    df = dropout_apply(dy, p, seed) if p > 0 else dy
+    return dy, df, dgamma, dbeta, (colsum(df) if want_bias else None)
 
 
 def attn_fwd(q, k, v, N, S, H, dk, dv, table, index, p_drop, seed):
@@ -511,7 +591,7 @@ class MHAFunction(torch.autograd.Function):
         op = maybe_pack(o)
         y = gemm(op if op is not None else o, wfc, trans_b=True, dropout=(p_fc, seed_f), residual=x2)
         if cfg["layer_norm"]:
-            z, mean, rstd = layernorm_fwd(y, ln_w, ln_b, 1e-6)
+            z, mean, rstd = layernorm_fwd(y, ln_w, ln_b, 1e-6, pack=True)
         else:
             z, mean, rstd = y, None, None
         ctx.packs = (xp, op) if training else (None, None)
@@ -527,12 +607,7 @@ class MHAFunction(torch.autograd.Function):
         c = ctx.cfg
         N, S, H, dk, dv = c["N"], c["S"], c["n_head"], c["d_k"], c["d_v"]
         dz2 = dz.contiguous().view(N * S, -1)
-        dln_w = dln_b = None
-        if c["layer_norm"]:
-            dy, dln_w, dln_b = layernorm_bwd(dz2, y, ln_w, mean, rstd)
-        else:
-            dy = dz2
-        df = dropout_apply(dy, c["p_fc"], c["seed_f"]) if c["p_fc"] > 0 else dy
+        dy, df, dln_w, dln_b, _ = layernorm_bwd_branch(dz2, y, ln_w, mean, rstd, c["p_fc"], c["seed_f"], c["layer_norm"], False)
         xp, op = ctx.packs
         dwfc = wgrad(df, o, op)
         do = gemm(df, wfc)                                   # [M, H*dv]
@@ -794,7 +869,7 @@ class FFNFunction(torch.autograd.Function):
         y = gemm(hp if hp is not None else h1, w2, trans_b=True, bias=b2, dropout=(p, seed), residual=x2)
         ctx.packs = (xp, hp) if cfg["training"] else (None, None)
         if cfg["layer_norm"]:
-            z, mean, rstd = layernorm_fwd(y, ln_w, ln_b, 1e-6)
+            z, mean, rstd = layernorm_fwd(y, ln_w, ln_b, 1e-6, pack=True)
         else:
             z, mean, rstd = y, None, None
         ctx.cfg = dict(cfg, p=p, seed=seed, shape=tuple(shape))
@@ -806,14 +881,8 @@ class FFNFunction(torch.autograd.Function):
         x2, w1, w2, ln_w, h1, y, mean, rstd = ctx.saved_tensors
         c = ctx.cfg
         dz2 = dz.contiguous().view(-1, dz.shape[-1])
-        dln_w = dln_b = None
-        if c["layer_norm"]:
-            dy, dln_w, dln_b = layernorm_bwd(dz2, y, ln_w, mean, rstd)
-        else:
-            dy = dz2
-        df = dropout_apply(dy, c["p"], c["seed"]) if c["p"] > 0 else dy
+        dy, df, dln_w, dln_b, db2 = layernorm_bwd_branch(dz2, y, ln_w, mean, rstd, c["p"], c["seed"], c["layer_norm"], True)
         xp, hp = ctx.packs
-        db2 = colsum(df)
         dw2 = wgrad(df, h1, hp)
         dh1 = gemm(df, w2, relu_mask=h1)                     # [M, F], relu' fused
         db1 = colsum(dh1)

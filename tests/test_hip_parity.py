@@ -1146,3 +1146,86 @@ def test_bf16_gradient_allreduce_wire_format_single_rank():
             assert red.payload_bytes() == sum(p.numel() for p in ps) * (4 if fmt == "fp32" else 2)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rows,d,p", [(256, 64, 0.0), (512, 2048, 0.2), (768, 1024, 0.1), (1280, 320, 0.3)])
+def test_layernorm_kernels_emit_the_packs_the_separate_passes_would(rows, d, p):
+    """lstc_layernorm_fwd_pack / lstc_layernorm_bwd_drop_pack against lstc_layernorm_fwd / _bwd + lstc_dropout_apply +
+    lstc_pack1: f32 results and the packed bf16 bytes are IDENTICAL (same registers, same rounding); the third partial plane
+    sums to the column sums of the dropped gradient (order differs: 1e-5 relative)."""
+    from lstc_vad_amd import functional as Fn, _lib
+    from lstc_vad_amd.functional import dev_ptr, stream_ptr, check
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(rows, d, device=DEV, generator=g) * 2 + 0.3
+    dz = torch.randn(rows, d, device=DEV, generator=g)
+    gamma = torch.randn(d, device=DEV, generator=g)
+    beta = torch.randn(d, device=DEV, generator=g)
+    seed = 0x1234567890ABCDEF
+    y0, mean0, rstd0 = Fn.layernorm_fwd(x, gamma, beta, 1e-6)
+    nb = int(lib.lstc_pack1_bytes(rows, d))
+    tiles = rows * d * 2                                    # bytes of the tile area (rows, d fill the grid exactly)
+    y1, mean1, rstd1 = torch.empty_like(x), torch.empty_like(mean0), torch.empty_like(rstd0)
+    pk = torch.zeros(nb, device=DEV, dtype=torch.uint8)
+    check(lib.lstc_layernorm_fwd_pack(dev_ptr(x), dev_ptr(gamma), dev_ptr(beta), dev_ptr(y1), dev_ptr(mean1), dev_ptr(rstd1),
+                                      rows, d, 1e-6, dev_ptr(pk), stream_ptr()), "fwd_pack")
+    ref = torch.zeros(nb, device=DEV, dtype=torch.uint8)
+    check(lib.lstc_pack1(dev_ptr(y0), rows, d, d, 0, dev_ptr(ref), stream_ptr()), "pack1")
+    assert torch.equal(y0, y1) and torch.equal(mean0, mean1) and torch.equal(rstd0, rstd1)
+    assert torch.equal(pk[:tiles], ref[:tiles])
+
+    dx0, dg0, db0 = Fn.layernorm_bwd(dz, x, gamma, mean0, rstd0)
+    df0 = Fn.dropout_apply(dx0, p, seed) if p > 0 else dx0
+    check(lib.lstc_pack1(dev_ptr(df0), rows, d, d, 0, dev_ptr(ref), stream_ptr()), "pack1")
+    n_partial = min(max(rows // 4, 1), 512)
+    part = torch.empty(3, n_partial, d, device=DEV)
+    dx1 = torch.empty_like(x)
+    pk.zero_()
+    check(lib.lstc_layernorm_bwd_drop_pack(dev_ptr(dz), dev_ptr(x), dev_ptr(gamma), dev_ptr(mean0), dev_ptr(rstd0), dev_ptr(dx1),
+                                           dev_ptr(part), n_partial, rows, d, p, seed, dev_ptr(pk), stream_ptr()), "bwd_pack")
+    assert torch.equal(dx0, dx1)
+    assert torch.equal(pk[:tiles], ref[:tiles])
+    assert max_abs_diff(part[0].double().sum(0), dg0.double()) <= 1e-5 * float(dg0.abs().max()) + 1e-6
+    assert max_abs_diff(part[1].double().sum(0), db0.double()) <= 1e-5 * float(db0.abs().max()) + 1e-6
+    bias = df0.double().sum(0)
+    assert max_abs_diff(part[2].double().sum(0), bias) <= 1e-5 * float(bias.abs().max()) + 1e-6
+    # shapes that do not fill the tile grid are refused (the caller packs separately), not half-written
+    assert lib.lstc_layernorm_fwd_pack(dev_ptr(x), dev_ptr(gamma), dev_ptr(beta), dev_ptr(y1), dev_ptr(mean1), dev_ptr(rstd1),
+                                       rows - 128, d, 1e-6, dev_ptr(pk), stream_ptr()) == -4     # LSTC_E_UNSUPPORTED
+
+
+def test_bf16_encoder_step_is_bitwise_the_same_with_and_without_fused_packs():
+    """bf16 mode, 256 sequences x 17 tokens x d=256 (4352 rows = 17 x 256): the encoder's forward and every parameter gradient
+    with the LayerNorm kernels emitting the packs (default) against LSTC_NO_FUSED_PACKS=1 behaviour (separate lstc_pack1 /
+    lstc_dropout_apply / lstc_colsum passes) - same dropout seeds, bit-identical outputs and weight gradients."""
+    from lstc_vad_amd import functional as Fn
+    from lstc_vad_amd.models import Encoder
+    torch.manual_seed(3)
+    enc = Encoder(n_layers=3, n_head=4, d_k=64, d_v=64, d_model=256, d_inner=512, MHA_attn_dropout=0.1, MHA_fc_dropout=0.1,
+                  FFN_dropout=0.1, MHA_layerNorm=True, FFN_layerNorm=True, relative_pe=False).to(DEV).train()
+    x = torch.randn(256, 16, 256, device=DEV)
+    outs = []
+    Fn.set_compute_dtype("bf16"); Fn.set_x3_threshold(0, 0, 0)
+    try:
+        for fuse in (True, False):
+            Fn._FUSE_PACKS = fuse
+            torch.manual_seed(17); Fn.reset_rng()
+            enc.zero_grad(set_to_none=True)
+            y = enc(x)
+            y.square().mean().backward()
+            torch.cuda.synchronize()
+            outs.append((y.detach().clone(), {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None}))
+            Fn.bump_weight_epoch()
+    finally:
+        Fn._FUSE_PACKS = True
+        Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
+    (y1, g1), (y0, g0) = outs
+    assert torch.equal(y1, y0)
+    assert g1.keys() == g0.keys() and len(g1) >= 30
+    for k in g1:
+        if k.endswith("w_2.bias") or ".layer_norm." in k:
+            # column sums (of df; of dz * xhat, dz): the fused kernel's per-workgroup partials cover other row sets than the
+            # separate passes' - same addends, another summation order
+            assert max_abs_diff(g1[k], g0[k]) <= 1e-5 * float(g0[k].abs().max()) + 1e-9, k
+        else:
+            assert torch.equal(g1[k], g0[k]), k
