@@ -4,7 +4,7 @@ The reference opens ``h5py.File(path, 'r')`` and reads whole datasets with ``h5[
 (utils/load_dataset.py:33-44, :285-286, :409-411).  ``h5py`` is not part of this image, so three interchangeable
 backends sit behind one class, picked from the path:
 
-* ``*.h5`` / ``*.hdf5``  - HDF5 through ``h5py`` when it is importable (raises a clear error otherwise);
+* ``*.h5`` / ``*.hdf5``  - HDF5 through ``lstc_vad_amd.hdf5`` (own reader of the file format: no h5py / libhdf5 needed);
 * ``*.npz``              - a numpy archive whose member names are the HDF5 keys (``"01_001.npy"`` ...);
 * a directory            - one ``.npy`` file per key (memory-mapped on read).
 
@@ -29,13 +29,9 @@ class FeatureArchive:
             self.kind = "npz"
             self._npz = np.load(path, allow_pickle=False)
         elif os.path.exists(path):
-            try:
-                import h5py
-            except ImportError as e:            # no silent fallback: say what to do
-                raise RuntimeError(f"{path}: reading HDF5 needs h5py, which is not installed; convert the file with "
-                                   "tools/h5_to_npz.py on a machine that has it, or pass a .npz / directory") from e
+            from . import hdf5
             self.kind = "h5"
-            self._h5 = h5py.File(path, "r")
+            self._h5 = hdf5.File(path, "r")
         else:
             raise FileNotFoundError(path)
 

@@ -3,7 +3,7 @@
 Flag names, types and defaults come from ``cli_flags.json`` — the surface extracted from the reference's own
 ``parser_arg()`` functions (author-machine absolute path defaults blanked) — so every reference
 command line parses unchanged.  Additions: ``--synthetic`` (default on when no ``--dataset_path`` is given: the feature
-files are external downloads and ``h5py`` is not available here), ``--synthetic_pairs``, ``--steps`` (stop after N
+files are external downloads; a given HDF5 / .npz / directory archive is read through ``lstc_vad_amd.archive``), ``--synthetic_pairs``, ``--steps`` (stop after N
 optimisation steps), ``--log_dir`` (the reference hard-codes ``/data/ssy/...`` and crashes elsewhere,
 utils/utils.py:152-173).  ``--gpu`` selects the device through ``HIP_VISIBLE_DEVICES`` (reference:
 ``CUDA_VISIBLE_DEVICES``, e.g. Train/temporal_transformer_shanghaitech.py:328).

@@ -1,11 +1,11 @@
 """Batch source with the reference DataLoader's tensor contract and window-sampling rule.
 
 The reference reads I3D features from HDF5 (utils/load_dataset.py:29-48) and samples ``part_num`` windows of
-``part_len`` clips per video (``sample_feat`` :56-88).  No feature files ship with the reference and ``h5py`` is not
-installed here, so this module provides (i) ``sample_windows`` — the reference's uniform / random rule restated, and
+``part_len`` clips per video (``sample_feat`` :56-88).  No feature files ship with the reference, so for throughput work and
+tests this module provides (i) ``sample_windows`` — the reference's uniform / random rule restated, and
 (ii) ``SyntheticVideos`` — seeded synthetic videos (lstc_vad_amd.synthetic) served through that rule, normal/abnormal
-pairs, ``drop_last`` batching, ``shuffle_keys`` per epoch.  An HDF5-backed source with the same interface is the "next"
-row.
+pairs, ``drop_last`` batching, ``shuffle_keys`` per epoch.  Real feature files (HDF5) go through ``load_dataset.py`` +
+``hdf5.py``.
 """
 from __future__ import annotations
 

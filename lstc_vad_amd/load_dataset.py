@@ -13,7 +13,7 @@ public classes only set the knobs.  What is kept exactly, because it decides whi
 * ``n_patch`` slicing at return time (:101-106), ten-crop variants returning ``crop_i`` as a fifth item (:229-232);
 * UCF: a video with ``n_clips <= part_len`` is repeated x2 along time before sampling (:417-418).
 
-Feature files go through ``lstc_vad_amd.archive.FeatureArchive`` (HDF5 when ``h5py`` exists, else ``.npz`` / directory).
+Feature files go through ``lstc_vad_amd.archive.FeatureArchive`` (HDF5 through the package's own reader ``lstc_vad_amd.hdf5``, ``.npz``, or a directory of ``.npy`` files).
 ``ResidentPairs`` is the MI355X-first way to serve the same items: the whole feature set lives in HBM (SHT train is
 ~2.4 GB, UCF-Crime ~90 GB of fp32 I3D features - both fit in 288 GB) and a batch is one device-side row gather
 (``lstc_gather_rows``) driven by the host-side window indices, so no feature bytes cross PCIe after start-up.

@@ -25,9 +25,25 @@ from oracle import lstc_oracle as orc                         # noqa: E402
 G = np.load(os.path.join(HERE, "golden", "pipeline.npz"))
 
 
+H5DIR = os.path.join(HERE, "golden", "hdf5")
+
+
 @pytest.fixture(scope="module")
-def world(tmp_path_factory):
+def world_npz(tmp_path_factory):
     return pw.build(str(tmp_path_factory.mktemp("world")), Encoder, Regressor, Classifier)
+
+
+@pytest.fixture(scope="module", params=["npz", "hdf5"])
+def world(request, world_npz):
+    """The synthetic world with its feature archives as numpy files, and again with the SHT / UCF feature archives and the UCF
+    ground truth as REAL HDF5 files (written by libhdf5: tests/golden/make_hdf5_fixtures.py) read by lstc_vad_amd.hdf5 - the
+    container the reference's datasets actually come in."""
+    if request.param == "npz":
+        return world_npz
+    W = dict(world_npz)
+    for tag in ("sht_feats", "ucf_feats", "ucf_gt"):
+        W[tag] = os.path.join(H5DIR, f"world_{tag}.h5")
+    return W
 
 
 def _fingerprint(t):
@@ -83,12 +99,9 @@ def test_archive_backends_agree(world):
     with pytest.raises(FileNotFoundError):
         FeatureArchive(os.path.join(world["root"], "missing.npz"))
     fake = os.path.join(world["root"], "fake.h5")
-    open(fake, "wb").write(b"\x89HDF\r\n\x1a\n")
-    try:
-        import h5py  # noqa: F401
-    except ImportError:
-        with pytest.raises(RuntimeError, match="h5py"):
-            FeatureArchive(fake)
+    open(fake, "wb").write(b"\x89HDF\r\n\x1a\n" + b"\xff" * 64)          # signature, then nothing a superblock could be
+    with pytest.raises(OSError):
+        FeatureArchive(fake)
 
 
 def test_missing_pseudo_label_file_exits_like_reference(world):
