@@ -118,6 +118,7 @@ def build_parser(script: str) -> argparse.ArgumentParser:
     p.add_argument("--synthetic", action="store_true", help="train on lstc_vad_amd.data.SyntheticVideos")
     p.add_argument("--synthetic_pairs", type=int, default=0, help="normal/abnormal pairs in the synthetic set (default 2*batch_size)")
     p.add_argument("--steps", type=int, default=0, help="stop after this many optimisation steps (0 = run all epochs)")
+    p.add_argument("--save_final", type=str, default="", help="path prefix: write <prefix>encoder.ckpt / <prefix>head.ckpt after the last step")
     p.add_argument("--log_dir", type=str, default="", help="log / checkpoint directory (default: ./log/<dataset>)")
     p.add_argument("--compute_dtype", type=str, default=os.environ.get("LSTC_COMPUTE_DTYPE", "fp32"), choices=["fp32", "f32x3", "bf16"],
                    help="GEMM arithmetic: fp32 = exact-f32 MFMA (reference numerics); f32x3 = f32-accurate products on the f16 "
@@ -202,11 +203,15 @@ def train(script: str, argv=None):
         head = Regressor(d_model, _get(args, "regressor_dropout", "", 0.6),
                          weight_init=_get(args, "regressor_weight_init", "", False))
         lr_head = _get(args, "lr_regressor", "", 1e-2)
+    strip = lambda sd: {k[7:] if k.startswith("module.") else k: v for k, v in sd.items()}
     if getattr(args, "load_model", False):          # state_dict files with the reference's key names (non-strict)
-        strip = lambda sd: {k[7:] if k.startswith("module.") else k: v for k, v in sd.items()}
-        enc_path = getattr(args, "load_temporal_model_path", None) or getattr(args, "load_spatio_model_path", "")
+        if script == "spatio_transformer_MIL_CE":    # Train/spatio_transformer_MIL_CE.py:72-90: --spatio_model_path / --regression_model_path
+            enc_path, head_path = args.spatio_model_path, args.regression_model_path
+        else:
+            enc_path = getattr(args, "load_temporal_model_path", None) or getattr(args, "load_spatio_model_path", "")
+            head_path = args.load_classifier_model_path
         enc.load_state_dict(strip(torch.load(enc_path, map_location="cpu")), False)
-        head.load_state_dict(strip(torch.load(args.load_classifier_model_path, map_location="cpu")), False)
+        head.load_state_dict(strip(torch.load(head_path, map_location="cpu")), False)
     enc, head = enc.to(dev).train(), head.to(dev).train()
 
     if args.batch_size % world:
@@ -219,11 +224,14 @@ def train(script: str, argv=None):
                           temporal_only=getattr(args, "temporal_only", False), clip_grad=getattr(args, "clip_grad", False))
     ts = TrainStep(step_args, mode, enc, head, _get(args, "lr_encoder", pre, 1e-4), lr_head, args.weight_decay)
 
-    ppath = getattr(args, "pseudo_labels_path", None) or getattr(args, "temporal_pseudo_path", None)
+    if script == "spatio_transformer_MIL_CE":
+        # round 0 (the only round: `for round_i in range(1)`, Train/spatio_transformer_MIL_CE.py:113-116) trains the STN on
+        # --spatio_pseudo_path, the labels the temporal model produced for it - read as given, no suffix added
+        ppath = getattr(args, "spatio_pseudo_path", None)
+    else:
+        ppath = getattr(args, "pseudo_labels_path", None)
     if ppath in ("", "None"):
         ppath = None
-    if ppath and not ppath.endswith(".npy"):
-        ppath += ".npy"                                     # Train/spatio_transformer_MIL_CE.py:142
     real = (not args.synthetic) and bool(getattr(args, "dataset_path", ""))
     if real:
         data, eval_fn = _real_data(script, args, mode, part_len, ppath, dev, rank, world, enc, head)
@@ -255,7 +263,8 @@ def train(script: str, argv=None):
             if args.steps and it >= args.steps:
                 break
         data.shuffle_keys()
-        if rank == 0 and epoch % inter == 0:
+        last = script == "spatio_transformer_MIL_CE" and epoch == epochs - 1          # MIL_CE.py:218 also evaluates the last epoch
+        if rank == 0 and (epoch % inter == 0 or last):
             auc_test, auc_train = eval_fn()
             enc.train(); head.train()
             save_auc, lines = sel.update(epoch, auc_test, auc_train)
@@ -273,6 +282,24 @@ def train(script: str, argv=None):
             logger.info('======================================================================================')
         if args.steps and it >= args.steps:
             break
+    if rank == 0 and getattr(args, "save_final", ""):
+        torch.save(enc.state_dict(), args.save_final + "encoder.ckpt")
+        torch.save(head.state_dict(), args.save_final + "head.ckpt")
+    if rank == 0 and script == "spatio_transformer_MIL_CE" and real and getattr(args, "temporal_pseudo_path", ""):
+        # end of the round (Train/spatio_transformer_MIL_CE.py:392-414): RE-LOAD --spatio_model_path / --regression_model_path
+        # (the files, not the weights just trained - upstream expects the user's best checkpoint there) and write the next
+        # temporal model's pseudo labels, score > --threshold else 0, to --temporal_pseudo_path (np.save appends .npy)
+        from . import bump_weight_epoch
+        from .pipeline import generate_pseudo_labels as gen
+        enc.load_state_dict(strip(torch.load(args.spatio_model_path, map_location="cpu")), False)
+        head.load_state_dict(strip(torch.load(args.regression_model_path, map_location="cpu")), False)
+        bump_weight_epoch()
+        dataset = str(getattr(args, "dataset", "SHT"))
+        gen(enc.eval(), head.eval(), "STN", dataset if dataset in ("UCF", "UBnormal") else "SHT", args.dataset_path, args.training_txt,
+            args.threshold, part_len=1, n_patch=args.n_patch, d_model=d_model, segment_len=args.segment_len,
+            out_path=args.temporal_pseudo_path)
+        enc.train(); head.train()
+        logger.info("temporal pseudo label generation finished.")
     if world > 1:
         dist.destroy_process_group()
     return sel.best_test if sel.rule["on"] == "test" else sel.best_train

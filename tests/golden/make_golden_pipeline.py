@@ -62,6 +62,7 @@ import Test.evaluation_shanghaitech_ubnormal as ref_eval_sht         # noqa: E40
 import Test.evaluation_UCF as ref_eval_ucf                           # noqa: E402
 import Train.temporal_transformer_shanghaitech as ref_train_ltn      # noqa: E402
 import Train.spatio_transformer_shanghaitech as ref_train_stn        # noqa: E402
+import Train.spatio_transformer_MIL_CE as ref_train_mce              # noqa: E402
 from models.Encoder import Encoder as RefEncoder                     # noqa: E402
 from models.Regressor import Regressor as RefRegressor               # noqa: E402
 from models.Classifier import Classifier as RefClassifier            # noqa: E402
@@ -69,10 +70,10 @@ from models.Classifier import Classifier as RefClassifier            # noqa: E40
 import utils.eval_utils as ref_eval_utils                             # noqa: E402
 
 assert_reference(ref_ds, ref_gen_s, ref_gen_t, ref_eval_sht, ref_eval_ucf, ref_eval_utils, RefEncoder, RefRegressor,
-                 RefClassifier, ref_train_ltn, ref_train_stn)
+                 RefClassifier, ref_train_ltn, ref_train_stn, ref_train_mce)
 
 import pipeline_world as pw                                          # noqa: E402
-from pipeline_cases import DATASET_CASES, build_dataset              # noqa: E402
+from pipeline_cases import CHAIN, DATASET_CASES, build_dataset, chain_argv, weight_fingerprint   # noqa: E402
 
 torch.set_num_threads(4)
 OUT = {}
@@ -235,6 +236,7 @@ def run_train_loops(W, tmp):
             def emit(self, rec):
                 lines.append(rec.getMessage())
         lg = logging.getLogger("golden_" + tag); lg.handlers.clear(); lg.addHandler(_H()); lg.setLevel(logging.INFO); lg.propagate = False
+        keep_attrs = {n: getattr(mod, n) for n in ("log_setting", "DataLoader", "eval")}
         mod.log_setting = lambda a, lg=lg: lg
         mod.DataLoader = lambda ds, batch_size, num_workers=0, worker_init_fn=None, drop_last=False: \
             TorchLoader(ds, batch_size=batch_size, num_workers=0, drop_last=drop_last)
@@ -244,7 +246,11 @@ def run_train_loops(W, tmp):
             return ref_eval_utils.eval(scores, labels, logger)
         mod.eval = capture
         np.random.seed(3); random.seed(3); torch.manual_seed(3)
-        mod.train(args)
+        try:
+            mod.train(args)
+        finally:                                    # later stages (run_coteach_chain) use the module's real DataLoader again
+            for n, v in keep_attrs.items():
+                setattr(mod, n, v)
         assert len(calls) == 2, len(calls)
         OUT[f"tl_eval/{tag}/test_scores"], OUT[f"tl_eval/{tag}/test_labels"] = calls[0]
         OUT[f"tl_eval/{tag}/train_scores"], OUT[f"tl_eval/{tag}/train_labels"] = calls[1]
@@ -291,6 +297,132 @@ def run_loader_workers(W):
         OUT[f"dlw/{name}/cfg"] = np.array([k, bs])
 
 
+def _gap_threshold(raw: np.ndarray) -> float:
+    """A threshold in the widest gap of the middle of the score distribution: no score sits within rounding of it, so the
+    build's scores (equal to 1e-4) fall on the same side."""
+    v = np.sort(np.unique(raw.astype(np.float64)))
+    lo, hi = int(0.15 * len(v)), max(int(0.85 * len(v)), int(0.15 * len(v)) + 2)
+    gaps = v[lo + 1:hi] - v[lo:hi - 1]
+    i = lo + int(np.argmax(gaps))
+    print("  scores", len(v), "range", v[0], v[-1], "threshold gap", v[i + 1] - v[i])
+    assert v[i + 1] - v[i] > 1e-3, "scores too dense for a safe threshold"
+    return float(0.5 * (v[i] + v[i + 1]))
+
+
+def run_coteach_chain(W, tmp):
+    """BASELINE.json config 3 in miniature, by the reference's own code end to end (README.md:21-36 order):
+    Train/spatio_transformer_shanghaitech.train -> pseudo_labels_generator_spatio.generator ->
+    Train/temporal_transformer_shanghaitech.train on those labels -> pseudo_labels_generator_temporal.generator ->
+    Train/spatio_transformer_MIL_CE.train (MIL + BCE on the LTN's labels, then its end-of-round label generation).
+    Real DataLoader worker processes, real learning rates, dropout 0.  Stored: every step's loss terms (hooked at the
+    scripts' loss functions: the log prints 4 digits), fingerprints of the trained weights, every pseudo-label file."""
+    import logging
+    C = CHAIN
+    lg = logging.getLogger("golden_chain"); lg.handlers.clear(); lg.addHandler(logging.NullHandler()); lg.propagate = False
+
+    def strip_ckpt(src, dst):
+        sd = torch.load(src)
+        torch.save({(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}, dst)
+        return dst
+
+    def run_train(mod, argv, loss_fns, classes):
+        keep = sys.argv
+        sys.argv = ["x"] + argv
+        try:
+            args = mod.parser_arg()
+        finally:
+            sys.argv = keep
+        made, losses = {}, []
+        saved = {n: getattr(mod, n) for n in list(classes) + list(loss_fns) + ["log_setting"]}
+        def build(_c, _n, *a, **k):
+            m = made.setdefault(_n, _c(*a, **k))
+            orig = m.load_state_dict
+
+            def load(sd, *la, **lk):                   # the state just before every load: MIL_CE re-loads its start checkpoint
+                made[_n + "@before_load"] = {kk: vv.detach().clone() for kk, vv in m.state_dict().items()}   # at the end of the round
+                return orig(sd, *la, **lk)
+            m.load_state_dict = load
+            return m
+        for n, cls in classes.items():
+            setattr(mod, n, (lambda *a, _c=cls, _n=n, **k: build(_c, _n, *a, **k)))
+        for n in loss_fns:
+            def rec(*a, _f=saved[n], _n=n, **k):
+                out = _f(*a, **k)
+                losses.append((_n, [float(x) for x in (out if isinstance(out, tuple) else (out,))]))
+                return out
+            setattr(mod, n, rec)
+        mod.log_setting = lambda a: lg
+        np.random.seed(C["seed"]); random.seed(C["seed"]); torch.manual_seed(C["seed"])      # utils/utils.py:107-116 (set_seeds in __main__)
+        try:
+            mod.train(args)
+        finally:
+            for n, v in saved.items():
+                setattr(mod, n, v)
+        return made, losses
+
+    def steps_of(losses, order):
+        """[steps, terms]: the hooked calls of one optimisation step, concatenated in ``order``."""
+        per = len(order)
+        assert len(losses) % per == 0 and all(losses[i][0] == order[i % per] for i in range(len(losses))), [l[0] for l in losses[:6]]
+        return np.array([sum((losses[i + j][1] for j in range(per)), []) for i in range(0, len(losses), per)], np.float64)
+
+    def store_weights(tag, **mods):
+        for n, m in mods.items():
+            norms, samp = weight_fingerprint(m if isinstance(m, dict) else m.state_dict())
+            OUT[f"chain/{tag}/{n}_norm"], OUT[f"chain/{tag}/{n}_samp"] = norms, samp
+
+    paths = dict(W, save=os.path.join(tmp, "chain_save") + os.sep,
+                 ltn_enc_in=strip_ckpt(W["ltn_sht_enc.ckpt"], os.path.join(tmp, "c_enc_l.ckpt")),
+                 ltn_cls_in=strip_ckpt(W["ltn_sht_cls.ckpt"], os.path.join(tmp, "c_cls_l.ckpt")),
+                 stn_enc_out=os.path.join(tmp, "c_stn_enc.ckpt"), stn_reg_out=os.path.join(tmp, "c_stn_reg.ckpt"),
+                 ltn_enc_out=os.path.join(tmp, "c_ltn_enc.ckpt"), ltn_cls_out=os.path.join(tmp, "c_ltn_cls.ckpt"),
+                 pl_s=os.path.join(tmp, "c_pl_s.npy"), pl_t=os.path.join(tmp, "c_pl_t.npy"), pl_mce=os.path.join(tmp, "c_pl_mce"))
+    os.makedirs(paths["save"])
+    # ---- 1. STN
+    made, losses = run_train(ref_train_stn, chain_argv("stn", paths), ["get_MIL_loss"], {"Encoder": RefEncoder, "Regressor": RefRegressor})
+    OUT["chain/stn/losses"] = steps_of(losses, ["get_MIL_loss"])
+    torch.save(made["Encoder"].state_dict(), paths["stn_enc_out"]); torch.save(made["Regressor"].state_dict(), paths["stn_reg_out"])
+    store_weights("stn", enc=made["Encoder"], head=made["Regressor"])
+    # ---- 2. STN pseudo labels (raw scores first: threshold in a gap)
+    ga = dict(n_hidden=47, MHA_layerNorm=False, relative_position_encoding=False, dataset_path=W["sht_feats"], training_txt=W["sht_train"],
+              spatio_model_path=paths["stn_enc_out"], regression_model_path=paths["stn_reg_out"], pseudo_labels_path=paths["pl_s"])
+    ref_gen_s.generator(gen_args(threshold=-1.0, **ga))
+    raw = np.concatenate([np.asarray(v, np.float32).ravel() for v in np.load(paths["pl_s"], allow_pickle=True).tolist().values()])
+    thr_s = _gap_threshold(raw)
+    ref_gen_s.generator(gen_args(threshold=thr_s, **ga))
+    for k, v in np.load(paths["pl_s"], allow_pickle=True).tolist().items():
+        OUT[f"chain/pl_s/{k}"] = np.asarray(v, np.float32)
+    # ---- 3. LTN on the STN's labels
+    made, losses = run_train(ref_train_ltn, chain_argv("ltn", paths), ["get_CE_loss", "get_MIL_loss"],
+                             {"Encoder": RefEncoder, "Classifier": RefClassifier})
+    OUT["chain/ltn/losses"] = steps_of(losses, ["get_CE_loss", "get_MIL_loss"])
+    torch.save(made["Encoder"].state_dict(), paths["ltn_enc_out"]); torch.save(made["Classifier"].state_dict(), paths["ltn_cls_out"])
+    store_weights("ltn", enc=made["Encoder"], head=made["Classifier"])
+    # ---- 4. LTN pseudo labels
+    ga = dict(dataset_path=W["sht_feats"], training_txt=W["sht_train"], temporal_model_path=paths["ltn_enc_out"],
+              classifier_model_path=paths["ltn_cls_out"], pseudo_labels_path=paths["pl_t"])
+    ref_gen_t.generator(gen_args(threshold=-1.0, **ga))
+    raw = np.concatenate([np.asarray(v, np.float32).ravel() for v in np.load(paths["pl_t"], allow_pickle=True).tolist().values()])
+    thr_t = _gap_threshold(raw)
+    ref_gen_t.generator(gen_args(threshold=thr_t, **ga))
+    for k, v in np.load(paths["pl_t"], allow_pickle=True).tolist().items():
+        OUT[f"chain/pl_t/{k}"] = np.asarray(v, np.float32)
+    # ---- 5. STN co-teaching: MIL + BCE on the LTN's labels; the round ends by re-loading --spatio_model_path and writing
+    # the next temporal pseudo labels (Train/spatio_transformer_MIL_CE.py:392-414)
+    OUT["chain/thr"] = np.array([thr_s, thr_t])
+    paths["thr_s"] = repr(thr_s)
+    made, losses = run_train(ref_train_mce, chain_argv("mce", paths), ["get_MIL_loss", "get_BCE_loss"],
+                             {"Encoder": RefEncoder, "Regressor": RefRegressor})
+    OUT["chain/mce/losses"] = steps_of(losses, ["get_MIL_loss", "get_BCE_loss"])
+    # the trained weights: the state just before the end-of-round re-load of --spatio_model_path / --regression_model_path
+    store_weights("mce", enc=made["Encoder@before_load"], head=made["Regressor@before_load"])
+    assert not torch.equal(made["Encoder@before_load"]["layer_stack.0.slf_attn.w_qs.weight"], made["Encoder"].state_dict()["layer_stack.0.slf_attn.w_qs.weight"])
+    for k, v in np.load(paths["pl_mce"] + ".npy", allow_pickle=True).tolist().items():
+        OUT[f"chain/pl_mce/{k}"] = np.asarray(v, np.float32)
+    print("chain: thresholds", thr_s, thr_t, "| steps", len(OUT["chain/stn/losses"]), len(OUT["chain/ltn/losses"]), len(OUT["chain/mce/losses"]),
+          "| first/last STN loss", OUT["chain/stn/losses"][0, 0], OUT["chain/stn/losses"][-1, 0])
+
+
 def main():
     with tempfile.TemporaryDirectory() as tmp:
         W = pw.build(os.path.join(tmp, "world"), RefEncoder, RefRegressor, RefClassifier)
@@ -300,6 +432,7 @@ def main():
         run_evals(W)
         run_train_loops(W, tmp)
         run_loader_workers(W)
+        run_coteach_chain(W, tmp)
     out_dir = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else HERE
     np.savez_compressed(os.path.join(out_dir, "pipeline.npz"), **OUT)
     print("pipeline.npz:", len(OUT), "arrays,", os.path.getsize(os.path.join(out_dir, "pipeline.npz")), "bytes")

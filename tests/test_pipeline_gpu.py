@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, os.path.join(HERE, "golden"))
 
 import pipeline_world as pw                                   # noqa: E402
-from pipeline_cases import DATASET_CASES, build_dataset       # noqa: E402
+from pipeline_cases import CHAIN, DATASET_CASES, build_dataset, chain_argv, weight_fingerprint   # noqa: E402
 from lstc_vad_amd import functional as F                      # noqa: E402
 from lstc_vad_amd import load_dataset as ds_mod               # noqa: E402
 from lstc_vad_amd import pipeline                             # noqa: E402
@@ -219,3 +219,85 @@ def test_coteaching_loop_chain(dtype, tmp_path):
         d = np.load(os.path.join(out, f), allow_pickle=True).tolist()
         assert len(d) == 16 and all(v.ndim == 2 and v.shape[1] == 1 and np.isfinite(v).all() for v in d.values())
     assert "spatio_loss" in r.stdout + r.stderr
+
+
+def test_coteaching_chain_matches_the_reference_run_stage_by_stage(world, tmp_path):
+    """BASELINE config 3 in miniature against the reference's own run of the same five stages on the same world
+    (tests/golden/make_golden_pipeline.py run_coteach_chain): Train/spatio_transformer_shanghaitech.py ->
+    pseudo_labels_generator_spatio.py -> Train/temporal_transformer_shanghaitech.py on those labels ->
+    pseudo_labels_generator_temporal.py -> Train/spatio_transformer_MIL_CE.py (MIL + BCE, then its end-of-round labels).
+    The build's stages are chained through the build's OWN files (weights, label files), so differences accumulate: six
+    optimisation steps per training stage at lr 1e-3 / 2e-3, fp32.  Bars: every step's loss terms 1e-3 (the log prints 4
+    digits), trained-weight norms 1e-3 relative, pseudo-label files 2e-3 with the same zero pattern (thresholds sit in gaps)."""
+    save = str(tmp_path / "ck") + os.sep
+    os.makedirs(save)
+    strip = lambda src, dst: (torch.save({(k[7:] if k.startswith("module.") else k): v for k, v in torch.load(src).items()}, dst), dst)[1]
+    thr_s, thr_t = (float(x) for x in G["chain/thr"])
+    P = dict(world, save=save, ltn_enc_in=strip(world["ltn_sht_enc.ckpt"], str(tmp_path / "enc_l.ckpt")),
+             ltn_cls_in=strip(world["ltn_sht_cls.ckpt"], str(tmp_path / "cls_l.ckpt")),
+             stn_enc_out=str(tmp_path / "stn_encoder.ckpt"), stn_reg_out=str(tmp_path / "stn_head.ckpt"),
+             pl_s=str(tmp_path / "pl_s.npy"), pl_t=str(tmp_path / "pl_t.npy"), pl_mce=str(tmp_path / "pl_mce"), thr_s=repr(thr_s))
+
+    def losses_of(stderr, key, fields):
+        rows = []
+        for line in stderr.splitlines():
+            if key in line and "]: " in line:
+                body = line.split("]: ", 1)[1].replace(",", " ").split()
+                vals = dict(zip(body[0::2], body[1::2]))
+                rows.append([float(vals[f]) for f in fields])
+        return np.array(rows)
+
+    def check_weights(tag, prefix):
+        for n, f in (("enc", "encoder.ckpt"), ("head", "head.ckpt")):
+            norms, samp = weight_fingerprint(torch.load(prefix + f, map_location="cpu"))
+            ref_n, ref_s = G[f"chain/{tag}/{n}_norm"], G[f"chain/{tag}/{n}_samp"]
+            assert norms.shape == ref_n.shape
+            assert np.all(np.abs(norms - ref_n) <= 1e-3 * np.abs(ref_n) + 1e-6), (tag, n, np.abs(norms - ref_n).max())
+            # Adagrad's early updates are lr * sign-like: an entry whose gradient is at rounding level may move the other way
+            assert np.mean(np.abs(samp - ref_s) < 2e-4) > 0.98 and np.abs(samp - ref_s).max() < 12 * float(CHAIN["lr_encoder"]) * 2, \
+                (tag, n, np.mean(np.abs(samp - ref_s) < 2e-4), np.abs(samp - ref_s).max())
+
+    def check_labels(path, prefix):
+        out = np.load(path, allow_pickle=True).tolist()
+        keys = [k[len(prefix):] for k in G.files if k.startswith(prefix)]
+        assert list(out.keys()) == keys
+        for k in keys:
+            ref, got = G[prefix + k], np.asarray(out[k], np.float32)
+            assert got.shape == ref.shape and np.array_equal(got > 0, ref > 0), k
+            assert np.abs(got - ref).max() < 2e-3, (k, np.abs(got - ref).max())
+
+    # 1. STN
+    r = _run("Train", "spatio_transformer_shanghaitech.py", chain_argv("stn", P) + ["--save_final", str(tmp_path / "stn_"), "--log_dir", str(tmp_path / "l1")])
+    assert r.returncode == 0, r.stderr[-2500:]
+    got = losses_of(r.stderr, "err", ["loss", "err", "l1"])
+    assert got.shape == G["chain/stn/losses"].shape and np.abs(got - G["chain/stn/losses"]).max() < 1e-3, (got, G["chain/stn/losses"])
+    check_weights("stn", str(tmp_path / "stn_"))
+    # 2. its pseudo labels
+    gen = ["--dataset_path", world["sht_feats"], "--training_txt", world["sht_train"], "--n_patch", "16", "--n_head", "2", "--d_model", "32",
+           "--d_k", "16", "--d_v", "16", "--FFN_layerNorm"]
+    r = _run("Train", "pseudo_labels_generator_spatio.py", gen + ["--n_hidden", "47", "--threshold", repr(thr_s), "--spatio_model_path", P["stn_enc_out"],
+                                                                  "--regression_model_path", P["stn_reg_out"], "--pseudo_labels_path", P["pl_s"]])
+    assert r.returncode == 0, r.stderr[-2500:]
+    check_labels(P["pl_s"], "chain/pl_s/")
+    # 3. LTN on those labels
+    r = _run("Train", "temporal_transformer_shanghaitech.py", chain_argv("ltn", P) + ["--save_final", str(tmp_path / "ltn_"), "--log_dir", str(tmp_path / "l3")])
+    assert r.returncode == 0, r.stderr[-2500:]
+    got = losses_of(r.stderr, "MIL_l1", ["CE_loss", "MIL_loss", "MIL_l1"])
+    ref = G["chain/ltn/losses"]                                         # [CE, MIL loss, err, l1]
+    assert got.shape[0] == ref.shape[0] and np.abs(got - ref[:, [0, 1, 3]]).max() < 1e-3, (got, ref)
+    check_weights("ltn", str(tmp_path / "ltn_"))
+    # 4. its pseudo labels
+    r = _run("Train", "pseudo_labels_generator_temporal.py", gen + ["--n_hidden", "64", "--part_len", "3", "--MHA_layerNorm", "--relative_position_encoding",
+                                                                    "--threshold", repr(thr_t), "--temporal_model_path", str(tmp_path / "ltn_encoder.ckpt"),
+                                                                    "--classifier_model_path", str(tmp_path / "ltn_head.ckpt"), "--pseudo_labels_path", P["pl_t"]])
+    assert r.returncode == 0, r.stderr[-2500:]
+    check_labels(P["pl_t"], "chain/pl_t/")
+    # 5. STN co-teaching on the LTN's labels + the end-of-round label file
+    r = _run("Train", "spatio_transformer_MIL_CE.py", chain_argv("mce", P) + ["--save_final", str(tmp_path / "mce_"), "--log_dir", str(tmp_path / "l5")])
+    assert r.returncode == 0, r.stderr[-2500:]
+    got = losses_of(r.stderr, "spatio_loss", ["MIL_loss", "err", "l1", "CE_loss"])
+    ref = G["chain/mce/losses"]                                         # [MIL loss, err, l1, BCE]
+    assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-3, (got, ref)
+    check_weights("mce", str(tmp_path / "mce_"))
+    check_labels(P["pl_mce"] + ".npy", "chain/pl_mce/")
+    assert "temporal pseudo label generation finished." in r.stderr
