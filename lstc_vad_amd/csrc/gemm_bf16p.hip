@@ -233,29 +233,30 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
         if (nkt > 1) { P1_DMA_UNIT(0, 1, 1); P1_DMA_UNIT(1, 1, 1); P1_DMA_UNIT(2, 1, 1); P1_DMA_UNIT(3, 1, 1); }
     };
 
-#define P1_MMA(ih, jj)                                                                                                 \
+#define P1_MMA(ih, jj, rs)                                                                                              \
     do {                                                                                                               \
         __builtin_amdgcn_s_setprio(1);                                                                                 \
         if constexpr (S16) {                                                                                           \
             _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)           \
                 _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                        \
                     a4[4 * (ih) + rt][2 * (jj) + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
-                        fa[2 * kk + (rt >> 1)][rt & 1], fb[jj][2 * kk + ct], a4[4 * (ih) + rt][2 * (jj) + ct], 0, 0, 0);  \
+                        fa[2 * kk + (rt >> 1)][rt & 1], fb[rs][2 * kk + ct], a4[4 * (ih) + rt][2 * (jj) + ct], 0, 0, 0);  \
         } else {                                                                                                       \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)               \
                 acc[S16 ? 0 : 2 * (ih) + ii][S16 ? 0 : jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                     \
-                    fa[q][ii], fb[jj][q], acc[S16 ? 0 : 2 * (ih) + ii][S16 ? 0 : jj], 0, 0, 0);                           \
+                    fa[q][ii], fb[rs][q], acc[S16 ? 0 : 2 * (ih) + ii][S16 ? 0 : jj], 0, 0, 0);                           \
         }                                                                                                              \
         __builtin_amdgcn_s_setprio(0);                                                                                 \
     } while (0)
-#define P1_SYNC_COMPUTE(ih, jj)                                                                                        \
+#define P1_SYNC_COMPUTE(ih, jj, rs, vmw)          /* vmw >= 0: s_waitcnt vmcnt(vmw) before the closing barrier */       \
     do {                                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         __builtin_amdgcn_s_barrier();                                                                                  \
         __builtin_amdgcn_s_waitcnt(0xC07F);          /* lgkmcnt(0): this phase's fragments are in registers */         \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        P1_MMA(ih, jj);                                                                                                \
+        P1_MMA(ih, jj, rs);                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if constexpr ((vmw) >= 0) __builtin_amdgcn_s_waitcnt(vmcnt_imm((vmw) >= 0 ? (vmw) : 0));                       \
         __builtin_amdgcn_s_barrier();                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     } while (0)
@@ -268,38 +269,56 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
         constexpr int PEND = decltype(pendc)::value;
         const bf16_t* cur = smem + CUR * P1_BUF;
         const bool has1 = tl + 1 < nkt, has2 = tl + 2 < nkt;
+        // Fragment reads per LOAD segment: 8 (fa rows 0-63) / 4 (fb cols 32-63) / 8 (fa rows 64-127) / 4 (fb cols 0-31 of step
+        // t+1, out of the other buffer) - 12 / 4 / 8 / 0 made phase 0's LOAD (x 4 waves on the LDS array, plus latency) longer than
+        // the partner's 256-cycle COMPUTE.  The two fb register sets swap roles every K step (the set that held cols 32-63 is
+        // free from phase 3 on and receives the next step's cols 0-31): X = set of cols 0-31 this step, Y = the other.
+        constexpr int X = CUR, Y = CUR ^ 1;        // an item's K steps alternate CUR = 0, 1, 0, ... from its HEAD step (CUR 0)
+        const bf16_t* nxt = smem + (CUR ^ 1) * P1_BUF;
         // ---- phase 0: quadrant (rows first 64, cols first 32)
+        if constexpr (HEAD) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) fb[0][q] = S16 ? rd_b16(cur, q & 1, q >> 1) : rd_b(cur, 0, q);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < 4; ++q) fb[X][q] = S16 ? rd_b16(cur, q & 1, q >> 1) : rd_b(cur, 0, q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             fa[q][0] = S16 ? rd_a16(cur, 0, 2 * (q & 1), q >> 1) : rd_a(cur, 0, q);
             fa[q][1] = S16 ? rd_a16(cur, 0, 2 * (q & 1) + 1, q >> 1) : rd_a(cur, 1, q);
         }
         if (!HEAD && has1) P1_DMA_UNIT(2, tl + 1, CUR ^ 1);
-        P1_SYNC_COMPUTE(0, 0);
+        P1_SYNC_COMPUTE(0, 0, X, -1);
         // ---- phase 1: (first 64 rows, second 32 cols)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) fb[1][q] = S16 ? rd_b16(cur, 2 + (q & 1), q >> 1) : rd_b(cur, 1, q);
+        for (int q = 0; q < 4; ++q) fb[Y][q] = S16 ? rd_b16(cur, 2 + (q & 1), q >> 1) : rd_b(cur, 1, q);
         if (!HEAD && has1) P1_DMA_UNIT(3, tl + 1, CUR ^ 1);
-        P1_SYNC_COMPUTE(0, 1);
-        // ---- phase 2: (second 64 rows, second 32 cols)
+        P1_SYNC_COMPUTE(0, 1, Y, -1);
+        // ---- phase 2: (second 64 rows, second 32 cols).  Before its closing barrier: unit U1 of step t+1 (B cols 0-31, issued
+        // >= 3 phases ago) has landed - younger operations: U2, U3 of t+1 (4), U0 of t+2 (2), the previous item's stores (HEAD)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             fa[q][0] = S16 ? rd_a16(cur, 1, 2 * (q & 1), q >> 1) : rd_a(cur, 2, q);
             fa[q][1] = S16 ? rd_a16(cur, 1, 2 * (q & 1) + 1, q >> 1) : rd_a(cur, 3, q);
         }
-        if (has2) P1_DMA_UNIT(0, tl + 2, CUR);
-        P1_SYNC_COMPUTE(1, 1);
-        // ---- phase 3: (second 64 rows, first 32 cols): no fragment reads; K step t+1 must have landed before the next read
+        if (has2) {
+            P1_DMA_UNIT(0, tl + 2, CUR);
+            P1_SYNC_COMPUTE(1, 1, Y, 6 + (HEAD ? PEND : 0));
+        } else {
+            P1_SYNC_COMPUTE(1, 1, Y, 4 + (HEAD ? PEND : 0));
+        }
+        // ---- phase 3: (second 64 rows, first 32 cols): reads fb cols 0-31 of step t+1 into the set phase 2 just released; K step
+        // t+1 must have landed whole before the next step's reads
+        if (has1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fb[Y][q] = S16 ? rd_b16(nxt, q & 1, q >> 1) : rd_b(nxt, 0, q);
+        }
         if (has2) {
             P1_DMA_UNIT(1, tl + 2, CUR);
             __builtin_amdgcn_s_waitcnt(vmcnt_imm(4 + (HEAD ? PEND : 0)));   // everything but U0, U1 of step t+2 (and the stores)
         } else {
             __builtin_amdgcn_s_waitcnt(vmcnt_imm(HEAD ? PEND : 0));
         }
-        P1_SYNC_COMPUTE(1, 0);
+        P1_SYNC_COMPUTE(1, 0, X, -1);
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
