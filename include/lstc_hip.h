@@ -71,7 +71,13 @@ enum { LSTC_F32 = 0, LSTC_BF16 = 1, LSTC_F32X3 = 2, LSTC_BF16P = 3 };
  */
 enum {
     LSTC_EPI_BIAS = 1, LSTC_EPI_RELU = 2, LSTC_EPI_DROPOUT = 4, LSTC_EPI_RESIDUAL = 8,
-    LSTC_EPI_RELU_MASK = 16, LSTC_EPI_ACCUM = 32, LSTC_EPI_OUT_F32 = 64
+    LSTC_EPI_RELU_MASK = 16, LSTC_EPI_ACCUM = 32, LSTC_EPI_OUT_F32 = 64,
+    /* LSTC_BF16P only, (0, 1) form, M and N multiples of 256, no K split (else LSTC_E_UNSUPPORTED):
+     *   OUT_PACK:       C is an lstc_pack1 buffer (lstc_pack1_bytes(M, N)) that receives the result rounded to bf16 in the layout
+     *                   of a packed [M, N] operand - the output of W1 (models/FFN.py:17) IS the A operand of W2 and of dW2, and
+     *                   the gradient of that hidden IS the operand of dW1 / dX: no f32 copy, no lstc_pack1 pass (ldc ignored);
+     *   RELU_MASK_PACK: relu_src is such a pack (the hidden's sign is read from its bf16 form; ld_relu ignored). */
+    LSTC_EPI_OUT_PACK = 128, LSTC_EPI_RELU_MASK_PACK = 256
 };
 
 typedef struct LstcGemmDesc {
@@ -129,6 +135,11 @@ int lstc_pack3(const float* src, int64_t rows, int64_t K, int64_t ld, int32_t k_
  * 16-B aligned.  Same nn.Linear products as lstc_gemm (models/MultiHeadAttention.py:97-99,123; models/FFN.py:17). */
 int64_t lstc_pack1_bytes(int64_t rows, int64_t K);
 int lstc_pack1(const float* src, int64_t rows, int64_t K, int64_t ld, int32_t k_major, void* dst, void* stream);
+/* out[k] (+)= sum over rows of the packed [rows, K] operand (bf16 values added in f32; two passes through `partial`
+ * [n_partial, K]): the bias gradient db1 = column sums of the hidden's gradient (autograd of models/FFN.py:17) when that
+ * gradient exists only as the packed output of a LSTC_EPI_OUT_PACK product. */
+int lstc_colsum_pack1(const void* packed, int64_t rows, int32_t K, float* partial, int32_t n_partial, float* out,
+                      int32_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------------ attention
  * Fused core of models/MultiHeadAttention.py:103-122 for one layer, all sequences, heads:

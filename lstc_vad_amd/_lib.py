@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "liblstc_hip.so")
 
 F32, BF16, F32X3, BF16P = 0, 1, 2, 3
 EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_RESIDUAL, EPI_RELU_MASK, EPI_ACCUM, EPI_OUT_F32 = 1, 2, 4, 8, 16, 32, 64
+EPI_OUT_PACK, EPI_RELU_MASK_PACK = 128, 256
 
 EXPORTS = (
     "lstc_gemm", "lstc_attn_fwd", "lstc_attn_bwd", "lstc_attn_cls_fwd", "lstc_attn_cls_bwd", "lstc_cls_dot", "lstc_cls_wsum",
@@ -23,7 +24,7 @@ EXPORTS = (
     "lstc_layernorm_bwd_drop_pack",
     "lstc_cls_concat_fwd", "lstc_cls_concat_bwd", "lstc_colsum", "lstc_dropout_apply", "lstc_dropout_mask",
     "lstc_head_out_fwd", "lstc_head_out_bwd", "lstc_vad_loss", "lstc_adagrad_step", "lstc_sqnorm_accum", "lstc_scale",
-    "lstc_gather_rows", "lstc_cast_f32_bf16", "lstc_cast_bf16_f32", "lstc_pack3", "lstc_pack3_bytes", "lstc_pack1", "lstc_pack1_bytes", "lstc_gemm_splits",
+    "lstc_gather_rows", "lstc_cast_f32_bf16", "lstc_cast_bf16_f32", "lstc_pack3", "lstc_pack3_bytes", "lstc_pack1", "lstc_pack1_bytes", "lstc_colsum_pack1", "lstc_gemm_splits",
     "lstc_version", "lstc_strerror",
 )
 
@@ -104,6 +105,7 @@ def load():
         "lstc_pack3": [vp, i64, i64, i64, C.c_int32, vp, vp],
         "lstc_pack3_bytes": [i64, i64],
         "lstc_pack1": [vp, i64, i64, i64, C.c_int32, vp, vp],
+        "lstc_colsum_pack1": [vp, i64, i32, vp, i32, vp, i32, vp],
         "lstc_pack1_bytes": [i64, i64],
         "lstc_gemm_splits": [i32, i32, i32],
         "lstc_version": [],

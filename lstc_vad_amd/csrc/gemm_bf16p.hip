@@ -121,6 +121,8 @@ struct P1Params {
     long long split_stride;                  // elements between the outputs of consecutive K splits (0: atomics into one C)
     int debug;                               // -DLSTC_TUNING builds only: 1 = skip the epilogue (timing ablation), 2 = narrow epilogue
     int vec_epi;                             // 16-B epilogue accesses allowed (N, ld's multiples of 4, pointers 16-B aligned)
+    int out_kbp;                             // LSTC_EPI_OUT_PACK: C is an lstc_pack1 buffer of [M, N]; its 32-k tiles per row block (else 0)
+    int mask_kbp;                            // LSTC_EPI_RELU_MASK_PACK: relu_src is an lstc_pack1 buffer of [M, N] (else 0)
 };
 
 constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
@@ -134,9 +136,13 @@ constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >>
 // = vmcnt(32 + younger DMA) a compile-time constant.  Every other epilogue drains (vmcnt(0)) and starts the next item cold.
 // S16 (NT form only): the products run on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 - same FLOP per cycle, same fragment
 // bytes, but the chip holds a higher clock on this shape under load (MI355X_MICROARCH.md, DVFS give-back item 7).
-template <bool TR, bool S16>
+// EPK (S16 only): 0 = f32 output / f32 ReLU-mask operand; 1 = the output is written as a packed bf16 operand (LSTC_EPI_OUT_PACK);
+// 2 = packed output AND the ReLU mask read from a packed operand (LSTC_EPI_RELU_MASK_PACK); 3 = packed mask, f32 output.
+template <bool TR, bool S16, int EPK = 0>
 __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
     static_assert(!(TR && S16), "the transposed-read form keeps the 32x32x16 shape");
+    static_assert(EPK == 0 || S16, "packed outputs / masks exist on the pipelined epilogue of the S16 form only");
+    constexpr bool OPK = EPK == 1 || EPK == 2, MPK = EPK == 2 || EPK == 3;
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_p1[];
     bf16_t* const smem = smem_p1;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -398,7 +404,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
         floatx4v fbias[2] = {floatx4v{0.f, 0.f, 0.f, 0.f}, floatx4v{0.f, 0.f, 0.f, 0.f}};
         if constexpr (S16) {
             const int f_ = p.flags;
-            fastepi = p.vec_epi && !(p.splits > 1 && p.split_stride == 0) && has_next && nkt > 1 && !(f_ & LSTC_EPI_ACCUM) &&
+            fastepi = p.vec_epi && !(p.splits > 1 && p.split_stride == 0) && !(f_ & LSTC_EPI_ACCUM) &&
                       !((f_ & LSTC_EPI_RESIDUAL) && (f_ & LSTC_EPI_RELU_MASK)) && (cmb + 1) * 256 <= p.M && (cnb + 1) * 256 <= p.N;
 #ifdef LSTC_TUNING
             if (p.debug) fastepi = false;
@@ -406,8 +412,9 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
             if (fastepi && (f_ & LSTC_EPI_BIAS)) {
 #pragma unroll
                 for (int cp2 = 0; cp2 < 2; ++cp2) {
-                    const float* bp = p.bias + (cnb * 256 + wc * 64 + (2 * cp2 + (c16 >> 1)) * 16 + 4 * (l15 >> 2));
-                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fbias[cp2]) : "v"(bp) : "memory");
+                    const float* bp = p.bias + (cnb * 256 + wc * 64 + 32 * cp2);                       // wave-uniform
+                    const uint32_t bo = ((c16 >> 1) * 16 + 4 * (l15 >> 2)) * 4u;
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(fbias[cp2]) : "v"(bo), "s"(bp) : "memory");
                 }
             }
         }
@@ -447,15 +454,36 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                 // operand loads / 4 stores of batch b = column pair b >> 2, row tiles 2 (b & 3), 2 (b & 3) + 1)
                 const float* aux = (flags & LSTC_EPI_RESIDUAL) ? p.res : (flags & LSTC_EPI_RELU_MASK) ? p.relu_src : nullptr;
                 const int ldx = (flags & LSTC_EPI_RESIDUAL) ? p.ldr : p.ld_relu;
+                // Addressing: wave-uniform base in SGPRs (tile, row tile, column pair: scalar arithmetic) + ONE per-lane byte offset
+                // shared by all 32 groups (row 4 (c16 & 1) + c4, column 16 (c16 >> 1) + 4 (l15 >> 2) of the group's 8 x 32 block)
                 const int c4 = lane & 3;
-                const int rowl = cmb * 256 + wr * 128 + 4 * (c16 & 1) + c4;                      // + 16 rt (+ 8 for the second store)
-                const int coll = cnb * 256 + wc * 64 + (c16 >> 1) * 16 + 4 * (l15 >> 2);         // + 32 cp2
+                const uint32_t lrow = 4 * (c16 & 1) + c4, lcol = (c16 >> 1) * 16 + 4 * (l15 >> 2);
+                const uint32_t offC = (lrow * (uint32_t)p.ldc + lcol) * 4u, offX = (lrow * (uint32_t)ldx + lcol) * 4u;
+                const int urow0 = cmb * 256 + wr * 128, ucol0 = cnb * 256 + wc * 64;
+                const uint32_t idx0 = (uint32_t)(urow0 + (int)lrow) * (uint32_t)p.N + (uint32_t)(ucol0 + (int)lcol);
                 floatx4v ax[2][4];
+                // packed [M, N] operand (output / mask): byte offset inside the group's 128-row x 32-k tile, rows +0 / +8
+                const uint32_t pch = (lcol & 31) >> 3;
+                const uint32_t offP0 = (lrow * 32 + ((pch ^ (c16 & 1)) << 3) + (lcol & 7)) * 2u;
+                const uint32_t offP1 = ((lrow + 8) * 32 + ((pch ^ (((c16 & 1) + 2) & 3)) << 3) + (lcol & 7)) * 2u;
+                typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+                typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+                uint2v axp[MPK ? 2 : 1][MPK ? 4 : 1];
+                const int hdma = has_next ? (nkt > 1 ? 16 : 8) : 0;                              // LDS-DMA of the next item in flight
 #define P1_FE_LOAD(b, set)                                                                                              \
                 do {                                                                                                    \
                     _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                   \
-                        const float* ap_ = aux + (size_t)(rowl + (2 * ((b) & 3) + (g_ >> 1)) * 16 + 8 * (g_ & 1)) * ldx + (coll + 32 * ((b) >> 2)); \
-                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ax[set][g_]) : "v"(ap_) : "memory");        \
+                        if constexpr (MPK) {                                                                            \
+                            const bf16_t* mb_ = reinterpret_cast<const bf16_t*>(p.relu_src) +                             \
+                                ((size_t)(2 * cmb + wr) * p.mask_kbp + cnb * 8 + wc * 2 + ((b) >> 2)) * P1_TILE + (2 * ((b) & 3) + (g_ >> 1)) * 512; \
+                            /* an ordinary load: the compiler waits for it itself (its count ignores the asm stores, so the wait  \
+                               also covers the previous batch's stores - the price of never having these registers in flight     \
+                               behind its back; the f32 operands below stay hand-counted) */                                      \
+                            axp[MPK ? set : 0][MPK ? g_ : 0] = *reinterpret_cast<const uint2v*>(reinterpret_cast<const char*>(mb_) + ((g_ & 1) ? offP1 : offP0)); \
+                        } else {                                                                                        \
+                            const float* ab_ = aux + (size_t)(urow0 + (2 * ((b) & 3) + (g_ >> 1)) * 16 + 8 * (g_ & 1)) * ldx + (ucol0 + 32 * ((b) >> 2)); \
+                            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ax[set][g_]) : "v"(offX), "s"(ab_) : "memory"); \
+                        }                                                                                               \
                     }                                                                                                   \
                 } while (0)
                 auto xpose2 = [&](float& v0, float& v1, float& v2, float& v3) {
@@ -469,12 +497,12 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                     r1 = __int_as_float(__builtin_amdgcn_mov_dpp(s1, 0xB1, 0xF, 0xF, true));
                     if (b0) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
                 };
-#define P1_FE_GROUP(v0, v1, v2, v3, row, col, bv, av)                                                                    \
+#define P1_FE_GROUP(v0, v1, v2, v3, rt, hf, cp, bv, av, mv)                                                                  \
                 do {                                                                                                    \
                     float4 v = make_float4((v0) * alpha + (bv)[0], (v1) * alpha + (bv)[1], (v2) * alpha + (bv)[2], (v3) * alpha + (bv)[3]); \
                     if (flags & LSTC_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); } \
                     if (flags & LSTC_EPI_DROPOUT) {                                                                      \
-                        const uint32_t idx = (uint32_t)(row) * (uint32_t)p.N + (uint32_t)(col);                          \
+                        const uint32_t idx = idx0 + (uint32_t)((rt) * 16 + 8 * (hf)) * (uint32_t)p.N + 32u * (cp);        \
                         v.x = drop_keep(idx, p.dk) ? v.x * p.dk.scale : 0.f;                                             \
                         v.y = drop_keep(idx + 1, p.dk) ? v.y * p.dk.scale : 0.f;                                         \
                         v.z = drop_keep(idx + 2, p.dk) ? v.z * p.dk.scale : 0.f;                                         \
@@ -482,12 +510,24 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                     }                                                                                                   \
                     if (flags & LSTC_EPI_RESIDUAL) { v.x += (av)[0]; v.y += (av)[1]; v.z += (av)[2]; v.w += (av)[3]; }    \
                     if (flags & LSTC_EPI_RELU_MASK) {                                                                    \
-                        v.x = (av)[0] > 0.f ? v.x : 0.f; v.y = (av)[1] > 0.f ? v.y : 0.f;                                 \
-                        v.z = (av)[2] > 0.f ? v.z : 0.f; v.w = (av)[3] > 0.f ? v.w : 0.f;                                 \
+                        if constexpr (MPK) {   /* bf16 > 0 <=> the element's 16 bits, as the upper half of an int32, are > 0 */ \
+                            v.x = (int)((mv)[0] << 16) > 0 ? v.x : 0.f; v.y = (int)((mv)[0] & 0xffff0000u) > 0 ? v.y : 0.f; \
+                            v.z = (int)((mv)[1] << 16) > 0 ? v.z : 0.f; v.w = (int)((mv)[1] & 0xffff0000u) > 0 ? v.w : 0.f; \
+                        } else {                                                                                        \
+                            v.x = (av)[0] > 0.f ? v.x : 0.f; v.y = (av)[1] > 0.f ? v.y : 0.f;                             \
+                            v.z = (av)[2] > 0.f ? v.z : 0.f; v.w = (av)[3] > 0.f ? v.w : 0.f;                             \
+                        }                                                                                               \
                     }                                                                                                   \
-                    float* cp_ = Cz + (size_t)(row) * p.ldc + (col);                                                     \
-                    const floatx4v sv_ = {v.x, v.y, v.z, v.w};                                                           \
-                    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(cp_), "v"(sv_) : "memory");       \
+                    if constexpr (OPK) {   /* the output IS the next product's packed operand: 4 bf16 = 8 B per group */   \
+                        bf16x4 h_; h_[0] = (bf16_t)v.x; h_[1] = (bf16_t)v.y; h_[2] = (bf16_t)v.z; h_[3] = (bf16_t)v.w;    \
+                        bf16_t* ob_ = reinterpret_cast<bf16_t*>(p.C) +                                                    \
+                            ((size_t)(2 * cmb + wr) * p.out_kbp + cnb * 8 + wc * 2 + (cp)) * P1_TILE + (rt) * 512;         \
+                        asm volatile("global_store_dwordx2 %0, %1, %2\n\ts_nop 1" :: "v"((hf) ? offP1 : offP0), "v"(h_), "s"(ob_) : "memory"); \
+                    } else {                                                                                            \
+                        float* cb_ = Cz + (size_t)(urow0 + (rt) * 16 + 8 * (hf)) * p.ldc + (ucol0 + 32 * (cp));          \
+                        const floatx4v sv_ = {v.x, v.y, v.z, v.w};                                                       \
+                        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(offC), "v"(sv_), "s"(cb_) : "memory"); \
+                    }                                                                                                   \
                 } while (0)
                 if (aux) { P1_FE_LOAD(0, 0); }
 #pragma unroll
@@ -495,10 +535,20 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                     if (aux) {
                         if (b < 7) { P1_FE_LOAD(b + 1, (b + 1) & 1); }
                         if (b == 0 || b == 7) __builtin_amdgcn_s_waitcnt(vmcnt_imm(4)); else __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));
-                    } else if (b == 0 && (flags & LSTC_EPI_BIAS)) {
-                        __builtin_amdgcn_s_waitcnt(vmcnt_imm(16));                                // the head DMA stays in flight
+                    } else if (b == 0 && (flags & LSTC_EPI_BIAS)) {                               // the head DMA stays in flight
+                        if (hdma == 16) __builtin_amdgcn_s_waitcnt(vmcnt_imm(16));
+                        else if (hdma == 8) __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));
+                        else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    // the asm loads' outputs count as "ready" for the compiler from the load on: pass them through an empty asm
+                    // AFTER the wait, so that nothing computed from them (a mask compare does not depend on the accumulators) can
+                    // be moved ahead of it
+                    if (b == 0) { asm volatile("" : "+v"(fbias[0]), "+v"(fbias[1])); }
+#pragma unroll
+                    for (int g_ = 0; g_ < 4; ++g_) {
+                        if constexpr (!MPK) asm volatile("" : "+v"(ax[b & 1][g_]));
+                    }
                     const int cp2 = b >> 2;
 #pragma unroll
                     for (int r2 = 0; r2 < 2; ++r2) {
@@ -517,18 +567,19 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                         } while (0)
                         P1_SWAP(x0, y0); P1_SWAP(x1, y1); P1_SWAP(x2, y2); P1_SWAP(x3, y3);
 #undef P1_SWAP
-                        const int row = rowl + rt * 16, col = coll + 32 * cp2;
-                        P1_FE_GROUP(x0, x1, x2, x3, row, col, fbias[cp2], ax[b & 1][2 * r2]);
-                        P1_FE_GROUP(y0, y1, y2, y3, row + 8, col, fbias[cp2], ax[b & 1][2 * r2 + 1]);
+                        P1_FE_GROUP(x0, x1, x2, x3, rt, 0, cp2, fbias[cp2], ax[b & 1][2 * r2], axp[MPK ? (b & 1) : 0][MPK ? 2 * r2 : 0]);
+                        P1_FE_GROUP(y0, y1, y2, y3, rt, 1, cp2, fbias[cp2], ax[b & 1][2 * r2 + 1], axp[MPK ? (b & 1) : 0][MPK ? 2 * r2 + 1 : 0]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #undef P1_FE_LOAD
 #undef P1_FE_GROUP
                 done = true;
-                pending = true;
+                if (has_next) pending = true;
+                else { pending = false; __builtin_amdgcn_s_waitcnt(vmcnt_imm(0)); }
             }
         }
+        if constexpr (EPK != 0) done = true;      // the launcher admits packed outputs / masks only where every tile takes the path above
         if (!done && p.vec_epi && !atomic) {
             // wide epilogue: a 32x32 accumulator holds, per lane, ONE column and 16 rows (4 consecutive rows per register
             // group); a 4x4 transpose inside each quad of lanes (DPP quad_perm, no LDS) turns a register group into 4
@@ -694,11 +745,11 @@ inline int64_t p1_kbp(int64_t K) { const int64_t kb = (K + 31) / 32; return kb +
 // Packed-operand bf16 GEMM behind lstc_gemm (dtype LSTC_BF16P): d->A / d->B point to lstc_pack1 outputs.
 int lstc_gemm_bf16p_impl(const LstcGemmDesc* d, hipStream_t st) {
     if (!d->A || !d->B || !d->C) return LSTC_E_NULL;
-    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->ldc < d->N) return LSTC_E_SHAPE;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (!(d->flags & LSTC_EPI_OUT_PACK) && d->ldc < d->N)) return LSTC_E_SHAPE;
     if (d->batch > 1) return LSTC_E_UNSUPPORTED;
     if ((d->flags & LSTC_EPI_BIAS) && !d->bias) return LSTC_E_NULL;
     if ((d->flags & LSTC_EPI_RESIDUAL) && (!d->residual || d->ldr < d->N)) return LSTC_E_NULL;
-    if ((d->flags & LSTC_EPI_RELU_MASK) && (!d->relu_src || d->ld_relu < d->N)) return LSTC_E_NULL;
+    if ((d->flags & LSTC_EPI_RELU_MASK) && (!d->relu_src || (!(d->flags & LSTC_EPI_RELU_MASK_PACK) && d->ld_relu < d->N))) return LSTC_E_NULL;
     if ((d->flags & LSTC_EPI_DROPOUT) && (uint64_t)d->M * (uint64_t)d->N > 0xffffffffull) return LSTC_E_RANGE;
     if (!aligned16(d->A) || !aligned16(d->B)) return LSTC_E_ALIGN;
     const int splits = d->split_k > 1 ? d->split_k : 1;
@@ -711,7 +762,16 @@ int lstc_gemm_bf16p_impl(const LstcGemmDesc* d, hipStream_t st) {
     p.split_stride = splits > 1 ? d->batch_stride_c : 0;
     p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = (float*)d->C;
     p.bias = d->bias; p.res = (const float*)d->residual; p.relu_src = (const float*)d->relu_src;
-    p.M = d->M; p.N = d->N; p.ldc = d->ldc; p.ldr = d->ldr; p.ld_relu = d->ld_relu; p.flags = d->flags; p.alpha = d->alpha;
+    p.M = d->M; p.N = d->N; p.ldc = d->ldc; p.ldr = d->ldr; p.ld_relu = d->ld_relu; p.alpha = d->alpha;
+    p.flags = d->flags & ~(LSTC_EPI_OUT_PACK | LSTC_EPI_RELU_MASK_PACK);
+    p.out_kbp = (d->flags & LSTC_EPI_OUT_PACK) ? (int)p1_kbp(d->N) : 0;
+    p.mask_kbp = (d->flags & LSTC_EPI_RELU_MASK_PACK) ? (int)p1_kbp(d->N) : 0;
+    if (p.out_kbp || p.mask_kbp) {
+        // packed outputs / mask operands exist on the pipelined epilogue only: NT form on whole 256 x 256 tiles, no K split
+        if (tr || splits > 1 || !P1_NT_S16 || d->M % 256 || d->N % 256 || (d->flags & LSTC_EPI_ACCUM) || d->variant != 0 ||
+            (p.mask_kbp && (!(d->flags & LSTC_EPI_RELU_MASK) || (d->flags & LSTC_EPI_RESIDUAL)))) return LSTC_E_UNSUPPORTED;
+        if (p.out_kbp && !aligned16(d->C)) return LSTC_E_ALIGN;
+    }
     p.dk = make_drop_key(d->dropout_p, d->dropout_seed);
 #ifdef LSTC_TUNING
     p.debug = d->variant >> 4;
@@ -722,7 +782,8 @@ int lstc_gemm_bf16p_impl(const LstcGemmDesc* d, hipStream_t st) {
     p.vec_epi = (d->N % 4 == 0) && (d->ldc % 4 == 0) && aligned16(d->C) && (p.split_stride % 4 == 0) &&
                 (!(d->flags & LSTC_EPI_BIAS) || aligned16(d->bias)) &&
                 (!(d->flags & LSTC_EPI_RESIDUAL) || (aligned16(d->residual) && d->ldr % 4 == 0)) &&
-                (!(d->flags & LSTC_EPI_RELU_MASK) || (aligned16(d->relu_src) && d->ld_relu % 4 == 0));
+                (!(d->flags & LSTC_EPI_RELU_MASK) || (aligned16(d->relu_src) && (p.mask_kbp || d->ld_relu % 4 == 0)));
+    if ((p.out_kbp || p.mask_kbp) && !p.vec_epi) return LSTC_E_ALIGN;
 #ifdef LSTC_TUNING
     if (p.debug & 2) p.vec_epi = 0;
 #endif
@@ -748,7 +809,20 @@ int lstc_gemm_bf16p_impl(const LstcGemmDesc* d, hipStream_t st) {
     }
     const int grid = p.total_items < n_cu ? p.total_items : n_cu;       // persistent: one workgroup per CU (128 KB of LDS each)
     if (tr) hipLaunchKernelGGL((gemm_bf16p_kernel<true, false>), dim3(grid), dim3(NT8), lds, st, p);
-    else if (P1_NT_S16) hipLaunchKernelGGL((gemm_bf16p_kernel<false, true>), dim3(grid), dim3(NT8), lds, st, p);
+    else if (P1_NT_S16) {
+        const int epk = p.out_kbp ? (p.mask_kbp ? 2 : 1) : (p.mask_kbp ? 3 : 0);
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        if (epk == 0) hipLaunchKernelGGL((gemm_bf16p_kernel<false, true, 0>), dim3(grid), dim3(NT8), lds, st, p);
+        else if (epk == 1) hipLaunchKernelGGL((gemm_bf16p_kernel<false, true, 1>), dim3(grid), dim3(NT8), lds, st, p);
+        else if (epk == 2) hipLaunchKernelGGL((gemm_bf16p_kernel<false, true, 2>), dim3(grid), dim3(NT8), lds, st, p);
+        else hipLaunchKernelGGL((gemm_bf16p_kernel<false, true, 3>), dim3(grid), dim3(NT8), lds, st, p);
+    }
     else hipLaunchKernelGGL((gemm_bf16p_kernel<false, false>), dim3(grid), dim3(NT8), lds, st, p);
     return lstc_launch_status();
 }

@@ -334,6 +334,39 @@ __global__ void __launch_bounds__(NT) ln_bwd_generic(const float* __restrict__ d
     }
 }
 
+// ------------------------------------------------------------------------------ column sums of a packed bf16 operand
+// partial[rg][k] = sum over the rows of row-block group rg of the lstc_pack1 operand [rows, K] (bf16 -> f32 adds): the bias
+// gradient of a Linear whose output gradient exists only in packed form (LSTC_EPI_OUT_PACK).  One workgroup per 32-k tile and
+// row-block group; a thread owns one 16-B chunk (8 k) of rows r and r + 64 of every tile of its group.
+__global__ void __launch_bounds__(NT) colsum_pack1_kernel(const __bf16* __restrict__ pk, int RB, int KBp, int K,
+                                                           float* __restrict__ partial) {
+    __shared__ float red[64][33];
+    const int kb = blockIdx.x, rg = blockIdx.y, ngrp = gridDim.y;
+    const int per = (RB + ngrp - 1) / ngrp, rb0 = rg * per, rb1 = min(RB, rb0 + per);
+    const int r = threadIdx.x >> 2, c = threadIdx.x & 3;             // row (and row + 64), LOGICAL chunk
+    typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int rb = rb0; rb < rb1; ++rb) {
+        const bf16x8v* t = reinterpret_cast<const bf16x8v*>(pk + ((size_t)rb * KBp + kb) * 4096);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int rr = r + 64 * hh;
+            const bf16x8v v = t[rr * 4 + (c ^ ((rr >> 2) & 3))];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[r][c * 8 + j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float s = 0.f;
+        for (int i = 0; i < 64; ++i) s += red[i][threadIdx.x];
+        const int k = kb * 32 + threadIdx.x;
+        if (k < K) partial[(size_t)rg * K + k] = s;
+    }
+}
+
 // ------------------------------------------------------------------------------ CLS concat
 // grid (N, ceil(d/NT)); thread owns one column (coalesced across the workgroup), walks the tokens.
 __global__ void __launch_bounds__(NT) cls_concat_fwd_kernel(const float* __restrict__ x, const float* __restrict__ x_hi,
@@ -709,6 +742,20 @@ int lstc_colsum(const float* x, int64_t rows, int32_t cols, int32_t ld, float* p
     const int np = (int)(rows < n_partial ? rows : n_partial);
     hipLaunchKernelGGL(colsum_pass1, dim3((cols + NT - 1) / NT, np), NT, 0, st, x, rows, cols, ld, partial);
     hipLaunchKernelGGL(colsum_pass2, dim3((cols + 63) / 64), NT, 0, st, partial, np, cols, out, accumulate);
+    return lstc_launch_status();
+}
+
+int lstc_colsum_pack1(const void* packed, int64_t rows, int32_t K, float* partial, int32_t n_partial, float* out,
+                      int32_t accumulate, void* stream) {
+    if (!packed || !partial || !out) return LSTC_E_NULL;
+    if (rows <= 0 || K <= 0 || n_partial <= 0) return LSTC_E_SHAPE;
+    if (!aligned16(packed)) return LSTC_E_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t rb = (rows + 127) / 128;
+    const int RB = (int)(rb + (rb & 1)), KB = (K + 31) / 32, KBp = KB + (KB & 1);        // padded rows are zeros
+    const int np = (int)(RB < n_partial ? RB : n_partial);
+    hipLaunchKernelGGL(colsum_pack1_kernel, dim3(KB, np), NT, 0, st, (const __bf16*)packed, RB, KBp, K, partial);
+    hipLaunchKernelGGL(colsum_pass2, dim3((K + 63) / 64), NT, 0, st, partial, np, K, out, accumulate);
     return lstc_launch_status();
 }
 

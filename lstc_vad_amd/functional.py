@@ -16,7 +16,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (EPI_ACCUM, EPI_BIAS, EPI_DROPOUT, EPI_RELU, EPI_RELU_MASK, EPI_RESIDUAL, F32, AttnDesc, GemmDesc,
+from ._lib import (EPI_ACCUM, EPI_BIAS, EPI_DROPOUT, EPI_OUT_PACK, EPI_RELU, EPI_RELU_MASK, EPI_RELU_MASK_PACK, EPI_RESIDUAL, F32, AttnDesc, GemmDesc,
                    LossDesc, check, dev_ptr, stream_ptr)
 
 # ------------------------------------------------------------------------------------------ RNG
@@ -236,7 +236,7 @@ def _mat(t: torch.Tensor):
 
 def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out: Optional[torch.Tensor] = None,
          bias=None, relu=False, dropout=None, residual=None, relu_mask=None, accumulate=False, alpha=1.0,
-         split_k=1, variant=0) -> torch.Tensor:
+         split_k=1, variant=0, out_pack=False) -> torch.Tensor:
     """``out = epi(alpha * op(a) @ op(b))`` through ``lstc_gemm`` (include/lstc_hip.h).  ``a`` / ``b`` may be ``Packed``
     operands (f32x3 mode): then they stand for the logical [M, K] / [N, K] matrices and trans_a / trans_b are moot."""
     dev = (a.buf if isinstance(a, Packed) else a).device
@@ -266,7 +266,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
         elif dtype == _lib.F32X3:
             dtype = F32
     parts = None
-    if out is None:
+    if out_pack:
+        # bf16 mode: the result is written ONLY as the packed bf16 operand of the products that consume it (LSTC_EPI_OUT_PACK)
+        if not (packed and dtype == _lib.BF16P and packed_out_shape(M, N)) or out is not None or split_k > 1 or accumulate:
+            raise RuntimeError(f"gemm(out_pack=True): [{M}, {N}] x K={K} does not qualify (bf16 packed product on whole 256-tiles)")
+        pbuf = torch.empty((int(_lib.load().lstc_pack1_bytes(M, N)),), device=dev, dtype=torch.uint8)
+    if out is None and not out_pack:
         if split_k > 1 and packed and _DETERMINISTIC_WGRAD:
             # K splits of the packed kernel into separate partials, summed in a fixed order afterwards (no atomics).  The
             # library launches lstc_gemm_splits() slices, possibly fewer than asked for: size and sum exactly that many
@@ -277,8 +282,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
             out = torch.empty((M, N), device=dev, dtype=torch.float32)
             if split_k > 1:
                 out.zero_()
-    pc, cr, cc, ldc = _mat(out)
-    assert (cr, cc) == (M, N)
+    if out_pack:
+        pc, ldc = dev_ptr(pbuf), N
+    else:
+        pc, cr, cc, ldc = _mat(out)
+        assert (cr, cc) == (M, N)
     d = GemmDesc()
     d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, lda, ldb, ldc
     d.transA, d.transB, d.dtype = int(trans_a), int(trans_b), dtype
@@ -296,13 +304,19 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
         pr, rr, rc_, ldr = _mat(residual)
         assert (rr, rc_) == (M, N)
         d.residual, d.ldr = pr, ldr
-    if relu_mask is not None:
+    if isinstance(relu_mask, Packed):
+        assert (relu_mask.rows, relu_mask.K, relu_mask.kind) == (M, N, _lib.BF16P)
+        flags |= EPI_RELU_MASK | EPI_RELU_MASK_PACK
+        d.relu_src, d.ld_relu = dev_ptr(relu_mask.buf), N
+    elif relu_mask is not None:
         flags |= EPI_RELU_MASK
         pm, mr, mc, ldm = _mat(relu_mask)
         assert (mr, mc) == (M, N)
         d.relu_src, d.ld_relu = pm, ldm
     if accumulate:
         flags |= EPI_ACCUM
+    if out_pack:
+        flags |= EPI_OUT_PACK
     d.flags, d.alpha, d.split_k, d.variant = flags, float(alpha), int(split_k), int(variant)
     d.A, d.B, d.C = pa, pb, pc
     if packed:
@@ -310,8 +324,26 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
         if parts is not None:
             d.batch_stride_c = M * N
     _launch_gemm(d, 2.0 * M * N * K)
+    if out_pack:
+        return Packed(pbuf, M, N, _lib.BF16P)
     if parts is not None:
         return colsum(parts).view(M, N)
+    return out
+
+
+def packed_out_shape(M: int, N: int) -> bool:
+    """[M, N] results that the bf16 packed kernel can emit as a packed operand (include/lstc_hip.h, LSTC_EPI_OUT_PACK)."""
+    return (_FUSE_PACKS and _packed_kind() == _lib.BF16P and M % 256 == 0 and N % 256 == 0 and
+            M >= max(_x3_min[0], 1) and N >= max(_x3_min[1], 256) and M * N * max(_x3_min[0], 256) >= _x3_min[2])
+
+
+def colsum_pack(pk: Packed) -> torch.Tensor:
+    """Column sums [K] of a packed bf16 operand [rows, K] (lstc_colsum_pack1)."""
+    n_partial = int(min((pk.rows + 127) // 128, 64))
+    partial = torch.empty((n_partial + 2, pk.K), device=pk.buf.device, dtype=torch.float32)
+    out = torch.empty((pk.K,), device=pk.buf.device, dtype=torch.float32)
+    check(_lib.load().lstc_colsum_pack1(dev_ptr(pk.buf), pk.rows, pk.K, dev_ptr(partial), n_partial, dev_ptr(out), 0, stream_ptr()),
+          "lstc_colsum_pack1")
     return out
 
 
@@ -352,7 +384,7 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, x_pack: Optional[Packed] = None) ->
     tokens, i.e. along the ROWS of the packs that the forward (X) and input-gradient (dY) products already made, so those
     packs are reused through the transposed-read form of the packed kernel (``x_pack`` = the forward's pack of ``x``)."""
     T, O = (dy.rows, dy.K) if isinstance(dy, Packed) else dy.shape
-    I = x.shape[1]
+    I = x.shape[1] if x is not None else x_pack.K
     pkind = _packed_kind()
     # split-K factor: 256x256 output tiles on the packed bf16 kernel, 128x128 everywhere else
     s = _wgrad_split(O, I, 256 if pkind == _lib.BF16P else 128) if T >= 4096 else 1
@@ -864,10 +896,14 @@ class FFNFunction(torch.autograd.Function):
         if p > 0:
             _note(cfg["site"] + "dropout", p, seed, shape)
         xp = maybe_pack(x2)
-        h1 = gemm(xp if xp is not None else x2, w1, trans_b=True, bias=b1, relu=True)
-        hp = maybe_pack(h1)
+        if xp is not None and packed_out_shape(x2.shape[0], w1.shape[0]) and w2.shape[0] >= max(_x3_min[0], 1):
+            # bf16 mode: the hidden exists only as the packed bf16 operand W2 (and dW2, and the ReLU mask of the backward) reads
+            h1, hp = None, gemm(xp, w1, trans_b=True, bias=b1, relu=True, out_pack=True)
+        else:
+            h1 = gemm(xp if xp is not None else x2, w1, trans_b=True, bias=b1, relu=True)
+            hp = maybe_pack(h1)
         y = gemm(hp if hp is not None else h1, w2, trans_b=True, bias=b2, dropout=(p, seed), residual=x2)
-        ctx.packs = (xp, hp) if cfg["training"] else (None, None)
+        ctx.packs = (xp, hp) if (cfg["training"] or h1 is None) else (None, None)
         if cfg["layer_norm"]:
             z, mean, rstd = layernorm_fwd(y, ln_w, ln_b, 1e-6, pack=True)
         else:
@@ -883,9 +919,14 @@ class FFNFunction(torch.autograd.Function):
         dz2 = dz.contiguous().view(-1, dz.shape[-1])
         dy, df, dln_w, dln_b, db2 = layernorm_bwd_branch(dz2, y, ln_w, mean, rstd, c["p"], c["seed"], c["layer_norm"], True)
         xp, hp = ctx.packs
-        dw2 = wgrad(df, h1, hp)
-        dh1 = gemm(df, w2, relu_mask=h1)                     # [M, F], relu' fused
-        db1 = colsum(dh1)
+        if h1 is None:        # packed hidden (forward): its gradient also lives only in packed form
+            dw2 = wgrad(df, None, hp)
+            dh1 = gemm(df, w2, relu_mask=hp, out_pack=True)                  # [M, F] packed, relu' from the packed hidden's sign
+            db1 = colsum_pack(dh1)
+        else:
+            dw2 = wgrad(df, h1, hp)
+            dh1 = gemm(df, w2, relu_mask=h1)                     # [M, F], relu' fused
+            db1 = colsum(dh1)
         dw1 = wgrad(dh1, x2, xp)
         dx = None
         if ctx.needs_input_grad[0]:

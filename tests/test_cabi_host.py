@@ -161,3 +161,15 @@ def test_dropout_hash_matches_host_restatement():
         m = keep(i, p, 0x1234567890ABCDEF)
         assert abs(m.mean() - (1 - p)) < 2e-3
         assert abs(np.corrcoef(m[:-1], m[1:])[0, 1]) < 5e-3
+
+
+def test_bf16p_epilogue_never_spills_a_register_with_a_load_in_flight():
+    """tools/isa_guard.py: gemm_bf16p.hip issues epilogue operand loads through inline asm with hand-counted waits; the build is
+    only correct if the register allocator leaves those destination registers alone until the wait (a spill there once made a
+    landing load overwrite an address register: GPU memory fault).  Checked on the generated gfx950 assembly."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "isa_guard.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("in-flight registers touched: []") >= 6, r.stdout

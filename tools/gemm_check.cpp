@@ -106,6 +106,7 @@ static int check(const Case& c) {
     if (pB) hipFree(pB);
     printf("%s %s M=%d N=%d K=%d tA=%d tB=%d flags=%d var=%d split=%d maxerr=%.3g pad_ok=%d\n", ok ? "PASS" : "FAIL",
            c.dtype == LSTC_F32X3 ? "f32x3" : c.dtype == LSTC_BF16P ? "bf16p" : c.dtype ? "bf16c" : "f32", M, N, K, c.tA, c.tB, c.flags, c.variant, c.split, maxerr, (int)pad_ok);
+    fflush(stdout);
     hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dbias); hipFree(dres); hipFree(dmask);
     return ok ? 0 : 1;
 }
@@ -171,6 +172,10 @@ int main(int argc, char** argv) {
         timeit(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]),
                atoi(argv[9]), argc > 10 ? atoi(argv[10]) : 3, argc > 11 ? atoi(argv[11]) : 0, argc > 12 ? atoi(argv[12]) : 0, argc > 13 ? atoi(argv[13]) : 0);
         return 0;
+    }
+    if (argc >= 12 && !strcmp(argv[1], "case")) {   // case M N K tA tB flags variant split dtype alignc
+        return check({atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]), atoi(argv[9]),
+                      atoi(argv[10]), atoi(argv[11])});
     }
     const bool time_only = argc > 1 && !strcmp(argv[1], "time");
     const bool check_only = argc > 1 && !strcmp(argv[1], "check");
@@ -254,6 +259,12 @@ int main(int argc, char** argv) {
             fails += check({257, 132, 67, 0, 1, LSTC_EPI_BIAS | LSTC_EPI_RELU, 1, 1, LSTC_BF16P, 1});
             fails += check({300, 200, 132, 0, 0, LSTC_EPI_RELU_MASK | LSTC_EPI_ACCUM, 0, 1, LSTC_BF16P, 1});
             fails += check({512, 256, 1152, 1, 0, 0, 7, 1, LSTC_BF16P, 1});
+            // hand-counted epilogue (whole 256 x 256 tiles, 16-B accesses), one operand stream at a time; 264 tiles: items with a successor
+            fails += check({512, 256, 256, 0, 1, LSTC_EPI_RELU_MASK, 1, 1, LSTC_BF16P, 1});
+            fails += check({512, 512, 320, 0, 1, LSTC_EPI_BIAS | LSTC_EPI_RELU, 1, 1, LSTC_BF16P, 1});
+            fails += check({1024, 256, 192, 0, 1, LSTC_EPI_BIAS | LSTC_EPI_DROPOUT | LSTC_EPI_RESIDUAL, 1, 1, LSTC_BF16P, 1});
+            fails += check({8448, 2048, 64, 0, 1, LSTC_EPI_RESIDUAL, 1, 1, LSTC_BF16P, 1});
+            fails += check({8448, 2048, 128, 0, 1, LSTC_EPI_RELU_MASK | LSTC_EPI_BIAS, 1, 1, LSTC_BF16P, 1});
         }
         printf("%s: %d failing cases\n", fails ? "FAILED" : "ALL PASS", fails);
     }
