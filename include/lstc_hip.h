@@ -230,6 +230,11 @@ int lstc_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
  * otherwise - the caller then packs with lstc_pack1) and `packed` of lstc_pack1_bytes(rows, d) bytes. */
 int lstc_layernorm_fwd_pack(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                             int64_t rows, int32_t d, float eps, void* packed, void* stream);
+/* The same fusion with an f32 result (fp32 / f32x3 modes): df = lstc_dropout_apply(dx, p, seed) written next to dx, `partial`
+ * [3, n_partial, d] with the column sums of df as third plane.  d = 512, 1024 or 2048 (LSTC_E_UNSUPPORTED otherwise). */
+int lstc_layernorm_bwd_drop(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                            float* dx, float* df, float* partial, int32_t n_partial, int64_t rows, int32_t d, float dropout_p,
+                            uint64_t dropout_seed, void* stream);
 int lstc_layernorm_bwd_drop_pack(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                  float* dx, float* partial, int32_t n_partial, int64_t rows, int32_t d, float dropout_p,
                                  uint64_t dropout_seed, void* packed, void* stream);

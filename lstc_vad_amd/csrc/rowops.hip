@@ -206,12 +206,15 @@ __global__ void __launch_bounds__(NT, NV == 8 ? 2 : 1) ln_bwd_vec(const float* _
 // Two waves per row (each NVH float4 per lane of its half of the columns): half the live registers of ln_bwd_vec<.., true>,
 // so three accumulator rows (dgamma, dbeta, column sums of df) fit at 3 waves/SIMD.  The row statistics cross the wave pair
 // through LDS (double-buffered by iteration parity: one barrier per row pair).
-template <int NVH, bool PACK>
+// MODE 0: dx and the two partials only; 1: + packed bf16 df + third partial (bf16 mode); 2: + f32 df + third partial (f32 modes:
+// `packed` is then a float [rows, d] - the dropout replay needs no pass of its own in any mode).
+template <int NVH, int MODE>
 __global__ void __launch_bounds__(NT) ln_bwd_pack2(const float* __restrict__ dy, const float* __restrict__ x,
                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
                                                     const float* __restrict__ rstd, float* __restrict__ dx,
                                                     float* __restrict__ partial, int64_t rows, int d,
                                                     __bf16* __restrict__ packed, int KBp, DropKey key) {
+    constexpr bool PACK = MODE != 0;
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][d] combine buffer, then [2][4][64][2] per-lane row sums
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, slot = wv >> 1, half = wv & 1;
     const int nv4 = d >> 2, hv4 = nv4 >> 1;
@@ -275,9 +278,13 @@ __global__ void __launch_bounds__(NT) ln_bwd_pack2(const float* __restrict__ dy,
                 f.z = drop_keep(fi + 2, key) ? ov.z * key.scale : 0.f;
                 f.w = drop_keep(fi + 3, key) ? ov.w * key.scale : 0.f;
                 ad[i].x += f.x; ad[i].y += f.y; ad[i].z += f.z; ad[i].w += f.w;
-                bf16x4v h;
-                h[0] = (__bf16)f.x; h[1] = (__bf16)f.y; h[2] = (__bf16)f.z; h[3] = (__bf16)f.w;
-                *reinterpret_cast<bf16x4v*>(packed + p1_offset(r, 4 * c, KBp)) = h;
+                if constexpr (MODE == 2) {
+                    reinterpret_cast<float4*>(reinterpret_cast<float*>(packed) + r * d)[c] = f;
+                } else {
+                    bf16x4v h;
+                    h[0] = (__bf16)f.x; h[1] = (__bf16)f.y; h[2] = (__bf16)f.z; h[3] = (__bf16)f.w;
+                    *reinterpret_cast<bf16x4v*>(packed + p1_offset(r, 4 * c, KBp)) = h;
+                }
             }
         }
     }
@@ -676,9 +683,9 @@ int lstc_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
         const size_t lds = (size_t)(NT / 64) * d * sizeof(float), lds2 = (size_t)(2 * d + 1024) * sizeof(float);
         const DropKey k0 = make_drop_key(0.f, 0);
         __bf16* np = nullptr;
-        if (d == 512) hipLaunchKernelGGL((ln_bwd_pack2<1, false>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, np, 0, k0);
-        else if (d == 1024) hipLaunchKernelGGL((ln_bwd_pack2<2, false>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, np, 0, k0);
-        else if (d == 2048) hipLaunchKernelGGL((ln_bwd_pack2<4, false>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, np, 0, k0);
+        if (d == 512) hipLaunchKernelGGL((ln_bwd_pack2<1, 0>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, np, 0, k0);
+        else if (d == 1024) hipLaunchKernelGGL((ln_bwd_pack2<2, 0>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, np, 0, k0);
+        else if (d == 2048) hipLaunchKernelGGL((ln_bwd_pack2<4, 0>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, np, 0, k0);
         else if (d <= 256) hipLaunchKernelGGL((ln_bwd_vec<1, false>), n_partial, NT, lds, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, np, 0, k0);
         else if (d <= 512) hipLaunchKernelGGL((ln_bwd_vec<2, false>), n_partial, NT, lds, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, np, 0, k0);
         else if (d <= 1024) hipLaunchKernelGGL((ln_bwd_vec<4, false>), n_partial, NT, lds, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, np, 0, k0);
@@ -707,13 +714,31 @@ int lstc_layernorm_bwd_drop_pack(const float* dy, const float* x, const float* g
     // d = 512 / 1024 / 2048 (the model widths): two waves per row at 3 waves/SIMD; its column-to-lane map and summation
     // order equal ln_bwd_vec's exactly at these widths.  Other widths: one wave per row.
     const size_t lds2 = (size_t)(2 * d + 1024) * sizeof(float), lds1 = (size_t)(NT / 64) * d * sizeof(float);
-    if (d == 512) hipLaunchKernelGGL((ln_bwd_pack2<1, true>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, pk, KBp, key);
-    else if (d == 1024) hipLaunchKernelGGL((ln_bwd_pack2<2, true>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, pk, KBp, key);
-    else if (d == 2048) hipLaunchKernelGGL((ln_bwd_pack2<4, true>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, pk, KBp, key);
+    if (d == 512) hipLaunchKernelGGL((ln_bwd_pack2<1, 1>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, pk, KBp, key);
+    else if (d == 1024) hipLaunchKernelGGL((ln_bwd_pack2<2, 1>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, pk, KBp, key);
+    else if (d == 2048) hipLaunchKernelGGL((ln_bwd_pack2<4, 1>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, pk, KBp, key);
     else if (d <= 256) hipLaunchKernelGGL((ln_bwd_vec<1, true>), n_partial, NT, lds1, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, pk, KBp, key);
     else if (d <= 512) hipLaunchKernelGGL((ln_bwd_vec<2, true>), n_partial, NT, lds1, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, pk, KBp, key);
     else if (d <= 1024) hipLaunchKernelGGL((ln_bwd_vec<4, true>), n_partial, NT, lds1, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, pk, KBp, key);
     else hipLaunchKernelGGL((ln_bwd_vec<8, true>), n_partial, NT, lds1, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, pk, KBp, key);
+    return lstc_launch_status();
+}
+
+int lstc_layernorm_bwd_drop(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                            float* dx, float* df, float* partial, int32_t n_partial, int64_t rows, int32_t d, float dropout_p,
+                            uint64_t dropout_seed, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !df || !partial) return LSTC_E_NULL;
+    if (rows <= 0 || d <= 0 || n_partial <= 0 || !(dropout_p >= 0.f && dropout_p < 1.f)) return LSTC_E_SHAPE;
+    if (d != 512 && d != 1024 && d != 2048) return LSTC_E_UNSUPPORTED;          // the two-waves-per-row kernel's widths
+    if ((uint64_t)rows * (uint64_t)d > 0xffffffffull) return LSTC_E_RANGE;      // 32-bit dropout counter
+    if (!(aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(df) && aligned16(gamma) && aligned16(partial))) return LSTC_E_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const DropKey key = make_drop_key(dropout_p, dropout_seed);
+    const size_t lds2 = (size_t)(2 * d + 1024) * sizeof(float);
+    __bf16* out = reinterpret_cast<__bf16*>(df);
+    if (d == 512) hipLaunchKernelGGL((ln_bwd_pack2<1, 2>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, out, 0, key);
+    else if (d == 1024) hipLaunchKernelGGL((ln_bwd_pack2<2, 2>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, out, 0, key);
+    else hipLaunchKernelGGL((ln_bwd_pack2<4, 2>), n_partial, NT, lds2, st, dy, x, gamma, mean, rstd, dx, partial, rows, d, out, 0, key);
     return lstc_launch_status();
 }
 

@@ -518,6 +518,18 @@ def layernorm_bwd_branch(dz2, y, gamma, mean, rstd, p: float, seed: int, layer_n
                                                dev_ptr(buf), stream_ptr()), "lstc_layernorm_bwd_drop_pack")
         return (dy, Packed(buf, rows, d, _lib.BF16P), colsum(partial[0]), colsum(partial[1]),
                 colsum(partial[2]) if want_bias else None)
+    if layer_norm and p > 0 and _FUSE_PACKS and d in (512, 1024, 2048) and rows * d <= 0xffffffff:
+        # f32 modes: the same kernel writes the dropped gradient as a second f32 result (no lstc_dropout_apply pass, and the
+        # bias gradient's column sums come out of the same pass)
+        lib = _lib.load()
+        dz2 = dz2.contiguous()
+        dy, df = torch.empty_like(y), torch.empty_like(y)
+        n_partial = int(min(max(rows // 4, 1), 768))
+        partial = torch.empty((3, n_partial, d), device=y.device, dtype=torch.float32)
+        check(lib.lstc_layernorm_bwd_drop(dev_ptr(dz2), dev_ptr(y), dev_ptr(gamma), dev_ptr(mean), dev_ptr(rstd), dev_ptr(dy),
+                                          dev_ptr(df), dev_ptr(partial), n_partial, rows, d, float(p), int(seed), stream_ptr()),
+              "lstc_layernorm_bwd_drop")
+        return dy, df, colsum(partial[0]), colsum(partial[1]), (colsum(partial[2]) if want_bias else None)
     dgamma = dbeta = None
     if layer_norm:
         dy, dgamma, dbeta = layernorm_bwd(dz2, y, gamma, mean, rstd)

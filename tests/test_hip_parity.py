@@ -1274,3 +1274,31 @@ def test_packed_output_and_packed_relu_mask_of_the_bf16_gemm(M, N, K):
             Fn.gemm(x[:300], w, trans_b=True, out_pack=True)
     finally:
         Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
+
+
+@pytest.mark.parametrize("rows,d,p", [(512, 2048, 0.2), (770, 1024, 0.1), (300, 512, 0.35)])
+def test_layernorm_backward_with_fused_f32_dropout_replay(rows, d, p):
+    """lstc_layernorm_bwd_drop (f32 modes) against lstc_layernorm_bwd + lstc_dropout_apply: dx and df identical bit for bit,
+    the three partial planes sum to dgamma, dbeta and the column sums of df."""
+    from lstc_vad_amd import functional as Fn, _lib
+    from lstc_vad_amd.functional import dev_ptr, stream_ptr, check
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(12)
+    x = torch.randn(rows, d, device=DEV, generator=g) * 2 + 0.3
+    dz = torch.randn(rows, d, device=DEV, generator=g)
+    gamma = torch.randn(d, device=DEV, generator=g)
+    beta = torch.randn(d, device=DEV, generator=g)
+    seed = 0x0FEDCBA987654321
+    _, mean, rstd = Fn.layernorm_fwd(x, gamma, beta, 1e-6)
+    dx0, dg0, db0 = Fn.layernorm_bwd(dz, x, gamma, mean, rstd)
+    df0 = Fn.dropout_apply(dx0, p, seed)
+    n_partial = min(max(rows // 4, 1), 768)
+    part = torch.empty(3, n_partial, d, device=DEV)
+    dx1, df1 = torch.empty_like(x), torch.empty_like(x)
+    check(lib.lstc_layernorm_bwd_drop(dev_ptr(dz), dev_ptr(x), dev_ptr(gamma), dev_ptr(mean), dev_ptr(rstd), dev_ptr(dx1), dev_ptr(df1),
+                                      dev_ptr(part), n_partial, rows, d, p, seed, stream_ptr()), "bwd_drop")
+    assert torch.equal(dx0, dx1) and torch.equal(df0, df1)
+    for plane, want in ((0, dg0.double()), (1, db0.double()), (2, df0.double().sum(0))):
+        assert max_abs_diff(part[plane].double().sum(0), want) <= 1e-5 * float(want.abs().max()) + 1e-6
+    assert lib.lstc_layernorm_bwd_drop(dev_ptr(dz), dev_ptr(x), dev_ptr(gamma), dev_ptr(mean), dev_ptr(rstd), dev_ptr(dx1), dev_ptr(df1),
+                                       dev_ptr(part), n_partial, rows, 768, p, seed, stream_ptr()) == -4
