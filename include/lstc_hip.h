@@ -95,7 +95,8 @@ typedef struct LstcGemmDesc {
                                        into C, which the caller must have zeroed (only alpha epilogue allowed).
                                        LSTC_F32X3 with batch_stride_c != 0: split z writes its partial product to
                                        C + z*batch_stride_c instead (no atomics; the caller sums the partials) */
-    int32_t variant;                /* 0 = library default tile; 1..11 select a documented tile variant (tuning / tests);
+    int32_t variant;                /* 0 = library default tile (LSTC_F32: 128x128, the rows of a mostly empty last tile round on the
+                                       64x64 variant - bit-identical results); 1..11 select a documented tile variant (tuning / tests);
                                        anything else -> LSTC_E_UNSUPPORTED.  Timing-only ablation variants exist only in
                                        -DLSTC_TUNING builds (tools/gemm_check), never in the production library */
     int32_t batch;                  /* 0/1 = single problem; >1: `batch` independent problems of identical shape, problem z

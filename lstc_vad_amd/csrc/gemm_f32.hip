@@ -54,6 +54,7 @@ struct GemmParams {
     long long batch_stride_a, batch_stride_b, batch_stride_c;   // elements between consecutive problems of a batch (grid.z)
     unsigned int a_bytes, b_bytes;   // operand extents for the buffer descriptors of PIPE 5 (operands < 4 GiB)
     int debug;     // timing-only ablations (tools/gemm_check): 1 = no global loads in the loop, 2 = no LDS writes, 4 = no barrier
+    int row_off;   // first row of this launch inside the caller's matrix (dropout counter of a row-split product)
 };
 
 // Stages one operand tile (R rows/cols x 32 k) global -> registers -> LDS.
@@ -651,7 +652,7 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParam
                 v += bv;
                 if (flags & LSTC_EPI_RELU) v = fmaxf(v, 0.f);
                 if (flags & LSTC_EPI_DROPOUT) {
-                    const uint32_t idx = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+                    const uint32_t idx = (uint32_t)(row + p.row_off) * (uint32_t)p.N + (uint32_t)col;
                     v = drop_keep(idx, p.dk) ? v * p.dk.scale : 0.f;
                 }
                 if (flags & LSTC_EPI_RESIDUAL) v += p.res[(size_t)row * p.ldr + col];
@@ -703,17 +704,20 @@ int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipS
     //   4 = PIPE 3 + buffer loads with scalar K offset, K loop unrolled x2 (PIPE 5) 145 / 143 / 151   <- default
     //       (steady loop: 49 instead of 72 non-MFMA instructions per 64 MFMAs; needs 16-B aligned operands < 4 GiB)
     //   9 = 256x128, 4 waves x (128x64), one wave per SIMD, PIPE 3                125 / 124 / 134
+    //  11 = 64x64, 4 waves x (32x32), plain double buffering: same k order per output element as every other variant, used for
+    //       the last rows of a product whose 128x128 tile count leaves the final round of workgroup slots mostly empty
     //  10 = 128x128, LDS-DMA staging (global_load_lds, swizzled unpadded images)  105 / 119 / 134   (correct, slower:
     //       the swizzled per-lane source addresses of K-contiguous operands and the one-iteration latency budget cost
     //       more than the ds_write + staging registers they remove)
     //   2, 6, 5 = 256x128 with 8 waves (PIPE 1 / 2 / 0)                           115-126, never the best
     //  12-15 = timing-only ablations of variant 8 (NT): no loads 142, no loads/LDS writes 146, +no barrier 146.5
     if (variant == 0) variant = 4;
-    const int BM = (variant == 2 || variant == 5 || variant == 6 || variant == 9) ? 256 : 128, BN = 128;
+    const int BM = (variant == 2 || variant == 5 || variant == 6 || variant == 9) ? 256 : variant == 11 ? 64 : 128, BN = variant == 11 ? 64 : 128;
     p.tilesM = (p.M + BM - 1) / BM;
     p.tilesN = (p.N + BN - 1) / BN;
     switch (variant) {
         case 1: return launch_cfg<128, 128, 2, 2, 0, A_KC, B_KC>(p, va, vb, splits, st);
+        case 11: return launch_cfg<64, 64, 2, 2, 0, A_KC, B_KC>(p, va, vb, splits, st);    // small tile: the tail rows of a row-split product
         case 3: return launch_cfg<128, 128, 2, 2, 2, A_KC, B_KC>(p, va, vb, splits, st);
         case 6: return launch_cfg<256, 128, 4, 2, 2, A_KC, B_KC>(p, va, vb, splits, st);
         case 2: return launch_cfg<256, 128, 4, 2, 1, A_KC, B_KC>(p, va, vb, splits, st);
@@ -723,7 +727,7 @@ int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipS
         case 9: return launch_cfg<256, 128, 4, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // 8 waves x (64x64), PIPE 3
         case 4: if (va && vb && p.a_bytes && p.b_bytes) return launch_cfg<128, 128, 2, 2, 5, A_KC, B_KC>(p, true, true, splits, st);
                 return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // buffer path: aligned, < 4 GiB operands
-        case 10: case 11: if (va && vb && p.K % BK == 0) return launch_cfg<128, 128, 2, 2, 4, A_KC, B_KC>(p, true, true, splits, st);
+        case 10: if (va && vb && p.K % BK == 0) return launch_cfg<128, 128, 2, 2, 4, A_KC, B_KC>(p, true, true, splits, st);
                  return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // LDS-DMA needs aligned rows, full K tiles
 #ifdef LSTC_TUNING      // timing-only ablations: products are WRONG by construction; never in the production library
         case 12: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 1, A_KC, B_KC>(p, va, vb, splits, st); return LSTC_E_UNSUPPORTED;
@@ -781,7 +785,44 @@ int lstc_gemm_f32_impl(const LstcGemmDesc* d, hipStream_t st) {
                     (p.batch <= 1 || d->batch_stride_a % 4 == 0);
     const bool vb = aligned16(d->B) && (d->ldb % 4 == 0) && ((d->transB ? d->K : d->N) % 4 == 0) &&
                     (p.batch <= 1 || d->batch_stride_b % 4 == 0);
-    if (!d->transA && d->transB) return launch_layout<true, true>(p, va, vb, eff_splits, d->variant, st);
-    if (!d->transA && !d->transB) return launch_layout<true, false>(p, va, vb, eff_splits, d->variant, st);
-    return launch_layout<false, false>(p, va, vb, eff_splits, d->variant, st);
+    p.row_off = 0;
+    auto launch = [&](GemmParams& q, int variant) {
+        if (!d->transA && d->transB) return launch_layout<true, true>(q, va, vb, eff_splits, variant, st);
+        if (!d->transA && !d->transB) return launch_layout<true, false>(q, va, vb, eff_splits, variant, st);
+        return launch_layout<false, false>(q, va, vb, eff_splits, variant, st);
+    };
+    // Tile-round quantisation: the default kernel runs two 128x128 workgroups per CU; a product whose tile count ends with a
+    // mostly empty round of those slots (12 544 rows x 2048 columns = 1568 tiles = 3.06 rounds of 512 - one rank of the 8-GPU
+    // job) pays a whole extra round.  The rows of that last round go to the 64x64-tile variant instead (4x the workgroups,
+    // 4 resident per CU): every output element keeps the same k order, so the result is bit-identical to the one-launch
+    // product (tests/test_hip_parity.py::test_row_split_f32_product_is_bitwise_the_single_launch_product).
+    if (d->variant == 0 && eff_splits == 1 && p.batch <= 1 && !d->transA) {
+        static int slots = 0;
+        if (slots == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            slots = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                        ? 2 * prop.multiProcessorCount : 512;
+        }
+        const int tM = (d->M + 127) / 128, tN = (d->N + 127) / 128;
+        const long long tiles = (long long)tM * tN;
+        const long long full = tiles / slots, rem = tiles % slots;
+        const int main_rows = (int)((full * slots) / tN);              // whole tile rows inside the full rounds
+        // (measured: a tail round up to ~30 % full gains - 4 pairs per rank 41.2 -> 40.1 ms per step; a half-full one does not)
+        if (full >= 1 && rem > 0 && rem * 10 <= (long long)slots * 3 && main_rows >= 1 && main_rows < tM) {
+            GemmParams pm = p, pt = p;
+            const int M_main = main_rows * 128;
+            pm.M = M_main;
+            pt.M = d->M - M_main;
+            pt.row_off = M_main;
+            pt.A += (size_t)M_main * d->lda;
+            pt.C += (size_t)M_main * d->ldc;
+            if (pt.res) pt.res += (size_t)M_main * d->ldr;
+            if (pt.relu_src) pt.relu_src += (size_t)M_main * d->ld_relu;
+            int rc = launch(pm, 0);
+            if (rc) return rc;
+            return launch(pt, 11);
+        }
+    }
+    return launch(p, d->variant);
 }

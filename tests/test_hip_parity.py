@@ -1302,3 +1302,24 @@ def test_layernorm_backward_with_fused_f32_dropout_replay(rows, d, p):
         assert max_abs_diff(part[plane].double().sum(0), want) <= 1e-5 * float(want.abs().max()) + 1e-6
     assert lib.lstc_layernorm_bwd_drop(dev_ptr(dz), dev_ptr(x), dev_ptr(gamma), dev_ptr(mean), dev_ptr(rstd), dev_ptr(dx1), dev_ptr(df1),
                                        dev_ptr(part), n_partial, rows, 768, p, seed, stream_ptr()) == -4
+
+
+@pytest.mark.parametrize("M,N,K,tb", [(12544, 2048, 256, True), (12544, 4096, 160, True), (8320, 2048, 192, False)])
+def test_row_split_f32_product_is_bitwise_the_single_launch_product(M, N, K, tb):
+    """Exact-f32 GEMM, tile-round quantisation remedy (csrc/gemm_f32.hip, lstc_gemm_f32_impl): when the 128x128 tile count ends
+    with a mostly empty round of the 512 workgroup slots, the rows of that round are computed by the 64x64-tile variant.  Same k
+    order per output element: the result - here with bias, ReLU, dropout (global row counter) and residual - equals the
+    one-launch product (variant 4 = the default kernel without the split) bit for bit."""
+    from lstc_vad_amd import functional as Fn
+    g = torch.Generator(device=DEV).manual_seed(31)
+    a = torch.randn(M, K, device=DEV, generator=g)
+    b = torch.randn((N, K) if tb else (K, N), device=DEV, generator=g) * 0.1
+    bias = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g)
+    kw = dict(trans_b=tb, bias=bias, relu=True, dropout=(0.2, 0xABCDEF12345), residual=res)
+    split = Fn.gemm(a, b, **kw)
+    single = Fn.gemm(a, b, variant=4, **kw)
+    assert torch.equal(split, single)
+    ref = torch.relu(a.double() @ (b.double().T if tb else b.double()) + bias.double())
+    keep = Fn.dropout_apply(torch.ones(M, N, device=DEV), 0.2, 0xABCDEF12345).double()
+    assert max_abs_diff(split, ref * keep + res.double()) < 1e-4 * (K ** 0.5)
