@@ -178,6 +178,14 @@ typedef struct LstcAttnDesc {
     int32_t variant;                /* 0 = default kernels; 1 = first-generation kernels (operands straight from global in
                                        MFMA lane layout) - kept for A/B measurements and as the fallback for shapes the
                                        staged kernels do not take (d_k or d_v not a multiple of 32, unaligned operands, S > 96) */
+    /* backward, bf16 mode: when all three are non-NULL, dQ / dK / dV are written ONLY as packed bf16 operands [N*S, H*dk|dv]
+     * (lstc_pack1 layout, lstc_pack1_bytes(N*S, H*dk|dv) bytes each; dQ / dK / dV may be NULL) - they feed the packed weight- and
+     * input-gradient products of the projections (autograd of models/MultiHeadAttention.py:97-99).  Needs the staged kernel
+     * (S <= 64, d_k, d_v multiples of 32), N*S a multiple of 256, H*dk and H*dv multiples of 64; else LSTC_E_UNSUPPORTED. */
+    void* dQ_pack; void* dK_pack; void* dV_pack;
+    /* pack_cols > 0: the three pointers name ONE pack of a [N*S, pack_cols] matrix (the fused Q|K|V projection's gradient) whose
+     * columns dQ_col0 / dK_col0 / dV_col0 .. + H*dk|dv receive dQ / dK / dV (multiples of 32, pack_cols a multiple of 64). */
+    int32_t pack_cols, dQ_col0, dK_col0, dV_col0;
 } LstcAttnDesc;
 
 int lstc_attn_fwd(const LstcAttnDesc* d, void* stream);

@@ -49,7 +49,9 @@ class AttnDesc(C.Structure):
                 ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p),
                 ("probs", C.c_void_p), ("table", C.c_void_p), ("index", C.c_void_p),
                 ("dO", C.c_void_p), ("dQ", C.c_void_p), ("dK", C.c_void_p), ("dV", C.c_void_p),
-                ("dtable", C.c_void_p), ("dtable_chunks", C.c_int32), ("variant", C.c_int32)]
+                ("dtable", C.c_void_p), ("dtable_chunks", C.c_int32), ("variant", C.c_int32),
+                ("dQ_pack", C.c_void_p), ("dK_pack", C.c_void_p), ("dV_pack", C.c_void_p),
+                ("pack_cols", C.c_int32), ("dQ_col0", C.c_int32), ("dK_col0", C.c_int32), ("dV_col0", C.c_int32)]
 
 
 class LossDesc(C.Structure):

@@ -35,6 +35,11 @@ struct AttnParams {
     int vec_qk, vec_v;     // float4 operand loads allowed for the dk / dv contractions
     int n_per_wg;
     int table_partials;     // 1: dtable is [gridDim.x][table_rows][H] partials (plain stores), 0: [rows][H] with atomics
+    // bf16 mode (staged backward only): dQ / dK / dV written as packed bf16 operands [N*S, H*dk|dv] (lstc_pack1 layout) instead
+    // of f32 - they are consumed only by the packed weight-gradient and input-gradient GEMMs
+    void *dQp, *dKp, *dVp;
+    int kbq, kbk, kbv;      // 32-k tiles per 128-row block of each pack
+    int tq0, tk0, tv0;      // first k tile of the dQ / dK / dV columns inside their pack (one fused pack: column offsets / 32)
 };
 
 __device__ __forceinline__ void load16(const float* __restrict__ p, int k0, int kdim, bool vec, float (&f)[16]) {
@@ -311,6 +316,8 @@ struct RtlJob {
     uint32_t brow, orow;               // row pitches in bytes
     float scale;
     int ct;                            // 32-column tile
+    int pk;                            // output as packed bf16: o = the whole pack, ptile = its k tile, pkb = tiles per row block
+    uint32_t ptile, pkb;
 };
 #define RTL_LOAD(J, bv_)                                                                                      \
     do {                                                                                                      \
@@ -334,11 +341,24 @@ struct RtlJob {
                     o_[t_] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[s_], bv_[8 * b_ + s_], o_[t_], 0, 0, 0); \
             }                                                                                                 \
         }                                                                                                     \
-        const uint32_t wo_ = (uint32_t)c31 * 4u + (uint32_t)(4 * h2) * J.orow + (uint32_t)(128 * J.ct);       \
-        _Pragma("unroll") for (int t_ = 0; t_ < T; ++t_)                                                        \
-            _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_)                                                   \
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o_[t_][r_] * J.scale), J.o, wo_, \
-                    (uint32_t)(32 * t_ + (r_ & 3) + 8 * (r_ >> 2)) * J.orow, 0);                              \
+        if (J.pk) {     /* packed bf16 rows: element (global row, k) -> tile / swizzled chunk (lstc_common.h, p1_offset) */ \
+            _Pragma("unroll") for (int t_ = 0; t_ < T; ++t_)                                                    \
+                _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                             \
+                    const int tok_ = 32 * t_ + (r_ & 3) + 8 * (r_ >> 2) + 4 * h2;                               \
+                    const uint32_t rg_ = prow0 + (uint32_t)tok_;                                                \
+                    const uint32_t e_ = ((rg_ >> 7) * J.pkb + J.ptile) * 4096u + (rg_ & 127u) * 32u +           \
+                                        (((((uint32_t)c31 >> 3) ^ ((rg_ >> 2) & 3u)) << 3) | ((uint32_t)c31 & 7u)); \
+                    const __bf16 hb_ = (__bf16)(o_[t_][r_] * J.scale);                                          \
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hb_), J.o,         \
+                        tok_ < S ? e_ * 2u : 0xFFFFFFFFu, 0, 0);                                              \
+                }                                                                                             \
+        } else {                                                                                              \
+            const uint32_t wo_ = (uint32_t)c31 * 4u + (uint32_t)(4 * h2) * J.orow + (uint32_t)(128 * J.ct);   \
+            _Pragma("unroll") for (int t_ = 0; t_ < T; ++t_)                                                    \
+                _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_)                                               \
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o_[t_][r_] * J.scale), J.o, wo_, \
+                        (uint32_t)(32 * t_ + (r_ & 3) + 8 * (r_ >> 2)) * J.orow, 0);                          \
+        }                                                                                                     \
     } while (0)
 
 #undef RTL_PLACEHOLDER
@@ -500,11 +520,20 @@ __global__ void __launch_bounds__(NT, 2) attn_bwd2_kernel(const AttnParams p) {
             const __amdgpu_buffer_rsrc_t r_dV = __builtin_amdgcn_make_buffer_rsrc(p.dV + (size_t)n * S * p.ldv + (size_t)h * p.dv, 0, (int)bytes_v, 0x00020000);
             const __amdgpu_buffer_rsrc_t r_dQ = __builtin_amdgcn_make_buffer_rsrc(p.dQ + (size_t)n * S * p.ldq + (size_t)h * p.dk, 0, (int)bytes_q, 0x00020000);
             const __amdgpu_buffer_rsrc_t r_dK = __builtin_amdgcn_make_buffer_rsrc(p.dK + (size_t)n * S * p.ldk + (size_t)h * p.dk, 0, (int)bytes_k, 0x00020000);
+            const bool pk = p.dQp != nullptr;
+            const uint32_t prow0 = (uint32_t)n * (uint32_t)S;                  // global row of the sequence's first token
+            const __amdgpu_buffer_rsrc_t r_dVp = __builtin_amdgcn_make_buffer_rsrc(pk ? p.dVp : (void*)p.dV, 0, (int)0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_dQp = __builtin_amdgcn_make_buffer_rsrc(pk ? p.dQp : (void*)p.dQ, 0, (int)0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_dKp = __builtin_amdgcn_make_buffer_rsrc(pk ? p.dKp : (void*)p.dK, 0, (int)0x7fffffff, 0x00020000);
             auto job = [&](int kj) -> RtlJob {
                 RtlJob J;
-                if (kj < jv) { J.A = Pm; J.b = r_dO; J.brow = (uint32_t)p.ldo * 4u; J.o = r_dV; J.orow = (uint32_t)p.ldv * 4u; J.scale = 1.f; J.ct = wave + 4 * kj; }
-                else if (kj < jv + jk) { J.A = DmT; J.b = r_K; J.brow = (uint32_t)p.ldk * 4u; J.o = r_dQ; J.orow = (uint32_t)p.ldq * 4u; J.scale = p.scale; J.ct = wave + 4 * (kj - jv); }
-                else { J.A = Dm; J.b = r_Q; J.brow = (uint32_t)p.ldq * 4u; J.o = r_dK; J.orow = (uint32_t)p.ldk * 4u; J.scale = p.scale; J.ct = wave + 4 * (kj - jv - jk); }
+                J.pk = pk ? 1 : 0;
+                if (kj < jv) { J.A = Pm; J.b = r_dO; J.brow = (uint32_t)p.ldo * 4u; J.o = pk ? r_dVp : r_dV; J.orow = (uint32_t)p.ldv * 4u; J.scale = 1.f; J.ct = wave + 4 * kj;
+                               J.pkb = (uint32_t)p.kbv; J.ptile = (uint32_t)(p.tv0 + ((h * p.dv) >> 5)) + (uint32_t)J.ct; }
+                else if (kj < jv + jk) { J.A = DmT; J.b = r_K; J.brow = (uint32_t)p.ldk * 4u; J.o = pk ? r_dQp : r_dQ; J.orow = (uint32_t)p.ldq * 4u; J.scale = p.scale; J.ct = wave + 4 * (kj - jv);
+                               J.pkb = (uint32_t)p.kbq; J.ptile = (uint32_t)(p.tq0 + ((h * p.dk) >> 5)) + (uint32_t)J.ct; }
+                else { J.A = Dm; J.b = r_Q; J.brow = (uint32_t)p.ldq * 4u; J.o = pk ? r_dKp : r_dK; J.orow = (uint32_t)p.ldk * 4u; J.scale = p.scale; J.ct = wave + 4 * (kj - jv - jk);
+                               J.pkb = (uint32_t)p.kbk; J.ptile = (uint32_t)(p.tk0 + ((h * p.dk) >> 5)) + (uint32_t)J.ct; }
                 return J;
             };
             constexpr int RB = SP / 2;
@@ -674,8 +703,10 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd2_kernel(const AttnParams p) {
         auto job = [&](int kj) -> RtlJob {
             RtlJob J;
             J.A = PT; J.b = r_V; J.brow = (uint32_t)p.ldv * 4u; J.o = r_O; J.orow = (uint32_t)p.ldo * 4u; J.scale = 1.f; J.ct = wave + 4 * kj;
+            J.pk = 0; J.ptile = 0; J.pkb = 0;
             return J;
         };
+        const uint32_t prow0 = 0;          // (packed outputs exist in the backward only)
         constexpr int RB = SP / 2;
         const int c31 = l31;
         float b0[RB], b1[RB];
@@ -703,7 +734,8 @@ int fill_params(const LstcAttnDesc* d, AttnParams& p, bool bwd) {
     if (d->dtype != LSTC_F32) return LSTC_E_UNSUPPORTED;
     if (!d->Q || !d->K || !d->V || !d->probs) return LSTC_E_NULL;
     if (!bwd && !d->O) return LSTC_E_NULL;
-    if (bwd && (!d->dO || !d->dQ || !d->dK || !d->dV)) return LSTC_E_NULL;
+    const bool gpk = bwd && d->dQ_pack && d->dK_pack && d->dV_pack;
+    if (bwd && (!d->dO || (!gpk && (!d->dQ || !d->dK || !d->dV)))) return LSTC_E_NULL;
     if (d->N <= 0 || d->S < 1 || d->H <= 0 || d->dk <= 0 || d->dv <= 0) return LSTC_E_SHAPE;
     if (d->S > 128) return LSTC_E_RANGE;
     if (d->ldq < d->H * d->dk || d->ldk < d->H * d->dk || d->ldv < d->H * d->dv || d->ldo < d->H * d->dv) return LSTC_E_SHAPE;
@@ -721,6 +753,9 @@ int fill_params(const LstcAttnDesc* d, AttnParams& p, bool bwd) {
     p.vec_qk = d->dk % 4 == 0 && d->ldq % 4 == 0 && d->ldk % 4 == 0 && aligned16(d->Q) && aligned16(d->K);
     p.vec_v = d->dv % 4 == 0 && d->ldv % 4 == 0 && d->ldo % 4 == 0 && aligned16(d->V) && (!bwd || aligned16(d->dO));
     p.n_per_wg = 1;
+    p.dQp = p.dKp = p.dVp = nullptr;
+    p.kbq = p.kbk = p.kbv = 0;
+    p.tq0 = p.tk0 = p.tv0 = 0;
     return 0;
 }
 
@@ -798,6 +833,23 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
     // S = 49: 1.63 vs 2.75 ms, S = 17: 0.53 vs 1.19 ms per LTN / STN layer (interleaved A/B); S = 81 (T = 3): 193 spilled
     // registers, no faster than the first generation (7.3 vs 7.1 ms) - stays there
     const bool v2 = T <= 2 && p.vec_qk && p.vec_v && (p.dk % 32) == 0 && (p.dv % 32) == 0 && d->variant == 0;
+    if (d->dQ_pack || d->dK_pack || d->dV_pack) {
+        // packed bf16 gradients: the staged kernel only, token rows and head columns filling the packs' even tile grid exactly
+        const int64_t M = (int64_t)p.N * p.S;
+        if (!(d->dQ_pack && d->dK_pack && d->dV_pack) || !v2 || M % 256 || (p.H * p.dk) % 64 || (p.H * p.dv) % 64 ||
+            M * (int64_t)(p.H * (p.dk > p.dv ? p.dk : p.dv)) * 2 > 0x7fffffffLL) return LSTC_E_UNSUPPORTED;
+        if (!aligned16(d->dQ_pack) || !aligned16(d->dK_pack) || !aligned16(d->dV_pack)) return LSTC_E_ALIGN;
+        p.dQp = d->dQ_pack; p.dKp = d->dK_pack; p.dVp = d->dV_pack;
+        p.kbq = p.kbk = (p.H * p.dk) / 32;
+        p.kbv = (p.H * p.dv) / 32;
+        if (d->pack_cols > 0) {           // one pack of [M, pack_cols]: dQ / dK / dV are column blocks of it
+            if (d->pack_cols % 64 || d->dQ_col0 % 32 || d->dK_col0 % 32 || d->dV_col0 % 32 || d->dQ_col0 < 0 || d->dK_col0 < 0 || d->dV_col0 < 0 ||
+                d->dQ_col0 + p.H * p.dk > d->pack_cols || d->dK_col0 + p.H * p.dk > d->pack_cols || d->dV_col0 + p.H * p.dv > d->pack_cols ||
+                M * (int64_t)d->pack_cols * 2 > 0x7fffffffLL) return LSTC_E_SHAPE;
+            p.kbq = p.kbk = p.kbv = d->pack_cols / 32;
+            p.tq0 = d->dQ_col0 / 32; p.tk0 = d->dK_col0 / 32; p.tv0 = d->dV_col0 / 32;
+        }
+    }
     if (v2) {
         const int SP = 32 * T;
         const size_t lds2 = ((size_t)((2 * SP * (SP + 1) + 3) & ~3) + (size_t)4 * SP * 32 + (size_t)(NT / 64) * p.table_rows) * sizeof(float);
@@ -813,6 +865,7 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
             return lstc_launch_status();
         }
     }
+    if (p.dQp) return LSTC_E_UNSUPPORTED;
 #define LSTC_BWD(TT)                                                         \
     do {                                                                     \
         static bool once = false;                                            \
@@ -976,7 +1029,8 @@ int fill_cls(const LstcAttnDesc* d, ClsParams& p, bool bwd) {
     if (d->dtype != LSTC_F32) return LSTC_E_UNSUPPORTED;
     if (!d->Q || !d->K || !d->V || !d->probs) return LSTC_E_NULL;
     if (!bwd && !d->O) return LSTC_E_NULL;
-    if (bwd && (!d->dO || !d->dQ || !d->dK || !d->dV)) return LSTC_E_NULL;
+    const bool gpk = bwd && d->dQ_pack && d->dK_pack && d->dV_pack;
+    if (bwd && (!d->dO || (!gpk && (!d->dQ || !d->dK || !d->dV)))) return LSTC_E_NULL;
     if (d->N <= 0 || d->S < 1 || d->H <= 0 || d->dk <= 0 || d->dv <= 0) return LSTC_E_SHAPE;
     if (d->S > CLS_MAXS) return LSTC_E_RANGE;
     if (d->ldq < d->H * d->dk || d->ldk < d->H * d->dk || d->ldv < d->H * d->dv || d->ldo < d->H * d->dv) return LSTC_E_SHAPE;

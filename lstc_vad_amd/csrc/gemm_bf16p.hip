@@ -275,15 +275,19 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
         }                                                                                                              \
         __builtin_amdgcn_s_setprio(0);                                                                                 \
     } while (0)
-#define P1_SYNC_COMPUTE(ih, jj, rs, vmw)          /* vmw >= 0: s_waitcnt vmcnt(vmw) before the closing barrier */       \
+/* vmw >= 0: s_waitcnt vmcnt(vmw) before the OPENING barrier.  Waves 4-7 run one barrier behind waves 0-3: the closing barrier of
+   waves 0-3 is the opening barrier of waves 4-7, so a wait that must precede a read which waves 0-3 issue right after their
+   closing barrier has to sit before the opening one (before the closing one it let waves 0-3 read pieces whose DMA waves 4-7 had
+   not waited for yet: a rare mismatch of a weight gradient on a cold first launch). */
+#define P1_SYNC_COMPUTE(ih, jj, rs, vmw)                                                                               \
     do {                                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if constexpr ((vmw) >= 0) __builtin_amdgcn_s_waitcnt(vmcnt_imm((vmw) >= 0 ? (vmw) : 0));                       \
         __builtin_amdgcn_s_barrier();                                                                                  \
         __builtin_amdgcn_s_waitcnt(0xC07F);          /* lgkmcnt(0): this phase's fragments are in registers */         \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         P1_MMA(ih, jj, rs);                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if constexpr ((vmw) >= 0) __builtin_amdgcn_s_waitcnt(vmcnt_imm((vmw) >= 0 ? (vmw) : 0));                       \
         __builtin_amdgcn_s_barrier();                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     } while (0)
@@ -320,7 +324,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
         for (int q = 0; q < 4; ++q) fb[Y][q] = S16 ? rd_b16(cur, 2 + (q & 1), q >> 1) : rd_b(cur, 1, q);
         if (!HEAD && has1) P1_DMA_UNIT(3, tl + 1, CUR ^ 1);
         P1_SYNC_COMPUTE(0, 1, Y, -1);
-        // ---- phase 2: (second 64 rows, second 32 cols).  Before its closing barrier: unit U1 of step t+1 (B cols 0-31, issued
+        // ---- phase 2: (second 64 rows, second 32 cols).  Before its OPENING barrier: unit U1 of step t+1 (B cols 0-31, issued
         // >= 3 phases ago) has landed - younger operations: U2, U3 of t+1 (4), U0 of t+2 (2), the previous item's stores (HEAD)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

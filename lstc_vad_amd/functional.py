@@ -558,12 +558,33 @@ def attn_fwd(q, k, v, N, S, H, dk, dv, table, index, p_drop, seed):
     return o, probs
 
 
-def attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, p_drop, seed, out=None):
-    dq, dk_, dv_ = out if out is not None else (torch.empty_like(q), torch.empty_like(k), torch.empty_like(v))
+def attn_bwd_packs(N, S, H, dk, dv) -> bool:
+    """bf16 mode: the staged attention backward can write dQ / dK / dV as packed bf16 operands (include/lstc_hip.h)."""
+    M = N * S
+    return (_FUSE_PACKS and _packed_kind() == _lib.BF16P and _ATTN_VARIANT == 0 and S <= 64 and dk % 32 == 0 and dv % 32 == 0 and
+            M % 256 == 0 and (H * dk) % 64 == 0 and (H * dv) % 64 == 0 and M * H * max(dk, dv) * 2 < 2 ** 31 and
+            M >= max(_x3_min[0], 1) and H * min(dk, dv) >= max(_x3_min[1], 256) and M * H * min(dk, dv) * max(_x3_min[0], 256) >= _x3_min[2])
+
+
+def attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, p_drop, seed, out=None, packed=False):
+    """``packed``: return dQ, dK, dV as ``Packed`` bf16 operands (no f32 copies) - see ``attn_bwd_packs``; ``packed="fused"``:
+    ONE Packed [N*S, H*(2 dk + dv)] with the column blocks dQ | dK | dV (gradient of the fused Q|K|V projection)."""
+    if packed:
+        lib = _lib.load()
+        M = N * S
+        widths = (H * (2 * dk + dv),) if packed == "fused" else (H * dk, H * dk, H * dv)
+        bufs = [torch.empty((int(lib.lstc_pack1_bytes(M, w)),), device=q.device, dtype=torch.uint8) for w in widths]
+        if packed == "fused":
+            if M * widths[0] * 2 >= 2 ** 31:
+                raise RuntimeError("attn_bwd(packed='fused'): pack larger than a buffer descriptor addresses")
+            bufs = bufs * 3
+        dq = dk_ = dv_ = None
+    else:
+        dq, dk_, dv_ = out if out is not None else (torch.empty_like(q), torch.empty_like(k), torch.empty_like(v))
     d = AttnDesc()
     d.N, d.S, d.H, d.dk, d.dv = N, S, H, dk, dv
     d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), do.stride(0)
-    assert dq.stride(0) == q.stride(0) and dk_.stride(0) == k.stride(0) and dv_.stride(0) == v.stride(0)
+    assert packed or (dq.stride(0) == q.stride(0) and dk_.stride(0) == k.stride(0) and dv_.stride(0) == v.stride(0))
     d.dtype = F32
     dtable = parts = None
     if table is not None:
@@ -577,11 +598,22 @@ def attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, p_drop, seed, ou
     d.scale = 1.0 / (dk ** 0.5)
     d.dropout_p, d.dropout_seed = float(p_drop), int(seed)
     d.Q, d.K, d.V, d.probs = dev_ptr(q), dev_ptr(k), dev_ptr(v), dev_ptr(probs)
-    d.dO, d.dQ, d.dK, d.dV = dev_ptr(do), dev_ptr(dq), dev_ptr(dk_), dev_ptr(dv_)
+    d.dO = dev_ptr(do)
+    if packed:
+        d.dQ_pack, d.dK_pack, d.dV_pack = (dev_ptr(b) for b in bufs)
+        if packed == "fused":
+            d.pack_cols, d.dQ_col0, d.dK_col0, d.dV_col0 = H * (2 * dk + dv), 0, H * dk, 2 * H * dk
+    else:
+        d.dQ, d.dK, d.dV = dev_ptr(dq), dev_ptr(dk_), dev_ptr(dv_)
     d.variant = _ATTN_VARIANT
     check(_lib.load().lstc_attn_bwd(C.byref(d), stream_ptr()), "lstc_attn_bwd")
     if parts is not None:
         dtable = colsum(parts).view(table.shape[0], H)
+    if packed == "fused":
+        return Packed(bufs[0], N * S, H * (2 * dk + dv), _lib.BF16P), None, None, dtable
+    if packed:
+        M = N * S
+        return (Packed(bufs[0], M, H * dk, _lib.BF16P), Packed(bufs[1], M, H * dk, _lib.BF16P), Packed(bufs[2], M, H * dv, _lib.BF16P), dtable)
     return dq, dk_, dv_, dtable
 
 
@@ -659,15 +691,20 @@ class MHAFunction(torch.autograd.Function):
         dx = None
         if wqkv is not None:
             rq, rk = wq.shape[0], wk.shape[0]
-            dqkv = torch.empty((N * S, wqkv.shape[0]), device=x2.device, dtype=torch.float32)
-            outs = (dqkv[:, :rq], dqkv[:, rq: rq + rk], dqkv[:, rq + rk:])
-            _, _, _, dtable = attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, c["p_attn"], c["seed_a"], out=outs)
+            if xp is not None and attn_bwd_packs(N, S, H, dk, dv) and N * S * wqkv.shape[0] * 2 < 2 ** 31:
+                # bf16 mode: the attention backward writes dQ | dK | dV straight into ONE packed bf16 operand
+                dqkv, _, _, dtable = attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, c["p_attn"], c["seed_a"], packed="fused")
+            else:
+                dqkv = torch.empty((N * S, wqkv.shape[0]), device=x2.device, dtype=torch.float32)
+                outs = (dqkv[:, :rq], dqkv[:, rq: rq + rk], dqkv[:, rq + rk:])
+                _, _, _, dtable = attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, c["p_attn"], c["seed_a"], out=outs)
             dwqkv = wgrad(dqkv, x2, xp)                           # one TN GEMM for the three weight gradients
             dwq, dwk, dwv = dwqkv[:rq], dwqkv[rq: rq + rk], dwqkv[rq + rk:]
             if ctx.needs_input_grad[0]:
                 dx = gemm(dqkv, wqkv, residual=dy).view(N, S, -1)   # dQ Wq + dK Wk + dV Wv + residual in one GEMM (K = 3*H*dk)
         else:
-            dq, dk_, dv_, dtable = attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, c["p_attn"], c["seed_a"])
+            dq, dk_, dv_, dtable = attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, c["p_attn"], c["seed_a"],
+                                            packed=xp is not None and attn_bwd_packs(N, S, H, dk, dv))
             dwq, dwk, dwv = wgrad(dq, x2, xp), wgrad(dk_, x2, xp), wgrad(dv_, x2, xp)
             if ctx.needs_input_grad[0]:
                 dx = gemm(dq, wq, residual=dy)

@@ -1232,7 +1232,7 @@ def test_bf16_encoder_step_is_bitwise_the_same_with_and_without_fused_packs():
             # separate passes' - same addends, another summation order
             assert max_abs_diff(g1[k], g0[k]) <= 1e-5 * float(g0[k].abs().max()) + 1e-9, k
         else:
-            assert torch.equal(g1[k], g0[k]), k
+            assert torch.equal(g1[k], g0[k]), (k, int((g1[k] != g0[k]).sum()), [(kk, int((g1[kk] != g0[kk]).sum())) for kk in g1 if not torch.equal(g1[kk], g0[kk])])
 
 
 @pytest.mark.parametrize("M,N,K", [(512, 256, 256), (1024, 768, 320)])
@@ -1323,3 +1323,36 @@ def test_row_split_f32_product_is_bitwise_the_single_launch_product(M, N, K, tb)
     ref = torch.relu(a.double() @ (b.double().T if tb else b.double()) + bias.double())
     keep = Fn.dropout_apply(torch.ones(M, N, device=DEV), 0.2, 0xABCDEF12345).double()
     assert max_abs_diff(split, ref * keep + res.double()) < 1e-4 * (K ** 0.5)
+
+
+@pytest.mark.parametrize("S", [49, 17])
+def test_attention_backward_packed_gradients_equal_the_packed_f32_gradients(S):
+    """lstc_attn_bwd with dQ_pack / dK_pack / dV_pack (bf16 mode): the packed bf16 gradients are lstc_pack1 of the f32 gradients
+    the same kernel writes without them, bit for bit; the bias-table gradient is unchanged."""
+    from lstc_vad_amd import functional as Fn
+    N, H, dk = 256, 4, 64
+    L = 3 if S == 49 else 1
+    g = torch.Generator(device=DEV).manual_seed(41)
+    M = N * S
+    q, k, v, do = (torch.randn(M, H * dk, device=DEV, generator=g) for _ in range(4))
+    table = torch.randn((2 * L - 1) * 49, H, device=DEV, generator=g) * 0.3 if S == 49 else None
+    index = None
+    if table is not None:
+        index = orc.relative_position_index_3d(L, 4).to(DEV)
+    Fn.set_compute_dtype("bf16"); Fn.set_x3_threshold(0, 0, 0)
+    try:
+        o, probs = Fn.attn_fwd(q, k, v, N, S, H, dk, dk, table, index, 0.1, 77)
+        dq, dk_, dv_, dt0 = Fn.attn_bwd(do, q, k, v, probs, N, S, H, dk, dk, table, index, 0.1, 77)
+        assert Fn.attn_bwd_packs(N, S, H, dk, dk)
+        pq, pk, pv, dt1 = Fn.attn_bwd(do, q, k, v, probs, N, S, H, dk, dk, table, index, 0.1, 77, packed=True)
+        n = M * H * dk * 2
+        for f32, pack in ((dq, pq), (dk_, pk), (dv_, pv)):
+            assert torch.equal(Fn.pack3(f32, False).buf[:n], pack.buf[:n])
+        if dt0 is not None:
+            assert torch.equal(dt0, dt1)
+        fused, _, _, dt2 = Fn.attn_bwd(do, q, k, v, probs, N, S, H, dk, dk, table, index, 0.1, 77, packed="fused")
+        cat = torch.cat([dq, dk_, dv_], dim=1).contiguous()
+        assert torch.equal(Fn.pack3(cat, False).buf[:3 * n], fused.buf[:3 * n])
+        torch.cuda.synchronize()
+    finally:
+        Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
