@@ -186,6 +186,10 @@ typedef struct LstcAttnDesc {
     /* pack_cols > 0: the three pointers name ONE pack of a [N*S, pack_cols] matrix (the fused Q|K|V projection's gradient) whose
      * columns dQ_col0 / dK_col0 / dV_col0 .. + H*dk|dv receive dQ / dK / dV (multiples of 32, pack_cols a multiple of 64). */
     int32_t pack_cols, dQ_col0, dK_col0, dV_col0;
+    /* forward, bf16 mode: when non-NULL, O is written ONLY as a packed bf16 operand [N*S, H*dv] (O may be NULL) - it feeds the
+     * packed products of the output projection fc (models/MultiHeadAttention.py:122-123) and of its weight gradient.  N*S a
+     * multiple of 256, H*dv a multiple of 64, d_v a multiple of 32; else LSTC_E_UNSUPPORTED. */
+    void* O_pack;
 } LstcAttnDesc;
 
 int lstc_attn_fwd(const LstcAttnDesc* d, void* stream);

@@ -51,7 +51,8 @@ class AttnDesc(C.Structure):
                 ("dO", C.c_void_p), ("dQ", C.c_void_p), ("dK", C.c_void_p), ("dV", C.c_void_p),
                 ("dtable", C.c_void_p), ("dtable_chunks", C.c_int32), ("variant", C.c_int32),
                 ("dQ_pack", C.c_void_p), ("dK_pack", C.c_void_p), ("dV_pack", C.c_void_p),
-                ("pack_cols", C.c_int32), ("dQ_col0", C.c_int32), ("dK_col0", C.c_int32), ("dV_col0", C.c_int32)]
+                ("pack_cols", C.c_int32), ("dQ_col0", C.c_int32), ("dK_col0", C.c_int32), ("dV_col0", C.c_int32),
+                ("O_pack", C.c_void_p)]
 
 
 class LossDesc(C.Structure):

@@ -40,6 +40,8 @@ struct AttnParams {
     void *dQp, *dKp, *dVp;
     int kbq, kbk, kbv;      // 32-k tiles per 128-row block of each pack
     int tq0, tk0, tv0;      // first k tile of the dQ / dK / dV columns inside their pack (one fused pack: column offsets / 32)
+    void* Op;               // forward, bf16 mode: O written as a packed bf16 operand [N*S, H*dv] instead of f32
+    int kbo;
 };
 
 __device__ __forceinline__ void load16(const float* __restrict__ p, int k0, int kdim, bool vec, float (&f)[16]) {
@@ -86,9 +88,13 @@ __device__ __forceinline__ void store_tile_lds(float* __restrict__ sm, int ti, i
 
 // Out[S, ncols] = scale * op(Alds) * B[S, ncols]   (op = transpose when TRANS).  Alds is SP x SP with
 // stride LD and MUST be zero wherever its contraction index is >= S.  Wave w owns column tiles w, w+4, ...
+// `pack` != nullptr: the result goes, rounded to bf16, into a packed [rows, K] operand (lstc_pack1 layout, `pkb` 32-k tiles per
+// 128-row block) at global rows prow0 + row and k tiles ptile0 + column tile, instead of into Out.
 template <int T, bool TRANS>
 __device__ __forceinline__ void lds_times_rows(const float* __restrict__ Alds, const float* __restrict__ B, int ldb, int S,
-                                               int ncols, float scale, float* __restrict__ Out, int ldo) {
+                                               int ncols, float scale, float* __restrict__ Out, int ldo,
+                                               __bf16* __restrict__ pack = nullptr, uint32_t prow0 = 0, uint32_t ptile0 = 0,
+                                               uint32_t pkb = 0) {
     constexpr int SP = 32 * T, LD = SP + 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c31 = lane & 31, h2 = lane >> 5;
     const int ctiles = (ncols + 31) >> 5;
@@ -128,7 +134,15 @@ __device__ __forceinline__ void lds_times_rows(const float* __restrict__ Alds, c
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h2;
-                    if (row < S) Out[(size_t)row * ldo + c] = acc[t][r] * scale;
+                    if (row >= S) continue;
+                    if (pack) {
+                        const uint32_t rg = prow0 + (uint32_t)row;
+                        const size_t e = ((size_t)(rg >> 7) * pkb + ptile0 + (uint32_t)ct) * 4096u + (rg & 127u) * 32u +
+                                         (((((uint32_t)c31 >> 3) ^ ((rg >> 2) & 3u)) << 3) | ((uint32_t)c31 & 7u));
+                        pack[e] = (__bf16)(acc[t][r] * scale);
+                    } else {
+                        Out[(size_t)row * ldo + c] = acc[t][r] * scale;
+                    }
                 }
         }
     }
@@ -200,7 +214,8 @@ __global__ void __launch_bounds__(NT, T <= 2 ? 4 : 2) attn_fwd_kernel(const Attn
         }
     }
     __syncthreads();
-    lds_times_rows<T, false>(sm, Vb, p.ldv, S, p.dv, 1.f, Ob, p.ldo);
+    lds_times_rows<T, false>(sm, Vb, p.ldv, S, p.dv, 1.f, Ob, p.ldo, reinterpret_cast<__bf16*>(p.Op), (uint32_t)n * (uint32_t)S,
+                             (uint32_t)((h * p.dv) >> 5), (uint32_t)p.kbo);
 }
 
 template <int T>
@@ -700,13 +715,14 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd2_kernel(const AttnParams p) {
         const uint32_t bytes_v = (uint32_t)S * (uint32_t)p.ldv * 4u, bytes_o = (uint32_t)S * (uint32_t)p.ldo * 4u;
         const __amdgpu_buffer_rsrc_t r_V = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vb), 0, (int)bytes_v, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_O = __builtin_amdgcn_make_buffer_rsrc(p.O + (size_t)n * S * p.ldo + (size_t)h * p.dv, 0, (int)bytes_o, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_Op = __builtin_amdgcn_make_buffer_rsrc(p.Op ? p.Op : (void*)p.O, 0, (int)0x7fffffff, 0x00020000);
         auto job = [&](int kj) -> RtlJob {
             RtlJob J;
-            J.A = PT; J.b = r_V; J.brow = (uint32_t)p.ldv * 4u; J.o = r_O; J.orow = (uint32_t)p.ldo * 4u; J.scale = 1.f; J.ct = wave + 4 * kj;
-            J.pk = 0; J.ptile = 0; J.pkb = 0;
+            J.A = PT; J.b = r_V; J.brow = (uint32_t)p.ldv * 4u; J.o = p.Op ? r_Op : r_O; J.orow = (uint32_t)p.ldo * 4u; J.scale = 1.f; J.ct = wave + 4 * kj;
+            J.pk = p.Op ? 1 : 0; J.ptile = (uint32_t)((h * p.dv) >> 5) + (uint32_t)J.ct; J.pkb = (uint32_t)p.kbo;
             return J;
         };
-        const uint32_t prow0 = 0;          // (packed outputs exist in the backward only)
+        const uint32_t prow0 = (uint32_t)n * (uint32_t)S;
         constexpr int RB = SP / 2;
         const int c31 = l31;
         float b0[RB], b1[RB];
@@ -733,7 +749,7 @@ int fill_params(const LstcAttnDesc* d, AttnParams& p, bool bwd) {
     if (!d) return LSTC_E_NULL;
     if (d->dtype != LSTC_F32) return LSTC_E_UNSUPPORTED;
     if (!d->Q || !d->K || !d->V || !d->probs) return LSTC_E_NULL;
-    if (!bwd && !d->O) return LSTC_E_NULL;
+    if (!bwd && !d->O && !d->O_pack) return LSTC_E_NULL;
     const bool gpk = bwd && d->dQ_pack && d->dK_pack && d->dV_pack;
     if (bwd && (!d->dO || (!gpk && (!d->dQ || !d->dK || !d->dV)))) return LSTC_E_NULL;
     if (d->N <= 0 || d->S < 1 || d->H <= 0 || d->dk <= 0 || d->dv <= 0) return LSTC_E_SHAPE;
@@ -756,6 +772,7 @@ int fill_params(const LstcAttnDesc* d, AttnParams& p, bool bwd) {
     p.dQp = p.dKp = p.dVp = nullptr;
     p.kbq = p.kbk = p.kbv = 0;
     p.tq0 = p.tk0 = p.tv0 = 0;
+    p.Op = nullptr; p.kbo = 0;
     return 0;
 }
 
@@ -772,6 +789,13 @@ int lstc_attn_fwd(const LstcAttnDesc* d, void* stream) {
     AttnParams p;
     int rc = fill_params(d, p, false);
     if (rc) return rc;
+    if (d->O_pack) {        // packed bf16 output: token rows and head columns fill the pack's even tile grid exactly
+        const int64_t M = (int64_t)p.N * p.S;
+        if (M % 256 || (p.H * p.dv) % 64 || p.dv % 32 || M * (int64_t)(p.H * p.dv) * 2 > 0x7fffffffLL) return LSTC_E_UNSUPPORTED;
+        if (!aligned16(d->O_pack)) return LSTC_E_ALIGN;
+        p.Op = d->O_pack;
+        p.kbo = (p.H * p.dv) / 32;
+    }
     hipStream_t st = (hipStream_t)stream;
     const int T = (p.S + 31) / 32;
     const size_t lds = (size_t)(32 * T) * (32 * T + 1) * sizeof(float);
@@ -1028,7 +1052,7 @@ int fill_cls(const LstcAttnDesc* d, ClsParams& p, bool bwd) {
     if (!d) return LSTC_E_NULL;
     if (d->dtype != LSTC_F32) return LSTC_E_UNSUPPORTED;
     if (!d->Q || !d->K || !d->V || !d->probs) return LSTC_E_NULL;
-    if (!bwd && !d->O) return LSTC_E_NULL;
+    if (!bwd && !d->O && !d->O_pack) return LSTC_E_NULL;
     const bool gpk = bwd && d->dQ_pack && d->dK_pack && d->dV_pack;
     if (bwd && (!d->dO || (!gpk && (!d->dQ || !d->dK || !d->dV)))) return LSTC_E_NULL;
     if (d->N <= 0 || d->S < 1 || d->H <= 0 || d->dk <= 0 || d->dv <= 0) return LSTC_E_SHAPE;

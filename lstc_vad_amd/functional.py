@@ -539,13 +539,26 @@ def layernorm_bwd_branch(dz2, y, gamma, mean, rstd, p: float, seed: int, layer_n
     return dy, df, dgamma, dbeta, (colsum(df) if want_bias else None)
 
 
-def attn_fwd(q, k, v, N, S, H, dk, dv, table, index, p_drop, seed):
+def attn_fwd_pack(N, S, H, dv) -> bool:
+    """bf16 mode: the attention forward can write O as a packed bf16 operand (include/lstc_hip.h, O_pack)."""
     M = N * S
-    o = torch.empty((M, H * dv), device=q.device, dtype=torch.float32)
+    return (_FUSE_PACKS and _packed_kind() == _lib.BF16P and dv % 32 == 0 and M % 256 == 0 and (H * dv) % 64 == 0 and
+            M * H * dv * 2 < 2 ** 31 and M >= max(_x3_min[0], 1) and H * dv >= max(_x3_min[1], 256) and
+            M * H * dv * max(_x3_min[0], 256) >= _x3_min[2])
+
+
+def attn_fwd(q, k, v, N, S, H, dk, dv, table, index, p_drop, seed, packed=False):
+    """``packed``: O comes back ONLY as a ``Packed`` bf16 operand (returns (Packed, probs)) - see ``attn_fwd_pack``."""
+    M = N * S
+    if packed:
+        o = None
+        obuf = torch.empty((int(_lib.load().lstc_pack1_bytes(M, H * dv)),), device=q.device, dtype=torch.uint8)
+    else:
+        o = torch.empty((M, H * dv), device=q.device, dtype=torch.float32)
     probs = torch.empty((N, H, S, S), device=q.device, dtype=torch.float32)
     d = AttnDesc()
     d.N, d.S, d.H, d.dk, d.dv = N, S, H, dk, dv
-    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
+    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), (H * dv if packed else o.stride(0))
     d.dtype = F32
     if table is not None:
         d.index_ld, d.table_rows = index.shape[1], table.shape[0]
@@ -553,8 +566,14 @@ def attn_fwd(q, k, v, N, S, H, dk, dv, table, index, p_drop, seed):
     d.scale = 1.0 / (dk ** 0.5)
     d.dropout_p, d.dropout_seed = float(p_drop), int(seed)
     d.variant = _ATTN_VARIANT
-    d.Q, d.K, d.V, d.O, d.probs = dev_ptr(q), dev_ptr(k), dev_ptr(v), dev_ptr(o), dev_ptr(probs)
+    d.Q, d.K, d.V, d.probs = dev_ptr(q), dev_ptr(k), dev_ptr(v), dev_ptr(probs)
+    if packed:
+        d.O_pack = dev_ptr(obuf)
+    else:
+        d.O = dev_ptr(o)
     check(_lib.load().lstc_attn_fwd(C.byref(d), stream_ptr()), "lstc_attn_fwd")
+    if packed:
+        return Packed(obuf, M, H * dv, _lib.BF16P), probs
     return o, probs
 
 
@@ -663,14 +682,19 @@ class MHAFunction(torch.autograd.Function):
             _note(cfg["site"] + "attn_dropout", p_attn, seed_a, (N, H, S, S))
         if p_fc > 0:
             _note(cfg["site"] + "dropout", p_fc, seed_f, (N, S, dm))
-        o, probs = attn_fwd(q, k, v, N, S, H, dk, dv, table, index, p_attn, seed_a)
-        op = maybe_pack(o)
+        if xp is not None and attn_fwd_pack(N, S, H, dv) and wfc.shape[0] >= max(_x3_min[0], 1):
+            # bf16 mode: the attention output exists only as the packed bf16 operand of fc (and of fc's weight gradient)
+            op, probs = attn_fwd(q, k, v, N, S, H, dk, dv, table, index, p_attn, seed_a, packed=True)
+            o = None
+        else:
+            o, probs = attn_fwd(q, k, v, N, S, H, dk, dv, table, index, p_attn, seed_a)
+            op = maybe_pack(o)
         y = gemm(op if op is not None else o, wfc, trans_b=True, dropout=(p_fc, seed_f), residual=x2)
         if cfg["layer_norm"]:
             z, mean, rstd = layernorm_fwd(y, ln_w, ln_b, 1e-6, pack=True)
         else:
             z, mean, rstd = y, None, None
-        ctx.packs = (xp, op) if training else (None, None)
+        ctx.packs = (xp, op) if (training or o is None) else (None, None)
         ctx.cfg = dict(cfg, N=N, S=S, p_attn=p_attn, p_fc=p_fc, seed_a=seed_a, seed_f=seed_f)
         ctx.save_for_backward(x2, wq, wk, wv, wfc, ln_w, table, index, q, k, v, o, probs,
                               y if cfg["layer_norm"] else None, mean, rstd)

@@ -1327,8 +1327,9 @@ def test_row_split_f32_product_is_bitwise_the_single_launch_product(M, N, K, tb)
 
 @pytest.mark.parametrize("S", [49, 17])
 def test_attention_backward_packed_gradients_equal_the_packed_f32_gradients(S):
-    """lstc_attn_bwd with dQ_pack / dK_pack / dV_pack (bf16 mode): the packed bf16 gradients are lstc_pack1 of the f32 gradients
-    the same kernel writes without them, bit for bit; the bias-table gradient is unchanged."""
+    """lstc_attn_fwd with O_pack and lstc_attn_bwd with dQ_pack / dK_pack / dV_pack (bf16 mode): the packed bf16 results are
+    lstc_pack1 of the f32 results the same kernels write without them, bit for bit (S = 49: first-generation forward, staged
+    backward; S = 17: both staged); probabilities and the bias-table gradient are unchanged."""
     from lstc_vad_amd import functional as Fn
     N, H, dk = 256, 4, 64
     L = 3 if S == 49 else 1
@@ -1342,6 +1343,9 @@ def test_attention_backward_packed_gradients_equal_the_packed_f32_gradients(S):
     Fn.set_compute_dtype("bf16"); Fn.set_x3_threshold(0, 0, 0)
     try:
         o, probs = Fn.attn_fwd(q, k, v, N, S, H, dk, dk, table, index, 0.1, 77)
+        assert Fn.attn_fwd_pack(N, S, H, dk)
+        op, probs_p = Fn.attn_fwd(q, k, v, N, S, H, dk, dk, table, index, 0.1, 77, packed=True)      # forward: O as a pack only
+        assert torch.equal(probs, probs_p) and torch.equal(Fn.pack3(o, False).buf[:M * H * dk * 2], op.buf[:M * H * dk * 2])
         dq, dk_, dv_, dt0 = Fn.attn_bwd(do, q, k, v, probs, N, S, H, dk, dk, table, index, 0.1, 77)
         assert Fn.attn_bwd_packs(N, S, H, dk, dk)
         pq, pk, pv, dt1 = Fn.attn_bwd(do, q, k, v, probs, N, S, H, dk, dk, table, index, 0.1, 77, packed=True)
