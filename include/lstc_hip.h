@@ -258,6 +258,10 @@ int lstc_layernorm_bwd_drop_pack(const float* dy, const float* x, const float* g
  * (Train/temporal_transformer_shanghaitech.py:120) is fused into this pass instead of costing its own copy. */
 int lstc_cls_concat_fwd(const float* x, const float* x_hi, int64_t n_lo, const float* cls_token, const float* pos,
                         float* y, int64_t N, int32_t S, int32_t d, void* stream);
+/* The same with the packed bf16 form of y ([N*S, d], lstc_pack1 layout) written next to it: layer 0's A operand in bf16 mode
+ * (N*S a multiple of 256, d a multiple of 64; else LSTC_E_UNSUPPORTED). */
+int lstc_cls_concat_fwd_pack(const float* x, const float* x_hi, int64_t n_lo, const float* cls_token, const float* pos,
+                             float* y, int64_t N, int32_t S, int32_t d, void* packed, void* stream);
 
 /* Gradient w.r.t. the Encoder input, needed only when something upstream is trainable (input_layerNorm,
  * models/Encoder.py:48-49): dx[n,t,:] = dy[n,t+1,:] + (mean_cls ? dy[n,0,:]/(S-1) : 0). */

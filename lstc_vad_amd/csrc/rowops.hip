@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(NT) colsum_pack1_kernel(const __bf16* __restri
 __global__ void __launch_bounds__(NT) cls_concat_fwd_kernel(const float* __restrict__ x, const float* __restrict__ x_hi,
                                                              int64_t n_lo, const float* __restrict__ cls,
                                                              const float* __restrict__ pos, float* __restrict__ y, int S,
-                                                             int d) {
+                                                             int d, __bf16* __restrict__ packed, int KBp) {
     const int64_t n = blockIdx.x;
     const int c = blockIdx.y * NT + threadIdx.x;
     if (c >= d) return;
@@ -390,11 +390,14 @@ __global__ void __launch_bounds__(NT) cls_concat_fwd_kernel(const float* __restr
     for (int t = 0; t < S - 1; ++t) {
         const float v = xr[(int64_t)t * d];
         s += v;
-        yr[(int64_t)(t + 1) * d] = pos ? v + pos[(int64_t)(t + 1) * d + c] : v;
+        const float w = pos ? v + pos[(int64_t)(t + 1) * d + c] : v;
+        yr[(int64_t)(t + 1) * d] = w;
+        if (packed) packed[p1_offset(n * S + t + 1, c, KBp)] = (__bf16)w;       // bf16 mode: layer 0's packed A operand
     }
     float cv = cls ? cls[c] : s / (float)(S - 1);
     if (pos) cv += pos[c];
     yr[0] = cv;
+    if (packed) packed[p1_offset(n * S, c, KBp)] = (__bf16)cv;
 }
 
 // dx[n,t,:] = dy[n,t+1,:] + (mean_cls ? dy[n,0,:]/(S-1) : 0)
@@ -747,7 +750,18 @@ int lstc_cls_concat_fwd(const float* x, const float* x_hi, int64_t n_lo, const f
     if (!x || !y) return LSTC_E_NULL;
     if (N <= 0 || S < 2 || d <= 0 || (x_hi && (n_lo < 0 || n_lo > N))) return LSTC_E_SHAPE;
     hipLaunchKernelGGL(cls_concat_fwd_kernel, dim3((unsigned)N, (d + NT - 1) / NT), NT, 0, (hipStream_t)stream, x, x_hi,
-                       n_lo, cls_token, pos, y, S, d);
+                       n_lo, cls_token, pos, y, S, d, (__bf16*)nullptr, 0);
+    return lstc_launch_status();
+}
+
+int lstc_cls_concat_fwd_pack(const float* x, const float* x_hi, int64_t n_lo, const float* cls_token, const float* pos,
+                             float* y, int64_t N, int32_t S, int32_t d, void* packed, void* stream) {
+    if (!x || !y || !packed) return LSTC_E_NULL;
+    if (N <= 0 || S < 2 || d <= 0 || (x_hi && (n_lo < 0 || n_lo > N))) return LSTC_E_SHAPE;
+    if ((N * S) % 256 != 0 || d % 64 != 0) return LSTC_E_UNSUPPORTED;      // the rows fill the pack's even tile grid exactly
+    if (!aligned16(packed)) return LSTC_E_ALIGN;
+    hipLaunchKernelGGL(cls_concat_fwd_kernel, dim3((unsigned)N, (d + NT - 1) / NT), NT, 0, (hipStream_t)stream, x, x_hi,
+                       n_lo, cls_token, pos, y, S, d, (__bf16*)packed, d / 32);
     return lstc_launch_status();
 }
 

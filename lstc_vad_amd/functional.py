@@ -1038,8 +1038,16 @@ class ClsConcatFunction(torch.autograd.Function):
         y = torch.empty((N, S, dm), device=x.device, dtype=torch.float32)
         pos_s = pos[0, :S].contiguous() if pos is not None else None
         cls_v = cls_token.reshape(-1) if cls_token is not None else None
-        check(_lib.load().lstc_cls_concat_fwd(dev_ptr(x), dev_ptr(x_hi), N_lo, dev_ptr(cls_v), dev_ptr(pos_s), dev_ptr(y),
-                                              N, S, dm, stream_ptr()), "lstc_cls_concat_fwd")
+        if _fused_pack_shape(N * S, dm):
+            # bf16 mode: the kernel also writes layer 0's packed A operand
+            lib = _lib.load()
+            buf = torch.empty((int(lib.lstc_pack1_bytes(N * S, dm)),), device=x.device, dtype=torch.uint8)
+            check(lib.lstc_cls_concat_fwd_pack(dev_ptr(x), dev_ptr(x_hi), N_lo, dev_ptr(cls_v), dev_ptr(pos_s), dev_ptr(y),
+                                               N, S, dm, dev_ptr(buf), stream_ptr()), "lstc_cls_concat_fwd_pack")
+            _register_pack(y.view(N * S, dm), Packed(buf, N * S, dm, _lib.BF16P))
+        else:
+            check(_lib.load().lstc_cls_concat_fwd(dev_ptr(x), dev_ptr(x_hi), N_lo, dev_ptr(cls_v), dev_ptr(pos_s), dev_ptr(y),
+                                                  N, S, dm, stream_ptr()), "lstc_cls_concat_fwd")
         ctx.two = x_hi is not None
         ctx.meta = (N, S, dm, cls_token is not None, pos.shape if pos is not None else None)
         return y
