@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
 #pragma unroll
                 for (int cp2 = 0; cp2 < 2; ++cp2) {
                     const float* bp = p.bias + (cnb * 256 + wc * 64 + 32 * cp2);                       // wave-uniform
-                    const uint32_t bo = ((c16 >> 1) * 16 + 4 * (l15 >> 2)) * 4u;
+                    const uint32_t bo = ((c16 & 1) * 16 + 4 * (l15 >> 2)) * 4u;          // the lane's columns after the tile exchange
                     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(fbias[cp2]) : "v"(bo), "s"(bp) : "memory");
                 }
             }
@@ -461,15 +461,19 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                 // Addressing: wave-uniform base in SGPRs (tile, row tile, column pair: scalar arithmetic) + ONE per-lane byte offset
                 // shared by all 32 groups (row 4 (c16 & 1) + c4, column 16 (c16 >> 1) + 4 (l15 >> 2) of the group's 8 x 32 block)
                 const int c4 = lane & 3;
-                const uint32_t lrow = 4 * (c16 & 1) + c4, lcol = (c16 >> 1) * 16 + 4 * (l15 >> 2);
+                // v_permlane16_swap below: lanes 0-15 / 32-47 keep the left tile's rows 0-3 / 8-11, lanes 16-31 / 48-63 receive the right
+                // tile's - the two 64-B halves of a 128-B output line then sit in ADJACENT quarter-waves of one store instruction
+                // (with the half-wave exchange they were two quarter-waves apart and reached L2 as separate half-line writes:
+                // WRITE_SIZE 1.006 GB for an 822-MB output)
+                const uint32_t lrow = 8 * (c16 >> 1) + c4, lcol = (c16 & 1) * 16 + 4 * (l15 >> 2);
                 const uint32_t offC = (lrow * (uint32_t)p.ldc + lcol) * 4u, offX = (lrow * (uint32_t)ldx + lcol) * 4u;
                 const int urow0 = cmb * 256 + wr * 128, ucol0 = cnb * 256 + wc * 64;
                 const uint32_t idx0 = (uint32_t)(urow0 + (int)lrow) * (uint32_t)p.N + (uint32_t)(ucol0 + (int)lcol);
                 floatx4v ax[2][4];
-                // packed [M, N] operand (output / mask): byte offset inside the group's 128-row x 32-k tile, rows +0 / +8
+                // packed [M, N] operand (output / mask): byte offset inside the group's 128-row x 32-k tile, rows +0 / +4
                 const uint32_t pch = (lcol & 31) >> 3;
-                const uint32_t offP0 = (lrow * 32 + ((pch ^ (c16 & 1)) << 3) + (lcol & 7)) * 2u;
-                const uint32_t offP1 = ((lrow + 8) * 32 + ((pch ^ (((c16 & 1) + 2) & 3)) << 3) + (lcol & 7)) * 2u;
+                const uint32_t offP0 = (lrow * 32 + ((pch ^ ((2 * (c16 >> 1)) & 3)) << 3) + (lcol & 7)) * 2u;
+                const uint32_t offP1 = ((lrow + 4) * 32 + ((pch ^ ((2 * (c16 >> 1) + 1) & 3)) << 3) + (lcol & 7)) * 2u;
                 typedef unsigned uint2v __attribute__((ext_vector_type(2)));
                 typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
                 uint2v axp[MPK ? 2 : 1][MPK ? 4 : 1];
@@ -485,7 +489,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                                behind its back; the f32 operands below stay hand-counted) */                                      \
                             axp[MPK ? set : 0][MPK ? g_ : 0] = *reinterpret_cast<const uint2v*>(reinterpret_cast<const char*>(mb_) + ((g_ & 1) ? offP1 : offP0)); \
                         } else {                                                                                        \
-                            const float* ab_ = aux + (size_t)(urow0 + (2 * ((b) & 3) + (g_ >> 1)) * 16 + 8 * (g_ & 1)) * ldx + (ucol0 + 32 * ((b) >> 2)); \
+                            const float* ab_ = aux + (size_t)(urow0 + (2 * ((b) & 3) + (g_ >> 1)) * 16 + 4 * (g_ & 1)) * ldx + (ucol0 + 32 * ((b) >> 2)); \
                             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ax[set][g_]) : "v"(offX), "s"(ab_) : "memory"); \
                         }                                                                                               \
                     }                                                                                                   \
@@ -506,7 +510,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                     float4 v = make_float4((v0) * alpha + (bv)[0], (v1) * alpha + (bv)[1], (v2) * alpha + (bv)[2], (v3) * alpha + (bv)[3]); \
                     if (flags & LSTC_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); } \
                     if (flags & LSTC_EPI_DROPOUT) {                                                                      \
-                        const uint32_t idx = idx0 + (uint32_t)((rt) * 16 + 8 * (hf)) * (uint32_t)p.N + 32u * (cp);        \
+                        const uint32_t idx = idx0 + (uint32_t)((rt) * 16 + 4 * (hf)) * (uint32_t)p.N + 32u * (cp);        \
                         v.x = drop_keep(idx, p.dk) ? v.x * p.dk.scale : 0.f;                                             \
                         v.y = drop_keep(idx + 1, p.dk) ? v.y * p.dk.scale : 0.f;                                         \
                         v.z = drop_keep(idx + 2, p.dk) ? v.z * p.dk.scale : 0.f;                                         \
@@ -528,7 +532,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                             ((size_t)(2 * cmb + wr) * p.out_kbp + cnb * 8 + wc * 2 + (cp)) * P1_TILE + (rt) * 512;         \
                         asm volatile("global_store_dwordx2 %0, %1, %2\n\ts_nop 1" :: "v"((hf) ? offP1 : offP0), "v"(h_), "s"(ob_) : "memory"); \
                     } else {                                                                                            \
-                        float* cb_ = Cz + (size_t)(urow0 + (rt) * 16 + 8 * (hf)) * p.ldc + (ucol0 + 32 * (cp));          \
+                        float* cb_ = Cz + (size_t)(urow0 + (rt) * 16 + 4 * (hf)) * p.ldc + (ucol0 + 32 * (cp));          \
                         const floatx4v sv_ = {v.x, v.y, v.z, v.w};                                                       \
                         asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(offC), "v"(sv_), "s"(cb_) : "memory"); \
                     }                                                                                                   \
@@ -566,7 +570,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                         typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 #define P1_SWAP(x, y)                                                                                                    \
                         do {                                                                                             \
-                            const uint2v r_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false); \
+                            const uint2v r_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false); \
                             x = __uint_as_float(r_[0]); y = __uint_as_float(r_[1]);                                       \
                         } while (0)
                         P1_SWAP(x0, y0); P1_SWAP(x1, y1); P1_SWAP(x2, y2); P1_SWAP(x3, y3);
