@@ -86,6 +86,37 @@ __device__ __forceinline__ void store_tile_lds(float* __restrict__ sm, int ti, i
     for (int r = 0; r < 16; ++r) sm[(32 * ti + (r & 3) + 8 * (r >> 2) + 4 * h2) * LD + 32 * tj + c] = acc[r];
 }
 
+// The 32-row tiles of one wave's result (MFMA 32x32 layout: lane = column c31, registers = rows) written as packed bf16 (lstc_pack1 layout,
+// lstc_common.h p1_offset: `pkb` 32-k tiles per 128-row block), rows prow0 + token, k tile `ptile`.  Neighbouring lanes trade one value of each
+// row pair (DPP quad_perm), so a lane holds two adjacent columns of ONE row and writes them as one dword: 64 B per row and instruction,
+// half the stores and address arithmetic of a 2-byte store per value.  Tokens >= S are dropped by the buffer bounds check.
+typedef float attn_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 attn_h2 __attribute__((ext_vector_type(2)));
+template <int T>
+__device__ __forceinline__ void store_rows_packed(const floatx16 (&acc)[T], float scale, __amdgpu_buffer_rsrc_t rs, uint32_t prow0,
+                                                  uint32_t ptile, uint32_t pkb, int S, int c31, int h2) {
+    const uint32_t odd = (uint32_t)c31 & 1u, c2 = (uint32_t)c31 & ~1u;
+    const uint32_t sel = odd ? 0x03020706u : 0x05040100u;      // even lane: (own lo, other lo) = row a; odd lane: (other hi, own hi) = row a + 1
+    const uint32_t tokl = 4u * (uint32_t)h2 + odd;
+    const uint32_t blk = (pkb - 1u) * 4096u;                    // element (row, k): row * 32 + (row >> 7) * (pkb - 1) * 4096 + tile * 4096 + chunk
+    const uint32_t base = ptile * 4096u + (c2 & 7u);
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t tok = tokl + (uint32_t)(32 * t + 2 * (j & 1) + 8 * (j >> 1));
+            const uint32_t rg = prow0 + tok;
+            attn_f2 f;
+            f[0] = acc[t][2 * j] * scale;
+            f[1] = acc[t][2 * j + 1] * scale;
+            const uint32_t own = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, attn_h2));
+            const uint32_t oth = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+            const uint32_t val = __builtin_amdgcn_perm(oth, own, sel);
+            const uint32_t e = rg * 32u + (rg >> 7) * blk + base + ((((c2 >> 3) ^ (rg >> 2)) & 3u) << 3);
+            __builtin_amdgcn_raw_buffer_store_b32(val, rs, tok < (uint32_t)S ? e * 2u : 0xFFFFFFFFu, 0, 0);
+        }
+}
+
 // Out[S, ncols] = scale * op(Alds) * B[S, ncols]   (op = transpose when TRANS).  Alds is SP x SP with
 // stride LD and MUST be zero wherever its contraction index is >= S.  Wave w owns column tiles w, w+4, ...
 // `pack` != nullptr: the result goes, rounded to bf16, into a packed [rows, K] operand (lstc_pack1 layout, `pkb` 32-k tiles per
@@ -128,21 +159,17 @@ __device__ __forceinline__ void lds_times_rows(const float* __restrict__ Alds, c
                 for (int s = 0; s < 8; ++s) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc[t], 0, 0, 0);
             }
         }
-        if (cvalid) {
+        if (pack) {          // ncols is a multiple of 32 here (launcher), so the whole wave is valid
+            store_rows_packed<T>(acc, scale, __builtin_amdgcn_make_buffer_rsrc(pack, 0, (int)0x7fffffff, 0x00020000), prow0,
+                                 ptile0 + (uint32_t)ct, pkb, S, c31, h2);
+        } else if (cvalid) {
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h2;
                     if (row >= S) continue;
-                    if (pack) {
-                        const uint32_t rg = prow0 + (uint32_t)row;
-                        const size_t e = ((size_t)(rg >> 7) * pkb + ptile0 + (uint32_t)ct) * 4096u + (rg & 127u) * 32u +
-                                         (((((uint32_t)c31 >> 3) ^ ((rg >> 2) & 3u)) << 3) | ((uint32_t)c31 & 7u));
-                        pack[e] = (__bf16)(acc[t][r] * scale);
-                    } else {
-                        Out[(size_t)row * ldo + c] = acc[t][r] * scale;
-                    }
+                    Out[(size_t)row * ldo + c] = acc[t][r] * scale;
                 }
         }
     }
@@ -356,17 +383,8 @@ struct RtlJob {
                     o_[t_] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[s_], bv_[8 * b_ + s_], o_[t_], 0, 0, 0); \
             }                                                                                                 \
         }                                                                                                     \
-        if (J.pk) {     /* packed bf16 rows: element (global row, k) -> tile / swizzled chunk (lstc_common.h, p1_offset) */ \
-            _Pragma("unroll") for (int t_ = 0; t_ < T; ++t_)                                                    \
-                _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                             \
-                    const int tok_ = 32 * t_ + (r_ & 3) + 8 * (r_ >> 2) + 4 * h2;                               \
-                    const uint32_t rg_ = prow0 + (uint32_t)tok_;                                                \
-                    const uint32_t e_ = ((rg_ >> 7) * J.pkb + J.ptile) * 4096u + (rg_ & 127u) * 32u +           \
-                                        (((((uint32_t)c31 >> 3) ^ ((rg_ >> 2) & 3u)) << 3) | ((uint32_t)c31 & 7u)); \
-                    const __bf16 hb_ = (__bf16)(o_[t_][r_] * J.scale);                                          \
-                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hb_), J.o,         \
-                        tok_ < S ? e_ * 2u : 0xFFFFFFFFu, 0, 0);                                              \
-                }                                                                                             \
+        if (J.pk) {     /* packed bf16 rows (store_rows_packed) */                                              \
+            store_rows_packed<T>(o_, J.scale, J.o, prow0, J.ptile, J.pkb, S, c31, h2);                          \
         } else {                                                                                              \
             const uint32_t wo_ = (uint32_t)c31 * 4u + (uint32_t)(4 * h2) * J.orow + (uint32_t)(128 * J.ct);   \
             _Pragma("unroll") for (int t_ = 0; t_ < T; ++t_)                                                    \

@@ -27,6 +27,15 @@ for (N, S, L) in ((2048, 49, 3), (2048, 17, 1), (2048, 81, 5)):
             tf, (o, p) = t(lambda: Fn.attn_fwd(q, k, v, N, S, H, dk, dk, tab, idx, 0.2, 7))
             tb, _ = t(lambda: Fn.attn_bwd(do, q, k, v, p, N, S, H, dk, dk, tab, idx, 0.2, 7))
             res.setdefault(variant, []).append((tf, tb))
+    if S == 49:                                # bf16-mode forms: O / dQ|dK|dV written as packed bf16 operands (staged backward only)
+        Fn._ATTN_VARIANT = 0
+        for rnd in range(2):
+            tf, (o, p) = t(lambda: Fn.attn_fwd(q, k, v, N, S, H, dk, dk, tab, idx, 0.2, 7, packed=True))
+            tb, _ = t(lambda: Fn.attn_bwd(do, q, k, v, p, N, S, H, dk, dk, tab, idx, 0.2, 7, packed=True))
+            tb3, _ = t(lambda: Fn.attn_bwd(do, q, k, v, p, N, S, H, dk, dk, tab, idx, 0.2, 7, packed="fused"))
+            res.setdefault("pk", []).append((tf, tb, tb3))
+        print(f"ATTN N={N} S={S} packed outputs: fwd {min(x[0] for x in res['pk']):.3f} ms, bwd {min(x[1] for x in res['pk']):.3f} ms, "
+              f"bwd fused pack {min(x[2] for x in res['pk']):.3f} ms", flush=True)
     for variant in (0, 1):
         tf, tb = min(x[0] for x in res[variant]), min(x[1] for x in res[variant])
         print(f"ATTN N={N} S={S} gen {2 - variant}: fwd {tf:.3f} ms ({gb / tf:.2f} TB/s alg), bwd {tb:.3f} ms ({2 * gb / tb:.2f} TB/s alg)", flush=True)
