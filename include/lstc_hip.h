@@ -4,7 +4,7 @@
  *
  * The reference (shengyangsun/LSTC_VAD) has no FFI / plugin layer: its hot path is the
  * Python class surface models.Encoder / MultiHeadAttention / FFN / Regressor / Classifier
- * plus the loss functions and torch.optim.Adagrad inside Train/*.py, all of it implicit
+ * plus the loss functions and torch.optim.Adagrad inside the Train/ scripts, all of it implicit
  * ATen kernels.  Each entry point below replaces the ATen work of the reference lines it
  * cites (paths relative to the reference root).  lstc_vad_amd/_lib.py binds them with
  * ctypes; INTEGRATION.md shows the reference-side stub.

@@ -1143,24 +1143,47 @@ __global__ void __launch_bounds__(NT) cls_dot_kernel(const float* __restrict__ U
     const int d4 = d >> 2;
     for (int i = threadIdx.x; i < H * d4; i += NT) reinterpret_cast<float4*>(Ul)[i] = reinterpret_cast<const float4*>(Un)[i];
     __syncthreads();
-    for (int j = wave; j < S; j += NT / 64) {
-        float part[HT];
+    // a wave takes two rows at a time and requests all of their float4 pieces (up to 16 KB in flight per wave) before the first
+    // product: the kernel is a stream over X, and the head vectors read from LDS serve both rows
+    constexpr int XC = 8, NW = NT / 64;
+    for (int j = wave; j < S; j += 2 * NW) {
+        const int j1 = j + NW;
+        const bool two = j1 < S;
+        const float4* x0p = reinterpret_cast<const float4*>(Xn + (size_t)j * d);
+        const float4* x1p = reinterpret_cast<const float4*>(Xn + (size_t)(two ? j1 : j) * d);
+        float part0[HT], part1[HT];
 #pragma unroll
-        for (int h = 0; h < HT; ++h) part[h] = 0.f;
-        for (int c = lane; c < d4; c += 64) {
-            const float4 x = reinterpret_cast<const float4*>(Xn + (size_t)j * d)[c];
+        for (int h = 0; h < HT; ++h) part0[h] = part1[h] = 0.f;
+        for (int c0 = lane; c0 < d4; c0 += 64 * XC) {
+            float4 x0[XC], x1[XC];
 #pragma unroll
-            for (int h = 0; h < HT; ++h)
-                if (h < H) {
-                    const float4 u = reinterpret_cast<const float4*>(Ul + (size_t)h * d)[c];
-                    part[h] += (x.x * u.x + x.y * u.y) + (x.z * u.z + x.w * u.w);
+            for (int i = 0; i < XC; ++i) {
+                const int c = min(c0 + 64 * i, d4 - 1);
+                x0[i] = x0p[c];
+                x1[i] = x1p[c];
+            }
+#pragma unroll
+            for (int i = 0; i < XC; ++i) {
+                const int c = c0 + 64 * i;
+                if (c < d4) {
+#pragma unroll
+                    for (int h = 0; h < HT; ++h)
+                        if (h < H) {
+                            const float4 u = reinterpret_cast<const float4*>(Ul + (size_t)h * d)[c];
+                            part0[h] += (x0[i].x * u.x + x0[i].y * u.y) + (x0[i].z * u.z + x0[i].w * u.w);
+                            part1[h] += (x1[i].x * u.x + x1[i].y * u.y) + (x1[i].z * u.z + x1[i].w * u.w);
+                        }
                 }
+            }
         }
 #pragma unroll
         for (int h = 0; h < HT; ++h)
             if (h < H) {
-                const float v = wave_sum(part[h]);
-                if (lane == 0) sc[h * S + j] = v;
+                const float v0 = wave_sum(part0[h]), v1 = wave_sum(part1[h]);
+                if (lane == 0) {
+                    sc[h * S + j] = v0;
+                    if (two) sc[h * S + j1] = v1;
+                }
             }
     }
     __syncthreads();
