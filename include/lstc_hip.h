@@ -156,7 +156,13 @@ int lstc_colsum_pack1(const void* packed, int64_t rows, int32_t K, float* partia
 typedef struct LstcAttnDesc {
     int32_t N, S, H, dk, dv;        /* dk, dv multiples of 32; S <= 128 */
     int32_t ldq, ldk, ldv, ldo;     /* token strides in elements (normally H*dk / H*dv) */
-    int32_t dtype;
+    int32_t dtype;                  /* LSTC_F32: every product on the exact-f32 MFMA.  LSTC_BF16 (bf16 training mode): the operands of
+                                       Q K^T, Pd V and of the four backward products are rounded to bf16 (RNE) in registers and
+                                       contracted by v_mfma_f32_32x32x16_bf16 with f32 accumulation; Q, K, V, O, probs and the
+                                       gradients stay f32 in memory, softmax / bias / dropout stay f32.  Taken by the staged
+                                       kernels (S <= 64, dk and dv multiples of 32, 16-B aligned operands, variant 0); every other
+                                       case computes the exact-f32 products (the first-generation loops are latency-bound and got
+                                       slower with bf16 products).  lstc_attn_cls_* : LSTC_F32 only */
     int32_t index_ld;               /* 0 = no relative bias */
     int32_t table_rows;             /* rows of `table` / `dtable` (backward: size of the per-workgroup LDS accumulator) */
     float   scale;                  /* 1/sqrt(d_k): multiplies Q (reference divides by temperature :49,:103) */

@@ -58,8 +58,29 @@ __device__ __forceinline__ void load16(const float* __restrict__ p, int k0, int 
     }
 }
 
+typedef __bf16 attn_h8 __attribute__((ext_vector_type(8)));
+
+// 32x32 accumulator += A[32 x 16] B[32 x 16]^T where lane half h2 supplies k = 8 h2 + s (s = 0..7) of both operands.
+// BF = false: eight exact-f32 v_mfma_f32_32x32x2_f32 (step s contracts k = s and k = 8 + s).  BF = true (bf16 mode,
+// LstcAttnDesc.dtype = LSTC_BF16): the eight values are rounded to bf16 (RNE) and contracted by ONE v_mfma_f32_32x32x16_bf16 -
+// the same k assignment, f32 accumulation; 1/16 of the matrix-core time, which leaves these kernels bound by their loads.
+template <bool BF>
+__device__ __forceinline__ floatx16 mma8(const float* a, const float* b, floatx16 acc) {
+    if constexpr (BF) {
+        attn_h8 ah, bh;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { ah[s] = (__bf16)a[s]; bh[s] = (__bf16)b[s]; }
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+        return acc;
+    }
+}
+
 // 32x32 tile of  A[rowA0.., :] * B[rowB0.., :]^T  contracted over kdim; rows beyond S-1 are clamped
 // (their results are discarded by the caller).  A is scaled by a_scale before the product.
+template <bool BF>
 __device__ __forceinline__ floatx16 tile_abt(const float* __restrict__ A, int lda, int rowA0, const float* __restrict__ B,
                                              int ldb, int rowB0, int S, int kdim, float a_scale, bool vec) {
     const int lane = threadIdx.x & 63, r = lane & 31, h2 = lane >> 5;
@@ -74,7 +95,9 @@ __device__ __forceinline__ floatx16 tile_abt(const float* __restrict__ A, int ld
         load16(pa, kb + 16 * h2, kdim, vec, a);
         load16(pb, kb + 16 * h2, kdim, vec, b);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s] * a_scale, b[s], acc, 0, 0, 0);
+        for (int s = 0; s < 16; ++s) a[s] *= a_scale;
+        acc = mma8<BF>(a, b, acc);
+        acc = mma8<BF>(a + 8, b + 8, acc);
     }
     return acc;
 }
@@ -121,7 +144,7 @@ __device__ __forceinline__ void store_rows_packed(const floatx16 (&acc)[T], floa
 // stride LD and MUST be zero wherever its contraction index is >= S.  Wave w owns column tiles w, w+4, ...
 // `pack` != nullptr: the result goes, rounded to bf16, into a packed [rows, K] operand (lstc_pack1 layout, `pkb` 32-k tiles per
 // 128-row block) at global rows prow0 + row and k tiles ptile0 + column tile, instead of into Out.
-template <int T, bool TRANS>
+template <int T, bool TRANS, bool BF>
 __device__ __forceinline__ void lds_times_rows(const float* __restrict__ Alds, const float* __restrict__ B, int ldb, int S,
                                                int ncols, float scale, float* __restrict__ Out, int ldo,
                                                __bf16* __restrict__ pack = nullptr, uint32_t prow0 = 0, uint32_t ptile0 = 0,
@@ -155,8 +178,7 @@ __device__ __forceinline__ void lds_times_rows(const float* __restrict__ Alds, c
                     const int k = jb + 8 * h2 + s;
                     av[s] = TRANS ? Alds[k * LD + i] : Alds[i * LD + k];
                 }
-#pragma unroll
-                for (int s = 0; s < 8; ++s) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc[t], 0, 0, 0);
+                acc[t] = mma8<BF>(av, bv, acc[t]);
             }
         }
         if (pack) {          // ncols is a multiple of 32 here (launcher), so the whole wave is valid
@@ -177,6 +199,7 @@ __device__ __forceinline__ void lds_times_rows(const float* __restrict__ Alds, c
 
 template <int T>
 __global__ void __launch_bounds__(NT, T <= 2 ? 4 : 2) attn_fwd_kernel(const AttnParams p) {
+    constexpr bool BF = false;       // first generation: exact-f32 products only (bf16 products made these latency-bound loops slower)
     constexpr int SP = 32 * T, LD = SP + 1, NJ = (SP + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int n = blockIdx.x, h = blockIdx.y, S = p.S;
@@ -190,7 +213,7 @@ __global__ void __launch_bounds__(NT, T <= 2 ? 4 : 2) attn_fwd_kernel(const Attn
     for (int t = wave; t < T * T; t += NT / 64) {
         const int ti = t / T, tj = t % T;
         if (32 * ti >= S || 32 * tj >= S) continue;   // fully padded tile: rows/cols are rewritten below
-        const floatx16 acc = tile_abt(Qb, p.ldq, 32 * ti, Kb, p.ldk, 32 * tj, S, p.dk, p.scale, p.vec_qk);
+        const floatx16 acc = tile_abt<BF>(Qb, p.ldq, 32 * ti, Kb, p.ldk, 32 * tj, S, p.dk, p.scale, p.vec_qk);
         store_tile_lds<LD>(sm, ti, tj, acc);
     }
     __syncthreads();
@@ -241,12 +264,13 @@ __global__ void __launch_bounds__(NT, T <= 2 ? 4 : 2) attn_fwd_kernel(const Attn
         }
     }
     __syncthreads();
-    lds_times_rows<T, false>(sm, Vb, p.ldv, S, p.dv, 1.f, Ob, p.ldo, reinterpret_cast<__bf16*>(p.Op), (uint32_t)n * (uint32_t)S,
+    lds_times_rows<T, false, BF>(sm, Vb, p.ldv, S, p.dv, 1.f, Ob, p.ldo, reinterpret_cast<__bf16*>(p.Op), (uint32_t)n * (uint32_t)S,
                              (uint32_t)((h * p.dv) >> 5), (uint32_t)p.kbo);
 }
 
 template <int T>
 __global__ void __launch_bounds__(NT, T <= 3 ? 2 : 1) attn_bwd_kernel(const AttnParams p) {
+    constexpr bool BF = false;       // first generation: exact-f32 products only (bf16 products made these latency-bound loops slower)
     constexpr int SP = 32 * T, LD = SP + 1, NJ = (SP + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Dm = sm;                 // dP~ then dA
@@ -273,7 +297,7 @@ __global__ void __launch_bounds__(NT, T <= 3 ? 2 : 1) attn_bwd_kernel(const Attn
         for (int t = wave; t < T * T; t += NT / 64) {
             const int ti = t / T, tj = t % T;
             if (32 * ti >= S || 32 * tj >= S) continue;
-            const floatx16 acc = tile_abt(dOb, p.ldo, 32 * ti, Vb, p.ldv, 32 * tj, S, p.dv, 1.f, p.vec_v);
+            const floatx16 acc = tile_abt<BF>(dOb, p.ldo, 32 * ti, Vb, p.ldv, 32 * tj, S, p.dv, 1.f, p.vec_v);
             store_tile_lds<LD>(Dm, ti, tj, acc);
         }
         __syncthreads();
@@ -314,9 +338,9 @@ __global__ void __launch_bounds__(NT, T <= 3 ? 2 : 1) attn_bwd_kernel(const Attn
             }
         }
         __syncthreads();
-        lds_times_rows<T, true>(Pm, dOb, p.ldo, S, p.dv, 1.f, p.dV + (size_t)n * S * p.ldv + (size_t)h * p.dv, p.ldv);
-        lds_times_rows<T, false>(Dm, Kb, p.ldk, S, p.dk, p.scale, p.dQ + (size_t)n * S * p.ldq + (size_t)h * p.dk, p.ldq);
-        lds_times_rows<T, true>(Dm, Qb, p.ldq, S, p.dk, p.scale, p.dK + (size_t)n * S * p.ldk + (size_t)h * p.dk, p.ldk);
+        lds_times_rows<T, true, BF>(Pm, dOb, p.ldo, S, p.dv, 1.f, p.dV + (size_t)n * S * p.ldv + (size_t)h * p.dv, p.ldv);
+        lds_times_rows<T, false, BF>(Dm, Kb, p.ldk, S, p.dk, p.scale, p.dQ + (size_t)n * S * p.ldq + (size_t)h * p.dk, p.ldq);
+        lds_times_rows<T, true, BF>(Dm, Qb, p.ldq, S, p.dk, p.scale, p.dK + (size_t)n * S * p.ldk + (size_t)h * p.dk, p.ldk);
     }
     if (has_bias) {
         __syncthreads();
@@ -379,8 +403,7 @@ struct RtlJob {
                 float av_[8];                                                                                 \
                 _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_)                                                \
                     av_[s_] = J.A[(16 * b_ + 8 * h2 + s_) * LD + 32 * t_ + c31];                              \
-                _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_)                                                \
-                    o_[t_] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[s_], bv_[8 * b_ + s_], o_[t_], 0, 0, 0); \
+                o_[t_] = mma8<BF>(av_, &bv_[8 * b_], o_[t_]);                                                  \
             }                                                                                                 \
         }                                                                                                     \
         if (J.pk) {     /* packed bf16 rows (store_rows_packed) */                                              \
@@ -406,7 +429,7 @@ struct StageDma {
     }
 };
 
-template <int T>
+template <int T, bool BF>
 __global__ void __launch_bounds__(NT, 2) attn_bwd2_kernel(const AttnParams p) {
     constexpr int SP = 32 * T, LD = SP + 1, NJ = (SP + 63) / 64;
     constexpr int CH = SP * 32;                  // floats of one staged operand chunk (SP rows x 32 features)
@@ -489,8 +512,8 @@ __global__ void __launch_bounds__(NT, 2) attn_bwd2_kernel(const AttnParams p) {
                         a[4 * q] = va.x; a[4 * q + 1] = va.y; a[4 * q + 2] = va.z; a[4 * q + 3] = va.w;
                         b[4 * q] = vb.x; b[4 * q + 1] = vb.y; b[4 * q + 2] = vb.z; b[4 * q + 3] = vb.w;
                     }
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc[tt], 0, 0, 0);
+                    acc[tt] = mma8<BF>(a, b, acc[tt]);
+                    acc[tt] = mma8<BF>(a + 8, b + 8, acc[tt]);
                 }
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): this chunk's fragments are in registers
@@ -602,7 +625,7 @@ __global__ void __launch_bounds__(NT, 2) attn_bwd2_kernel(const AttnParams p) {
 // Second-generation forward: Q K^T with both operands staged by LDS-DMA (as dO V^T in the backward), softmax as in
 // attn_fwd_kernel but writing the dropped probabilities BOTH ways (row-major for nothing but symmetry with the backward is not
 // needed: only the [k][i] copy feeds P V), then O = Pd V as the job pipeline of the backward (A = Pd^T tile, B = V rows).
-template <int T>
+template <int T, bool BF>
 __global__ void __launch_bounds__(NT, 2) attn_fwd2_kernel(const AttnParams p) {
     constexpr int SP = 32 * T, LD = SP + 1, NJ = (SP + 63) / 64;
     constexpr int CH = SP * 32;
@@ -671,7 +694,9 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd2_kernel(const AttnParams p) {
                     b[4 * q] = vb.x; b[4 * q + 1] = vb.y; b[4 * q + 2] = vb.z; b[4 * q + 3] = vb.w;
                 }
 #pragma unroll
-                for (int s = 0; s < 16; ++s) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s] * p.scale, b[s], acc[tt], 0, 0, 0);
+                for (int s = 0; s < 16; ++s) a[s] *= p.scale;
+                acc[tt] = mma8<BF>(a, b, acc[tt]);
+                acc[tt] = mma8<BF>(a + 8, b + 8, acc[tt]);
             }
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -765,7 +790,7 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd2_kernel(const AttnParams p) {
 
 int fill_params(const LstcAttnDesc* d, AttnParams& p, bool bwd) {
     if (!d) return LSTC_E_NULL;
-    if (d->dtype != LSTC_F32) return LSTC_E_UNSUPPORTED;
+    if (d->dtype != LSTC_F32 && d->dtype != LSTC_BF16) return LSTC_E_UNSUPPORTED;
     if (!d->Q || !d->K || !d->V || !d->probs) return LSTC_E_NULL;
     if (!bwd && !d->O && !d->O_pack) return LSTC_E_NULL;
     const bool gpk = bwd && d->dQ_pack && d->dK_pack && d->dV_pack;
@@ -815,36 +840,40 @@ int lstc_attn_fwd(const LstcAttnDesc* d, void* stream) {
         p.kbo = (p.H * p.dv) / 32;
     }
     hipStream_t st = (hipStream_t)stream;
+    const bool bf = d->dtype == LSTC_BF16;
     const int T = (p.S + 31) / 32;
     const size_t lds = (size_t)(32 * T) * (32 * T + 1) * sizeof(float);
     dim3 grid(p.N, p.H);
-    if (T == 1 && p.vec_qk && p.vec_v && (p.dk % 32) == 0 && (p.dv % 32) == 0 && d->variant == 0) {
+    if (T <= (bf ? 2 : 1) && p.vec_qk && p.vec_v && (p.dk % 32) == 0 && (p.dv % 32) == 0 && d->variant == 0) {
         // second-generation kernel (LDS-DMA staged Q K^T, register-resident V rows): S <= 32 only.  Interleaved A/B on one
         // MI355X (tools/attn_time.py): S = 17 0.283 vs 0.350 ms; S = 49 1.10 vs 1.02 ms (the first generation's 4 waves per
         // SIMD hide more latency than this kernel's 2); S = 81 needs 86 KB of LDS (one workgroup per CU) - both stay on
-        // the first generation.  
+        // the first generation.  With bf16 products (LSTC_BF16) the staged kernel also takes 32 < S <= 64: 1.24 vs 1.45 ms.
         const int SP = 32 * T;
         const size_t lds2 = ((size_t)((SP * (SP + 1) + 3) & ~3) + (size_t)4 * SP * 32) * sizeof(float);
-#define LSTC_FWD2(TT)                                                          \
-    do {                                                                       \
-        static bool once2 = false;                                             \
-        if (!once2) { set_lds(attn_fwd2_kernel<TT>, 160 * 1024); once2 = true; } \
-        hipLaunchKernelGGL(attn_fwd2_kernel<TT>, grid, NT, lds2, st, p);       \
+#define LSTC_FWD2(TT, BB)                                                          \
+    do {                                                                           \
+        static bool once2 = false;                                                 \
+        if (!once2) { set_lds(attn_fwd2_kernel<TT, BB>, 160 * 1024); once2 = true; } \
+        hipLaunchKernelGGL((attn_fwd2_kernel<TT, BB>), grid, NT, lds2, st, p);     \
     } while (0)
-        LSTC_FWD2(1);
+        if (!bf) LSTC_FWD2(1, false); else if (T == 1) LSTC_FWD2(1, true); else LSTC_FWD2(2, true);
 #undef LSTC_FWD2
         return lstc_launch_status();
     }
+#define LSTC_FWD(TT)                                                      \
+    do {                                                                  \
+        static bool once = false;                                         \
+        if (!once) { set_lds(attn_fwd_kernel<TT>, 160 * 1024); once = true; } \
+        hipLaunchKernelGGL(attn_fwd_kernel<TT>, grid, NT, lds, st, p);    \
+    } while (0)
     switch (T) {
-        case 1: hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, NT, lds, st, p); break;
-        case 2: hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, NT, lds, st, p); break;
-        case 3: hipLaunchKernelGGL(attn_fwd_kernel<3>, grid, NT, lds, st, p); break;
-        default: {
-            static bool once = false;
-            if (!once) { set_lds(attn_fwd_kernel<4>, lds); once = true; }
-            hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, NT, lds, st, p);
-        }
+        case 1: LSTC_FWD(1); break;
+        case 2: LSTC_FWD(2); break;
+        case 3: LSTC_FWD(3); break;
+        default: LSTC_FWD(4); break;
     }
+#undef LSTC_FWD
     return lstc_launch_status();
 }
 
@@ -854,6 +883,7 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
     int rc = fill_params(d, p, true);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    const bool bf = d->dtype == LSTC_BF16;
     const int T = (p.S + 31) / 32;
     p.table_rows = (d->index_ld > 0 && d->dtable) ? d->table_rows : 0;
     if (d->index_ld > 0 && d->dtable && d->table_rows <= 0) return LSTC_E_SHAPE;
@@ -896,13 +926,14 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
         const int SP = 32 * T;
         const size_t lds2 = ((size_t)((2 * SP * (SP + 1) + 3) & ~3) + (size_t)4 * SP * 32 + (size_t)(NT / 64) * p.table_rows) * sizeof(float);
         if (lds2 <= 160 * 1024) {
-#define LSTC_BWD2(TT)                                                          \
-    do {                                                                       \
-        static bool once2 = false;                                             \
-        if (!once2) { set_lds(attn_bwd2_kernel<TT>, 160 * 1024); once2 = true; } \
-        hipLaunchKernelGGL(attn_bwd2_kernel<TT>, grid, NT, lds2, st, p);       \
+#define LSTC_BWD2(TT, BB)                                                          \
+    do {                                                                           \
+        static bool once2 = false;                                                 \
+        if (!once2) { set_lds(attn_bwd2_kernel<TT, BB>, 160 * 1024); once2 = true; } \
+        hipLaunchKernelGGL((attn_bwd2_kernel<TT, BB>), grid, NT, lds2, st, p);     \
     } while (0)
-            if (T == 1) LSTC_BWD2(1); else LSTC_BWD2(2);
+            if (T == 1) { if (bf) LSTC_BWD2(1, true); else LSTC_BWD2(1, false); }
+            else { if (bf) LSTC_BWD2(2, true); else LSTC_BWD2(2, false); }
 #undef LSTC_BWD2
             return lstc_launch_status();
         }

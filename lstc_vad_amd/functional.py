@@ -68,8 +68,9 @@ def set_compute_dtype(name: str):
     operand scaled by a power of two and split into two f16 planes, three plane products, f32 accumulation -
     csrc/gemm_pk.hip; small GEMMs stay on the exact-f32 kernel) or "bf16" (operands rounded to bf16 RNE, f32 accumulate and
     f32 storage everywhere: BASELINE.json configs 3 / 5; large products run on packed bf16 tiles - lstc_pack1 +
-    csrc/gemm_bf16p.hip - small or batched ones convert while staging, csrc/gemm_bf16c.hip).  Attention, LayerNorm, loss and
-    Adagrad stay f32."""
+    csrc/gemm_bf16p.hip - small or batched ones convert while staging, csrc/gemm_bf16c.hip; the attention products Q K^T, P V
+    and their gradients round their operands to bf16 the same way, LstcAttnDesc.dtype = LSTC_BF16, unless LSTC_ATTN_F32=1).
+    Softmax, LayerNorm, loss and Adagrad stay f32."""
     global _compute_dtype
     if name in ("fp32", "f32", "float32"):
         _compute_dtype = F32
@@ -108,6 +109,7 @@ _pack_prof = None          # list of (bytes_in, start_event, end_event) while be
 _wepoch = 0
 _memo_stack = []           # activation packs made inside one autograd-node body are shared by the GEMMs of that body
 _x3_min = (256, 256, 1 << 30)   # min(M, N), K, M*N*K from which a product goes to the packed kernel
+_ATTN_F32 = os.environ.get("LSTC_ATTN_F32", "0") == "1"          # bf16 mode: keep the attention products on the exact-f32 MFMA
 _ATTN_VARIANT = int(os.environ.get("LSTC_ATTN_VARIANT", "0"))     # 1: first-generation attention kernels (A/B measurements)
 _DETERMINISTIC_WGRAD = os.environ.get("LSTC_ATOMIC_SPLITK", "0") != "1"   # split-K weight gradients: partials + ordered sum, not atomics
 
@@ -539,6 +541,11 @@ def layernorm_bwd_branch(dz2, y, gamma, mean, rstd, p: float, seed: int, layer_n
     return dy, df, dgamma, dbeta, (colsum(df) if want_bias else None)
 
 
+def _attn_dtype():
+    """LstcAttnDesc.dtype of the current compute mode: bf16 mode contracts bf16-rounded operands on the bf16 MFMA."""
+    return _lib.BF16 if (_compute_dtype == _lib.BF16 and not _ATTN_F32) else F32
+
+
 def attn_fwd_pack(N, S, H, dv) -> bool:
     """bf16 mode: the attention forward can write O as a packed bf16 operand (include/lstc_hip.h, O_pack)."""
     M = N * S
@@ -559,7 +566,7 @@ def attn_fwd(q, k, v, N, S, H, dk, dv, table, index, p_drop, seed, packed=False)
     d = AttnDesc()
     d.N, d.S, d.H, d.dk, d.dv = N, S, H, dk, dv
     d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), (H * dv if packed else o.stride(0))
-    d.dtype = F32
+    d.dtype = _attn_dtype()
     if table is not None:
         d.index_ld, d.table_rows = index.shape[1], table.shape[0]
         d.table, d.index = dev_ptr(table), dev_ptr(index)
@@ -604,7 +611,7 @@ def attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, p_drop, seed, ou
     d.N, d.S, d.H, d.dk, d.dv = N, S, H, dk, dv
     d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), do.stride(0)
     assert packed or (dq.stride(0) == q.stride(0) and dk_.stride(0) == k.stride(0) and dv_.stride(0) == v.stride(0))
-    d.dtype = F32
+    d.dtype = _attn_dtype()
     dtable = parts = None
     if table is not None:
         # one partial table per chunk of sequences, summed in a fixed order afterwards: no float atomics anywhere

@@ -1092,6 +1092,59 @@ def test_attention_backward_staged_kernel_matches_first_generation_and_f64(S, L,
         assert max_abs_diff(dt1, dt2) < 1e-5 * float(td.grad.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("S,L,dk", [(17, 1, 64), (49, 3, 64), (81, 5, 64), (49, 3, 256), (33, 2, 32)])
+def test_attention_bf16_products_track_the_f64_reference(S, L, dk):
+    """bf16 training mode (LstcAttnDesc.dtype = LSTC_BF16): Q K^T, Pd V and the four backward products contract bf16-rounded
+    operands on v_mfma_f32_32x32x16_bf16 with f32 accumulation; softmax, bias, dropout stay f32.  The staged kernels
+    (S <= 64) against the f64 autograd reference on the UNROUNDED operands: relative Frobenius error of every result at the
+    level of bf16 operand rounding (2^-9 per element, averaged over the contraction) - and not zero-ish, i.e. the bf16 path
+    really ran.  S = 81 has no staged kernel: the same descriptor must give the exact-f32 results bit for bit."""
+    from lstc_vad_amd import functional as Fn
+    from lstc_vad_amd.models.MultiHeadAttention import relative_position_index_3d
+    N, H, p_drop, seed = 5, 3, 0.25, 79
+    g = torch.Generator(device=DEV).manual_seed(S * 17 + dk)
+    M = N * S
+    q, k, v, do = (torch.randn(M, H * dk, device=DEV, generator=g) for _ in range(4))
+    idx = relative_position_index_3d(L, 4).to(DEV) if (S - 1) % 16 == 0 else None
+    tab = torch.randn((2 * L - 1) * 49, H, device=DEV, generator=g) * 0.3 if idx is not None else None
+
+    def run():
+        o, probs = Fn.attn_fwd(q, k, v, N, S, H, dk, dk, tab, idx, p_drop, seed)
+        return (o, probs) + tuple(Fn.attn_bwd(do, q, k, v, probs, N, S, H, dk, dk, tab, idx, p_drop, seed))
+    exact = run()
+    Fn.set_compute_dtype("bf16")
+    try:
+        assert Fn._attn_dtype() == Fn._lib.BF16
+        got = run()
+        torch.cuda.synchronize()
+    finally:
+        Fn.set_compute_dtype("fp32")
+    names = ("O", "P", "dQ", "dK", "dV", "dtable")
+    if S > 64:
+        for name, a, b in zip(names, got, exact):
+            assert a is None and b is None or torch.equal(a, b), name
+        return
+    mask = Fn.dropout_mask((N, H, S, S), p_drop, seed, DEV).cpu().double() / (1.0 - p_drop)
+    qd, kd, vd = (t.cpu().double().view(N, S, H, dk).transpose(1, 2).requires_grad_(True) for t in (q, k, v))
+    a = (qd / dk ** 0.5) @ kd.transpose(-1, -2)
+    td = None
+    if idx is not None:
+        td = tab.cpu().double().requires_grad_(True)
+        bias = td[idx.cpu()[: S - 1, : S - 1].reshape(-1)].view(S - 1, S - 1, H).permute(2, 0, 1)
+        a = a + torch.nn.functional.pad(bias, (1, 0, 1, 0)).unsqueeze(0)
+    pr = torch.softmax(a, -1)
+    out = (pr * mask) @ vd
+    out.backward(do.cpu().double().view(N, S, H, dk).transpose(1, 2))
+    ref = [out.detach().transpose(1, 2).reshape(M, H * dk), pr.detach()] + \
+          [t.grad.transpose(1, 2).reshape(M, H * dk) for t in (qd, kd, vd)] + [None if td is None else td.grad]
+    for name, x, e, r in zip(names, got, exact, ref):
+        if r is None:
+            continue
+        err = float((x.detach().cpu().double() - r).norm() / r.norm())
+        err_exact = float((e.detach().cpu().double() - r).norm() / r.norm())
+        assert err_exact < 1e-5 and 10 * err_exact < err < 8e-3, (name, err, err_exact)
+
+
 @pytest.mark.parametrize("epi", ["plain", "bias_relu", "dropout_residual"])
 def test_bf16p_persistent_items_match_f32_kernel_on_rounded_operands(epi):
     """The persistent packed-bf16 kernel with SEVERAL work items per workgroup (25 152 x 2048 output = 792 tiles on 256

@@ -27,6 +27,15 @@ for (N, S, L) in ((2048, 49, 3), (2048, 17, 1), (2048, 81, 5)):
             tf, (o, p) = t(lambda: Fn.attn_fwd(q, k, v, N, S, H, dk, dk, tab, idx, 0.2, 7))
             tb, _ = t(lambda: Fn.attn_bwd(do, q, k, v, p, N, S, H, dk, dk, tab, idx, 0.2, 7))
             res.setdefault(variant, []).append((tf, tb))
+    Fn.set_compute_dtype("bf16")               # bf16 mode: products on v_mfma_f32_32x32x16_bf16 (LstcAttnDesc.dtype = LSTC_BF16)
+    for variant in (0, 1):
+        Fn._ATTN_VARIANT = variant
+        best = [1e9, 1e9]
+        for rnd in range(2):
+            tf, (o, p) = t(lambda: Fn.attn_fwd(q, k, v, N, S, H, dk, dk, tab, idx, 0.2, 7))
+            tb, _ = t(lambda: Fn.attn_bwd(do, q, k, v, p, N, S, H, dk, dk, tab, idx, 0.2, 7))
+            best = [min(best[0], tf), min(best[1], tb)]
+        print(f"ATTN N={N} S={S} bf16 products gen {2 - variant}: fwd {best[0]:.3f} ms ({gb / best[0]:.2f} TB/s alg), bwd {best[1]:.3f} ms ({2 * gb / best[1]:.2f} TB/s alg)", flush=True)
     if S == 49:                                # bf16-mode forms: O / dQ|dK|dV written as packed bf16 operands (staged backward only)
         Fn._ATTN_VARIANT = 0
         for rnd in range(2):
@@ -34,8 +43,10 @@ for (N, S, L) in ((2048, 49, 3), (2048, 17, 1), (2048, 81, 5)):
             tb, _ = t(lambda: Fn.attn_bwd(do, q, k, v, p, N, S, H, dk, dk, tab, idx, 0.2, 7, packed=True))
             tb3, _ = t(lambda: Fn.attn_bwd(do, q, k, v, p, N, S, H, dk, dk, tab, idx, 0.2, 7, packed="fused"))
             res.setdefault("pk", []).append((tf, tb, tb3))
-        print(f"ATTN N={N} S={S} packed outputs: fwd {min(x[0] for x in res['pk']):.3f} ms, bwd {min(x[1] for x in res['pk']):.3f} ms, "
+        Fn.set_compute_dtype("fp32")
+        print(f"ATTN N={N} S={S} packed outputs (bf16 products): fwd {min(x[0] for x in res['pk']):.3f} ms, bwd {min(x[1] for x in res['pk']):.3f} ms, "
               f"bwd fused pack {min(x[2] for x in res['pk']):.3f} ms", flush=True)
+    Fn.set_compute_dtype("fp32")
     for variant in (0, 1):
         tf, tb = min(x[0] for x in res[variant]), min(x[1] for x in res[variant])
         print(f"ATTN N={N} S={S} gen {2 - variant}: fwd {tf:.3f} ms ({gb / tf:.2f} TB/s alg), bwd {tb:.3f} ms ({2 * gb / tb:.2f} TB/s alg)", flush=True)
