@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(NT, T <= 3 ? 2 : 1) attn_bwd_kernel(const Attn
 }
 
 // =====================================================================================================
-// Second-generation backward (T <= 3, d_k and d_v multiples of 32, 16-B aligned operands): same math, same LDS score tiles,
+// Second-generation backward (T <= 3, NW = 4 waves for T <= 2 and 8 for T = 3; d_k and d_v multiples of 32, 16-B aligned operands): same math, same LDS score tiles,
 // same bias-table accumulation as attn_bwd_kernel, but the operands reach the MFMAs differently.
 //   * dP = dO V^T contracts over FEATURES, so the MFMA lane layout (lane = row, 16 consecutive floats per lane) makes a
 //     direct global load touch 32 different 128-B lines per instruction.  Here dO and V are staged through LDS in 32-feature
@@ -429,24 +429,24 @@ struct StageDma {
     }
 };
 
-template <int T, bool BF>
-__global__ void __launch_bounds__(NT, 2) attn_bwd2_kernel(const AttnParams p) {
+template <int T, bool BF, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) attn_bwd2_kernel(const AttnParams p) {
     constexpr int SP = 32 * T, LD = SP + 1, NJ = (SP + 63) / 64;
     constexpr int CH = SP * 32;                  // floats of one staged operand chunk (SP rows x 32 features)
-    constexpr int NPW = 2 * T;                   // DMA pieces per wave and chunk: 2 operands x SP/8 pieces / 4 waves
+    constexpr int NPW = 2 * (SP / 8) / NW;                       // DMA pieces per wave and chunk: 2 operands x SP/8 pieces / 4 waves
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Dm = sm;                              // dP~ then dA
     float* Pm = sm + SP * LD;                    // dropped probabilities
     constexpr int ST0 = (2 * SP * LD + 3) & ~3;  // staging ring: [buf][operand][SP][32], 16-B aligned
     float* stage = sm + ST0;
     float* DmT = stage;                          // dA^T (phase 2 / 3): the staging ring is idle after phase 1 (SP * LD <= 4 * CH)
-    float* tacc = stage + 4 * CH;                // [NT/64][table_rows]
+    float* tacc = stage + 4 * CH;                // [NW][table_rows]
     const int h = blockIdx.y, S = p.S;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, h2 = lane >> 5;
     const bool has_bias = p.index_ld > 0 && p.dtable != nullptr;
     if (has_bias)
-        for (int i = threadIdx.x; i < (NT / 64) * p.table_rows; i += NT) tacc[i] = 0.f;
+        for (int i = threadIdx.x; i < NW * p.table_rows; i += 64 * NW) tacc[i] = 0.f;
     float* const tw = tacc + wave * p.table_rows;
     const int n_begin = blockIdx.x * p.n_per_wg;
     const int n_end = min(p.N, n_begin + p.n_per_wg);
@@ -463,27 +463,28 @@ __global__ void __launch_bounds__(NT, 2) attn_bwd2_kernel(const AttnParams p) {
         auto issue_chunk = [&](int kc, int buf) {
 #pragma unroll
             for (int j = 0; j < NPW; ++j) {
-                const int piece = wave + 4 * j;                  // 0 .. 2*SP/8-1: first half dO, second half V
+                const int piece = wave + NW * j;                  // 0 .. 2*SP/8-1: first half dO, second half V
                 const int op = piece >= SP / 8 ? 1 : 0, pj = piece - op * (SP / 8);
                 StageDma::issue(op ? Vb : dOb, op ? p.ldv : p.ldo, S, 8 * pj, kc, stage_b + (uint32_t)(((buf * 2 + op) * CH + pj * 256) * 4));
             }
         };
-        floatx16 acc[(T * T + 3) / 4];
+        constexpr int NA = (T * T + NW - 1) / NW;     // 32x32 score tiles per wave
+        floatx16 acc[NA];
 #pragma unroll
-        for (int t = 0; t < (T * T + 3) / 4; ++t)
+        for (int t = 0; t < NA; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
         issue_chunk(0, 0);
         // the probabilities of this wave's rows (phase 2) are requested now and land under phase 1 (first version: one exposed
         // global-load latency per row, 16 rows per wave)
         const float* pr_base = p.probs + ((size_t)n * p.H + h) * S * S;
-        float pvr[SP / 4][NJ];
-        int idxr[SP / 4][NJ];                 // bias-table row of (i, j), -1 where no bias applies
+        float pvr[SP / NW][NJ];
+        int idxr[SP / NW][NJ];                 // bias-table row of (i, j), -1 where no bias applies
 #pragma unroll
-        for (int ii = 0; ii < SP / 4; ++ii)
+        for (int ii = 0; ii < SP / NW; ++ii)
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) {
-                const int i = wave + 4 * ii, j = lane + 64 * jj;
+                const int i = wave + NW * ii, j = lane + 64 * jj;
                 pvr[ii][jj] = (i < S && j < S) ? pr_base[(size_t)i * S + j] : 0.f;
                 idxr[ii][jj] = (has_bias && i >= 1 && j >= 1 && i < S && j < S) ? (int)p.index[(size_t)(i - 1) * p.index_ld + (j - 1)] : -1;
             }
@@ -500,8 +501,8 @@ __global__ void __launch_bounds__(NT, 2) attn_bwd2_kernel(const AttnParams p) {
             const float* sA = stage + (buf * 2 + 0) * CH;
             const float* sB = stage + (buf * 2 + 1) * CH;
 #pragma unroll
-            for (int tt = 0; tt < (T * T + 3) / 4; ++tt) {
-                const int t = wave + 4 * tt;
+            for (int tt = 0; tt < NA; ++tt) {
+                const int t = wave + NW * tt;
                 if (t < T * T) {
                     const int ra = 32 * (t / T) + l31, rb = 32 * (t % T) + l31;
                     float a[16], b[16];
@@ -520,16 +521,16 @@ __global__ void __launch_bounds__(NT, 2) attn_bwd2_kernel(const AttnParams p) {
             __builtin_amdgcn_s_barrier();                        // buffer kc & 1 may be refilled (chunk kc + 2)
         }
 #pragma unroll
-        for (int tt = 0; tt < (T * T + 3) / 4; ++tt) {
-            const int t = wave + 4 * tt;
+        for (int tt = 0; tt < NA; ++tt) {
+            const int t = wave + NW * tt;
             if (t < T * T) store_tile_lds<LD>(Dm, t / T, t % T, acc[tt]);
         }
         __syncthreads();
         // ---- phase 2: dA = P (dP - rowsum(dP P)), bias-table gradient (as attn_bwd_kernel)
         const uint32_t flat0 = ((uint32_t)n * p.H + h) * (uint32_t)(S * S);
 #pragma unroll
-        for (int ii = 0; ii < SP / 4; ++ii) {
-            const int i = wave + 4 * ii;
+        for (int ii = 0; ii < SP / NW; ++ii) {
+            const int i = wave + NW * ii;
             float* drow = Dm + i * LD;
             float* prow = Pm + i * LD;
             if (i >= S) {
@@ -566,7 +567,7 @@ __global__ void __launch_bounds__(NT, 2) attn_bwd2_kernel(const AttnParams p) {
         // ---- phase 3: dV = Pd^T dO, dQ = scale (dA^T)^T K, dK = scale dA^T Q: one pipeline over this wave's (product, column
         // tile) jobs; dV's tiles first, then dQ's, then dK's
         {
-            const int jv = ((p.dv >> 5) - wave + 3) >> 2, jk = ((p.dk >> 5) - wave + 3) >> 2;      // tiles of this wave
+            const int jv = ((p.dv >> 5) - wave + NW - 1) / NW, jk = ((p.dk >> 5) - wave + NW - 1) / NW;      // tiles of this wave
             const int njobs = jv + 2 * jk;
             const uint32_t bytes_v = (uint32_t)S * (uint32_t)p.ldv * 4u, bytes_o = (uint32_t)S * (uint32_t)p.ldo * 4u;
             const uint32_t bytes_q = (uint32_t)S * (uint32_t)p.ldq * 4u, bytes_k = (uint32_t)S * (uint32_t)p.ldk * 4u;
@@ -584,11 +585,11 @@ __global__ void __launch_bounds__(NT, 2) attn_bwd2_kernel(const AttnParams p) {
             auto job = [&](int kj) -> RtlJob {
                 RtlJob J;
                 J.pk = pk ? 1 : 0;
-                if (kj < jv) { J.A = Pm; J.b = r_dO; J.brow = (uint32_t)p.ldo * 4u; J.o = pk ? r_dVp : r_dV; J.orow = (uint32_t)p.ldv * 4u; J.scale = 1.f; J.ct = wave + 4 * kj;
+                if (kj < jv) { J.A = Pm; J.b = r_dO; J.brow = (uint32_t)p.ldo * 4u; J.o = pk ? r_dVp : r_dV; J.orow = (uint32_t)p.ldv * 4u; J.scale = 1.f; J.ct = wave + NW * kj;
                                J.pkb = (uint32_t)p.kbv; J.ptile = (uint32_t)(p.tv0 + ((h * p.dv) >> 5)) + (uint32_t)J.ct; }
-                else if (kj < jv + jk) { J.A = DmT; J.b = r_K; J.brow = (uint32_t)p.ldk * 4u; J.o = pk ? r_dQp : r_dQ; J.orow = (uint32_t)p.ldq * 4u; J.scale = p.scale; J.ct = wave + 4 * (kj - jv);
+                else if (kj < jv + jk) { J.A = DmT; J.b = r_K; J.brow = (uint32_t)p.ldk * 4u; J.o = pk ? r_dQp : r_dQ; J.orow = (uint32_t)p.ldq * 4u; J.scale = p.scale; J.ct = wave + NW * (kj - jv);
                                J.pkb = (uint32_t)p.kbq; J.ptile = (uint32_t)(p.tq0 + ((h * p.dk) >> 5)) + (uint32_t)J.ct; }
-                else { J.A = Dm; J.b = r_Q; J.brow = (uint32_t)p.ldq * 4u; J.o = pk ? r_dKp : r_dK; J.orow = (uint32_t)p.ldk * 4u; J.scale = p.scale; J.ct = wave + 4 * (kj - jv - jk);
+                else { J.A = Dm; J.b = r_Q; J.brow = (uint32_t)p.ldq * 4u; J.o = pk ? r_dKp : r_dK; J.orow = (uint32_t)p.ldk * 4u; J.scale = p.scale; J.ct = wave + NW * (kj - jv - jk);
                                J.pkb = (uint32_t)p.kbk; J.ptile = (uint32_t)(p.tk0 + ((h * p.dk) >> 5)) + (uint32_t)J.ct; }
                 return J;
             };
@@ -612,10 +613,10 @@ __global__ void __launch_bounds__(NT, 2) attn_bwd2_kernel(const AttnParams p) {
     }
     if (has_bias) {
         __syncthreads();
-        for (int i = threadIdx.x; i < p.table_rows; i += NT) {
+        for (int i = threadIdx.x; i < p.table_rows; i += 64 * NW) {
             float v = tacc[i];
 #pragma unroll
-            for (int w = 1; w < NT / 64; ++w) v += tacc[w * p.table_rows + i];
+            for (int w = 1; w < NW; ++w) v += tacc[w * p.table_rows + i];
             if (p.table_partials) p.dtable[((size_t)blockIdx.x * p.table_rows + i) * p.H + h] = v;
             else atomicAdd(&p.dtable[(size_t)i * p.H + h], v);
         }
@@ -625,11 +626,11 @@ __global__ void __launch_bounds__(NT, 2) attn_bwd2_kernel(const AttnParams p) {
 // Second-generation forward: Q K^T with both operands staged by LDS-DMA (as dO V^T in the backward), softmax as in
 // attn_fwd_kernel but writing the dropped probabilities BOTH ways (row-major for nothing but symmetry with the backward is not
 // needed: only the [k][i] copy feeds P V), then O = Pd V as the job pipeline of the backward (A = Pd^T tile, B = V rows).
-template <int T, bool BF>
-__global__ void __launch_bounds__(NT, 2) attn_fwd2_kernel(const AttnParams p) {
+template <int T, bool BF, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) attn_fwd2_kernel(const AttnParams p) {
     constexpr int SP = 32 * T, LD = SP + 1, NJ = (SP + 63) / 64;
     constexpr int CH = SP * 32;
-    constexpr int NPW = 2 * T;
+    constexpr int NPW = 2 * (SP / 8) / NW;    
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Am = sm;                              // logits, then probabilities (row-major)
     constexpr int ST0 = (SP * LD + 3) & ~3;
@@ -646,25 +647,26 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd2_kernel(const AttnParams p) {
     auto issue_chunk = [&](int kc, int buf) {
 #pragma unroll
         for (int j = 0; j < NPW; ++j) {
-            const int piece = wave + 4 * j;
+            const int piece = wave + NW * j;
             const int op = piece >= SP / 8 ? 1 : 0, pj = piece - op * (SP / 8);
             StageDma::issue(op ? Kb : Qb, op ? p.ldk : p.ldq, S, 8 * pj, kc, stage_b + (uint32_t)(((buf * 2 + op) * CH + pj * 256) * 4));
         }
     };
-    floatx16 acc[(T * T + 3) / 4];
+    constexpr int NA = (T * T + NW - 1) / NW;     // 32x32 score tiles per wave
+    floatx16 acc[NA];
 #pragma unroll
-    for (int t = 0; t < (T * T + 3) / 4; ++t)
+    for (int t = 0; t < NA; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     issue_chunk(0, 0);
     // relative-position bias of this wave's softmax rows: table[index[i-1, j-1], h] is two DEPENDENT global loads per element;
     // requested here they land under the Q K^T phase (first version: in the row loop, one exposed double latency per row)
-    float biasr[SP / 4][NJ];
+    float biasr[SP / NW][NJ];
 #pragma unroll
-    for (int ii = 0; ii < SP / 4; ++ii)
+    for (int ii = 0; ii < SP / NW; ++ii)
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) {
-            const int i = wave + 4 * ii, j = lane + 64 * jj;
+            const int i = wave + NW * ii, j = lane + 64 * jj;
             biasr[ii][jj] = (p.index_ld > 0 && i >= 1 && j >= 1 && i < S && j < S)
                                 ? p.table[(size_t)p.index[(size_t)(i - 1) * p.index_ld + (j - 1)] * p.H + h] : 0.f;
         }
@@ -681,8 +683,8 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd2_kernel(const AttnParams p) {
         const float* sA = stage + (buf * 2 + 0) * CH;
         const float* sB = stage + (buf * 2 + 1) * CH;
 #pragma unroll
-        for (int tt = 0; tt < (T * T + 3) / 4; ++tt) {
-            const int t = wave + 4 * tt;
+        for (int tt = 0; tt < NA; ++tt) {
+            const int t = wave + NW * tt;
             if (t < T * T) {
                 const int ra = 32 * (t / T) + l31, rb = 32 * (t % T) + l31;
                 float a[16], b[16];
@@ -703,8 +705,8 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd2_kernel(const AttnParams p) {
         __builtin_amdgcn_s_barrier();
     }
 #pragma unroll
-    for (int tt = 0; tt < (T * T + 3) / 4; ++tt) {
-        const int t = wave + 4 * tt;
+    for (int tt = 0; tt < NA; ++tt) {
+        const int t = wave + NW * tt;
         if (t < T * T) store_tile_lds<LD>(Am, t / T, t % T, acc[tt]);
     }
     __syncthreads();
@@ -712,8 +714,8 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd2_kernel(const AttnParams p) {
     float* pr_base = p.probs + ((size_t)n * p.H + h) * S * S;
     const uint32_t flat0 = ((uint32_t)n * p.H + h) * (uint32_t)(S * S);
 #pragma unroll
-    for (int ii = 0; ii < SP / 4; ++ii) {
-        const int i = wave + 4 * ii;
+    for (int ii = 0; ii < SP / NW; ++ii) {
+        const int i = wave + NW * ii;
         float* row = Am + i * LD;
         if (i >= S) {
             for (int j = lane; j < SP; j += 64) PT[j * LD + i] = 0.f;
@@ -754,14 +756,14 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd2_kernel(const AttnParams p) {
     __syncthreads();
     // ---- O = Pd V: job pipeline over this wave's 32-column tiles
     {
-        const int njobs = ((p.dv >> 5) - wave + 3) >> 2;
+        const int njobs = ((p.dv >> 5) - wave + NW - 1) / NW;
         const uint32_t bytes_v = (uint32_t)S * (uint32_t)p.ldv * 4u, bytes_o = (uint32_t)S * (uint32_t)p.ldo * 4u;
         const __amdgpu_buffer_rsrc_t r_V = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vb), 0, (int)bytes_v, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_O = __builtin_amdgcn_make_buffer_rsrc(p.O + (size_t)n * S * p.ldo + (size_t)h * p.dv, 0, (int)bytes_o, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_Op = __builtin_amdgcn_make_buffer_rsrc(p.Op ? p.Op : (void*)p.O, 0, (int)0x7fffffff, 0x00020000);
         auto job = [&](int kj) -> RtlJob {
             RtlJob J;
-            J.A = PT; J.b = r_V; J.brow = (uint32_t)p.ldv * 4u; J.o = p.Op ? r_Op : r_O; J.orow = (uint32_t)p.ldo * 4u; J.scale = 1.f; J.ct = wave + 4 * kj;
+            J.A = PT; J.b = r_V; J.brow = (uint32_t)p.ldv * 4u; J.o = p.Op ? r_Op : r_O; J.orow = (uint32_t)p.ldo * 4u; J.scale = 1.f; J.ct = wave + NW * kj;
             J.pk = p.Op ? 1 : 0; J.ptile = (uint32_t)((h * p.dv) >> 5) + (uint32_t)J.ct; J.pkb = (uint32_t)p.kbo;
             return J;
         };
@@ -844,20 +846,22 @@ int lstc_attn_fwd(const LstcAttnDesc* d, void* stream) {
     const int T = (p.S + 31) / 32;
     const size_t lds = (size_t)(32 * T) * (32 * T + 1) * sizeof(float);
     dim3 grid(p.N, p.H);
-    if (T <= (bf ? 2 : 1) && p.vec_qk && p.vec_v && (p.dk % 32) == 0 && (p.dv % 32) == 0 && d->variant == 0) {
-        // second-generation kernel (LDS-DMA staged Q K^T, register-resident V rows): S <= 32 only.  Interleaved A/B on one
-        // MI355X (tools/attn_time.py): S = 17 0.283 vs 0.350 ms; S = 49 1.10 vs 1.02 ms (the first generation's 4 waves per
-        // SIMD hide more latency than this kernel's 2); S = 81 needs 86 KB of LDS (one workgroup per CU) - both stay on
-        // the first generation.  With bf16 products (LSTC_BF16) the staged kernel also takes 32 < S <= 64: 1.24 vs 1.45 ms.
+    if ((T == 1 || T == 3 || (bf && T == 2)) && p.vec_qk && p.vec_v && (p.dk % 32) == 0 && (p.dv % 32) == 0 && d->variant == 0) {
+        // second-generation kernel (LDS-DMA staged Q K^T, register-resident V rows).  Interleaved A/B on one MI355X
+        // (tools/attn_time.py): S = 17 0.283 vs 0.350 ms; S = 49 with exact-f32 products 1.10 vs 1.02 ms (the first generation's 4
+        // waves per SIMD hide more latency than this kernel's 2) - stays on the first generation; with bf16 products (LSTC_BF16)
+        // the staged kernel wins there too (0.87 vs 1.16 ms).  64 < S <= 96 needs 86 KB of LDS (one workgroup per CU): that
+        // instantiation runs 8 waves.
         const int SP = 32 * T;
         const size_t lds2 = ((size_t)((SP * (SP + 1) + 3) & ~3) + (size_t)4 * SP * 32) * sizeof(float);
-#define LSTC_FWD2(TT, BB)                                                          \
-    do {                                                                           \
-        static bool once2 = false;                                                 \
-        if (!once2) { set_lds(attn_fwd2_kernel<TT, BB>, 160 * 1024); once2 = true; } \
-        hipLaunchKernelGGL((attn_fwd2_kernel<TT, BB>), grid, NT, lds2, st, p);     \
+#define LSTC_FWD2(TT, BB, WW)                                                              \
+    do {                                                                                   \
+        static bool once2 = false;                                                         \
+        if (!once2) { set_lds(attn_fwd2_kernel<TT, BB, WW>, 160 * 1024); once2 = true; }   \
+        hipLaunchKernelGGL((attn_fwd2_kernel<TT, BB, WW>), grid, 64 * WW, lds2, st, p);    \
     } while (0)
-        if (!bf) LSTC_FWD2(1, false); else if (T == 1) LSTC_FWD2(1, true); else LSTC_FWD2(2, true);
+        if (!bf) { if (T == 1) LSTC_FWD2(1, false, 4); else LSTC_FWD2(3, false, 8); }
+        else if (T == 1) LSTC_FWD2(1, true, 4); else if (T == 2) LSTC_FWD2(2, true, 4); else LSTC_FWD2(3, true, 8);
 #undef LSTC_FWD2
         return lstc_launch_status();
     }
@@ -902,9 +906,10 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
     dim3 grid((p.N + npw - 1) / npw, p.H);
     if (p.table_partials && (int)grid.x != d->dtable_chunks) return LSTC_E_SHAPE;
     // second-generation kernel (LDS-DMA staged dP, register-resident B rows): d_k, d_v multiples of 32, aligned operands
-    // S = 49: 1.63 vs 2.75 ms, S = 17: 0.53 vs 1.19 ms per LTN / STN layer (interleaved A/B); S = 81 (T = 3): 193 spilled
-    // registers, no faster than the first generation (7.3 vs 7.1 ms) - stays there
-    const bool v2 = T <= 2 && p.vec_qk && p.vec_v && (p.dk % 32) == 0 && (p.dv % 32) == 0 && d->variant == 0;
+    // S = 49: 1.63 vs 2.75 ms, S = 17: 0.53 vs 1.19 ms per LTN / STN layer (interleaved A/B); S = 81 (T = 3): 138 KB of LDS =
+    // one workgroup per CU; with 4 waves that was no faster than the first generation (193 spilled registers, 7.3 vs 7.1 ms),
+    // the 8-wave instantiation (two waves per SIMD, 12 rows / 3 DMA pieces / <= 2 jobs per wave) runs 4.3 ms
+    const bool v2 = T <= 3 && p.vec_qk && p.vec_v && (p.dk % 32) == 0 && (p.dv % 32) == 0 && d->variant == 0;
     if (d->dQ_pack || d->dK_pack || d->dV_pack) {
         // packed bf16 gradients: the staged kernel only, token rows and head columns filling the packs' even tile grid exactly
         const int64_t M = (int64_t)p.N * p.S;
@@ -923,17 +928,18 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
         }
     }
     if (v2) {
-        const int SP = 32 * T;
-        const size_t lds2 = ((size_t)((2 * SP * (SP + 1) + 3) & ~3) + (size_t)4 * SP * 32 + (size_t)(NT / 64) * p.table_rows) * sizeof(float);
+        const int SP = 32 * T, NW = T == 3 ? 8 : 4;      // 64 < S <= 96: 138 KB of LDS = one workgroup per CU, so that one runs 8 waves
+        const size_t lds2 = ((size_t)((2 * SP * (SP + 1) + 3) & ~3) + (size_t)4 * SP * 32 + (size_t)NW * p.table_rows) * sizeof(float);
         if (lds2 <= 160 * 1024) {
-#define LSTC_BWD2(TT, BB)                                                          \
-    do {                                                                           \
-        static bool once2 = false;                                                 \
-        if (!once2) { set_lds(attn_bwd2_kernel<TT, BB>, 160 * 1024); once2 = true; } \
-        hipLaunchKernelGGL((attn_bwd2_kernel<TT, BB>), grid, NT, lds2, st, p);     \
+#define LSTC_BWD2(TT, BB, WW)                                                              \
+    do {                                                                                   \
+        static bool once2 = false;                                                         \
+        if (!once2) { set_lds(attn_bwd2_kernel<TT, BB, WW>, 160 * 1024); once2 = true; }   \
+        hipLaunchKernelGGL((attn_bwd2_kernel<TT, BB, WW>), grid, 64 * WW, lds2, st, p);    \
     } while (0)
-            if (T == 1) { if (bf) LSTC_BWD2(1, true); else LSTC_BWD2(1, false); }
-            else { if (bf) LSTC_BWD2(2, true); else LSTC_BWD2(2, false); }
+            if (T == 1) { if (bf) LSTC_BWD2(1, true, 4); else LSTC_BWD2(1, false, 4); }
+            else if (T == 2) { if (bf) LSTC_BWD2(2, true, 4); else LSTC_BWD2(2, false, 4); }
+            else { if (bf) LSTC_BWD2(3, true, 8); else LSTC_BWD2(3, false, 8); }
 #undef LSTC_BWD2
             return lstc_launch_status();
         }

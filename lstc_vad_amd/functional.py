@@ -587,7 +587,7 @@ def attn_fwd(q, k, v, N, S, H, dk, dv, table, index, p_drop, seed, packed=False)
 def attn_bwd_packs(N, S, H, dk, dv) -> bool:
     """bf16 mode: the staged attention backward can write dQ / dK / dV as packed bf16 operands (include/lstc_hip.h)."""
     M = N * S
-    return (_FUSE_PACKS and _packed_kind() == _lib.BF16P and _ATTN_VARIANT == 0 and S <= 64 and dk % 32 == 0 and dv % 32 == 0 and
+    return (_FUSE_PACKS and _packed_kind() == _lib.BF16P and _ATTN_VARIANT == 0 and S <= 96 and dk % 32 == 0 and dv % 32 == 0 and
             M % 256 == 0 and (H * dk) % 64 == 0 and (H * dv) % 64 == 0 and M * H * max(dk, dv) * 2 < 2 ** 31 and
             M >= max(_x3_min[0], 1) and H * min(dk, dv) >= max(_x3_min[1], 256) and M * H * min(dk, dv) * max(_x3_min[0], 256) >= _x3_min[2])
 

@@ -1092,13 +1092,13 @@ def test_attention_backward_staged_kernel_matches_first_generation_and_f64(S, L,
         assert max_abs_diff(dt1, dt2) < 1e-5 * float(td.grad.abs().max()) + 1e-6
 
 
-@pytest.mark.parametrize("S,L,dk", [(17, 1, 64), (49, 3, 64), (81, 5, 64), (49, 3, 256), (33, 2, 32)])
+@pytest.mark.parametrize("S,L,dk", [(17, 1, 64), (49, 3, 64), (81, 5, 64), (49, 3, 256), (33, 2, 32), (81, 5, 128), (113, 7, 32)])
 def test_attention_bf16_products_track_the_f64_reference(S, L, dk):
     """bf16 training mode (LstcAttnDesc.dtype = LSTC_BF16): Q K^T, Pd V and the four backward products contract bf16-rounded
     operands on v_mfma_f32_32x32x16_bf16 with f32 accumulation; softmax, bias, dropout stay f32.  The staged kernels
-    (S <= 64) against the f64 autograd reference on the UNROUNDED operands: relative Frobenius error of every result at the
+    (S <= 96) against the f64 autograd reference on the UNROUNDED operands: relative Frobenius error of every result at the
     level of bf16 operand rounding (2^-9 per element, averaged over the contraction) - and not zero-ish, i.e. the bf16 path
-    really ran.  S = 81 has no staged kernel: the same descriptor must give the exact-f32 results bit for bit."""
+    really ran.  S = 113 has no staged kernel: the same descriptor must give the exact-f32 results bit for bit."""
     from lstc_vad_amd import functional as Fn
     from lstc_vad_amd.models.MultiHeadAttention import relative_position_index_3d
     N, H, p_drop, seed = 5, 3, 0.25, 79
@@ -1120,7 +1120,7 @@ def test_attention_bf16_products_track_the_f64_reference(S, L, dk):
     finally:
         Fn.set_compute_dtype("fp32")
     names = ("O", "P", "dQ", "dK", "dV", "dtable")
-    if S > 64:
+    if S > 96:
         for name, a, b in zip(names, got, exact):
             assert a is None and b is None or torch.equal(a, b), name
         return
@@ -1378,18 +1378,18 @@ def test_row_split_f32_product_is_bitwise_the_single_launch_product(M, N, K, tb)
     assert max_abs_diff(split, ref * keep + res.double()) < 1e-4 * (K ** 0.5)
 
 
-@pytest.mark.parametrize("S", [49, 17])
+@pytest.mark.parametrize("S", [49, 17, 81])
 def test_attention_backward_packed_gradients_equal_the_packed_f32_gradients(S):
     """lstc_attn_fwd with O_pack and lstc_attn_bwd with dQ_pack / dK_pack / dV_pack (bf16 mode): the packed bf16 results are
-    lstc_pack1 of the f32 results the same kernels write without them, bit for bit (S = 49: first-generation forward, staged
-    backward; S = 17: both staged); probabilities and the bias-table gradient are unchanged."""
+    lstc_pack1 of the f32 results the same kernels write without them, bit for bit (staged kernels; S = 81 is the 8-wave
+    instantiation); probabilities and the bias-table gradient are unchanged."""
     from lstc_vad_amd import functional as Fn
     N, H, dk = 256, 4, 64
-    L = 3 if S == 49 else 1
+    L = {49: 3, 17: 1, 81: 5}[S]
     g = torch.Generator(device=DEV).manual_seed(41)
     M = N * S
     q, k, v, do = (torch.randn(M, H * dk, device=DEV, generator=g) for _ in range(4))
-    table = torch.randn((2 * L - 1) * 49, H, device=DEV, generator=g) * 0.3 if S == 49 else None
+    table = torch.randn((2 * L - 1) * 49, H, device=DEV, generator=g) * 0.3 if S != 17 else None
     index = None
     if table is not None:
         index = orc.relative_position_index_3d(L, 4).to(DEV)
