@@ -165,11 +165,13 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
 #define P1_ABL_RD (p.debug & 8)
 #define P1_ABL_NOSTORE (p.debug & 16)      /* epilogue arithmetic, no store instruction */
 #define P1_ABL_L2STORE (p.debug & 32)      /* every tile stores into rows 0-255 (the output stays in L2) */
+#define P1_ABL_HOTDMA (p.debug & 64)       /* every DMA reads K step 0 of tile (0, 0): same instruction stream, always cache hits */
 #else
 #define P1_ABL_DMA 0
 #define P1_ABL_RD 0
 #define P1_ABL_NOSTORE 0
 #define P1_ABL_L2STORE 0
+#define P1_ABL_HOTDMA 0
 #endif
     // ---- LDS-DMA: per unit one wave-uniform global base (SGPRs) + LDS byte address; pieces j = 0, 1 are consecutive KBs
     // (the instruction's immediate offset applies to both sides).  Element offsets.
@@ -189,7 +191,9 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
         const bool isb = slot >= 8;
         const int s = slot & 7;
         const bf16_t* base = isb ? p.B : p.A;
-        const int KBx = isb ? p.KBb : p.KBa, ob = isb ? nb : mb;
+        const int KBx = isb ? p.KBb : p.KBa;
+        int ob = isb ? nb : mb;
+        if (P1_ABL_HOTDMA) { ob = 0; kt = 0; }
         if (TR) return base + ((size_t)(kt >> 1) * KBx + 8 * ob + s) * P1_TILE + (kt & 1) * P1_SLOT;
         return base + ((size_t)(2 * ob + (s >> 2)) * KBx + 2 * kt + (s & 1)) * P1_TILE + ((s >> 1) & 1) * P1_SLOT;
     };
@@ -260,18 +264,29 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
         if (nkt > 1) { P1_DMA_UNIT(0, 1, 1); P1_DMA_UNIT(1, 1, 1); P1_DMA_UNIT(2, 1, 1); P1_DMA_UNIT(3, 1, 1); }
     };
 
-#define P1_MMA(ih, jj, rs)                                                                                              \
+#ifndef P1_DMA_IN_COMPUTE
+#define P1_DMA_IN_COMPUTE 0
+#endif
+/* MID: statement issued between the two halves of the phase's MFMA burst (P1_DMA_IN_COMPUTE: this phase's LDS-DMA unit, so that
+   the LOAD segment holds nothing but the fragment reads) */
+#define P1_MMA(ih, jj, rs, ...)                                                                                         \
     do {                                                                                                               \
         __builtin_amdgcn_s_setprio(1);                                                                                 \
         if constexpr (S16) {                                                                                           \
-            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)           \
-                _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                        \
-                    a4[4 * (ih) + rt][2 * (jj) + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
-                        fa[2 * kk + (rt >> 1)][rt & 1], fb[rs][2 * kk + ct], a4[4 * (ih) + rt][2 * (jj) + ct], 0, 0, 0);  \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                          \
+                _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                        \
+                    _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                    \
+                        a4[4 * (ih) + rt][2 * (jj) + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
+                            fa[2 * kk + (rt >> 1)][rt & 1], fb[rs][2 * kk + ct], a4[4 * (ih) + rt][2 * (jj) + ct], 0, 0, 0); \
+                if (kk == 0) { __builtin_amdgcn_sched_barrier(0); __VA_ARGS__; __builtin_amdgcn_sched_barrier(0); }     \
+            }                                                                                                          \
         } else {                                                                                                       \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)               \
-                acc[S16 ? 0 : 2 * (ih) + ii][S16 ? 0 : jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                     \
-                    fa[q][ii], fb[rs][q], acc[S16 ? 0 : 2 * (ih) + ii][S16 ? 0 : jj], 0, 0, 0);                           \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                             \
+                _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                        \
+                    acc[S16 ? 0 : 2 * (ih) + ii][S16 ? 0 : jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                 \
+                        fa[q][ii], fb[rs][q], acc[S16 ? 0 : 2 * (ih) + ii][S16 ? 0 : jj], 0, 0, 0);                       \
+                if (q == 1) { __builtin_amdgcn_sched_barrier(0); __VA_ARGS__; __builtin_amdgcn_sched_barrier(0); }      \
+            }                                                                                                          \
         }                                                                                                              \
         __builtin_amdgcn_s_setprio(0);                                                                                 \
     } while (0)
@@ -279,14 +294,14 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
    waves 0-3 is the opening barrier of waves 4-7, so a wait that must precede a read which waves 0-3 issue right after their
    closing barrier has to sit before the opening one (before the closing one it let waves 0-3 read pieces whose DMA waves 4-7 had
    not waited for yet: a rare mismatch of a weight gradient on a cold first launch). */
-#define P1_SYNC_COMPUTE(ih, jj, rs, vmw)                                                                               \
+#define P1_SYNC_COMPUTE(ih, jj, rs, vmw, ...)                                                                             \
     do {                                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         if constexpr ((vmw) >= 0) __builtin_amdgcn_s_waitcnt(vmcnt_imm((vmw) >= 0 ? (vmw) : 0));                       \
         __builtin_amdgcn_s_barrier();                                                                                  \
         __builtin_amdgcn_s_waitcnt(0xC07F);          /* lgkmcnt(0): this phase's fragments are in registers */         \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        P1_MMA(ih, jj, rs);                                                                                            \
+        P1_MMA(ih, jj, rs, __VA_ARGS__);                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         __builtin_amdgcn_s_barrier();                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
@@ -317,13 +332,21 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
             fa[q][0] = S16 ? rd_a16(cur, 0, 2 * (q & 1), q >> 1) : rd_a(cur, 0, q);
             fa[q][1] = S16 ? rd_a16(cur, 0, 2 * (q & 1) + 1, q >> 1) : rd_a(cur, 1, q);
         }
-        if (!HEAD && has1) P1_DMA_UNIT(2, tl + 1, CUR ^ 1);
-        P1_SYNC_COMPUTE(0, 0, X, -1);
+        if constexpr (P1_DMA_IN_COMPUTE) {
+            P1_SYNC_COMPUTE(0, 0, X, -1, if (!HEAD && has1) P1_DMA_UNIT(2, tl + 1, CUR ^ 1));
+        } else {
+            if (!HEAD && has1) P1_DMA_UNIT(2, tl + 1, CUR ^ 1);
+            P1_SYNC_COMPUTE(0, 0, X, -1, (void)0);
+        }
         // ---- phase 1: (first 64 rows, second 32 cols)
 #pragma unroll
         for (int q = 0; q < 4; ++q) fb[Y][q] = S16 ? rd_b16(cur, 2 + (q & 1), q >> 1) : rd_b(cur, 1, q);
-        if (!HEAD && has1) P1_DMA_UNIT(3, tl + 1, CUR ^ 1);
-        P1_SYNC_COMPUTE(0, 1, Y, -1);
+        if constexpr (P1_DMA_IN_COMPUTE) {
+            P1_SYNC_COMPUTE(0, 1, Y, -1, if (!HEAD && has1) P1_DMA_UNIT(3, tl + 1, CUR ^ 1));
+        } else {
+            if (!HEAD && has1) P1_DMA_UNIT(3, tl + 1, CUR ^ 1);
+            P1_SYNC_COMPUTE(0, 1, Y, -1, (void)0);
+        }
         // ---- phase 2: (second 64 rows, second 32 cols).  Before its OPENING barrier: unit U1 of step t+1 (B cols 0-31, issued
         // >= 3 phases ago) has landed - younger operations: U2, U3 of t+1 (4), U0 of t+2 (2), the previous item's stores (HEAD)
 #pragma unroll
@@ -331,11 +354,13 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
             fa[q][0] = S16 ? rd_a16(cur, 1, 2 * (q & 1), q >> 1) : rd_a(cur, 2, q);
             fa[q][1] = S16 ? rd_a16(cur, 1, 2 * (q & 1) + 1, q >> 1) : rd_a(cur, 3, q);
         }
-        if (has2) {
+        if constexpr (P1_DMA_IN_COMPUTE) {      // U0 of step t+2 is issued after the wait: younger ops are U2, U3 of t+1 only
+            P1_SYNC_COMPUTE(1, 1, Y, 4 + (HEAD ? PEND : 0), if (has2) P1_DMA_UNIT(0, tl + 2, CUR));
+        } else if (has2) {
             P1_DMA_UNIT(0, tl + 2, CUR);
-            P1_SYNC_COMPUTE(1, 1, Y, 6 + (HEAD ? PEND : 0));
+            P1_SYNC_COMPUTE(1, 1, Y, 6 + (HEAD ? PEND : 0), (void)0);
         } else {
-            P1_SYNC_COMPUTE(1, 1, Y, 4 + (HEAD ? PEND : 0));
+            P1_SYNC_COMPUTE(1, 1, Y, 4 + (HEAD ? PEND : 0), (void)0);
         }
         // ---- phase 3: (second 64 rows, first 32 cols): reads fb cols 0-31 of step t+1 into the set phase 2 just released; K step
         // t+1 must have landed whole before the next step's reads
@@ -343,13 +368,19 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) fb[Y][q] = S16 ? rd_b16(nxt, q & 1, q >> 1) : rd_b(nxt, 0, q);
         }
-        if (has2) {
-            P1_DMA_UNIT(1, tl + 2, CUR);
-            __builtin_amdgcn_s_waitcnt(vmcnt_imm(4 + (HEAD ? PEND : 0)));   // everything but U0, U1 of step t+2 (and the stores)
+        if constexpr (P1_DMA_IN_COMPUTE) {      // U1 of step t+2 is issued after the wait: only U0 of t+2 (and the stores) may be open
+            if (has2) __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 + (HEAD ? PEND : 0)));
+            else __builtin_amdgcn_s_waitcnt(vmcnt_imm(HEAD ? PEND : 0));
+            P1_SYNC_COMPUTE(1, 0, X, -1, if (has2) P1_DMA_UNIT(1, tl + 2, CUR));
         } else {
-            __builtin_amdgcn_s_waitcnt(vmcnt_imm(HEAD ? PEND : 0));
+            if (has2) {
+                P1_DMA_UNIT(1, tl + 2, CUR);
+                __builtin_amdgcn_s_waitcnt(vmcnt_imm(4 + (HEAD ? PEND : 0)));   // everything but U0, U1 of step t+2 (and the stores)
+            } else {
+                __builtin_amdgcn_s_waitcnt(vmcnt_imm(HEAD ? PEND : 0));
+            }
+            P1_SYNC_COMPUTE(1, 0, X, -1, (void)0);
         }
-        P1_SYNC_COMPUTE(1, 0, X, -1);
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
