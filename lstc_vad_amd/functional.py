@@ -963,6 +963,20 @@ class MHAClsFunction(torch.autograd.Function):
         return dx, dwq, dwk, dwv, dwfc, dln_w, dln_b, dtable, None
 
 
+_PAD_HIDDEN = os.environ.get("LSTC_NO_PAD_HIDDEN", "0") != "1"
+
+
+def _padded_hidden(F: int) -> int:
+    """Width the FFN block runs at for n_hidden = F: the next multiple of 256 (full GEMM tiles in every mode, packed bf16
+    hidden) when that adds at most 5 % of columns, else the next multiple of 4 (16-B aligned rows); F itself when aligned."""
+    if not _PAD_HIDDEN or F % 256 == 0:
+        return F
+    up = (F + 255) // 256 * 256
+    if (up - F) * 20 <= F:
+        return up
+    return (F + 3) // 4 * 4
+
+
 class FFNFunction(torch.autograd.Function):
     """models/FFN.py:14-22: LN?( dropout(W2 relu(W1 x + b1) + b2) + x )."""
 
@@ -975,6 +989,21 @@ class FFNFunction(torch.autograd.Function):
         seed = next_seed() if p > 0 else 0
         if p > 0:
             _note(cfg["site"] + "dropout", p, seed, shape)
+        F = w1.shape[0]
+        Fp = _padded_hidden(F)
+        ctx.F = F
+        if Fp != F:
+            # hidden width that leaves rows unaligned (the reference's STN: n_hidden = 3027): run the block at the padded width with
+            # zero rows / columns / bias entries appended to W1, b1, W2 - the extra hidden units are relu(0) = 0 and meet zero
+            # weights, so y, dx and the real rows of every gradient are unchanged, and all five products with the hidden in
+            # them take the aligned (vector-load, full-tile, packable) paths
+            w1p = torch.zeros((Fp, dm), device=x2.device, dtype=torch.float32)
+            w1p[:F].copy_(w1)
+            b1p = torch.zeros((Fp,), device=x2.device, dtype=torch.float32)
+            b1p[:F].copy_(b1)
+            w2p = torch.zeros((w2.shape[0], Fp), device=x2.device, dtype=torch.float32)
+            w2p[:, :F].copy_(w2)
+            w1, b1, w2 = w1p, b1p, w2p
         xp = maybe_pack(x2)
         if xp is not None and packed_out_shape(x2.shape[0], w1.shape[0]) and w2.shape[0] >= max(_x3_min[0], 1):
             # bf16 mode: the hidden exists only as the packed bf16 operand W2 (and dW2, and the ReLU mask of the backward) reads
@@ -1011,6 +1040,8 @@ class FFNFunction(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = gemm(dh1, w1, residual=dy).view(c["shape"])
+        if w1.shape[0] != ctx.F:          # padded hidden width: the real rows / columns of the gradients
+            dw1, db1, dw2 = dw1[:ctx.F], db1[:ctx.F].contiguous(), dw2[:, :ctx.F].contiguous()
         return dx, dw1, db1, dw2, db2, dln_w, dln_b, None
 
 

@@ -111,6 +111,35 @@ def test_training_step_matches_reference_golden(name, cls_only):
             assert float(diff.max()) <= 4 * lr + 1e-6, (k, float(diff.max()))
 
 
+def test_unaligned_hidden_width_matches_golden_padded_and_unpadded(monkeypatch):
+    """n_hidden = 47 (the reduced stand-in of the reference's STN n_hidden = 3027): the FFN block normally runs at the padded
+    width 48 (zero rows / columns appended to W1, b1, W2 - functional._padded_hidden); with the padding off the same step
+    goes through the scalar-load GEMM instantiations at the true width.  Both match the reference golden (the padded arm
+    is the parametrized test above); the two arms agree with each other to rounding, gradients included."""
+    from lstc_vad_amd import functional as Fn
+    assert Fn._padded_hidden(47) == 48 and Fn._padded_hidden(3027) == 3072 and Fn._padded_hidden(4096) == 4096
+    assert Fn._padded_hidden(40) == 40 and Fn._padded_hidden(300) == 300 and Fn._padded_hidden(250) == 256
+    grads = {}
+    for pad in (True, False):
+        monkeypatch.setattr(Fn, "_PAD_HIDDEN", pad)
+        test_training_step_matches_reference_golden("stn_sht", False)
+        z, mode, ekw, skw = load_case("stn_sht")
+        d = ekw["d_model"]
+        enc, head = _models(mode, ekw, d)
+        enc.load_state_dict(sub(z, "enc_init."), strict=True)
+        head.load_state_dict(sub(z, "head_init."), strict=True)
+        enc, head = enc.to(DEV).train(), head.to(DEV).train()
+        nf, af, al = (torch.from_numpy(z[k]).to(DEV) for k in ("norm_feats", "abnorm_feats", "abnorm_labs"))
+        _, _, loss, _ = _step(enc, head, mode, _args(mode, skw), nf, af, al, d, False)
+        loss.backward()
+        grads[pad] = {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None}
+    assert set(grads[True]) == set(grads[False])
+    for k in grads[True]:
+        assert grads[True][k].shape == grads[False][k].shape, k
+        tol = 1e-5 * float(grads[False][k].abs().max()) + 1e-8
+        assert max_abs_diff(grads[True][k], grads[False][k]) <= tol, (k, max_abs_diff(grads[True][k], grads[False][k]), tol)
+
+
 @pytest.mark.parametrize("name", ["ltn_sht", "stn_sht", "ltn_ubnormal"])
 def test_eval_mode_and_short_tail(name):
     z, mode, ekw, skw = load_case(name)
@@ -771,7 +800,7 @@ def test_full_width_training_step_matches_reference_golden(name, cls_only):
     gradient and the weights after two Adagrad steps against the real reference's run (tests/golden/make_golden.py
     ``run_full_case``; sampled entries + norms, weights regenerate from the seed).  This is the oracle check of the
     production-size backward: PIPE 5 steady loop in NT/NN/TN, batched split-K weight gradients, attn_bwd at d_k = 256,
-    the scalar-load GEMM path of n_hidden = 3027."""
+    n_hidden = 3027 at its padded width 3072 (test_full_width_unpadded_hidden_... below runs the scalar-load path)."""
     from cases import sample_index
     from lstc_vad_amd.optim import Adagrad
     z, mode, skw, d, enc, head, nf, af, al = _full_width_models(name)
@@ -823,6 +852,14 @@ def test_full_width_training_step_matches_reference_golden(name, cls_only):
             assert float((w - init[(pre, k)].reshape(-1)).abs().max()) > 0 or z[f"{pre}_w2s.{k}"].size == 0 or \
                 np.array_equal(z[f"{pre}_w2s.{k}"], init[(pre, k)].reshape(-1)[idx].cpu().numpy())
 
+
+
+def test_full_width_unpadded_hidden_takes_the_scalar_load_path_and_matches_golden(monkeypatch):
+    """stn_full with the hidden-width padding off: the five products that touch the [tokens, 3027] hidden run the
+    unaligned (scalar-load) GEMM instantiations at production size, against the same reference golden."""
+    from lstc_vad_amd import functional as Fn
+    monkeypatch.setattr(Fn, "_PAD_HIDDEN", False)
+    test_full_width_training_step_matches_reference_golden("stn_full", True)
 
 @pytest.mark.parametrize("name", ["ltn_sht", "stn_sht", "stn_mil_ce"])
 def test_two_emulated_ranks_through_trainstep(name):
