@@ -997,13 +997,19 @@ class FFNFunction(torch.autograd.Function):
             # zero rows / columns / bias entries appended to W1, b1, W2 - the extra hidden units are relu(0) = 0 and meet zero
             # weights, so y, dx and the real rows of every gradient are unchanged, and all five products with the hidden in
             # them take the aligned (vector-load, full-tile, packable) paths
-            w1p = torch.zeros((Fp, dm), device=x2.device, dtype=torch.float32)
-            w1p[:F].copy_(w1)
-            b1p = torch.zeros((Fp,), device=x2.device, dtype=torch.float32)
-            b1p[:F].copy_(b1)
-            w2p = torch.zeros((w2.shape[0], Fp), device=x2.device, dtype=torch.float32)
-            w2p[:, :F].copy_(w2)
-            w1, b1, w2 = w1p, b1p, w2p
+            # (copies cached on the W1 parameter until the weights change: evaluation loops call the block per video)
+            stamp = (_wepoch, Fp, w1._version, b1._version, w2._version, w1.data_ptr(), b1.data_ptr(), w2.data_ptr())
+            hit = w1.__dict__.get("_lstc_padded")
+            if hit is None or hit[0] != stamp:
+                w1p = torch.zeros((Fp, dm), device=x2.device, dtype=torch.float32)
+                w1p[:F].copy_(w1.detach())
+                b1p = torch.zeros((Fp,), device=x2.device, dtype=torch.float32)
+                b1p[:F].copy_(b1.detach())
+                w2p = torch.zeros((w2.shape[0], Fp), device=x2.device, dtype=torch.float32)
+                w2p[:, :F].copy_(w2.detach())
+                hit = (stamp, (w1p, b1p, w2p))
+                w1.__dict__["_lstc_padded"] = hit
+            w1, b1, w2 = hit[1]
         xp = maybe_pack(x2)
         if xp is not None and packed_out_shape(x2.shape[0], w1.shape[0]) and w2.shape[0] >= max(_x3_min[0], 1):
             # bf16 mode: the hidden exists only as the packed bf16 operand W2 (and dW2, and the ReLU mask of the backward) reads
