@@ -166,12 +166,14 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
 #define P1_ABL_NOSTORE (p.debug & 16)      /* epilogue arithmetic, no store instruction */
 #define P1_ABL_L2STORE (p.debug & 32)      /* every tile stores into rows 0-255 (the output stays in L2) */
 #define P1_ABL_HOTDMA (p.debug & 64)       /* every DMA reads K step 0 of tile (0, 0): same instruction stream, always cache hits */
+#define P1_ABL_NOXPOSE (p.debug & 128)     /* fast epilogue without the quad transposes / 16-lane exchange (values land in wrong places) */
 #else
 #define P1_ABL_DMA 0
 #define P1_ABL_RD 0
 #define P1_ABL_NOSTORE 0
 #define P1_ABL_L2STORE 0
 #define P1_ABL_HOTDMA 0
+#define P1_ABL_NOXPOSE 0
 #endif
     // ---- LDS-DMA: per unit one wave-uniform global base (SGPRs) + LDS byte address; pieces j = 0, 1 are consecutive KBs
     // (the instruction's immediate offset applies to both sides).  Element offsets.
@@ -442,7 +444,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
             fastepi = p.vec_epi && !(p.splits > 1 && p.split_stride == 0) && !(f_ & LSTC_EPI_ACCUM) &&
                       !((f_ & LSTC_EPI_RESIDUAL) && (f_ & LSTC_EPI_RELU_MASK)) && (cmb + 1) * 256 <= p.M && (cnb + 1) * 256 <= p.N;
 #ifdef LSTC_TUNING
-            if (p.debug) fastepi = false;
+            if (p.debug & ~128) fastepi = false;
 #endif
             if (fastepi && (f_ & LSTC_EPI_BIAS)) {
 #pragma unroll
@@ -596,15 +598,17 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                         float x2 = a4[S16 ? rt : 0][S16 ? 2 * cp2 : 0][2], x3 = a4[S16 ? rt : 0][S16 ? 2 * cp2 : 0][3];
                         float y0 = a4[S16 ? rt : 0][S16 ? 2 * cp2 + 1 : 0][0], y1 = a4[S16 ? rt : 0][S16 ? 2 * cp2 + 1 : 0][1];
                         float y2 = a4[S16 ? rt : 0][S16 ? 2 * cp2 + 1 : 0][2], y3 = a4[S16 ? rt : 0][S16 ? 2 * cp2 + 1 : 0][3];
+                        if (!P1_ABL_NOXPOSE) {
                         xpose2(x0, x1, x2, x3);
                         xpose2(y0, y1, y2, y3);
+                        }
                         typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 #define P1_SWAP(x, y)                                                                                                    \
                         do {                                                                                             \
                             const uint2v r_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false); \
                             x = __uint_as_float(r_[0]); y = __uint_as_float(r_[1]);                                       \
                         } while (0)
-                        P1_SWAP(x0, y0); P1_SWAP(x1, y1); P1_SWAP(x2, y2); P1_SWAP(x3, y3);
+                        if (!P1_ABL_NOXPOSE) { P1_SWAP(x0, y0); P1_SWAP(x1, y1); P1_SWAP(x2, y2); P1_SWAP(x3, y3); }
 #undef P1_SWAP
                         P1_FE_GROUP(x0, x1, x2, x3, rt, 0, cp2, fbias[cp2], ax[b & 1][2 * r2], axp[MPK ? (b & 1) : 0][MPK ? 2 * r2 : 0]);
                         P1_FE_GROUP(y0, y1, y2, y3, rt, 1, cp2, fbias[cp2], ax[b & 1][2 * r2 + 1], axp[MPK ? (b & 1) : 0][MPK ? 2 * r2 + 1 : 0]);
