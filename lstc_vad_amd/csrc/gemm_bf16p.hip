@@ -269,6 +269,9 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
 #ifndef P1_DMA_IN_COMPUTE
 #define P1_DMA_IN_COMPUTE 0
 #endif
+#ifndef P1_DMA_FIRST
+#define P1_DMA_FIRST 0        /* 1: a LOAD segment issues its LDS-DMA unit BEFORE its fragment reads */
+#endif
 /* MID: statement issued between the two halves of the phase's MFMA burst (P1_DMA_IN_COMPUTE: this phase's LDS-DMA unit, so that
    the LOAD segment holds nothing but the fragment reads) */
 #define P1_MMA(ih, jj, rs, ...)                                                                                         \
@@ -329,6 +332,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
             for (int q = 0; q < 4; ++q) fb[X][q] = S16 ? rd_b16(cur, q & 1, q >> 1) : rd_b(cur, 0, q);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (P1_DMA_FIRST) { if (!HEAD && has1) P1_DMA_UNIT(2, tl + 1, CUR ^ 1); }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             fa[q][0] = S16 ? rd_a16(cur, 0, 2 * (q & 1), q >> 1) : rd_a(cur, 0, q);
@@ -337,20 +341,22 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
         if constexpr (P1_DMA_IN_COMPUTE) {
             P1_SYNC_COMPUTE(0, 0, X, -1, if (!HEAD && has1) P1_DMA_UNIT(2, tl + 1, CUR ^ 1));
         } else {
-            if (!HEAD && has1) P1_DMA_UNIT(2, tl + 1, CUR ^ 1);
+            if constexpr (!P1_DMA_FIRST) { if (!HEAD && has1) P1_DMA_UNIT(2, tl + 1, CUR ^ 1); }
             P1_SYNC_COMPUTE(0, 0, X, -1, (void)0);
         }
         // ---- phase 1: (first 64 rows, second 32 cols)
+        if constexpr (P1_DMA_FIRST) { if (!HEAD && has1) P1_DMA_UNIT(3, tl + 1, CUR ^ 1); }
 #pragma unroll
         for (int q = 0; q < 4; ++q) fb[Y][q] = S16 ? rd_b16(cur, 2 + (q & 1), q >> 1) : rd_b(cur, 1, q);
         if constexpr (P1_DMA_IN_COMPUTE) {
             P1_SYNC_COMPUTE(0, 1, Y, -1, if (!HEAD && has1) P1_DMA_UNIT(3, tl + 1, CUR ^ 1));
         } else {
-            if (!HEAD && has1) P1_DMA_UNIT(3, tl + 1, CUR ^ 1);
+            if constexpr (!P1_DMA_FIRST) { if (!HEAD && has1) P1_DMA_UNIT(3, tl + 1, CUR ^ 1); }
             P1_SYNC_COMPUTE(0, 1, Y, -1, (void)0);
         }
         // ---- phase 2: (second 64 rows, second 32 cols).  Before its OPENING barrier: unit U1 of step t+1 (B cols 0-31, issued
         // >= 3 phases ago) has landed - younger operations: U2, U3 of t+1 (4), U0 of t+2 (2), the previous item's stores (HEAD)
+        if constexpr (P1_DMA_FIRST) { if (has2) P1_DMA_UNIT(0, tl + 2, CUR); }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             fa[q][0] = S16 ? rd_a16(cur, 1, 2 * (q & 1), q >> 1) : rd_a(cur, 2, q);
@@ -359,13 +365,14 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
         if constexpr (P1_DMA_IN_COMPUTE) {      // U0 of step t+2 is issued after the wait: younger ops are U2, U3 of t+1 only
             P1_SYNC_COMPUTE(1, 1, Y, 4 + (HEAD ? PEND : 0), if (has2) P1_DMA_UNIT(0, tl + 2, CUR));
         } else if (has2) {
-            P1_DMA_UNIT(0, tl + 2, CUR);
+            if constexpr (!P1_DMA_FIRST) P1_DMA_UNIT(0, tl + 2, CUR);
             P1_SYNC_COMPUTE(1, 1, Y, 6 + (HEAD ? PEND : 0), (void)0);
         } else {
             P1_SYNC_COMPUTE(1, 1, Y, 4 + (HEAD ? PEND : 0), (void)0);
         }
         // ---- phase 3: (second 64 rows, first 32 cols): reads fb cols 0-31 of step t+1 into the set phase 2 just released; K step
         // t+1 must have landed whole before the next step's reads
+        if constexpr (P1_DMA_FIRST) { if (has2) P1_DMA_UNIT(1, tl + 2, CUR); }
         if (has1) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) fb[Y][q] = S16 ? rd_b16(nxt, q & 1, q >> 1) : rd_b(nxt, 0, q);
@@ -376,7 +383,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
             P1_SYNC_COMPUTE(1, 0, X, -1, if (has2) P1_DMA_UNIT(1, tl + 2, CUR));
         } else {
             if (has2) {
-                P1_DMA_UNIT(1, tl + 2, CUR);
+                if constexpr (!P1_DMA_FIRST) P1_DMA_UNIT(1, tl + 2, CUR);
                 __builtin_amdgcn_s_waitcnt(vmcnt_imm(4 + (HEAD ? PEND : 0)));   // everything but U0, U1 of step t+2 (and the stores)
             } else {
                 __builtin_amdgcn_s_waitcnt(vmcnt_imm(HEAD ? PEND : 0));
