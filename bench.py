@@ -419,7 +419,7 @@ def main():
         kname = {"fp32": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
                  "f32x3": "gemm_pk2s_kernel (3 x v_mfma_f32_32x32x16_f16 per f32 product, packed 2-plane operands; small products "
                           "on gemm_f32_kernel)",
-                 "bf16": "gemm_bf16p_kernel (v_mfma_f32_32x32x16_bf16 on packed bf16 tiles streamed by LDS-DMA, 256x256x64; small / batched products on gemm_bf16c_kernel)"}[dtype]
+                 "bf16": "gemm_bf16p_kernel (v_mfma_f32_16x16x32_bf16 (forward / input-gradient form) and v_mfma_f32_32x32x16_bf16 (weight-gradient form) on packed bf16 tiles streamed by LDS-DMA, 256x256x64; small / batched products on gemm_bf16c_kernel)"}[dtype]
         k = res["prof_steps"]
         roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": len(prof) // k,
