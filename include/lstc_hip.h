@@ -336,6 +336,18 @@ int lstc_vad_loss(const LstcLossDesc* d, void* stream);
  * `gscale` carries the clip_grad_norm_ coefficient (:139-141) or 1. */
 int lstc_adagrad_step(float* w, const float* grad, float* state, int64_t n, float lr, float weight_decay,
                       float eps, float gscale, void* stream);
+
+/* The same update for every parameter of an optimizer step in ONE launch (the reference's Adagrad loops over ~45 tensors,
+ * torch/optim/adagrad.py; here the items ride in the kernel arguments, 48 per launch).  `items` is a HOST array; element
+ * arithmetic and order are those of lstc_adagrad_step - bit-identical results. */
+typedef struct LstcAdagradItem {
+    float* w;
+    const float* grad;
+    float* state;
+    int64_t n;
+    float lr, weight_decay, eps, grad_scale;
+} LstcAdagradItem;
+int lstc_adagrad_multi(const LstcAdagradItem* items, int32_t count, void* stream);
 /* out[0] += sum(x^2) (f32 atomics over workgroup partials; caller zeroes) — for clip_grad_norm_. */
 int lstc_sqnorm_accum(const float* x, int64_t n, float* out, void* stream);
 

@@ -23,7 +23,7 @@ EXPORTS = (
     "lstc_cls_outer", "lstc_layernorm_fwd", "lstc_layernorm_bwd", "lstc_layernorm_fwd_pack",
     "lstc_layernorm_bwd_drop_pack", "lstc_layernorm_bwd_drop",
     "lstc_cls_concat_fwd", "lstc_cls_concat_fwd_pack", "lstc_cls_concat_bwd", "lstc_colsum", "lstc_dropout_apply", "lstc_dropout_mask",
-    "lstc_head_out_fwd", "lstc_head_out_bwd", "lstc_vad_loss", "lstc_adagrad_step", "lstc_sqnorm_accum", "lstc_scale",
+    "lstc_head_out_fwd", "lstc_head_out_bwd", "lstc_vad_loss", "lstc_adagrad_step", "lstc_adagrad_multi", "lstc_sqnorm_accum", "lstc_scale",
     "lstc_gather_rows", "lstc_cast_f32_bf16", "lstc_cast_bf16_f32", "lstc_pack3", "lstc_pack3_bytes", "lstc_pack1", "lstc_pack1_bytes", "lstc_colsum_pack1", "lstc_gemm_splits",
     "lstc_version", "lstc_strerror",
 )
@@ -53,6 +53,12 @@ class AttnDesc(C.Structure):
                 ("dQ_pack", C.c_void_p), ("dK_pack", C.c_void_p), ("dV_pack", C.c_void_p),
                 ("pack_cols", C.c_int32), ("dQ_col0", C.c_int32), ("dK_col0", C.c_int32), ("dV_col0", C.c_int32),
                 ("O_pack", C.c_void_p)]
+
+
+class AdagradItem(C.Structure):
+    """LstcAdagradItem (include/lstc_hip.h)."""
+    _fields_ = [("w", C.c_void_p), ("grad", C.c_void_p), ("state", C.c_void_p), ("n", C.c_int64),
+                ("lr", C.c_float), ("weight_decay", C.c_float), ("eps", C.c_float), ("grad_scale", C.c_float)]
 
 
 class LossDesc(C.Structure):
@@ -102,6 +108,7 @@ def load():
         "lstc_head_out_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],
         "lstc_vad_loss": [C.POINTER(LossDesc), vp],
         "lstc_adagrad_step": [vp, vp, vp, i64, f32, f32, f32, f32, vp],
+        "lstc_adagrad_multi": [C.POINTER(AdagradItem), i32, vp],
         "lstc_sqnorm_accum": [vp, i64, vp, vp],
         "lstc_scale": [vp, i64, f32, vp],
         "lstc_gather_rows": [vp, i64, vp, vp, i64, i64, vp],

@@ -590,6 +590,61 @@ __global__ void __launch_bounds__(NT) adagrad_kernel(float* __restrict__ w, cons
     }
 }
 
+// All parameters of an optimizer step in ONE launch: up to ADA_MAX tensors ride in the kernel arguments (no device-side table,
+// no host-to-device copy); a workgroup finds its tensor by scanning the prefix of workgroup counts and then runs the same
+// element update as adagrad_kernel on its slice.  Element arithmetic and order are adagrad_kernel's: results are bit-identical.
+constexpr int ADA_MAX = 48;
+constexpr int ADA_PER_WG = NT * 4 * 8;        // elements per workgroup: 8 float4 per thread
+struct AdaBatch {
+    float* w[ADA_MAX];
+    const float* g[ADA_MAX];
+    float* s[ADA_MAX];
+    long long n[ADA_MAX];
+    float lr[ADA_MAX], wd[ADA_MAX], eps[ADA_MAX], gscale[ADA_MAX];
+    int first_wg[ADA_MAX + 1];
+    int count;
+};
+__global__ void __launch_bounds__(NT) adagrad_multi_kernel(const AdaBatch b) {
+    int t = 0;
+    while (t + 1 < b.count && (int)blockIdx.x >= b.first_wg[t + 1]) ++t;          // wave-uniform scan (scalar loads of the arguments)
+    float* __restrict__ w = b.w[t];
+    const float* __restrict__ g = b.g[t];
+    float* __restrict__ s = b.s[t];
+    const int64_t n = b.n[t];
+    const float lr = b.lr[t], wd = b.wd[t], eps = b.eps[t], gscale = b.gscale[t];
+    const int64_t e0 = (int64_t)((int)blockIdx.x - b.first_wg[t]) * ADA_PER_WG;
+    const int64_t e1 = min(n, e0 + ADA_PER_WG);
+    const bool vec = aligned16(w) && aligned16(g) && aligned16(s);
+    if (vec) {
+        const int64_t v1 = e1 == n ? (n >> 2) : (e1 >> 2);
+        for (int64_t i = (e0 >> 2) + threadIdx.x; i < v1; i += NT) {
+            float4 wv = reinterpret_cast<float4*>(w)[i], sv = reinterpret_cast<float4*>(s)[i];
+            const float4 gv = reinterpret_cast<const float4*>(g)[i];
+            float gg;
+            gg = gv.x * gscale + wd * wv.x; sv.x += gg * gg; wv.x -= lr * gg / (sqrtf(sv.x) + eps);
+            gg = gv.y * gscale + wd * wv.y; sv.y += gg * gg; wv.y -= lr * gg / (sqrtf(sv.y) + eps);
+            gg = gv.z * gscale + wd * wv.z; sv.z += gg * gg; wv.z -= lr * gg / (sqrtf(sv.z) + eps);
+            gg = gv.w * gscale + wd * wv.w; sv.w += gg * gg; wv.w -= lr * gg / (sqrtf(sv.w) + eps);
+            reinterpret_cast<float4*>(w)[i] = wv;
+            reinterpret_cast<float4*>(s)[i] = sv;
+        }
+        if (e1 != n) return;
+        for (int64_t i = (n >> 2) * 4 + threadIdx.x; i < n; i += NT) {          // the tensor's last 0-3 elements
+            const float gg = g[i] * gscale + wd * w[i];
+            const float sv = s[i] + gg * gg;
+            s[i] = sv;
+            w[i] -= lr * gg / (sqrtf(sv) + eps);
+        }
+        return;
+    }
+    for (int64_t i = e0 + threadIdx.x; i < e1; i += NT) {
+        const float gg = g[i] * gscale + wd * w[i];
+        const float sv = s[i] + gg * gg;
+        s[i] = sv;
+        w[i] -= lr * gg / (sqrtf(sv) + eps);
+    }
+}
+
 __global__ void __launch_bounds__(NT) sqnorm_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
     __shared__ float red[NT / 64];
     const int64_t stride = (int64_t)gridDim.x * NT;
@@ -838,6 +893,35 @@ int lstc_adagrad_step(float* w, const float* grad, float* state, int64_t n, floa
     hipLaunchKernelGGL(adagrad_kernel, grid_for(n, NT * 4), NT, 0, (hipStream_t)stream, w, grad, state, n, lr,
                        weight_decay, eps, gscale);
     return lstc_launch_status();
+}
+
+int lstc_adagrad_multi(const LstcAdagradItem* items, int32_t count, void* stream) {
+    if (!items) return LSTC_E_NULL;
+    if (count <= 0) return LSTC_E_SHAPE;
+    for (int32_t i = 0; i < count; ++i) {
+        if (!items[i].w || !items[i].grad || !items[i].state) return LSTC_E_NULL;
+        if (items[i].n <= 0) return LSTC_E_SHAPE;
+    }
+    for (int32_t base = 0; base < count; base += ADA_MAX) {
+        AdaBatch b;
+        b.count = count - base < ADA_MAX ? count - base : ADA_MAX;
+        int wg = 0;
+        for (int i = 0; i < b.count; ++i) {
+            const LstcAdagradItem& it = items[base + i];
+            b.w[i] = it.w; b.g[i] = it.grad; b.s[i] = it.state; b.n[i] = it.n;
+            b.lr[i] = it.lr; b.wd[i] = it.weight_decay; b.eps[i] = it.eps; b.gscale[i] = it.grad_scale;
+            b.first_wg[i] = wg;
+            const int64_t nwg = (it.n + ADA_PER_WG - 1) / ADA_PER_WG;
+            if (nwg > 0x7fffffff - wg) return LSTC_E_RANGE;
+            wg += (int)nwg;
+        }
+        b.first_wg[b.count] = wg;
+        for (int i = b.count + 1; i <= ADA_MAX; ++i) b.first_wg[i] = wg;
+        hipLaunchKernelGGL(adagrad_multi_kernel, dim3((unsigned)wg), NT, 0, (hipStream_t)stream, b);
+        const int rc = lstc_launch_status();
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int lstc_scale(float* x, int64_t n, float alpha, void* stream) {

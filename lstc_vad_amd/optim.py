@@ -30,7 +30,7 @@ class Adagrad(torch.optim.Optimizer):
     def step(self, closure=None, grad_scales=None):
         """``grad_scales``: optional {group index: device-or-host scale} from ``clip_grad_norm_`` below."""
         lib = _lib.load()
-        st = stream_ptr()
+        items, keep = [], []
         for gi, group in enumerate(self.param_groups):
             gs = 1.0 if not grad_scales else float(grad_scales.get(gi, 1.0))
             for p in group["params"]:
@@ -39,9 +39,12 @@ class Adagrad(torch.optim.Optimizer):
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 state = self.state[p]
                 state["step"] += 1
-                check(lib.lstc_adagrad_step(dev_ptr(p.data), dev_ptr(g), dev_ptr(state["sum"]), p.numel(),
-                                            float(group["lr"]), float(group["weight_decay"]), float(group["eps"]),
-                                            gs, st), "lstc_adagrad_step")
+                keep.append(g)
+                items.append((dev_ptr(p.data), dev_ptr(g), dev_ptr(state["sum"]), p.numel(), float(group["lr"]),
+                              float(group["weight_decay"]), float(group["eps"]), gs))
+        if items:           # every parameter in ONE launch (lstc_adagrad_multi; element arithmetic of lstc_adagrad_step)
+            arr = (_lib.AdagradItem * len(items))(*items)
+            check(lib.lstc_adagrad_multi(arr, len(items), stream_ptr()), "lstc_adagrad_multi")
         from .functional import bump_weight_epoch
         bump_weight_epoch()          # weights changed through raw pointers: packed copies (f32x3 GEMM) are stale
         return None

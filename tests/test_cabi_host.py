@@ -37,8 +37,8 @@ def test_descriptor_layouts_match_header(lib, tmp_path):
     """The ctypes mirrors against the C compiler's own layout of include/lstc_hip.h: sizeof and the offset of every field of
     the three descriptors (a C program built with gcc prints them)."""
     import subprocess
-    from lstc_vad_amd._lib import GemmDesc, AttnDesc, LossDesc
-    structs = {"LstcGemmDesc": GemmDesc, "LstcAttnDesc": AttnDesc, "LstcLossDesc": LossDesc}
+    from lstc_vad_amd._lib import GemmDesc, AttnDesc, LossDesc, AdagradItem
+    structs = {"LstcGemmDesc": GemmDesc, "LstcAttnDesc": AttnDesc, "LstcLossDesc": LossDesc, "LstcAdagradItem": AdagradItem}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "lstc_hip.h"', 'int main(void) {']
     for cname, ct in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -100,6 +100,15 @@ def test_host_side_validation_error_codes(lib):
     assert lib.lstc_vad_loss(C.byref(l), None) == -1
     assert lib.lstc_layernorm_fwd(None, None, None, None, None, None, 1, 1, 1e-6, None) == -1
     assert lib.lstc_adagrad_step(16, 16, 16, 0, 0.1, 0.0, 1e-10, 1.0, None) == -2
+    from lstc_vad_amd._lib import AdagradItem
+    assert lib.lstc_adagrad_multi(None, 1, None) == -1
+    it = (AdagradItem * 2)()
+    it[0].w = it[0].grad = it[0].state = 16
+    it[0].n = 8
+    assert lib.lstc_adagrad_multi(it, 0, None) == -2
+    assert lib.lstc_adagrad_multi(it, 2, None) == -1           # second item has NULL pointers
+    it[1].w = it[1].grad = it[1].state = 16
+    assert lib.lstc_adagrad_multi(it, 2, None) == -2           # ... and n = 0
     assert b"NULL" in lib.lstc_strerror(-1) and lib.lstc_strerror(0) == b"ok"
 
 

@@ -140,6 +140,36 @@ def test_unaligned_hidden_width_matches_golden_padded_and_unpadded(monkeypatch):
         assert max_abs_diff(grads[True][k], grads[False][k]) <= tol, (k, max_abs_diff(grads[True][k], grads[False][k]), tol)
 
 
+def test_multi_tensor_adagrad_is_bitwise_the_per_tensor_kernel():
+    """lstc_adagrad_multi (every parameter of a step in one launch, items in the kernel arguments, 48 per launch) against
+    lstc_adagrad_step tensor by tensor: weights and accumulators bit-identical - 60 tensors (two launches), sizes that are
+    not multiples of 4, of the per-workgroup slice (8192) or of anything, one unaligned view, per-item lr / decay / scale."""
+    import ctypes as C
+    from lstc_vad_amd import _lib
+    from lstc_vad_amd._lib import AdagradItem, check, dev_ptr, stream_ptr
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    sizes = [1, 3, 4, 5, 17, 1000, 8192, 8193, 16384, 70001, 2048 * 2048 + 3, 512 * 2048] + [257 + 13 * i for i in range(48)]
+    ws, gs, ss = [], [], []
+    for i, n in enumerate(sizes):
+        off = 1 if i == 7 else 0                                    # one tensor whose storage is only 4-B aligned
+        w = torch.randn(n + off, device=DEV, generator=g)[off:]
+        ws.append(w); gs.append(torch.randn(n, device=DEV, generator=g)); ss.append(torch.rand(n, device=DEV, generator=g))
+    hyper = [(1e-2 * (1 + i % 3), 1e-3 * (i % 2), 1e-10, 1.0 if i % 5 else 0.37) for i in range(len(sizes))]
+    w1, s1 = [w.clone() for w in ws], [s.clone() for s in ss]
+    for w, gr, st, (lr, wd, eps, sc) in zip(w1, gs, s1, hyper):
+        check(lib.lstc_adagrad_step(dev_ptr(w), dev_ptr(gr), dev_ptr(st), w.numel(), lr, wd, eps, sc, stream_ptr()), "step")
+    w2, s2 = [w.clone() for w in ws], [s.clone() for s in ss]
+    w2[7] = torch.cat([torch.zeros(1, device=DEV), ws[7]])[1:]      # keep the unaligned case unaligned after the clone
+    arr = (AdagradItem * len(sizes))(*[(dev_ptr(w), dev_ptr(gr), dev_ptr(st), w.numel(), lr, wd, eps, sc)
+                                       for w, gr, st, (lr, wd, eps, sc) in zip(w2, gs, s2, hyper)])
+    check(lib.lstc_adagrad_multi(arr, len(sizes), stream_ptr()), "multi")
+    torch.cuda.synchronize()
+    for i in range(len(sizes)):
+        assert torch.equal(w1[i], w2[i]) and torch.equal(s1[i], s2[i]), (i, sizes[i])
+        assert not torch.equal(w1[i], ws[i])
+
+
 @pytest.mark.parametrize("name", ["ltn_sht", "stn_sht", "ltn_ubnormal"])
 def test_eval_mode_and_short_tail(name):
     z, mode, ekw, skw = load_case(name)
