@@ -456,6 +456,34 @@ __global__ void __launch_bounds__(NT) colsum_pass2(const float* __restrict__ par
     }
 }
 
+// A few rows (the partial products of a split-K weight gradient: 2-8 rows of out*in columns): ONE pass, float4 columns, the
+// summation order of pass 1 + pass 2 on the same input (row p goes to accumulator p & 3 in increasing p, then (a0 + a1) +
+// (a2 + a3)), so the result is bit-identical to the two-pass form - which copied the rows once before adding them.
+__global__ void __launch_bounds__(NT) colsum_few(const float* __restrict__ x, int rows, int cols, int ld, float* __restrict__ out,
+                                                  int accumulate) {
+    const int c4 = (blockIdx.x * NT + threadIdx.x) * 4;
+    if (c4 >= cols) return;
+    float4 a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r0 = 0; r0 < rows; r0 += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (r0 + j < rows) {
+                const float4 v = *reinterpret_cast<const float4*>(x + (size_t)(r0 + j) * ld + c4);
+                a[j].x += v.x; a[j].y += v.y; a[j].z += v.z; a[j].w += v.w;
+            }
+    }
+    float4 s;
+    s.x = (a[0].x + a[1].x) + (a[2].x + a[3].x);
+    s.y = (a[0].y + a[1].y) + (a[2].y + a[3].y);
+    s.z = (a[0].z + a[1].z) + (a[2].z + a[3].z);
+    s.w = (a[0].w + a[1].w) + (a[2].w + a[3].w);
+    float4* o = reinterpret_cast<float4*>(out + c4);
+    if (accumulate) { const float4 q = *o; s.x = q.x + s.x; s.y = q.y + s.y; s.z = q.z + s.z; s.w = q.w + s.w; }
+    *o = s;
+}
+
 // --------------------------------------------------------------------------------- dropout
 __global__ void __launch_bounds__(NT) dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                             int64_t n, DropKey k) {
@@ -834,6 +862,10 @@ int lstc_colsum(const float* x, int64_t rows, int32_t cols, int32_t ld, float* p
     if (rows <= 0 || cols <= 0 || ld < cols || n_partial <= 0) return LSTC_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int np = (int)(rows < n_partial ? rows : n_partial);
+    if (rows <= 12 && rows <= n_partial && cols % 4 == 0 && ld % 4 == 0 && aligned16(x) && aligned16(out)) {
+        hipLaunchKernelGGL(colsum_few, dim3((cols / 4 + NT - 1) / NT), NT, 0, st, x, (int)rows, cols, ld, out, accumulate);
+        return lstc_launch_status();
+    }
     hipLaunchKernelGGL(colsum_pass1, dim3((cols + NT - 1) / NT, np), NT, 0, st, x, rows, cols, ld, partial);
     hipLaunchKernelGGL(colsum_pass2, dim3((cols + 63) / 64), NT, 0, st, partial, np, cols, out, accumulate);
     return lstc_launch_status();

@@ -140,6 +140,37 @@ def test_unaligned_hidden_width_matches_golden_padded_and_unpadded(monkeypatch):
         assert max_abs_diff(grads[True][k], grads[False][k]) <= tol, (k, max_abs_diff(grads[True][k], grads[False][k]), tol)
 
 
+@pytest.mark.parametrize("rows", [1, 2, 3, 4, 7, 12, 13])
+def test_colsum_of_a_few_rows_keeps_the_two_pass_summation_order(rows):
+    """lstc_colsum on the partial products of a split-K weight gradient (2-8 rows of out*in columns) runs ONE pass
+    (colsum_few) with the order of the two-pass form: row p into accumulator p & 3 in increasing p, then (a0 + a1) + (a2 + a3) -
+    restated here with elementwise torch adds (exact IEEE, so equality is bitwise).  13 rows take the two-pass kernels, whose
+    4-way unrolled accumulation is a different order: compared against f64."""
+    from lstc_vad_amd import functional as Fn
+    g = torch.Generator(device=DEV).manual_seed(rows)
+    cols = 2048 * 6 + 8
+    x = torch.randn(rows, cols, device=DEV, generator=g) * 3
+    base = torch.randn(cols, device=DEV, generator=g)
+    got = Fn.colsum(x)
+    acc = Fn.colsum(x, out=base.clone(), accumulate=True)
+    torch.cuda.synchronize()
+    if rows > 12:
+        ref = x.double().sum(0)
+        assert float((got.double() - ref).abs().max()) < 1e-5 and float((acc.double() - (ref + base.double())).abs().max()) < 1e-5
+        return
+    a = [torch.zeros(cols, device=DEV) for _ in range(4)]
+    for p in range(rows):
+        a[p & 3] = a[p & 3] + x[p]
+    want = (a[0] + a[1]) + (a[2] + a[3])
+    assert torch.equal(got, want)
+    assert torch.equal(acc, base + want)
+    odd = torch.randn(rows, 1001, device=DEV, generator=g)           # columns not a multiple of 4: two-pass path, same order here
+    a = [torch.zeros(1001, device=DEV) for _ in range(4)]
+    for p in range(rows):
+        a[p & 3] = a[p & 3] + odd[p]
+    assert torch.equal(Fn.colsum(odd), (a[0] + a[1]) + (a[2] + a[3]))
+
+
 def test_multi_tensor_adagrad_is_bitwise_the_per_tensor_kernel():
     """lstc_adagrad_multi (every parameter of a step in one launch, items in the kernel arguments, 48 per launch) against
     lstc_adagrad_step tensor by tensor: weights and accumulators bit-identical - 60 tensors (two launches), sizes that are
