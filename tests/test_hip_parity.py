@@ -259,7 +259,7 @@ def test_dropout_run_replays_through_oracle(name, cls_only):
     out = orc.forward_loss(enc_P, head_P, ecfg, st, nf.cpu(), af.cpu(), al.cpu(), training=True, masks=masks)
     out["loss"].backward()
     assert max_abs_diff(outputs.reshape(out["outputs"].shape), out["outputs"]) < 1e-4
-    assert abs(float(sc[0]) - float(out["loss"])) < 2e-5
+    assert abs(float(sc[0]) - float(out["loss"].detach())) < 2e-5
     for k, pr in enc.named_parameters():
         if pr.grad is None:
             assert enc_P[k].grad is None, k
