@@ -106,3 +106,21 @@ def test_bench_launches_its_own_ranks(tmp_path):
     t0 = time.time()
     assert bench.launch_ranks(2, [], script=str(bad)) == 1         # rank 1 fails -> rank 0 is stopped, run fails
     assert time.time() - t0 < 20
+
+
+def test_host_shape_rules_of_the_packed_and_padded_paths():
+    """Pure host logic of lstc_vad_amd.functional that decides kernel paths: the width an unaligned FFN hidden runs at, and
+    the shapes for which producers may emit packed bf16 operands (both must agree with what include/lstc_hip.h documents)."""
+    from lstc_vad_amd import functional as Fn
+    assert [Fn._padded_hidden(f) for f in (3027, 4096, 47, 40, 250, 300, 1, 255, 256, 257)] == \
+        [3072, 4096, 48, 40, 256, 300, 4, 256, 256, 260]
+    Fn.set_compute_dtype("bf16")
+    try:
+        assert Fn._attn_dtype() == Fn._lib.BF16
+        assert Fn._fused_pack_shape(100352, 2048) and not Fn._fused_pack_shape(100352 + 128, 2048) and not Fn._fused_pack_shape(100352, 4096)
+        assert Fn.attn_bwd_packs(2048, 49, 8, 256, 256) and Fn.attn_bwd_packs(2048, 81, 8, 128, 128)
+        assert not Fn.attn_bwd_packs(2048, 113, 8, 256, 256) and not Fn.attn_bwd_packs(2048, 49, 8, 48, 48)
+        assert Fn.attn_fwd_pack(2048, 49, 8, 256) and not Fn.attn_fwd_pack(2047, 49, 8, 256)
+    finally:
+        Fn.set_compute_dtype("fp32")
+    assert Fn._attn_dtype() == Fn._lib.F32 and not Fn._fused_pack_shape(100352, 2048)
