@@ -26,6 +26,11 @@ CASES = {
                                            FFN_layerNorm=True, relative_pe=True, window_size=4, window_depth=3),
                                dict(batch_size=2, part_num=3, part_len=3, n_patch=16, temporal_only=True,
                                     clip_grad=True)),
+    # d_k = 32 at S = 81: the shape rules of the LDS-DMA staged attention kernels (d_k, d_v multiples of 32) hold, so this
+    # case runs their 8-wave S > 64 instantiation inside a whole training step (every other reduced case has d_k = 16)
+    "ltn_ubnormal_dk32": ("LTN", dict(d_model=32, n_head=2, d_k=32, d_v=32, d_inner=48, MHA_layerNorm=True,
+                                      FFN_layerNorm=True, relative_pe=True, window_size=4, window_depth=5),
+                          dict(batch_size=2, part_num=2, part_len=5, n_patch=16)),
 }
 
 
