@@ -337,8 +337,9 @@ int lstc_vad_loss(const LstcLossDesc* d, void* stream);
 int lstc_adagrad_step(float* w, const float* grad, float* state, int64_t n, float lr, float weight_decay,
                       float eps, float gscale, void* stream);
 
-/* The same update for every parameter of an optimizer step in ONE launch (the reference's Adagrad loops over ~45 tensors,
- * torch/optim/adagrad.py; here the items ride in the kernel arguments, 48 per launch).  `items` is a HOST array; element
+/* optimizer.step() (Train/temporal_transformer_shanghaitech.py:142; Train/spatio_transformer_shanghaitech.py:109): the same
+ * update for EVERY parameter of the step in ONE launch (torch.optim.Adagrad loops over the ~45 tensors; here the items ride in
+ * the kernel arguments, 48 per launch).  `items` is a HOST array; element
  * arithmetic and order are those of lstc_adagrad_step - bit-identical results. */
 typedef struct LstcAdagradItem {
     float* w;
