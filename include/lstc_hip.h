@@ -160,7 +160,7 @@ typedef struct LstcAttnDesc {
                                        Q K^T, Pd V and of the four backward products are rounded to bf16 (RNE) in registers and
                                        contracted by v_mfma_f32_32x32x16_bf16 with f32 accumulation; Q, K, V, O, probs and the
                                        gradients stay f32 in memory, softmax / bias / dropout stay f32.  Taken by the staged
-                                       kernels (S <= 64, dk and dv multiples of 32, 16-B aligned operands, variant 0); every other
+                                       kernels (S <= 96, dk and dv multiples of 32, 16-B aligned operands, variant 0); every other
                                        case computes the exact-f32 products (the first-generation loops are latency-bound and got
                                        slower with bf16 products).  lstc_attn_cls_* : LSTC_F32 only */
     int32_t index_ld;               /* 0 = no relative bias */
@@ -187,7 +187,7 @@ typedef struct LstcAttnDesc {
     /* backward, bf16 mode: when all three are non-NULL, dQ / dK / dV are written ONLY as packed bf16 operands [N*S, H*dk|dv]
      * (lstc_pack1 layout, lstc_pack1_bytes(N*S, H*dk|dv) bytes each; dQ / dK / dV may be NULL) - they feed the packed weight- and
      * input-gradient products of the projections (autograd of models/MultiHeadAttention.py:97-99).  Needs the staged kernel
-     * (S <= 64, d_k, d_v multiples of 32), N*S a multiple of 256, H*dk and H*dv multiples of 64; else LSTC_E_UNSUPPORTED. */
+     * (S <= 96, d_k, d_v multiples of 32), N*S a multiple of 256, H*dk and H*dv multiples of 64; else LSTC_E_UNSUPPORTED. */
     void* dQ_pack; void* dK_pack; void* dV_pack;
     /* pack_cols > 0: the three pointers name ONE pack of a [N*S, pack_cols] matrix (the fused Q|K|V projection's gradient) whose
      * columns dQ_col0 / dK_col0 / dV_col0 .. + H*dk|dv receive dQ / dK / dV (multiples of 32, pack_cols a multiple of 64). */

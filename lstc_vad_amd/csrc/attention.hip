@@ -856,8 +856,9 @@ int lstc_attn_fwd(const LstcAttnDesc* d, void* stream) {
         const size_t lds2 = ((size_t)((SP * (SP + 1) + 3) & ~3) + (size_t)4 * SP * 32) * sizeof(float);
 #define LSTC_FWD2(TT, BB, WW)                                                              \
     do {                                                                                   \
-        static bool once2 = false;                                                         \
-        if (!once2) { set_lds(attn_fwd2_kernel<TT, BB, WW>, 160 * 1024); once2 = true; }   \
+        static LstcDevOnce once2;                                                          \
+        const int dev2_ = once2.begin();                                                   \
+        if (dev2_ >= 0) { set_lds(attn_fwd2_kernel<TT, BB, WW>, 160 * 1024); once2.end(dev2_); } \
         hipLaunchKernelGGL((attn_fwd2_kernel<TT, BB, WW>), grid, 64 * WW, lds2, st, p);    \
     } while (0)
         if (!bf) { if (T == 1) LSTC_FWD2(1, false, 4); else LSTC_FWD2(3, false, 8); }
@@ -867,8 +868,9 @@ int lstc_attn_fwd(const LstcAttnDesc* d, void* stream) {
     }
 #define LSTC_FWD(TT)                                                      \
     do {                                                                  \
-        static bool once = false;                                         \
-        if (!once) { set_lds(attn_fwd_kernel<TT>, 160 * 1024); once = true; } \
+        static LstcDevOnce once;                                          \
+        const int dev_ = once.begin();                                    \
+        if (dev_ >= 0) { set_lds(attn_fwd_kernel<TT>, 160 * 1024); once.end(dev_); } \
         hipLaunchKernelGGL(attn_fwd_kernel<TT>, grid, NT, lds, st, p);    \
     } while (0)
     switch (T) {
@@ -933,8 +935,9 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
         if (lds2 <= 160 * 1024) {
 #define LSTC_BWD2(TT, BB, WW)                                                              \
     do {                                                                                   \
-        static bool once2 = false;                                                         \
-        if (!once2) { set_lds(attn_bwd2_kernel<TT, BB, WW>, 160 * 1024); once2 = true; }   \
+        static LstcDevOnce once2;                                                          \
+        const int dev2_ = once2.begin();                                                   \
+        if (dev2_ >= 0) { set_lds(attn_bwd2_kernel<TT, BB, WW>, 160 * 1024); once2.end(dev2_); } \
         hipLaunchKernelGGL((attn_bwd2_kernel<TT, BB, WW>), grid, 64 * WW, lds2, st, p);    \
     } while (0)
             if (T == 1) { if (bf) LSTC_BWD2(1, true, 4); else LSTC_BWD2(1, false, 4); }
@@ -947,8 +950,9 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
     if (p.dQp) return LSTC_E_UNSUPPORTED;
 #define LSTC_BWD(TT)                                                         \
     do {                                                                     \
-        static bool once = false;                                            \
-        if (!once) { set_lds(attn_bwd_kernel<TT>, 160 * 1024); once = true; } \
+        static LstcDevOnce once;                                             \
+        const int dev_ = once.begin();                                       \
+        if (dev_ >= 0) { set_lds(attn_bwd_kernel<TT>, 160 * 1024); once.end(dev_); } \
         hipLaunchKernelGGL(attn_bwd_kernel<TT>, grid, NT, lds, st, p);       \
     } while (0)
     switch (T) {
@@ -1376,13 +1380,14 @@ int lstc_cls_dot(const float* U, const float* X, float* out, float* probs, int64
     if ((uint64_t)N * H * S * S > 0xffffffffull) return LSTC_E_RANGE;
     const size_t lds = ((size_t)H * d + (size_t)H * S) * sizeof(float);
     if (lds > 96 * 1024) return LSTC_E_RANGE;
-    static bool once = false;
-    if (!once) {
+    static LstcDevOnce once;
+    const int dev_ = once.begin();
+    if (dev_ >= 0) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cls_dot_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cls_dot_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cls_dot_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cls_dot_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        once = true;
+        once.end(dev_);
     }
     const DropKey dk = make_drop_key(dropout_p, seed);
     const int has_drop = dropout_p > 0.f;

@@ -273,11 +273,12 @@ int launch_cfg(const GemmParams& p, bool va, bool vb, int splits, hipStream_t st
 #define LSTC_GO(VA, VB)                                                                                          \
     do {                                                                                                         \
         auto kern = gemm_bf16c_kernel<BM, BN, WGM, WGN, A_KC, B_KC, VA, VB>;                                     \
-        static bool attr_done = false;                                                                           \
-        if (!attr_done) {                                                                                        \
+        static LstcDevOnce attr_done;                                                                            \
+        const int dev_ = attr_done.begin();                                                                      \
+        if (dev_ >= 0) {                                                                                         \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)lds);                                                                 \
-            attr_done = true;                                                                                    \
+            attr_done.end(dev_);                                                                                 \
         }                                                                                                        \
         hipLaunchKernelGGL(kern, grid, block, lds, st, p);                                                       \
     } while (0)

@@ -847,27 +847,30 @@ int lstc_gemm_bf16p_impl(const LstcGemmDesc* d, hipStream_t st) {
     p.splits = eff_splits;
     p.total_items = tilesM * p.tilesN * eff_splits;
     constexpr size_t lds = (size_t)2 * P1_BUF * sizeof(bf16_t);
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
+    // per device: the CU count sizes the persistent grid and the 128-KB dynamic-LDS opt-in is a per-device kernel attribute
+    static std::atomic<int> n_cu_dev[64];
+    static LstcDevOnce setup;
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) cur = 0;
+    const int dev_ = setup.begin();
+    if (dev_ >= 0) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
+        int n = 0;
+        if (hipGetDeviceProperties(&prop, dev_) == hipSuccess) n = prop.multiProcessorCount;
+        n_cu_dev[dev_ & 63].store(n > 0 ? n : 256, std::memory_order_relaxed);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        setup.end(dev_);
     }
+    const int n_cu = n_cu_dev[cur & 63].load(std::memory_order_relaxed);
     const int grid = p.total_items < n_cu ? p.total_items : n_cu;       // persistent: one workgroup per CU (128 KB of LDS each)
     if (tr) hipLaunchKernelGGL((gemm_bf16p_kernel<true, false>), dim3(grid), dim3(NT8), lds, st, p);
     else if (P1_NT_S16) {
         const int epk = p.out_kbp ? (p.mask_kbp ? 2 : 1) : (p.mask_kbp ? 3 : 0);
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
         if (epk == 0) hipLaunchKernelGGL((gemm_bf16p_kernel<false, true, 0>), dim3(grid), dim3(NT8), lds, st, p);
         else if (epk == 1) hipLaunchKernelGGL((gemm_bf16p_kernel<false, true, 1>), dim3(grid), dim3(NT8), lds, st, p);
         else if (epk == 2) hipLaunchKernelGGL((gemm_bf16p_kernel<false, true, 2>), dim3(grid), dim3(NT8), lds, st, p);

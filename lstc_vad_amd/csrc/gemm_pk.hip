@@ -774,11 +774,12 @@ int lstc_gemm_f32x3_impl(const LstcGemmDesc* d, hipStream_t st) {
         const int tM = (d->M + 255) / 256;
         p.tilesN = (d->N + 127) / 128;
         constexpr size_t ldsw = (size_t)3 * WD_STAGE * sizeof(pk_t);
-        static bool attrw = false;
-        if (!attrw) {
+        static LstcDevOnce attrw;
+        const int devw = attrw.begin();
+        if (devw >= 0) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pkw_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pkw_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
-            attrw = true;
+            attrw.end(devw);
         }
         if (tr) hipLaunchKernelGGL(gemm_pkw_kernel<true>, dim3(tM * p.tilesN, eff_splits), dim3(NT), ldsw, st, p);
         else hipLaunchKernelGGL(gemm_pkw_kernel<false>, dim3(tM * p.tilesN, eff_splits), dim3(NT), ldsw, st, p);
@@ -790,22 +791,24 @@ int lstc_gemm_f32x3_impl(const LstcGemmDesc* d, hipStream_t st) {
     // 5.39 ms of the three-stage one (variant 1) on the 100352 x {2048 x 2048, 2048 x 4096, 4096 x 2048} forward shapes
     if (d->variant != 1) {
         constexpr size_t lds3 = (size_t)2 * PK_STAGE * sizeof(pk_t);
-        static bool attr3 = false;
-        if (!attr3) {
+        static LstcDevOnce attr3;
+        const int dev3 = attr3.begin();
+        if (dev3 >= 0) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pk2s_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pk2s_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-            attr3 = true;
+            attr3.end(dev3);
         }
         if (tr) hipLaunchKernelGGL(gemm_pk2s_kernel<true>, dim3(tilesM * p.tilesN, eff_splits), dim3(NT), lds3, st, p);
         else hipLaunchKernelGGL(gemm_pk2s_kernel<false>, dim3(tilesM * p.tilesN, eff_splits), dim3(NT), lds3, st, p);
         return lstc_launch_status();
     }
     constexpr size_t lds = (size_t)PK_NSTAGE * PK_STAGE * sizeof(pk_t);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static LstcDevOnce attr_done;
+    const int dev_ = attr_done.begin();
+    if (dev_ >= 0) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pk_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pk_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
+        attr_done.end(dev_);
     }
     if (tr) hipLaunchKernelGGL(gemm_pk_kernel<true>, dim3(tilesM * p.tilesN, eff_splits), dim3(NT), lds, st, p);
     else hipLaunchKernelGGL(gemm_pk_kernel<false>, dim3(tilesM * p.tilesN, eff_splits), dim3(NT), lds, st, p);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/lstc_hip.h"
 
 #define LSTC_WAVE 64
@@ -80,5 +81,19 @@ static inline int lstc_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
+
+// One-time per-DEVICE launch setup.  Kernel attributes (the dynamic-LDS opt-in above 64 KB) belong to a device, so a process
+// that launches on a second GPU must set them again there:
+//     static LstcDevOnce once;  const int dev = once.begin();  if (dev >= 0) { hipFuncSetAttribute(...); once.end(dev); }
+// The guarded calls are idempotent: two host threads racing through their first launch merely repeat them; the flag word is atomic.
+struct LstcDevOnce {
+    std::atomic<uint64_t> mask{0};
+    int begin() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        return ((mask.load(std::memory_order_acquire) >> (dev & 63)) & 1ull) ? -1 : dev;
+    }
+    void end(int dev) { mask.fetch_or(1ull << (dev & 63), std::memory_order_release); }
+};
 
 __host__ __device__ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

@@ -391,8 +391,12 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, x_pack: Optional[Packed] = None) ->
     # split-K factor: 256x256 output tiles on the packed bf16 kernel, 128x128 everywhere else
     s = _wgrad_split(O, I, 256 if pkind == _lib.BF16P else 128) if T >= 4096 else 1
     tr_ok = T % 128 == 0 and (pkind == _lib.BF16P or (O % 128 == 0 and I % 128 == 0))
+    # a gradient that already IS a packed operand (layernorm_bwd_branch emits df packed whenever [rows, d_model] fills the tile
+    # grid, whatever the width of its partner) always takes the packed TR form; the partner is packed on demand (the TR kernel
+    # handles ragged O / I) - e.g. n_hidden < 256 or H*d_v < 256, where the forward kept no pack of the hidden / of O
     if pkind is not None and tr_ok and \
-            (x_pack is not None or (min(O, I) >= _x3_min[0] and T >= _x3_min[1] and T * O * I >= _x3_min[2])):
+            (x_pack is not None or (isinstance(dy, Packed) and x is not None and dy.kind == pkind) or
+             (min(O, I) >= _x3_min[0] and T >= _x3_min[1] and T * O * I >= _x3_min[2])):
         ap = _packed_operand(dy, False)
         bp = x_pack if x_pack is not None else _packed_operand(x, False)
         dev = ap.buf.device

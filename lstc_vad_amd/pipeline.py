@@ -168,7 +168,12 @@ def evaluate_train_auc(enc, head, mode, dataset, train_archive, training_txt, ma
             key = fields[0]
             if dataset in ("SHT", "MT_SHT"):
                 abnormal = int(fields[1]) == 1
+            elif len(fields) > 1 and fields[1].strip() in ("0", "1"):
+                # the upstream pass reads the second column as the 0/1 class (Train/temporal_transformer_UBnormal.py:198)
+                abnormal = int(fields[1]) == 1
             else:
+                # the published UBnormal list holds a FRAME COUNT there (train_video_names_frames.txt; upstream then looks for
+                # a mask of every video and stops) - the class of such a line comes from the file name
                 abnormal = not key.startswith("normal")
             f = _dev(arc[key + ".npy"], device, n_patch)
             if mode != "LTN":

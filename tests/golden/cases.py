@@ -45,6 +45,17 @@ FULL_CASES = {
                  dict(batch_size=4, part_num=16, part_len=3, n_patch=16), 31),     # 128 sequences, S = 49, 6272 tokens
     "stn_full": ("STN", dict(d_model=2048, n_head=8, d_k=256, d_v=256, d_inner=3027, FFN_layerNorm=True),
                  dict(batch_size=2, part_num=16, part_len=4, n_patch=16), 32),     # 256 sequences, S = 17, 4352 tokens
+    # BASELINE config 4 (UCF-Crime: n_patch = 9, part_num = 32, part_len = 2, README.md:59): S = 19, and the 3-D index is
+    # built for a 4x4 window ([32, 32]) but only its top-left [18, 18] is read (models/MultiHeadAttention.py:107-111) -
+    # the row stride of the index (32) differs from S - 1 (18) in the production attention instantiation (d_k = 256)
+    "ltn_ucf_full": ("LTN", dict(d_model=2048, n_head=8, d_k=256, d_v=256, d_inner=4096, MHA_layerNorm=True,
+                                 FFN_layerNorm=True, relative_pe=True, window_size=4, window_depth=2),
+                     dict(batch_size=4, part_num=32, part_len=2, n_patch=9), 33),   # 256 sequences, S = 19, 4864 tokens
+    # BASELINE config 5's UBnormal half (README.md:55: --d_model 1024 --part_len 5): d_model = 1024 != H*d_k = 2048
+    # (rectangular projections), S = 81 (the 8-wave staged attention instantiation at d_k = 256), table [441, 8]
+    "ltn_ubnormal_full": ("LTN", dict(d_model=1024, n_head=8, d_k=256, d_v=256, d_inner=4096, MHA_layerNorm=True,
+                                      FFN_layerNorm=True, relative_pe=True, window_size=4, window_depth=5),
+                          dict(batch_size=2, part_num=16, part_len=5, n_patch=16), 34),   # 64 sequences, S = 81, 5184 tokens
 }
 N_SAMPLE = 256
 

@@ -69,7 +69,9 @@ def test_make_golden_pipeline_reproduces_committed_fixture(tmp_path):
 
 
 def test_make_golden_full_width_reproduces_committed_fixtures(tmp_path):
-    """The two BASELINE-width cases (about 30 s of reference CPU time)."""
-    _run("make_golden.py", tmp_path, "--only", "ltn_full,stn_full")
-    for name in ("ltn_full", "stn_full"):
+    """The BASELINE-width cases - SHT LTN / STN, UCF (S = 19, sliced index), UBnormal (d_model = 1024, S = 81) - about a
+    minute of reference CPU time."""
+    from cases import FULL_CASES
+    _run("make_golden.py", tmp_path, "--only", ",".join(FULL_CASES))
+    for name in FULL_CASES:
         _same(os.path.join(tmp_path, name + ".npz"), os.path.join(GOLD, name + ".npz"))

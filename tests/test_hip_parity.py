@@ -857,8 +857,11 @@ def _full_width_models(name):
     return z, mode, skw, d, enc, head, nf, af, al
 
 
+FULL_NAMES = ["ltn_full", "stn_full", "ltn_ucf_full", "ltn_ubnormal_full"]
+
+
 @pytest.mark.parametrize("cls_only", [True, False])
-@pytest.mark.parametrize("name", ["ltn_full", "stn_full"])
+@pytest.mark.parametrize("name", FULL_NAMES)
 def test_full_width_training_step_matches_reference_golden(name, cls_only):
     """BASELINE widths (d=2048, H=8x256, F=4096 / 3027, 3 layers), T >= 4096 tokens: forward, loss, EVERY parameter
     gradient and the weights after two Adagrad steps against the real reference's run (tests/golden/make_golden.py
@@ -1043,7 +1046,7 @@ def test_f32x3_wgrad_with_uneven_k_splits(T):
     assert max_abs_diff(dw, ref) < 2e-4 * (T ** 0.5) * 0.05
 
 
-@pytest.mark.parametrize("name", ["ltn_full", "stn_full"])
+@pytest.mark.parametrize("name", FULL_NAMES)
 def test_full_width_bf16_step_tracks_reference(name):
     """bf16 GEMM mode (packed bf16 kernel on every large product incl. TR weight gradients, bf16c on the heads) at BASELINE
     widths against the reference's fp32 run: scores within 2e-2, loss within 2e-2, every large gradient tensor's direction
@@ -1134,7 +1137,15 @@ def test_mixed_step_bf16_vs_fp32_auc_on_the_mixed_pair():
         assert abs(l32 - l16) < 5e-2
 
 
-@pytest.mark.parametrize("S,L,dk", [(17, 1, 64), (49, 3, 64), (33, 2, 32), (81, 5, 64), (64, 3, 96), (49, 3, 256)])
+# (S, window depth L of the model's 3-D index, d_k).  The index is [16 L, 16 L]; a sequence reads its top-left [S-1, S-1]
+# (models/MultiHeadAttention.py:107-111), so the index's row stride exceeds S - 1 for UCF (S = 19: 9 patches, L = 2 - the
+# production shape of BASELINE config 4, Test/evaluation_UCF.py:112) and for the short tail parts of an L = 3 model
+# (S = 17 / 33, Train/pseudo_labels_generator_temporal.py:110-137).  (81, 5, 256) = UBnormal's production instantiation.
+STAGED_SHAPES = [(17, 1, 64), (49, 3, 64), (33, 2, 32), (81, 5, 64), (64, 3, 96), (49, 3, 256),
+                 (19, 2, 256), (17, 3, 64), (33, 3, 64), (81, 5, 256), (19, 2, 32)]
+
+
+@pytest.mark.parametrize("S,L,dk", STAGED_SHAPES)
 def test_attention_backward_staged_kernel_matches_first_generation_and_f64(S, L, dk):
     """lstc_attn_fwd / lstc_attn_bwd's second-generation kernels (LDS-DMA staged operands, register-resident B rows, one job
     pipeline; forward for S <= 32, backward for S <= 64; larger S runs the first generation in both arms)
@@ -1146,8 +1157,9 @@ def test_attention_backward_staged_kernel_matches_first_generation_and_f64(S, L,
     g = torch.Generator(device=DEV).manual_seed(S * 131 + dk)
     M = N * S
     q, k, v, do = (torch.randn(M, H * dk, device=DEV, generator=g) for _ in range(4))
-    use_bias = (S - 1) % 16 == 0
+    use_bias = S - 1 <= 16 * L
     idx = relative_position_index_3d(L, 4).to(DEV) if use_bias else None
+    assert idx is None or idx.shape == (16 * L, 16 * L)
     tab = torch.randn((2 * L - 1) * 49, H, device=DEV, generator=g) * 0.3 if use_bias else None
     o, probs = Fn.attn_fwd(q, k, v, N, S, H, dk, dk, tab, idx, p_drop, seed)
     keep = os.environ.pop("LSTC_ATTN_VARIANT", None)
@@ -1193,7 +1205,8 @@ def test_attention_backward_staged_kernel_matches_first_generation_and_f64(S, L,
         assert max_abs_diff(dt1, dt2) < 1e-5 * float(td.grad.abs().max()) + 1e-6
 
 
-@pytest.mark.parametrize("S,L,dk", [(17, 1, 64), (49, 3, 64), (81, 5, 64), (49, 3, 256), (33, 2, 32), (81, 5, 128), (113, 7, 32)])
+@pytest.mark.parametrize("S,L,dk", [(17, 1, 64), (49, 3, 64), (81, 5, 64), (49, 3, 256), (33, 2, 32), (81, 5, 128), (113, 7, 32),
+                                    (19, 2, 256), (17, 3, 64), (33, 3, 64), (81, 5, 256)])
 def test_attention_bf16_products_track_the_f64_reference(S, L, dk):
     """bf16 training mode (LstcAttnDesc.dtype = LSTC_BF16): Q K^T, Pd V and the four backward products contract bf16-rounded
     operands on v_mfma_f32_32x32x16_bf16 with f32 accumulation; softmax, bias, dropout stay f32.  The staged kernels
@@ -1206,7 +1219,7 @@ def test_attention_bf16_products_track_the_f64_reference(S, L, dk):
     g = torch.Generator(device=DEV).manual_seed(S * 17 + dk)
     M = N * S
     q, k, v, do = (torch.randn(M, H * dk, device=DEV, generator=g) for _ in range(4))
-    idx = relative_position_index_3d(L, 4).to(DEV) if (S - 1) % 16 == 0 else None
+    idx = relative_position_index_3d(L, 4).to(DEV) if S - 1 <= 16 * L else None
     tab = torch.randn((2 * L - 1) * 49, H, device=DEV, generator=g) * 0.3 if idx is not None else None
 
     def run():
@@ -1479,14 +1492,14 @@ def test_row_split_f32_product_is_bitwise_the_single_launch_product(M, N, K, tb)
     assert max_abs_diff(split, ref * keep + res.double()) < 1e-4 * (K ** 0.5)
 
 
-@pytest.mark.parametrize("S", [49, 17, 81])
+@pytest.mark.parametrize("S", [49, 17, 81, 19])
 def test_attention_backward_packed_gradients_equal_the_packed_f32_gradients(S):
     """lstc_attn_fwd with O_pack and lstc_attn_bwd with dQ_pack / dK_pack / dV_pack (bf16 mode): the packed bf16 results are
     lstc_pack1 of the f32 results the same kernels write without them, bit for bit (staged kernels; S = 81 is the 8-wave
     instantiation); probabilities and the bias-table gradient are unchanged."""
     from lstc_vad_amd import functional as Fn
     N, H, dk = 256, 4, 64
-    L = {49: 3, 17: 1, 81: 5}[S]
+    L = {49: 3, 17: 1, 81: 5, 19: 2}[S]       # S = 19: UCF, the [32, 32] index read through its top-left [18, 18]
     g = torch.Generator(device=DEV).manual_seed(41)
     M = N * S
     q, k, v, do = (torch.randn(M, H * dk, device=DEV, generator=g) for _ in range(4))
