@@ -97,22 +97,40 @@ def cpu_baseline(cfg_name, threads):
 
 
 # ---------------------------------------------------------------------------------------------- N-rank launcher
-def launch_ranks(n, argv, script=None):
+def _tail(path, n=25):
+    try:
+        with open(path, "r", errors="replace") as f:
+            return f.readlines()[-n:]
+    except OSError:
+        return []
+
+
+def launch_ranks(n, argv, script=None, rank_timeout_s=600.0):
     """``python bench.py --gpus N`` without a launcher: start N fresh rank processes (this parent has not touched the GPU and
     never will), relay rank 0's JSON line, fail if any rank fails.  Replaces the reference's single-process
-    ``nn.DataParallel`` wrap (Train/temporal_transformer_shanghaitech.py:76-78) with one process per GPU."""
+    ``nn.DataParallel`` wrap (Train/temporal_transformer_shanghaitech.py:76-78) with one process per GPU.
+
+    Watchdog: a rank stuck in RCCL initialisation (or anywhere else) would otherwise hang the parent until the caller's own
+    timeout with nothing to read.  After ``rank_timeout_s`` seconds the exact child PIDs started here are terminated (then
+    killed), every rank's last stderr lines are printed and the launcher returns 1.  Every rank's stderr goes to its own
+    temporary file (relayed to this process's stderr at the end), so the tails exist whichever rank is the stuck one."""
     import socket
     import subprocess
+    import tempfile
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    procs = []
+    procs, errs = [], []
+    t_start = time.monotonic()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this pool
+        ef = tempfile.NamedTemporaryFile("w+", prefix=f"lstc_bench_rank{r}_", suffix=".err", delete=False)
+        errs.append(ef)
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+                                      stdout=subprocess.PIPE if r == 0 else ef, stderr=ef, text=True))
     line = None
     failed = None
+    timed_out = False
     out0 = procs[0].stdout
     import selectors
     sel = selectors.DefaultSelector()
@@ -133,13 +151,38 @@ def launch_ranks(n, argv, script=None):
             time.sleep(0.2)
         codes = [p.poll() for p in procs]
         bad = [i for i, c in enumerate(codes) if c not in (None, 0)]
-        if bad and failed is None:
+        if bad and failed is None and not timed_out:
             failed = (bad[0], codes[bad[0]])
             for p in procs:                                      # exact PIDs we started, nothing by pattern
                 if p.poll() is None:
                     p.terminate()
-        if all(c is not None for c in codes) and not open0:
+        if not timed_out and failed is None and rank_timeout_s > 0 and time.monotonic() - t_start > rank_timeout_s and \
+                any(c is None for c in codes):
+            timed_out = True
+            stuck = [i for i, c in enumerate(codes) if c is None]
+            sys.stderr.write(f"[bench] watchdog: rank(s) {stuck} still running after {rank_timeout_s:.0f} s; stopping all ranks\n")
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.monotonic() + 10.0
+            while time.monotonic() < t_kill and any(p.poll() is None for p in procs):
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        if all(c is not None for c in codes) and (not open0 or timed_out):
             break
+    for r, ef in enumerate(errs):                                # relay the ranks' stderr: rank 0 whole, the others' tails
+        ef.flush(); ef.close()
+        lines = _tail(ef.name, 10 ** 6 if r == 0 and failed is None and not timed_out else 25)
+        if lines and (r == 0 or failed is not None or timed_out):
+            sys.stderr.write(f"---- rank {r} stderr{' (last lines)' if (failed is not None or timed_out) else ''} ----\n" + "".join(lines))
+        try:
+            os.unlink(ef.name)
+        except OSError:
+            pass
+    if timed_out:
+        return 1
     if failed is not None:
         sys.stderr.write(f"[bench] rank {failed[0]} exited with code {failed[1]}; all ranks stopped\n")
         return 1
@@ -229,8 +272,8 @@ class SyntheticResidentPairs:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="ltn_sht", choices=list(CONFIGS) + ["mixed_ubn_sht"],
                     help="mixed_ubn_sht = BASELINE config 5: half the videos UBnormal (d=1024, L=5), half SHT (d=2048, L=3), two "
                          "model pairs stepped in one iteration (lstc_vad_amd.engine.MixedStep)")
@@ -247,8 +290,11 @@ def main():
     ap.add_argument("--lr_scale", type=float, default=1e-3, help="multiplies the reference learning rates (1e-4 / 1e-2): with "
                     "i.i.d. synthetic features the classifier saturates within two Adagrad steps at the reference rates and the "
                     "backward then runs on near-zero operands; timing does not depend on it")
-    ap.add_argument("--h2d", action="store_true", help="also time the step with the batch arriving from pinned host memory "
+    ap.add_argument("--h2d", action="store_true", help="(default at N=1) also time the step with the batch arriving from host memory "
                     "every step through lstc_vad_amd.feed.PinnedFeeder (reported as pcie_inclusive, never as value)")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the pcie_inclusive pass")
+    ap.add_argument("--rank_timeout_s", type=float, default=600.0, help="--gpus N launcher watchdog: stop every rank and fail when "
+                    "one is still running after this many seconds (0 = no watchdog)")
     ap.add_argument("--naive-last-layer", action="store_true", help="evaluate the last encoder layer for every token like the "
                     "reference (A/B only: the default skips rows/projections nobody reads, with identical results)")
     ap.add_argument("--fuse_qkv", default="auto", choices=["auto", "on", "off"], help="Q/K/V projections as one GEMM per layer (auto: when "
@@ -262,7 +308,7 @@ def main():
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))             # before anything initialises the GPU in this process
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:], rank_timeout_s=a.rank_timeout_s))   # before anything initialises the GPU here
 
     # The JSON line must be the only thing on stdout: RCCL prints a version banner through C stdio when a communicator is
     # created (flushed at exit, i.e. AFTER our line).  Keep the real stdout aside and point fd 1 at stderr for everything else.
@@ -364,11 +410,15 @@ def main():
         Fn.set_gemm_profiling(prof)
         Fn._pack_prof = None
         scs = []
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # step boundaries on the launch stream
         t0 = time.perf_counter()
-        for _ in range(steps):
+        marks[0].record()
+        for i in range(steps):
             scs.append(run_step())
+            marks[i + 1].record()
         sync()
         dt = time.perf_counter() - t0
+        step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
         Fn.set_gemm_profiling(None)
         pprof, prof_steps = None, steps
         if want_events and not inline_events:
@@ -388,7 +438,12 @@ def main():
         first, last = torch.stack([scs[0], scs[-1]]).clone()
         if world > 1:                      # scalars are rank-local contributions: their sum is the global loss
             both = torch.stack([first, last]); dist.all_reduce(both); first, last = both
-        res = {"dt": dt, "steps": steps, "prof": prof, "pprof": pprof, "prof_steps": prof_steps, "events_inline": inline_events, "loss_first": float(first[0]), "loss_last": float(last[0]),
+        med = step_ms[steps // 2] if steps % 2 else 0.5 * (step_ms[steps // 2 - 1] + step_ms[steps // 2])
+        if world > 1:
+            tm = torch.tensor([med], device=dev, dtype=torch.float64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            med = float(tm.item())
+        res = {"dt": dt, "steps": steps, "step_ms_median": med, "step_ms_min": step_ms[0], "step_ms_max": step_ms[-1], "prof": prof, "pprof": pprof, "prof_steps": prof_steps, "events_inline": inline_events, "loss_first": float(first[0]), "loss_last": float(last[0]),
                "hbm": torch.cuda.max_memory_allocated(dev),
                "allreduce_MB": round(sum(t.reducer.payload_bytes() for t in tss if t.reducer is not None) / 1e6, 1),
                "bank_GB": None if mixed or src is None else round(src.bank_GB, 2)}
@@ -446,18 +501,27 @@ def main():
         return tot / 1e12
 
     def pmc_traffic(cfg, dtype):
-        """HBM-side bytes per launch of the dominant GEMM shape from the committed PMC passes (profiles/gemm_pmc_traffic.json)."""
+        """HBM-side bytes of ONE launch of the dominant GEMM shape, read from the committed rocprofv3 --pmc passes
+        (profiles/gemm_pmc_traffic.json) - a per-launch counter figure for that one shape, not a per-step sum, and labelled so."""
         pmc = os.path.join(ROOT, "profiles", "gemm_pmc_traffic.json")
         if not os.path.exists(pmc) or world != 1:
             return None
         try:
-            return json.load(open(pmc)).get(cfg if dtype == "fp32" else f"{cfg}_{dtype}")
+            tab = json.load(open(pmc))
+            key = cfg if dtype == "fp32" else f"{cfg}_{dtype}"
+            if key not in tab:
+                return None
+            return {"bytes": tab[key], "algorithmic_bytes": tab.get(key + "_algorithmic"),
+                    "scope": tab.get(key + "_scope", "one launch of the dominant GEMM shape, profiles/gemm_pmc_traffic.json"),
+                    "source": "rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE, separate passes; static figure from the committed "
+                              "profile, not measured in this run"}
         except Exception:
             return None
 
     def sub_object(res, cfg, dtype):
         o = {"value": round(snippets_per_step(cfg) * res["steps"] / res["dt"], 1), "unit": "snippets/s",
-             "ms_per_step": round(1e3 * res["dt"] / res["steps"], 3), "loss_first_timed_step": res["loss_first"],
+             "ms_per_step": round(1e3 * res["dt"] / res["steps"], 3), "ms_per_step_median": round(res["step_ms_median"], 3),
+             "loss_first_timed_step": res["loss_first"],
              "loss_last_timed_step": res["loss_last"], "hbm_peak_GB": round(res["hbm"] / 1e9, 2)}
         r = roofline_of(res, dtype, cfg)
         if r:
@@ -488,26 +552,34 @@ def main():
                                    dtype="f32 storage and accumulation; products of the large GEMMs on the f16 matrix cores (two scaled "
                                          "f16 planes per operand, hh + hl + lh); narrower than IEEE f32 products, reported as an extra")
     pcie = None
-    if a.h2d and world == 1 and a.config != "mixed_ubn_sht":
+    if (a.h2d or not a.no_h2d) and world == 1 and not force_dist and a.config != "mixed_ubn_sht":
         from lstc_vad_amd.feed import PinnedFeeder
         Fn.set_compute_dtype(a.dtype)
         ts, nxt, _ = make(a.config, bs_local, bs_global, 0, "static")
         nf, af, al = nxt()
         host = tuple(t.cpu() for t in (nf, torch.zeros_like(al), af, al))
-        feeder = PinnedFeeder((host for _ in range(a.steps + 2)), dev)
+        h_steps = a.steps if a.h2d else min(a.steps, 10)
+        feeder = PinnedFeeder((host for _ in range(h_steps + 2)), dev)
         t1 = None
         for i, (hnf, _, haf, hal) in enumerate(feeder):
             if i == 2:
                 torch.cuda.synchronize(); t1 = time.perf_counter()
             ts.step(hnf, haf, hal)
         torch.cuda.synchronize()
-        dth = (time.perf_counter() - t1) / a.steps
+        dth = (time.perf_counter() - t1) / h_steps
         Fn.set_compute_dtype("fp32")
         pcie = {"value": round(snippets_per_step(a.config) / dth, 1), "unit": "snippets/s", "ms_per_step": round(1e3 * dth, 3),
-                "batch_MB": round(sum(t.numel() * 4 for t in host) / 1e6, 1),
-                "note": "batch copied pageable->pinned->HBM every step on a side stream, overlapped with the previous step"}
+                "batch_MB": round(sum(t.numel() * 4 for t in host) / 1e6, 1), "steps": h_steps,
+                "note": "the reference's per-step H2D (Train/temporal_transformer_shanghaitech.py:115-118): the batch is copied "
+                        "pageable->pinned->HBM every step on a side stream, overlapped with the previous step; never `value`"}
         del ts, nxt, feeder
 
+    rccl_ranks = 1
+    if dist.is_initialized():
+        # ranks that really joined the communicator: every rank contributes a 1 to a sum-all-reduce over RCCL
+        one = torch.ones(1, device=dev, dtype=torch.float32)
+        dist.all_reduce(one)
+        rccl_ranks = int(round(float(one.item())))
     if rank == 0:
         mixed = a.config == "mixed_ubn_sht"
         last = "ltn_sht" if mixed else a.config
@@ -530,7 +602,14 @@ def main():
             "one fixed HBM-resident batch (no batch formation in the timed region)"
         out = {"metric": "snippets/sec training step (B=64,T=32,P=16,d=2048)", "value": round(value, 1),
                "unit": "snippets/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(1e3 * head_res["dt"] / a.steps, 3), "higher_is_better": True, "scaling": a.scaling,
+               "ms_per_step": round(1e3 * head_res["dt"] / a.steps, 3),
+               "ms_per_step_median": round(head_res["step_ms_median"], 3),
+               "ms_per_step_min_max": [round(head_res["step_ms_min"], 3), round(head_res["step_ms_max"], 3)],
+               "value_at_median_step": round(snippets_per_step(a.config) / (head_res["step_ms_median"] * 1e-3), 1),
+               "timing": "value and ms_per_step = K steps between barrier + synchronize (wall clock, max over ranks); "
+                         "ms_per_step_median = median of the K per-step intervals between HIP events on the launch stream "
+                         "(SURVEY 8d's t_step)",
+               "higher_is_better": True, "scaling": a.scaling,
                "vs_baseline": None, "dtype": {"fp32": "f32", "f32x3": "f32 (operands split into 2 scaled f16 planes, 3 f16-MFMA products, f32 accumulate)",
                                               "bf16": "bf16 (f32 storage/accumulate)"}[a.dtype], "data": "synthetic",
                "config": {"workload": ("mixed batch (BASELINE config 5): UBnormal videos (d=1024, L=5, S=81) + SHT videos (d=2048, L=3, "
@@ -543,7 +622,7 @@ def main():
                                       f"fresh weights and Adagrad state for the timed pass",
                           "feed": feed_txt, "global_videos": 2 * bs_global, "parallelism": f"dp{world}",
                           "per_rank_pairs": bs_local, "per_rank_sequences": nseq, "allreduce_MB": head_res["allreduce_MB"],
-                          "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1},
+                          "rccl_ranks": rccl_ranks},
                "loss_first_timed_step": head_res["loss_first"], "loss_last_timed_step": head_res["loss_last"],
                "hbm_peak_GB": round(head_res["hbm"] / 1e9, 2), "roofline": roof}
         out.update(extras)

@@ -108,6 +108,33 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert time.time() - t0 < 20
 
 
+def test_bench_launcher_watchdog_stops_a_stuck_rank(tmp_path, capfd):
+    """A rank that never finishes (e.g. stuck in RCCL initialisation) must not hang ``bench.py --gpus N``: after
+    --rank_timeout_s the launcher stops the PIDs it started, prints every rank's last stderr lines and returns 1 - even a
+    rank that ignores SIGTERM (killed after the grace period)."""
+    import importlib.util
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lstc_bench_wd", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    stuck = tmp_path / "rank_stuck.py"
+    stuck.write_text("import os, sys, time, signal\n"
+                     "r = int(os.environ['RANK'])\n"
+                     "print('rank', r, 'entering init', file=sys.stderr, flush=True)\n"
+                     "if r == 1:\n"
+                     "    signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"
+                     "    print('rank 1 waiting for a peer that never comes', file=sys.stderr, flush=True)\n"
+                     "    time.sleep(600)\n"
+                     "time.sleep(600)\n")
+    t0 = time.time()
+    rc = bench.launch_ranks(2, [], script=str(stuck), rank_timeout_s=3.0)
+    took = time.time() - t0
+    assert rc == 1 and took < 30, (rc, took)
+    err = capfd.readouterr().err
+    assert "watchdog" in err and "rank 1 waiting for a peer that never comes" in err and "rank 0 entering init" in err
+
+
 def test_host_shape_rules_of_the_packed_and_padded_paths():
     """Pure host logic of lstc_vad_amd.functional that decides kernel paths: the width an unaligned FFN hidden runs at, and
     the shapes for which producers may emit packed bf16 operands (both must agree with what include/lstc_hip.h documents)."""

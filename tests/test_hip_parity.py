@@ -508,6 +508,46 @@ def test_bf16_compute_training_step_close_to_golden(name):
             assert cos > 0.9, (k, cos)
 
 
+@pytest.mark.parametrize("d_inner,d_head", [(203, 128), (512, 64), (203, 64)])
+def test_bf16_step_with_narrow_hidden_or_heads_at_default_thresholds(d_inner, d_head):
+    """bf16 mode at the DEFAULT packing thresholds with d_model = 256 and enough tokens (17 408 = 68 x 256) that the LayerNorm
+    backward emits its gradient as a packed operand, while the weight-gradient partner was never packed in the forward: the
+    FFN hidden when n_hidden < 256 (203 is what tools/coteach_loop_synthetic.sh passes) and the attention output when
+    H*d_v < 256.  wgrad must take the packed TR form with the partner packed on demand (it used to raise); gradients against
+    the same step in fp32 mode."""
+    from lstc_vad_amd import functional as Fn
+    from lstc_vad_amd import synthetic as syn
+    from cases import fill_params
+    d, H = 256, 2
+    ekw = dict(d_model=d, n_head=H, d_k=d_head, d_v=d_head, d_inner=d_inner, MHA_layerNorm=True, FFN_layerNorm=True)
+    skw = dict(batch_size=2, part_num=16, part_len=16, n_patch=16)            # 1024 sequences x S = 17
+    args = _args("STN", skw)
+    nf, _, af, al = syn.training_batch(2, 16, 16, 16, d, seed=5, with_pseudo=True, threshold=0.6)
+    nf, af, al = (torch.from_numpy(x).to(DEV) for x in (nf, af, al))
+    grads = {}
+    for mode in ("fp32", "bf16"):
+        enc, head = _models("STN", dict(ekw), d)
+        fill_params(enc, 51); fill_params(head, 52)
+        enc, head = enc.to(DEV).train(), head.to(DEV).train()
+        Fn.set_compute_dtype(mode)
+        try:
+            assert mode == "fp32" or Fn._fused_pack_shape(1024 * 17, d)
+            _, outputs, loss, sc = _step(enc, head, "STN", args, nf, af, al, d, cls_only=False)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            Fn.set_compute_dtype("fp32")
+        grads[mode] = ({k: p.grad.detach().clone() for k, p in enc.named_parameters() if p.grad is not None}, float(sc[0]))
+    assert abs(grads["bf16"][1] - grads["fp32"][1]) < 2e-2
+    assert set(grads["bf16"][0]) == set(grads["fp32"][0])
+    for k, g in grads["fp32"][0].items():
+        if g.numel() < 4096 or float(g.norm()) == 0.0:
+            continue
+        b = grads["bf16"][0][k]
+        cos = float((g.double() * b.double()).sum() / (g.double().norm() * b.double().norm() + 1e-30))
+        assert torch.isfinite(b).all() and cos > 0.97, (k, cos)
+
+
 def test_fused_qkv_buffer_matches_separate_projections():
     """MultiHeadAttention.fuse_qkv_ (w_qs/w_ks/w_vs as row blocks of one buffer -> one GEMM each for projection, weight
     gradient and input gradient) must not change values, parameter names or the optimizer's view of the weights."""
