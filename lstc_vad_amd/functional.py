@@ -221,6 +221,18 @@ def _packed_operand(t, k_major):
     return pack3(t, k_major)
 
 
+_ffn_hidden_hook = None
+
+
+def set_ffn_hidden_hook(fn):
+    """Test instrumentation: ``fn(site, h)`` sees (and may edit in place) the f32 FFN hidden relu(W1 x + b1) [rows, n_hidden] of
+    every FFNFunction.forward before anything consumes it; ``None`` removes it.  The full-width parity tests use it to take the
+    reference's ReLU decision at the few dozen hidden units whose pre-activation lies within float32 rounding of zero (which
+    side of zero such a unit lands on depends on the summation order of the 2048 products, tests/golden/make_golden.py)."""
+    global _ffn_hidden_hook
+    _ffn_hidden_hook = fn
+
+
 def set_gemm_profiling(sink):
     """``sink`` = list to append (flops, start_event, end_event) per lstc_gemm launch, or None to stop."""
     global _gemm_prof
@@ -1020,6 +1032,8 @@ class FFNFunction(torch.autograd.Function):
             h1, hp = None, gemm(xp, w1, trans_b=True, bias=b1, relu=True, out_pack=True)
         else:
             h1 = gemm(xp if xp is not None else x2, w1, trans_b=True, bias=b1, relu=True)
+            if _ffn_hidden_hook is not None:
+                _ffn_hidden_hook(cfg["site"], h1)      # parity tests: see set_ffn_hidden_hook
             hp = maybe_pack(h1)
         y = gemm(hp if hp is not None else h1, w2, trans_b=True, bias=b2, dropout=(p, seed), residual=x2)
         ctx.packs = (xp, hp) if (cfg["training"] or h1 is None) else (None, None)

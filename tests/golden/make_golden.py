@@ -181,6 +181,9 @@ def run_case(name, mode, enc_kw, st_kw, seed):
           f"({os.path.getsize(os.path.join(OUT_DIR, name + '.npz')) / 1024:.0f} KiB)")
 
 
+RELU_EDGE = 4e-6     # |W1 x + b1| below which a ReLU decision is treated as summation-order dependent (f32, K = 2048, |x| ~ 1)
+
+
 def run_full_case(name, mode, enc_kw, st_kw, seed):
     """Full-width step on the reference: two training steps; keeps samples, norms and scalars only."""
     bs, pn, L, P = st_kw["batch_size"], st_kw["part_num"], st_kw["part_len"], st_kw["n_patch"]
@@ -198,11 +201,34 @@ def run_full_case(name, mode, enc_kw, st_kw, seed):
     opt = torch.optim.Adagrad([{"params": enc.parameters(), "lr": 1e-4},
                                {"params": head.parameters(), "lr": 1e-2}], weight_decay=1e-3)
     tnf, taf, tal = torch.from_numpy(nf), torch.from_numpy(af), torch.from_numpy(al)
+    # ReLU decisions that depend on the summation order.  At this size each FFN layer holds ~2e7 hidden units per step and a few
+    # dozen of their pre-activations W1 x + b1 lie within float32 rounding of zero (|pre| < RELU_EDGE): whether such a unit
+    # counts as active is decided by the order in which an implementation adds the 2048 products (any two f32 BLAS disagree
+    # on a handful of them - measured: 4 / 1 / 2 per layer between rocBLAS sgemm and an f64 product, the same between the
+    # HIP kernel and f64), and one flipped unit with a large upstream gradient moves the small layer-0 attention gradients by
+    # up to 1e-3 of their maximum.  The fixture therefore records WHICH units the reference run found on the edge and what it
+    # decided there (its pre-activation value); the GPU test lets the HIP step take the same decisions at exactly these
+    # units (tests/test_hip_parity.py, ``_align_relu_edges``) and compares everything else at the strict tolerances.
+    edges = {}
+    hooks = []
+    for li, layer in enumerate(enc.layer_stack):
+        def grab(mod, inp, outp, li=li):
+            if li in edges:
+                return                              # first step only
+            pre = outp.detach().reshape(-1, outp.shape[-1])
+            t, j = torch.nonzero(pre.abs() < RELU_EDGE, as_tuple=True)
+            edges[li] = (torch.stack([t, j], 1).numpy().astype(np.int64), pre[t, j].numpy().copy())
+        hooks.append(layer.pos_ffn.w_1.register_forward_hook(grab))
     for step in range(2):
         enc_out, outputs, score, loss, mil, err, l1, aux = ref_forward_loss(mode, args, enc, head, tnf, taf, tal)
         opt.zero_grad()
         loss.backward()
         if step == 0:
+            for h in hooks:
+                h.remove()
+            for li, (tj, val) in edges.items():
+                out[f"relu_edge.{li}"] = tj             # [n, 2]: (token row of the [N*S, n_hidden] hidden, hidden unit)
+                out[f"relu_edge_pre.{li}"] = val        # the reference's pre-activation there (its decision: > 0)
             eo = enc_out.detach()
             out["cls_rows"] = eo[:, 0, :].numpy().copy()[::max(1, eo.shape[0] // 16)][:16]       # 16 sequences' CLS rows
             out["tok_rows"] = eo[::max(1, eo.shape[0] // 8), eo.shape[1] // 2, :].numpy().copy()[:8]   # 8 mid-sequence rows

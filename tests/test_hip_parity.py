@@ -900,14 +900,69 @@ def _full_width_models(name):
 FULL_NAMES = ["ltn_full", "stn_full", "ltn_ucf_full", "ltn_ubnormal_full"]
 
 
-@pytest.mark.parametrize("cls_only", [True, False])
-@pytest.mark.parametrize("name", FULL_NAMES)
-def test_full_width_training_step_matches_reference_golden(name, cls_only):
-    """BASELINE widths (d=2048, H=8x256, F=4096 / 3027, 3 layers), T >= 4096 tokens: forward, loss, EVERY parameter
+class _align_relu_edges:
+    """``with _align_relu_edges(z, n_seq, S) as st:`` - the HIP step takes the reference's ReLU decision at the hidden units the
+    reference run found within float32 rounding of zero (fixture keys ``relu_edge.{layer}`` = (token row, unit),
+    ``relu_edge_pre.{layer}`` = the reference's pre-activation there; |pre| < 4e-6, a few dozen of ~2e7 units per layer).
+    Which side of zero such a unit lands on is decided by the summation order of the 2048 products - rocBLAS sgemm, the
+    reference's CPU sgemm and this repo's k-ordered MFMA chain each disagree with an f64 product on a handful of them
+    (tools/relu_flip_probe.py) - and ONE flipped unit with a large upstream gradient moves the small layer-0 attention
+    gradients by up to 1e-3 of their maximum (tools/block_probe.py).  The hidden is set to relu(reference pre-activation)
+    at exactly the listed units (values < 4e-6: the forward is unchanged at the 1e-4 bar), nowhere else; ``st.changed`` counts
+    the decisions that differed, ``st.listed`` the units visited.  A CLS-only last layer holds one row per sequence: only the
+    listed rows that are CLS tokens exist there."""
+
+    def __init__(self, z, n_seq, S):
+        self.z, self.n_seq, self.S = z, n_seq, S
+        self.changed = self.listed = 0
+
+    def _hook(self, site, h):
+        li = int(site.split(".")[1])
+        key = f"relu_edge.{li}"
+        if key not in self.z.files or self.z[key].shape[0] == 0:
+            return
+        tj = torch.from_numpy(self.z[key]).to(h.device)
+        pre = torch.from_numpy(self.z[f"relu_edge_pre.{li}"]).to(h.device)
+        rows, cols = tj[:, 0], tj[:, 1]
+        if h.shape[0] == self.n_seq and self.S > 1:          # CLS-only last layer: row = sequence, only s == 0 tokens exist
+            keep = rows % self.S == 0
+            rows, cols, pre = rows[keep] // self.S, cols[keep], pre[keep]
+        else:
+            assert h.shape[0] == self.n_seq * self.S, (h.shape, self.n_seq, self.S)
+        assert float(pre.abs().max()) < 4e-6 if pre.numel() else True
+        want = pre.clamp_min(0.0)
+        got = h[rows, cols]
+        assert float((got - want).abs().max()) < 2e-5 if pre.numel() else True     # same values up to f32 rounding of the product
+        self.changed += int(((got > 0) != (want > 0)).sum())
+        self.listed += int(pre.numel())
+        h[rows, cols] = want
+
+    def __enter__(self):
+        from lstc_vad_amd import functional as Fn
+        Fn.set_ffn_hidden_hook(self._hook)
+        return self
+
+    def __exit__(self, *exc):
+        from lstc_vad_amd import functional as Fn
+        Fn.set_ffn_hidden_hook(None)
+        return False
+
+
+def _full_width_golden_check(name, cls_only, compute_dtype="fp32"):
+    """Body of the full-width golden tests (``compute_dtype``: GEMM mode of the HIP step).  BASELINE widths (d=2048, H=8x256, F=4096 / 3027, 3 layers), T >= 4096 tokens: forward, loss, EVERY parameter
     gradient and the weights after two Adagrad steps against the real reference's run (tests/golden/make_golden.py
     ``run_full_case``; sampled entries + norms, weights regenerate from the seed).  This is the oracle check of the
     production-size backward: PIPE 5 steady loop in NT/NN/TN, batched split-K weight gradients, attn_bwd at d_k = 256,
     n_hidden = 3027 at its padded width 3072 (test_full_width_unpadded_hidden_... below runs the scalar-load path)."""
+    from lstc_vad_amd import functional as Fn
+    Fn.set_compute_dtype(compute_dtype)
+    try:
+        _full_width_golden_body(name, cls_only)
+    finally:
+        Fn.set_compute_dtype("fp32")
+
+
+def _full_width_golden_body(name, cls_only):
     from cases import sample_index
     from lstc_vad_amd.optim import Adagrad
     z, mode, skw, d, enc, head, nf, af, al = _full_width_models(name)
@@ -917,8 +972,16 @@ def test_full_width_training_step_matches_reference_golden(name, cls_only):
     opt = Adagrad([{"params": enc.parameters(), "lr": 1e-4}, {"params": head.parameters(), "lr": 1e-2}], weight_decay=1e-3)
     init = {("enc", k): p.detach().clone() for k, p in enc.named_parameters()}
     init.update({("head", k): p.detach().clone() for k, p in head.named_parameters()})
+    n_seq_all = 2 * skw["batch_size"] * skw["part_num"] * (1 if mode == "LTN" else skw["part_len"])
+    S_all = 1 + skw["n_patch"] * (skw["part_len"] if mode == "LTN" else 1)
     for step in range(2):
-        enc_out, outputs, loss, sc = _step(enc, head, mode, args, nf, af, al, d, cls_only)
+        if step == 0:
+            with _align_relu_edges(z, n_seq_all, S_all) as edges:
+                enc_out, outputs, loss, sc = _step(enc, head, mode, args, nf, af, al, d, cls_only)
+            # a few dozen edge units per layer were visited, and at most a handful of decisions differed
+            assert edges.listed > 0 and edges.changed <= max(8, edges.listed // 4), (edges.listed, edges.changed)
+        else:
+            enc_out, outputs, loss, sc = _step(enc, head, mode, args, nf, af, al, d, cls_only)
         opt.zero_grad()
         loss.backward()
         if step == 0:
@@ -961,12 +1024,30 @@ def test_full_width_training_step_matches_reference_golden(name, cls_only):
 
 
 
+
+@pytest.mark.parametrize("cls_only", [True, False])
+@pytest.mark.parametrize("name", FULL_NAMES)
+def test_full_width_training_step_matches_reference_golden(name, cls_only):
+    """Exact-f32 MFMA path (the mode ``value`` of bench.py is measured in) at the widths of BASELINE configs 2 (ltn_full), 1
+    (stn_full), 4 (ltn_ucf_full: S = 19, [32, 32] index read through [:18, :18]) and 5 (ltn_ubnormal_full: d_model = 1024,
+    S = 81) against the reference's own run - see _full_width_golden_check."""
+    _full_width_golden_check(name, cls_only)
+
+
+@pytest.mark.parametrize("name", FULL_NAMES)
+def test_f32x3_full_width_training_step_matches_reference_golden(name):
+    """The f32x3 GEMM mode (products of the large GEMMs on the f16 matrix cores, csrc/gemm_pk.hip) at its DEFAULT thresholds
+    meets the reference's full-width run at the SAME tolerances as the exact-f32 path: scores 1e-4, gradient entries 2e-4 of
+    the tensor maximum, norms 1e-4 - the mode is checked against the reference, not only against the exact-f32 HIP step."""
+    _full_width_golden_check(name, True, "f32x3")
+
+
 def test_full_width_unpadded_hidden_takes_the_scalar_load_path_and_matches_golden(monkeypatch):
     """stn_full with the hidden-width padding off: the five products that touch the [tokens, 3027] hidden run the
     unaligned (scalar-load) GEMM instantiations at production size, against the same reference golden."""
     from lstc_vad_amd import functional as Fn
     monkeypatch.setattr(Fn, "_PAD_HIDDEN", False)
-    test_full_width_training_step_matches_reference_golden("stn_full", True)
+    _full_width_golden_check("stn_full", True)
 
 @pytest.mark.parametrize("name", ["ltn_sht", "stn_sht", "stn_mil_ce"])
 def test_two_emulated_ranks_through_trainstep(name):
