@@ -144,6 +144,13 @@ def _register_pack(t: torch.Tensor, pk: "Packed"):
     _producer_packs[_pack_key(t)] = (t, t._version, pk)
 
 
+def drop_producer_packs():
+    """Forget the packs no GEMM picked up.  Encoder.forward / forward_cls call it on the way out, so an entry (it holds the
+    producing f32 tensor and its pack: 1.2 GB at the headline shape) never outlives one encoder call - evaluation and
+    pseudo-label loops never reach the optimizer's bump_weight_epoch()."""
+    _producer_packs.clear()
+
+
 def _producer_pack(t: torch.Tensor, kind):
     hit = _producer_packs.pop(_pack_key(t), None)
     if hit is None or hit[1] != t._version or hit[0]._version != hit[1] or hit[2].kind != kind:
@@ -1038,7 +1045,9 @@ class FFNFunction(torch.autograd.Function):
         y = gemm(hp if hp is not None else h1, w2, trans_b=True, bias=b2, dropout=(p, seed), residual=x2)
         ctx.packs = (xp, hp) if (cfg["training"] or h1 is None) else (None, None)
         if cfg["layer_norm"]:
-            z, mean, rstd = layernorm_fwd(y, ln_w, ln_b, 1e-6, pack=True)
+            # the packed bf16 copy of the result is worth its 2 B / element only when a full encoder layer consumes it next
+            # (Encoder sets emit_pack: not for the layer that feeds the CLS-only last layer or the caller)
+            z, mean, rstd = layernorm_fwd(y, ln_w, ln_b, 1e-6, pack=cfg.get("emit_pack", True))
         else:
             z, mean, rstd = y, None, None
         ctx.cfg = dict(cfg, p=p, seed=seed, shape=tuple(shape))

@@ -2,7 +2,7 @@
 import torch
 from torch import nn
 
-from ..functional import ClsConcatFunction, DropoutFunction, LayerNormFunction
+from ..functional import ClsConcatFunction, DropoutFunction, LayerNormFunction, drop_producer_packs
 from .EncoderLayer import EncoderLayer
 
 
@@ -76,9 +76,13 @@ class Encoder(nn.Module):
         FFN for that token alone (K/V still use every token).  Saves ~25 % of the step's FLOPs at 3 layers."""
         # enc_output_hi: optional second half of the batch (the abnormal sequences) so the caller need not cat
         enc_output = self._embed(enc_output, enc_output_hi)
-        for layer in self.layer_stack[:-1]:
+        n = len(self.layer_stack)
+        for i, layer in enumerate(self.layer_stack[:-1]):
+            layer.pos_ffn._emit_pack = i + 1 < n - 1          # the CLS-only last layer reads no packed operand
             enc_output = layer(enc_output)[0]
-        return self.layer_stack[-1].forward_cls(enc_output)
+        out = self.layer_stack[-1].forward_cls(enc_output)
+        drop_producer_packs()
+        return out
 
     def forward(self, enc_output, src_mask=None, return_attn=False, return_attn_v=False):
         attn_list, v_list = [], []
@@ -88,13 +92,15 @@ class Encoder(nn.Module):
                                              self.position_enc if self.position_encoding else None)
         if self.position_encoding and self.training and self.position_dropout.p > 0:
             enc_output = DropoutFunction.apply(enc_output, self.position_dropout.p, "position_dropout")
-        for layer in self.layer_stack:
+        for i, layer in enumerate(self.layer_stack):
+            layer.pos_ffn._emit_pack = i + 1 < len(self.layer_stack)      # the last layer's output goes to the caller
             res = layer(enc_output, slf_attn_mask=src_mask, return_attn=return_attn, return_attn_v=return_attn_v)
             enc_output = res[0]
             if return_attn or return_attn_v:
                 attn_list.append(res[1])
             if return_attn_v:
                 v_list.append(res[2])
+        drop_producer_packs()
         if return_attn_v:
             return enc_output, attn_list, v_list
         if return_attn:

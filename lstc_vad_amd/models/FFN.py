@@ -13,9 +13,11 @@ class PositionwiseFeedForward(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.layerNorm_flag = layerNorm
         self._site = ""
+        self._emit_pack = True     # bf16 mode: the LayerNorm also writes the packed operand of the NEXT full layer (set by Encoder)
 
     def forward(self, x):
-        cfg = dict(dropout=self.dropout.p, training=self.training, layer_norm=self.layerNorm_flag, site=self._site)
+        cfg = dict(dropout=self.dropout.p, training=self.training, layer_norm=self.layerNorm_flag, site=self._site,
+                   emit_pack=self._emit_pack)
         return FFNFunction.apply(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias,
                                  self.layer_norm.weight if self.layerNorm_flag else None,
                                  self.layer_norm.bias if self.layerNorm_flag else None, cfg)
