@@ -301,6 +301,8 @@ def main():
                     "the rank's token count leaves the three separate products with badly filled tile rounds, engine.TrainStep)")
     ap.add_argument("--grad_reduce_dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient all-reduce "
                     "(bf16: buckets rounded by lstc_cast_f32_bf16, half the xGMI bytes; default fp32 = the reference's numerics)")
+    ap.add_argument("--graph", action="store_true", help="run the step as ONE captured HIP graph (lstc_vad_amd.engine.GraphedStep; N=1 "
+                    "only): removes the ~340-launch train that small per-rank batches cannot hide")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
@@ -396,12 +398,19 @@ def main():
             tss = [p[0] for p in parts]
         else:
             ts, nxt, src = make(cfg, bs_local, bs_global, 0, feed)
-            run_step = lambda: ts.step(*nxt())
+            if a.graph:
+                if world > 1:
+                    raise SystemExit("--graph captures the single-rank step only")
+                from lstc_vad_amd.engine import GraphedStep
+                gs = GraphedStep(ts, *nxt())
+                run_step = lambda: gs.step(*nxt())
+            else:
+                run_step = lambda: ts.step(*nxt())
             tss = [ts]
         for _ in range(warmup):
             run_step()
         sync()
-        want_events = gemm_events and not a.no_gemm_events
+        want_events = gemm_events and not a.no_gemm_events and not a.graph      # a replayed graph records no per-GEMM events
         # exact-f32 steps are long (280 ms): the events around every GEMM ride inside the timed region.  In the 16-bit modes a
         # step is 5x shorter and the ~360 event records per step cost the HOST 2-5 ms of it (bf16, 8 pairs: 23.1 vs 17.8 ms per
         # step with / without events), so there the K steps are timed clean and the events are taken on 3 further steps.
@@ -617,7 +626,8 @@ def main():
                                       f"{last}: {mode} full training step (batch formation+fwd+loss+bwd+"
                                       f"{'allreduce+' if world > 1 else ''}Adagrad), GLOBAL batch B={2 * bs_global} videos x T={pn} parts x "
                                       f"L={L} snippets x P={P} patches, d_model={d}, n_hidden={ekw['d_inner']}, S={S}, "
-                                      f"dropout={'off' if a.no_dropout else 'reference rates'}, lr = reference x {a.lr_scale:g}, last layer: "
+                                      f"dropout={'off' if a.no_dropout else 'reference rates'}, lr = reference x {a.lr_scale:g}, "
+                                      f"{'step replayed as one captured HIP graph, ' if a.graph else ''}last layer: "
                                       f"{'all tokens (naive)' if a.naive_last_layer else 'CLS token only, K/V projections re-associated (exact)'}; "
                                       f"fresh weights and Adagrad state for the timed pass",
                           "feed": feed_txt, "global_videos": 2 * bs_global, "parallelism": f"dp{world}",

@@ -282,6 +282,14 @@ int lstc_colsum(const float* x, int64_t rows, int32_t cols, int32_t ld, float* p
 int lstc_dropout_apply(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
 /* mask[i] = keep(i) ? 1 : 0 — exported so tests can replay a HIP dropout run through the oracle. */
 int lstc_dropout_mask(uint8_t* mask, int64_t n, float p, uint64_t seed, void* stream);
+/* Dropout seeds for a captured step (hipGraph).  Every entry that draws a dropout mask takes its 64-bit seed BY VALUE, so a
+ * captured launch would replay one mask for ever.  While `dev_word` is non-NULL, every such launch of this process (from any host
+ * thread - the autograd backward runs on its own) carries the pointer and uses  seed + *dev_word,  read ON THE DEVICE when the
+ * kernel runs: the caller bumps the word between replays (by the number of seeds a step draws) and the replayed step sees the
+ * masks the eager step with those seeds would have seen, bit for bit.  NULL (the default) restores plain by-value seeds.
+ * Process-wide launch context, meant to bracket a stream capture; the word must outlive every graph that captured it.
+ * Replaces nothing upstream: the reference draws its masks from torch's global generator (nn.Dropout, models/FFN.py:12). */
+int lstc_dropout_seed_device(const uint64_t* dev_word);
 
 /* Last head layer fused with its activation: out = sigmoid(x W^T + b) (c=1, models/Regressor.py:9) or
  * softmax(x W^T + b) (c=2, models/Classifier.py:10).  x [rows, 32]. */

@@ -6,7 +6,15 @@ int lstc_gemm_bf16_impl(const LstcGemmDesc* d, hipStream_t st) __attribute__((we
 int lstc_gemm_f32x3_impl(const LstcGemmDesc* d, hipStream_t st);
 int lstc_gemm_bf16p_impl(const LstcGemmDesc* d, hipStream_t st);
 
+static std::atomic<const uint64_t*> g_seed_dev{nullptr};
+const uint64_t* lstc_seed_dev_current() { return g_seed_dev.load(std::memory_order_acquire); }
+
 extern "C" {
+
+int lstc_dropout_seed_device(const uint64_t* dev_word) {
+    g_seed_dev.store(dev_word, std::memory_order_release);
+    return LSTC_OK;
+}
 
 int lstc_gemm(const LstcGemmDesc* d, void* stream) {
     if (!d) return LSTC_E_NULL;

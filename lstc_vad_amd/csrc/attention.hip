@@ -199,6 +199,7 @@ __device__ __forceinline__ void lds_times_rows(const float* __restrict__ Alds, c
 
 template <int T>
 __global__ void __launch_bounds__(NT, T <= 2 ? 4 : 2) attn_fwd_kernel(const AttnParams p) {
+    const DropKey dkn = drop_key_now(p.dkey);
     constexpr bool BF = false;       // first generation: exact-f32 products only (bf16 products made these latency-bound loops slower)
     constexpr int SP = 32 * T, LD = SP + 1, NJ = (SP + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(NT, T <= 2 ? 4 : 2) attn_fwd_kernel(const Attn
                 if (j < S) {
                     pv = v[jj] / s;
                     pr_base[(size_t)i * S + j] = pv;
-                    if (p.has_drop) pv = drop_keep(flat0 + (uint32_t)(i * S + j), p.dkey) ? pv * p.dkey.scale : 0.f;
+                    if (p.has_drop) pv = drop_keep(flat0 + (uint32_t)(i * S + j), dkn) ? pv * dkn.scale : 0.f;
                 }
                 row[j] = pv;
             }
@@ -270,6 +271,7 @@ __global__ void __launch_bounds__(NT, T <= 2 ? 4 : 2) attn_fwd_kernel(const Attn
 
 template <int T>
 __global__ void __launch_bounds__(NT, T <= 3 ? 2 : 1) attn_bwd_kernel(const AttnParams p) {
+    const DropKey dkn = drop_key_now(p.dkey);
     constexpr bool BF = false;       // first generation: exact-f32 products only (bf16 products made these latency-bound loops slower)
     constexpr int SP = 32 * T, LD = SP + 1, NJ = (SP + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -319,7 +321,7 @@ __global__ void __launch_bounds__(NT, T <= 3 ? 2 : 1) attn_bwd_kernel(const Attn
                 pv[jj] = dp[jj] = keep[jj] = 0.f;
                 if (j < S) {
                     pv[jj] = pr_base[(size_t)i * S + j];
-                    keep[jj] = p.has_drop ? (drop_keep(flat0 + (uint32_t)(i * S + j), p.dkey) ? p.dkey.scale : 0.f) : 1.f;
+                    keep[jj] = p.has_drop ? (drop_keep(flat0 + (uint32_t)(i * S + j), dkn) ? dkn.scale : 0.f) : 1.f;
                     dp[jj] = drow[j] * keep[jj];
                     s += dp[jj] * pv[jj];
                 }
@@ -431,6 +433,7 @@ struct StageDma {
 
 template <int T, bool BF, int NW>
 __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) attn_bwd2_kernel(const AttnParams p) {
+    const DropKey dkn = drop_key_now(p.dkey);
     constexpr int SP = 32 * T, LD = SP + 1, NJ = (SP + 63) / 64;
     constexpr int CH = SP * 32;                  // floats of one staged operand chunk (SP rows x 32 features)
     constexpr int NPW = 2 * (SP / 8) / NW;                       // DMA pieces per wave and chunk: 2 operands x SP/8 pieces / 4 waves
@@ -545,7 +548,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) attn_bwd2_kernel(con
                 pv[jj] = dp[jj] = keep[jj] = 0.f;
                 if (j < S) {
                     pv[jj] = pvr[ii][jj];
-                    keep[jj] = p.has_drop ? (drop_keep(flat0 + (uint32_t)(i * S + j), p.dkey) ? p.dkey.scale : 0.f) : 1.f;
+                    keep[jj] = p.has_drop ? (drop_keep(flat0 + (uint32_t)(i * S + j), dkn) ? dkn.scale : 0.f) : 1.f;
                     dp[jj] = drow[j] * keep[jj];
                     s += dp[jj] * pv[jj];
                 }
@@ -628,6 +631,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) attn_bwd2_kernel(con
 // needed: only the [k][i] copy feeds P V), then O = Pd V as the job pipeline of the backward (A = Pd^T tile, B = V rows).
 template <int T, bool BF, int NW>
 __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) attn_fwd2_kernel(const AttnParams p) {
+    const DropKey dkn = drop_key_now(p.dkey);
     constexpr int SP = 32 * T, LD = SP + 1, NJ = (SP + 63) / 64;
     constexpr int CH = SP * 32;
     constexpr int NPW = 2 * (SP / 8) / NW;    
@@ -747,7 +751,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) attn_fwd2_kernel(con
                 if (j < S) {
                     pv = v[jj] / s;
                     pr_base[(size_t)i * S + j] = pv;
-                    if (p.has_drop) pv = drop_keep(flat0 + (uint32_t)(i * S + j), p.dkey) ? pv * p.dkey.scale : 0.f;
+                    if (p.has_drop) pv = drop_keep(flat0 + (uint32_t)(i * S + j), dkn) ? pv * dkn.scale : 0.f;
                 }
                 PT[j * LD + i] = pv;
             }
@@ -993,6 +997,7 @@ struct ClsParams {
 constexpr int CLS_MAXS = 128;
 
 __global__ void __launch_bounds__(NT) attn_cls_fwd_kernel(const ClsParams p) {
+    const DropKey dkn = drop_key_now(p.dkey);
     __shared__ float sc[NT / 64][CLS_MAXS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pair = blockIdx.x * (NT / 64) + wave;
@@ -1031,7 +1036,7 @@ __global__ void __launch_bounds__(NT) attn_cls_fwd_kernel(const ClsParams p) {
         if (j < S) {
             float pv = v[jj] / sum;
             p.probs[((size_t)n * p.H + h) * S + j] = pv;
-            if (p.has_drop) pv = drop_keep(flat0 + (uint32_t)j, p.dkey) ? pv * p.dkey.scale : 0.f;
+            if (p.has_drop) pv = drop_keep(flat0 + (uint32_t)j, dkn) ? pv * dkn.scale : 0.f;
             s[j] = pv;
         }
     }
@@ -1045,6 +1050,7 @@ __global__ void __launch_bounds__(NT) attn_cls_fwd_kernel(const ClsParams p) {
 }
 
 __global__ void __launch_bounds__(NT) attn_cls_bwd_kernel(const ClsParams p) {
+    const DropKey dkn = drop_key_now(p.dkey);
     __shared__ float sp[NT / 64][CLS_MAXS];      // dropped probabilities
     __shared__ float sd[NT / 64][CLS_MAXS];      // d(logit)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1075,7 +1081,7 @@ __global__ void __launch_bounds__(NT) attn_cls_bwd_kernel(const ClsParams p) {
         pv[jj] = dp[jj] = keep[jj] = 0.f;
         if (j < S) {
             pv[jj] = p.probs[((size_t)n * p.H + h) * S + j];
-            keep[jj] = p.has_drop ? (drop_keep(flat0 + (uint32_t)j, p.dkey) ? p.dkey.scale : 0.f) : 1.f;
+            keep[jj] = p.has_drop ? (drop_keep(flat0 + (uint32_t)j, dkn) ? dkn.scale : 0.f) : 1.f;
             dp[jj] = ds[j] * keep[jj];
             rs += dp[jj] * pv[jj];
         }
@@ -1175,6 +1181,7 @@ template <int HT>
 __global__ void __launch_bounds__(NT) cls_dot_kernel(const float* __restrict__ U, const float* __restrict__ X,
                                                       float* __restrict__ out, float* __restrict__ probs, int S, int H, int d,
                                                       int mode, DropKey dkey, int has_drop) {
+    dkey = drop_key_now(dkey);
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Ul = sm;                   // [H][d]
     float* sc = sm + (size_t)H * d;   // [H][S]

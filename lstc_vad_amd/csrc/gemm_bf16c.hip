@@ -147,6 +147,7 @@ __device__ __forceinline__ bf16x8 read_frag(const __bf16* __restrict__ lds, int 
 template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC, bool VA, bool VB>
 __global__ void __launch_bounds__(WGM* WGN * 64) gemm_bf16c_kernel(const GemmParams p_in) {
     GemmParams p = p_in;
+    p.dk = drop_key_now(p.dk);          // graph replays: seed + device offset (lstc_dropout_seed_device)
     p.A += (size_t)blockIdx.z * p.batch_stride_a;
     p.B += (size_t)blockIdx.z * p.batch_stride_b;
     p.C += (size_t)blockIdx.z * p.batch_stride_c;

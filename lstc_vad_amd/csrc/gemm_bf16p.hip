@@ -140,6 +140,7 @@ constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >>
 // 2 = packed output AND the ReLU mask read from a packed operand (LSTC_EPI_RELU_MASK_PACK); 3 = packed mask, f32 output.
 template <bool TR, bool S16, int EPK = 0>
 __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
+    const DropKey dkn = drop_key_now(p.dk);      // graph replays: seed + device offset (lstc_dropout_seed_device)
     static_assert(!(TR && S16), "the transposed-read form keeps the 32x32x16 shape");
     static_assert(EPK == 0 || S16, "packed outputs / masks exist on the pipelined epilogue of the S16 form only");
     constexpr bool OPK = EPK == 1 || EPK == 2, MPK = EPK == 2 || EPK == 3;
@@ -551,10 +552,10 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                     if (flags & LSTC_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); } \
                     if (flags & LSTC_EPI_DROPOUT) {                                                                      \
                         const uint32_t idx = idx0 + (uint32_t)((rt) * 16 + 4 * (hf)) * (uint32_t)p.N + 32u * (cp);        \
-                        v.x = drop_keep(idx, p.dk) ? v.x * p.dk.scale : 0.f;                                             \
-                        v.y = drop_keep(idx + 1, p.dk) ? v.y * p.dk.scale : 0.f;                                         \
-                        v.z = drop_keep(idx + 2, p.dk) ? v.z * p.dk.scale : 0.f;                                         \
-                        v.w = drop_keep(idx + 3, p.dk) ? v.w * p.dk.scale : 0.f;                                         \
+                        v.x = drop_keep(idx, dkn) ? v.x * dkn.scale : 0.f;                                             \
+                        v.y = drop_keep(idx + 1, dkn) ? v.y * dkn.scale : 0.f;                                         \
+                        v.z = drop_keep(idx + 2, dkn) ? v.z * dkn.scale : 0.f;                                         \
+                        v.w = drop_keep(idx + 3, dkn) ? v.w * dkn.scale : 0.f;                                         \
                     }                                                                                                   \
                     if (flags & LSTC_EPI_RESIDUAL) { v.x += (av)[0]; v.y += (av)[1]; v.z += (av)[2]; v.w += (av)[3]; }    \
                     if (flags & LSTC_EPI_RELU_MASK) {                                                                    \
@@ -656,10 +657,10 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                 if (flags & LSTC_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); } \
                 if (flags & LSTC_EPI_DROPOUT) {                                                                            \
                     const uint32_t idx = (uint32_t)(row) * (uint32_t)p.N + (uint32_t)(col);                                \
-                    v.x = drop_keep(idx, p.dk) ? v.x * p.dk.scale : 0.f;                                                   \
-                    v.y = drop_keep(idx + 1, p.dk) ? v.y * p.dk.scale : 0.f;                                               \
-                    v.z = drop_keep(idx + 2, p.dk) ? v.z * p.dk.scale : 0.f;                                               \
-                    v.w = drop_keep(idx + 3, p.dk) ? v.w * p.dk.scale : 0.f;                                               \
+                    v.x = drop_keep(idx, dkn) ? v.x * dkn.scale : 0.f;                                                   \
+                    v.y = drop_keep(idx + 1, dkn) ? v.y * dkn.scale : 0.f;                                               \
+                    v.z = drop_keep(idx + 2, dkn) ? v.z * dkn.scale : 0.f;                                               \
+                    v.w = drop_keep(idx + 3, dkn) ? v.w * dkn.scale : 0.f;                                               \
                 }                                                                                                        \
                 if (flags & LSTC_EPI_RESIDUAL) {                                                                           \
                     const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)(row) * p.ldr + (col));              \
@@ -766,7 +767,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                         if (flags & LSTC_EPI_RELU) v = fmaxf(v, 0.f);
                         if (flags & LSTC_EPI_DROPOUT) {
                             const uint32_t idx = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
-                            v = drop_keep(idx, p.dk) ? v * p.dk.scale : 0.f;
+                            v = drop_keep(idx, dkn) ? v * dkn.scale : 0.f;
                         }
                         if (flags & LSTC_EPI_RESIDUAL) v += p.res[(size_t)row * p.ldr + col];
                         if (flags & LSTC_EPI_RELU_MASK) v = p.relu_src[(size_t)row * p.ld_relu + col] > 0.f ? v : 0.f;

@@ -182,6 +182,7 @@ struct StepTag { static constexpr int smode = SMODE, cur = CUR; };
 // and the fragments (8 consecutive tokens of one feature) come out of ds_read_b64_tr_b16, the hardware transpose read.
 template <bool TR>
 __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
+    const DropKey dkn = drop_key_now(p.dk);
     extern __shared__ __attribute__((aligned(16))) pk_t smem_pk[];
     pk_t* const smem = smem_pk;
     int pid = blockIdx.x;
@@ -360,7 +361,7 @@ __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
                 if (flags & LSTC_EPI_RELU) v = fmaxf(v, 0.f);
                 if (flags & LSTC_EPI_DROPOUT) {
                     const uint32_t idx = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
-                    v = drop_keep(idx, p.dk) ? v * p.dk.scale : 0.f;
+                    v = drop_keep(idx, dkn) ? v * dkn.scale : 0.f;
                 }
                 if (flags & LSTC_EPI_RESIDUAL) v += p.res[(size_t)row * p.ldr + col];
                 if (flags & LSTC_EPI_RELU_MASK) v = p.relu_src[(size_t)row * p.ld_relu + col] > 0.f ? v : 0.f;
@@ -378,6 +379,7 @@ __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
 
 template <bool TR>
 __global__ void __launch_bounds__(NT, 2) gemm_pk2s_kernel(const PkParams p) {
+    const DropKey dkn = drop_key_now(p.dk);
     extern __shared__ __attribute__((aligned(16))) pk_t smem_pk[];
     pk_t* const smem = smem_pk;
     int pid = blockIdx.x;
@@ -536,7 +538,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_pk2s_kernel(const PkParams p) {
                 if (flags & LSTC_EPI_RELU) v = fmaxf(v, 0.f);
                 if (flags & LSTC_EPI_DROPOUT) {
                     const uint32_t idx = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
-                    v = drop_keep(idx, p.dk) ? v * p.dk.scale : 0.f;
+                    v = drop_keep(idx, dkn) ? v * dkn.scale : 0.f;
                 }
                 if (flags & LSTC_EPI_RESIDUAL) v += p.res[(size_t)row * p.ldr + col];
                 if (flags & LSTC_EPI_RELU_MASK) v = p.relu_src[(size_t)row * p.ld_relu + col] > 0.f ? v : 0.f;
@@ -557,6 +559,7 @@ constexpr int WD_STAGE = 3 * PK_TILE;       // 48 KB
 
 template <bool TR>
 __global__ void __launch_bounds__(NT, 1) gemm_pkw_kernel(const PkParams p) {
+    const DropKey dkn = drop_key_now(p.dk);
     extern __shared__ __attribute__((aligned(16))) pk_t smem_pk[];
     pk_t* const smem = smem_pk;
     int pid = blockIdx.x;
@@ -718,7 +721,7 @@ __global__ void __launch_bounds__(NT, 1) gemm_pkw_kernel(const PkParams p) {
                 if (flags & LSTC_EPI_RELU) v = fmaxf(v, 0.f);
                 if (flags & LSTC_EPI_DROPOUT) {
                     const uint32_t idx = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
-                    v = drop_keep(idx, p.dk) ? v * p.dk.scale : 0.f;
+                    v = drop_keep(idx, dkn) ? v * dkn.scale : 0.f;
                 }
                 if (flags & LSTC_EPI_RESIDUAL) v += p.res[(size_t)row * p.ldr + col];
                 if (flags & LSTC_EPI_RELU_MASK) v = p.relu_src[(size_t)row * p.ld_relu + col] > 0.f ? v : 0.f;

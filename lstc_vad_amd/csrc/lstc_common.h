@@ -16,15 +16,33 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 struct DropKey {
     uint32_t k0, k1, thr;
     float scale;
+    uint64_t seed;                 // the seed k0 / k1 were derived from
+    const uint64_t* seed_dev;      // device word ADDED to the seed when the kernel runs (lstc_dropout_seed_device), or NULL
 };
 
-__host__ __device__ inline DropKey make_drop_key(float p, uint64_t seed) {
-    DropKey k;
+__host__ __device__ inline void drop_key_mix(DropKey& k, uint64_t seed) {
     k.k0 = (uint32_t)(seed & 0xffffffffu) * 0x9E3779B1u + 0x7F4A7C15u;
     k.k1 = (uint32_t)(seed >> 32) * 0x85EBCA77u + 0x165667B1u;
+}
+
+// lstc_dropout_seed_device (api.hip): while set, every launch of this process that draws a dropout mask carries the pointer
+// and re-derives its key from seed + *pointer ON THE DEVICE - a captured (hipGraph) step replays with fresh masks.
+const uint64_t* lstc_seed_dev_current();
+
+inline DropKey make_drop_key(float p, uint64_t seed) {
+    DropKey k;
+    drop_key_mix(k, seed);
     double t = (double)p * 4294967296.0;
     k.thr = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
     k.scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
+    k.seed = seed;
+    k.seed_dev = lstc_seed_dev_current();
+    return k;
+}
+
+// Called ONCE at the top of a kernel (wave-uniform scalar work): the key this launch uses.
+__device__ inline DropKey drop_key_now(DropKey k) {
+    if (k.seed_dev) drop_key_mix(k, k.seed + *k.seed_dev);
     return k;
 }
 

@@ -115,6 +115,7 @@ __global__ void __launch_bounds__(NT, NV == 8 ? 2 : 1) ln_bwd_vec(const float* _
                                                   const float* __restrict__ rstd, float* __restrict__ dx,
                                                   float* __restrict__ partial, int64_t rows, int d,
                                                   __bf16* __restrict__ packed, int KBp, DropKey key) {
+    key = drop_key_now(key);
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [NT/64][d], reused per partial kind
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave0 = (int64_t)blockIdx.x * (NT / 64) + wv;
@@ -214,6 +215,7 @@ __global__ void __launch_bounds__(NT) ln_bwd_pack2(const float* __restrict__ dy,
                                                     const float* __restrict__ rstd, float* __restrict__ dx,
                                                     float* __restrict__ partial, int64_t rows, int d,
                                                     __bf16* __restrict__ packed, int KBp, DropKey key) {
+    key = drop_key_now(key);
     constexpr bool PACK = MODE != 0;
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][d] combine buffer, then [2][4][64][2] per-lane row sums
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, slot = wv >> 1, half = wv & 1;
@@ -487,11 +489,13 @@ __global__ void __launch_bounds__(NT) colsum_few(const float* __restrict__ x, in
 // --------------------------------------------------------------------------------- dropout
 __global__ void __launch_bounds__(NT) dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                             int64_t n, DropKey k) {
+    k = drop_key_now(k);
     const int64_t stride = (int64_t)gridDim.x * NT;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride)
         y[i] = drop_keep((uint32_t)i, k) ? x[i] * k.scale : 0.f;
 }
 __global__ void __launch_bounds__(NT) dropout_mask_kernel(uint8_t* __restrict__ m, int64_t n, DropKey k) {
+    k = drop_key_now(k);
     const int64_t stride = (int64_t)gridDim.x * NT;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) m[i] = drop_keep((uint32_t)i, k) ? 1 : 0;
 }

@@ -100,6 +100,97 @@ class TrainStep:
         return scalars
 
 
+class GraphedStep:
+    """``TrainStep.step`` captured ONCE into a HIP graph and replayed per step: forward, loss, backward and the Adagrad
+    launch - about 340 kernel launches in the LTN step - become one graph launch.  At the headline batch the GPU is never
+    idle between launches, so this buys nothing there; it matters for the small per-rank batches of a strong-scaled job,
+    where the launch train itself (2.7 of 8.5 ms at 4 pairs per rank in bf16 mode) is what is left of the step.
+
+    What makes the capture replayable:
+      * dropout: every kernel takes its mask seed by value, so a replay would repeat one mask.  The capture is bracketed by
+        ``lstc_dropout_seed_device`` (include/lstc_hip.h): each launch then uses  seed + *word  read on the device, and the
+        graph's last node adds the number of seeds a step draws to the word - replay k sees exactly the masks the k-th eager
+        step would have drawn (``functional.next_seed`` is advanced alongside), so the weights are bit-identical to eager
+        steps (tests/test_hip_parity.py::test_graphed_step_is_bitwise_the_eager_step);
+      * inputs live in static buffers (``step`` copies the batch in); gradients, activations and split-K partials come out
+        of the graph's private memory pool; the optimizer's one launch carries the parameter pointers, which never move;
+      * no host sync and no host-dependent control flow inside a step (the five scalars stay on the device).
+    Not captured: the gradient all-reduce / bag exchange of a multi-rank job and ``clip_grad`` (it reads the norm back on
+    the host like upstream) - ``GraphedStep`` refuses those and the caller keeps ``TrainStep.step``."""
+
+    def __init__(self, ts: TrainStep, norm_feats, abnorm_feats, abnorm_labs, warmup: int = 1):
+        from . import _lib
+        from . import functional as Fn
+        if ts.reducer is not None or ts.world > 1 or ts.loss_exchange is not None:
+            raise RuntimeError("GraphedStep: the multi-rank step (gradient all-reduce, bag exchange) is not captured")
+        if getattr(ts.args, "clip_grad", False):
+            raise RuntimeError("GraphedStep: --clip_grad reads the gradient norm on the host; not capturable")
+        self.ts = ts
+        dev = norm_feats.device
+        self.nf, self.af, self.al = (torch.empty_like(t) for t in (norm_feats, abnorm_feats, abnorm_labs))
+        for dst, src in ((self.nf, norm_feats), (self.af, abnorm_feats), (self.al, abnorm_labs)):
+            dst.copy_(src)
+        self.seed_word = torch.zeros(1, device=dev, dtype=torch.int64)
+        params = [p for g in ts.optimizer.param_groups for p in g["params"]]
+        # 1. warm-up on a side stream (lazy kernel attributes, autograd threads, allocator pools), then put weights, Adagrad
+        #    state and the seed counter back: constructing a GraphedStep leaves the training state untouched
+        keep_w = [p.detach().clone() for p in params]
+        keep_s = [ts.optimizer.state[p]["sum"].clone() for p in params]
+        keep_n = [ts.optimizer.state[p]["step"] for p in params]
+        c0 = Fn._counter
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                Fn.reset_rng(c0)
+                ts.step(self.nf, self.af, self.al)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.seeds_per_step = Fn._counter - c0
+        with torch.no_grad():
+            for p, w, s_, n in zip(params, keep_w, keep_s, keep_n):
+                p.copy_(w)
+                ts.optimizer.state[p]["sum"].copy_(s_)
+                ts.optimizer.state[p]["step"] = n
+        del keep_w, keep_s
+        Fn.bump_weight_epoch()
+        Fn.reset_rng(c0)
+        # 2. capture one step; the seeds drawn here are baked in by value and offset by the device word at run time
+        lib = _lib.load()
+        self.graph = torch.cuda.CUDAGraph()
+        ts.optimizer.zero_grad(set_to_none=True)
+        torch.cuda.synchronize(dev)
+        _lib.check(lib.lstc_dropout_seed_device(self.seed_word.data_ptr()), "lstc_dropout_seed_device")
+        try:
+            with torch.cuda.graph(self.graph):
+                loss, scalars, _ = ts.forward_loss(self.nf, self.af, self.al)
+                loss.backward()
+                ts.optimizer.step()
+                self.seed_word.add_(self.seeds_per_step)
+        finally:
+            _lib.check(lib.lstc_dropout_seed_device(None), "lstc_dropout_seed_device")
+        self.scalars = scalars
+        assert Fn._counter - c0 == self.seeds_per_step, "a step must draw the same number of dropout seeds every time"
+        Fn.reset_rng(c0)                      # nothing ran: the first replay IS the step with these seeds
+        for p, n in zip(params, keep_n):
+            ts.optimizer.state[p]["step"] = n
+        self._params = params
+
+    def step(self, norm_feats, abnorm_feats, abnorm_labs):
+        """One optimisation step on this batch (shapes as at construction).  Returns the five scalars (a fresh device
+        tensor; no host sync)."""
+        from . import functional as Fn
+        if norm_feats is not self.nf:
+            self.nf.copy_(norm_feats.reshape(self.nf.shape))
+            self.af.copy_(abnorm_feats.reshape(self.af.shape))
+            self.al.copy_(abnorm_labs.reshape(self.al.shape))
+        self.graph.replay()
+        Fn.reset_rng(Fn._counter + self.seeds_per_step)
+        for p in self._params:
+            self.ts.optimizer.state[p]["step"] += 1
+        Fn.bump_weight_epoch()
+        return self.scalars.clone()
+
+
 class MixedStep:
     """Several (encoder, head) replicas with different feature widths stepped in ONE iteration - BASELINE config 5
     (UBnormal d_model=1024 / part_len=5 mixed with ShanghaiTech d_model=2048 / part_len=3 in one batch).

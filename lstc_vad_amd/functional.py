@@ -26,15 +26,17 @@ _recorder = None          # list collecting (site, p, seed, shape) while record_
 
 
 def next_seed() -> int:
-    """64-bit seed for one dropout site invocation: a hash of torch's seed and a call counter, so a run
-    is reproducible under ``torch.manual_seed`` without touching torch's generators."""
+    """64-bit seed for one dropout site invocation: a hash of torch's seed PLUS a call counter, so a run is reproducible
+    under ``torch.manual_seed`` without touching torch's generators.  Linear in the counter on purpose: a captured step
+    (engine.GraphedStep) replays with  seed + device word  (lstc_dropout_seed_device) and must land on the seeds the eager
+    steps draw; the kernels' key derivation and per-element hash (csrc/lstc_common.h) do the mixing."""
     global _counter
     _counter += 1
-    x = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _counter * 0xD1342543DE82EF95) & _MASK64
+    x = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0xD1342543DE82EF95) & _MASK64
     x ^= x >> 32
     x = (x * 0xD6E8FEB86659FD93) & _MASK64
     x ^= x >> 32
-    return x
+    return (x + _counter) & _MASK64
 
 
 def reset_rng(counter: int = 0):

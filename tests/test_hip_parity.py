@@ -548,6 +548,53 @@ def test_bf16_step_with_narrow_hidden_or_heads_at_default_thresholds(d_inner, d_
         assert torch.isfinite(b).all() and cos > 0.97, (k, cos)
 
 
+@pytest.mark.parametrize("name,mode_", [("ltn_sht", "fp32"), ("stn_mil_ce", "fp32"), ("ltn_ubnormal_dk32", "bf16"), ("ltn_sht", "bf16p")])
+def test_graphed_step_is_bitwise_the_eager_step(name, mode_):
+    """engine.GraphedStep: the whole training step captured into one HIP graph and replayed.  Four replays with dropout ON
+    (three different batches) against four eager TrainStep.step calls from the same weights and seed counter: the five
+    scalars of every step and every weight after the last one are bit-identical - the device-side seed word
+    (lstc_dropout_seed_device) gives replay k the masks of eager step k, forward and backward.  ``bf16p`` forces the packed
+    bf16 GEMM (its hand-scheduled epilogue draws the dropout mask too) on the reduced case."""
+    from lstc_vad_amd import functional as Fn
+    from lstc_vad_amd.engine import GraphedStep, TrainStep
+    z, mode, ekw, skw = load_case(name)
+    d = ekw["d_model"]
+    args = _args(mode, skw)
+    g = torch.Generator().manual_seed(5)
+    batches = []
+    for i in range(3):
+        nf = torch.from_numpy(z["norm_feats"]) * (1.0 + 0.1 * i) + 0.01 * torch.randn(z["norm_feats"].shape, generator=g).abs()
+        af = torch.from_numpy(z["abnorm_feats"]) * (1.0 - 0.05 * i)
+        batches.append((nf.to(DEV), af.to(DEV), torch.from_numpy(z["abnorm_labs"]).to(DEV)))
+    res = {}
+    Fn.set_compute_dtype("bf16" if mode_.startswith("bf16") else mode_)
+    if mode_ == "bf16p":
+        Fn.set_x3_threshold(0, 0, 0)
+    try:
+        for how in ("eager", "graph"):
+            enc, head = _models(mode, dict(ekw), d, dropout=0.2, head_dropout=0.3)
+            enc.load_state_dict(sub(z, "enc_init."), strict=True)
+            head.load_state_dict(sub(z, "head_init."), strict=True)
+            enc, head = enc.to(DEV).train(), head.to(DEV).train()
+            ts = TrainStep(args, mode, enc, head, 1e-3, 1e-2, 1e-3, fuse_qkv="off")
+            Fn.reset_rng(11)
+            stepper = ts if how == "eager" else GraphedStep(ts, *batches[0])
+            assert Fn._counter == 11
+            scs = [stepper.step(*batches[i % 3]).clone() for i in range(4)]
+            torch.cuda.synchronize()
+            res[how] = (scs, {k: p.detach().clone() for k, p in list(enc.named_parameters()) + list(head.named_parameters())}, Fn._counter)
+            if how == "graph":
+                assert stepper.seeds_per_step >= 6
+    finally:
+        Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
+    assert res["eager"][2] == res["graph"][2]                                   # same number of seeds consumed
+    for a, b in zip(res["eager"][0], res["graph"][0]):
+        assert torch.equal(a, b), (a, b)
+    assert not torch.equal(res["eager"][0][0], res["eager"][0][3])              # (the steps do differ from one another)
+    for k, w in res["eager"][1].items():
+        assert torch.equal(w, res["graph"][1][k]), k
+
+
 def test_fused_qkv_buffer_matches_separate_projections():
     """MultiHeadAttention.fuse_qkv_ (w_qs/w_ks/w_vs as row blocks of one buffer -> one GEMM each for projection, weight
     gradient and input gradient) must not change values, parameter names or the optimizer's view of the weights."""
