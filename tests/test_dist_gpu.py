@@ -1,0 +1,131 @@
+"""The N-rank training step on real hardware: TWO processes, each a full rank of the data-parallel job - HIP kernels, the
+sharded loss (lstc_vad_loss phases 0 / 1 around the bag all-reduce), lstc_vad_amd.dist.GradAllReducer's backward-ordered
+buckets launched from autograd hooks, Adagrad on the reduced gradients - sharing the ONE GPU of the test box.  RCCL refuses two
+ranks on one device, so the collectives travel over gloo (which stages device tensors through the host); everything else is
+exactly what ``torchrun --nproc-per-node N Train/*.py`` / ``bench.py --gpus N`` executes per rank.  Checked against the
+reference's single-process golden vectors: the ranks' loss contributions add up to the reference loss, the all-reduced
+gradients and the weights after two Adagrad steps equal the reference's, and both ranks hold bit-identical weights."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank(rank, world, port, name, compute, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from argparse import Namespace
+        from lstc_vad_amd import functional as Fn
+        from lstc_vad_amd.engine import TrainStep
+        from lstc_vad_amd.models import Classifier, Encoder, Regressor
+        from util import load_case, sub
+        dev = torch.device("cuda", 0)
+        z, mode, ekw, skw = load_case(name)
+        d, bs = ekw["d_model"], skw["batch_size"]
+        h = bs // world
+        enc = Encoder(n_layers=3, MHA_attn_dropout=0.0, MHA_fc_dropout=0.0, FFN_dropout=0.0, position_dropout=0.0,
+                      weight_init=False, **ekw)
+        head = (Classifier if mode == "LTN" else Regressor)(d, 0.0, weight_init=False)
+        enc.load_state_dict(sub(z, "enc_init."), strict=True)
+        head.load_state_dict(sub(z, "head_init."), strict=True)
+        enc, head = enc.to(dev).train(), head.to(dev).train()
+        args = Namespace(batch_size=h, part_num=skw["part_num"], part_len=skw["part_len"], n_patch=skw["n_patch"], lambda_1=0.01,
+                         lambda_MIL=1.0, lambda_CE=0.8, lambda_BCE=1.0, lambda_normal=0.2, lambda_abnormal=2.0,
+                         temporal_only=False, clip_grad=False)
+        Fn.set_compute_dtype(compute)
+        ts = TrainStep(args, mode, enc, head, 1e-4, 1e-2, 1e-3, fuse_qkv="off")
+        assert ts.reducer is not None and ts.reducer.active and ts.world == world
+        sl = slice(rank * h, (rank + 1) * h)                      # rank r owns pairs [r*bs/N, (r+1)*bs/N)
+        nf, af, al = (torch.from_numpy(z[k])[sl].to(dev) for k in ("norm_feats", "abnorm_feats", "abnorm_labs"))
+        out = {}
+        for step in range(2):
+            sc = ts.step(nf, af, al).clone()
+            dist.all_reduce(sc)                                   # rank-local contributions -> the global scalars
+            out[f"scalars{step}"] = sc.cpu().double().numpy()
+            if step == 0:
+                # after step(): .grad are the bucket views holding the all-reduced gradients of step 0
+                # (numpy through the queue: torch tensors travel by file descriptor and need the sender alive at receive time)
+                out["grads"] = {("enc." + k): p.grad.detach().cpu().numpy().copy() for k, p in enc.named_parameters() if p.grad is not None}
+                out["grads"].update({("head." + k): p.grad.detach().cpu().numpy().copy() for k, p in head.named_parameters() if p.grad is not None})
+        torch.cuda.synchronize()
+        w = {("enc." + k): v.detach().cpu() for k, v in enc.state_dict().items() if v.is_floating_point()}
+        w.update({("head." + k): v.detach().cpu() for k, v in head.state_dict().items()})
+        # every rank applied the same reduced gradients: the replicas must be bit-identical
+        flat = torch.cat([v.reshape(-1) for v in w.values()]).to(dev)
+        both = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        out["replicas_identical"] = all(torch.equal(both[0], b) for b in both[1:])
+        out["payload"] = ts.reducer.payload_bytes()
+        if rank == 0:
+            out["weights"] = {k: v.numpy().copy() for k, v in w.items()}
+            q.put(out)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("name,compute", [("ltn_sht", "fp32"), ("stn_mil_ce", "fp32"), ("ltn_ubnormal_dk32", "bf16")])
+def test_two_rank_hip_step_over_gloo_matches_reference_golden(name, compute):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from util import load_case, sub
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, name, compute, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = q.get(timeout=420)
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    z, mode, ekw, skw = load_case(name)
+    assert res["replicas_identical"] and res["payload"] > 0
+    tight = compute == "fp32"
+    assert np.max(np.abs(res["scalars0"] - z["scalars"])) < (2e-5 if tight else 3e-2)
+    assert np.max(np.abs(res["scalars1"] - z["scalars_step2"])) < (1e-4 if tight else 3e-2)
+    ref_g = {("enc." + k): v for k, v in sub(z, "enc_grad.").items()}
+    ref_g.update({("head." + k): v for k, v in sub(z, "head_grad.").items()})
+    assert set(res["grads"]) == set(ref_g), set(res["grads"]) ^ set(ref_g)
+    for k, g in ref_g.items():
+        got = torch.from_numpy(res["grads"][k])
+        if tight:
+            tol = 2e-4 * float(g.abs().max()) + 1e-7
+            assert float((got - g).abs().max()) < tol, (k, float((got - g).abs().max()), tol)
+        elif g.numel() > 64 and float(g.norm()) > 0:
+            cos = float((got * g).sum() / (got.norm() * g.norm() + 1e-20))
+            assert cos > 0.9, (k, cos)
+    if tight:
+        ref_w = {("enc." + k): v for k, v in sub(z, "enc_after2.").items() if v.is_floating_point()}
+        ref_w.update({("head." + k): v for k, v in sub(z, "head_after2.").items()})
+        for k, v in res["weights"].items():
+            diff = (torch.from_numpy(v) - ref_w[k]).abs()
+            lr = 1e-4 if k.startswith("enc.") else 1e-2
+            assert float((diff > 5e-5).float().mean()) <= (1e-3 if k.startswith("enc.") else 1e-2), (k, float(diff.max()))
+            assert float(diff.max()) <= 4 * lr + 1e-6, (k, float(diff.max()))
