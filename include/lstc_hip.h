@@ -96,7 +96,8 @@ typedef struct LstcGemmDesc {
                                        LSTC_F32X3 with batch_stride_c != 0: split z writes its partial product to
                                        C + z*batch_stride_c instead (no atomics; the caller sums the partials) */
     int32_t variant;                /* 0 = library default tile (LSTC_F32: 128x128, the rows of a mostly empty last tile round on the
-                                       64x64 variant - bit-identical results); 1..11 select a documented tile variant (tuning / tests);
+                                       64x64 variant, K <= 2048 / N <= 2048 products on the persistent walk of the same loop - bit-identical
+                                       results); 1..12 select a documented tile variant (tuning / tests; 12 = the persistent kernel);
                                        anything else -> LSTC_E_UNSUPPORTED.  Timing-only ablation variants exist only in
                                        -DLSTC_TUNING builds (tools/gemm_check), never in the production library */
     int32_t batch;                  /* 0/1 = single problem; >1: `batch` independent problems of identical shape, problem z

@@ -55,6 +55,7 @@ struct GemmParams {
     unsigned int a_bytes, b_bytes;   // operand extents for the buffer descriptors of PIPE 5 (operands < 4 GiB)
     int debug;     // timing-only ablations (tools/gemm_check): 1 = no global loads in the loop, 2 = no LDS writes, 4 = no barrier
     int row_off;   // first row of this launch inside the caller's matrix (dropout counter of a row-split product)
+    int epi_f4;    // 0: scalar epilogue; 1 / 2: float4 epilogue allowed, without / with ONE per-element operand (epilogue_f4)
 };
 
 // Stages one operand tile (R rows/cols x 32 k) global -> registers -> LDS.
@@ -208,6 +209,96 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int row
         const float* p = lds + (16 * h + 8 * half) * R + row;
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = p[j * R];
+    }
+}
+
+template <int CTRL>
+__device__ __forceinline__ float quad_dpp(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+// 4 x 4 transpose across (4 registers) x (the 4 lanes of a quad): afterwards register k of lane c holds what register c of lane k held
+__device__ __forceinline__ void quad_transpose(float& r0, float& r1, float& r2, float& r3, int c) {
+    { const float x = (c & 1) ? r0 : r1; const float y = quad_dpp<0xB1>(x); if (c & 1) r0 = y; else r1 = y; }    // quad_perm [1,0,3,2]
+    { const float x = (c & 1) ? r2 : r3; const float y = quad_dpp<0xB1>(x); if (c & 1) r2 = y; else r3 = y; }
+    { const float x = (c & 2) ? r0 : r2; const float y = quad_dpp<0x4E>(x); if (c & 2) r0 = y; else r2 = y; }    // quad_perm [2,3,0,1]
+    { const float x = (c & 2) ? r1 : r3; const float y = quad_dpp<0x4E>(x); if (c & 2) r1 = y; else r3 = y; }
+}
+
+// Epilogue of one wave's (32 TM) x (32 TN) block whose top-left element is (mw0, nw0): quad-transposed float4 form (see
+// gemm_f32_persist_kernel).  Needs N, ldc (and the operand's ld) multiples of 4 and 16-B aligned pointers; AUX = the launch has
+// exactly one per-element operand (residual | ReLU-mask source | accumulate target).
+struct EpiArgs {       // passed BY VALUE: a reference to the kernel's (modified) parameter copy would pin that struct in scratch memory
+    float* C;
+    const float* bias;
+    const float* aux;  // the one per-element operand: residual | ReLU-mask source | accumulate target (AUX)
+    int M, N, ldc, ldaux, flags, row_off;
+    float alpha;
+    DropKey dk;
+};
+__device__ __forceinline__ EpiArgs make_epi_args(const float* A_unused, float* C, const float* bias, const float* res, const float* relu_src,
+                                                  int M, int N, int ldc, int ldr, int ld_relu, int flags, int row_off, float alpha, DropKey dk) {
+    EpiArgs e;
+    e.C = C; e.bias = bias;
+    e.aux = (flags & LSTC_EPI_RESIDUAL) ? res : (flags & LSTC_EPI_RELU_MASK) ? relu_src : C;
+    e.ldaux = (flags & LSTC_EPI_RESIDUAL) ? ldr : (flags & LSTC_EPI_RELU_MASK) ? ld_relu : ldc;
+    e.M = M; e.N = N; e.ldc = ldc; e.flags = flags; e.row_off = row_off; e.alpha = alpha; e.dk = dk;
+    return e;
+}
+#define LSTC_EPI_ARGS(p) make_epi_args(nullptr, (p).C, (p).bias, (p).res, (p).relu_src, (p).M, (p).N, (p).ldc, (p).ldr, (p).ld_relu, (p).flags, (p).row_off, (p).alpha, (p).dk)
+
+template <int TM, int TN, bool AUX>
+__device__ __forceinline__ void epilogue_f4(const EpiArgs p, floatx16 (&acc)[TM][TN], int mw0, int nw0, int lane) {
+    const int l31 = lane & 31, h = lane >> 5;
+    // ---- epilogue: quad-transposed, one float4 of a row per lane and register group.  Straight-line code: the per-element
+    // operand (AUX: residual, ReLU-mask source or the accumulate target - at most one of them on this kernel) is loaded
+    // unconditionally from clamped addresses, four groups ahead of its use, and only the store is predicated - a load inside
+    // a flag branch makes the compiler drain vmcnt(0) at every join (16 serialized store round trips per tile, and the next
+    // tile's prefetch with them).
+    const int flags = p.flags;
+    const int c = lane & 3, q = l31 >> 2;
+    const float* aux = p.aux;
+    const int ldaux = p.ldaux;
+    const bool f_relu = flags & LSTC_EPI_RELU, f_drop = flags & LSTC_EPI_DROPOUT, f_mask = flags & LSTC_EPI_RELU_MASK;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = nw0 + j * 32 + 4 * q;
+        const int colc = min(col, p.N - 4);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (flags & LSTC_EPI_BIAS) bv = *reinterpret_cast<const float4*>(p.bias + colc);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rbase = mw0 + i * 32 + 4 * h + c;
+            float4 ax[4];
+            if constexpr (AUX) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    ax[g] = *reinterpret_cast<const float4*>(aux + (size_t)min(rbase + 8 * g, p.M - 1) * ldaux + colc);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float r0 = acc[i][j][4 * g + 0], r1 = acc[i][j][4 * g + 1], r2 = acc[i][j][4 * g + 2], r3 = acc[i][j][4 * g + 3];
+                quad_transpose(r0, r1, r2, r3, c);
+                const int row = rbase + 8 * g;
+                float4 v = make_float4(r0 * p.alpha + bv.x, r1 * p.alpha + bv.y, r2 * p.alpha + bv.z, r3 * p.alpha + bv.w);
+                if (f_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (f_drop) {
+                    const uint32_t idx = (uint32_t)(row + p.row_off) * (uint32_t)p.N + (uint32_t)col;
+                    v.x = drop_keep(idx, p.dk) ? v.x * p.dk.scale : 0.f;
+                    v.y = drop_keep(idx + 1, p.dk) ? v.y * p.dk.scale : 0.f;
+                    v.z = drop_keep(idx + 2, p.dk) ? v.z * p.dk.scale : 0.f;
+                    v.w = drop_keep(idx + 3, p.dk) ? v.w * p.dk.scale : 0.f;
+                }
+                if constexpr (AUX) {
+                    const float4 x = ax[g];
+                    if (f_mask) {
+                        v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f; v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
+                    } else {                                 // residual or accumulate: both add the operand
+                        v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                    }
+                }
+                if (row < p.M && col < p.N) *reinterpret_cast<float4*>(p.C + (size_t)row * p.ldc + col) = v;
+            }
+        }
     }
 }
 
@@ -630,6 +721,14 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParam
     }
 
     // ---- epilogue
+    if constexpr (TM <= 2 && TN <= 2 && (PIPE_ABL & 15) == 5) {
+        if (p.epi_f4 && gridDim.y == 1) {                       // float4 form (host checked alignment and the operand count)
+            const EpiArgs ea = LSTC_EPI_ARGS(p);
+            if (p.epi_f4 == 2) epilogue_f4<TM, TN, true>(ea, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
+            else epilogue_f4<TM, TN, false>(ea, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
+            return;
+        }
+    }
     const int flags = p.flags;
     const bool atomic = gridDim.y > 1;
 #pragma unroll
@@ -663,6 +762,202 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParam
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PERSISTENT form of the PIPE 5 kernel (variant 12; aligned operands, K a multiple of 32, >= 4 K tiles, no split-K, no batch).
+// Per-tile fixed cost of the one-tile-per-workgroup kernel: t(tile) = 12.3 us + 0.1087 us/k on the headline shapes (K = 2048:
+// 234.9 us, K = 4096: 457.5 us) - first-load latency of the prologue plus 64 scattered 4-byte stores per lane in the epilogue,
+// 5 % of a K = 2048 tile.  Here min(tiles, 2 x CUs) workgroups walk the tiles round by round (per round an XCD's workgroups own
+// one contiguous run of tiles, N fastest), and
+//   * the first K tile of the NEXT output tile is requested into the staging registers BEFORE the epilogue of the current one
+//     (its latency runs under the epilogue's stores),
+//   * the epilogue transposes each 4-register group across its lane quad (two DPP quad_perm steps), so a lane owns four
+//     consecutive columns of one row: 16 global_store_dwordx4 per lane instead of 64 global_store_dword, every wave-level
+//     store = 8 rows x 128-B full lines, and bias / residual / ReLU-mask operands are float4 loads.
+// The K loop and the k order of every output element are those of PIPE 5: results are bit-identical to variant 4.
+template <bool A_KC, bool B_KC, bool AUX>
+__global__ void __launch_bounds__(256) gemm_f32_persist_kernel(const GemmParams p_in) {
+    GemmParams p = p_in;
+    p.dk = drop_key_now(p.dk);
+    constexpr int BM = 128, BN = 128, WGN = 2, NT = 256, WTM = 64, WTN = 64, TM = 2, TN = 2;
+    constexpr int A_ST = stage_floats<BM, A_KC>();
+    constexpr int B_ST = stage_floats<BN, B_KC>();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As = smem;
+    float* const Bs = smem + 2 * A_ST;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int ntiles = p.tilesM * p.tilesN;
+    const int G = gridDim.x, per = G >> 3;                  // G is a multiple of 8 (launcher)
+    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int nkt = p.ktiles;                               // >= 4, all full (launcher)
+    // tile of round r for this workgroup (-1: none).  Full rounds: XCD x owns tiles [r G + x per, r G + (x + 1) per).  The last,
+    // partial round deals its tiles to the XCDs evenly (first `pl` workgroups of every XCD) instead of filling XCD 0 first.
+    auto tile_of = [&](int r) -> int {
+        const int base = r * G, rem = ntiles - base;
+        if (rem <= 0) return -1;
+        if (rem >= G) return base + xcd * per + loc;
+        const int pl = (rem + 7) >> 3;
+        const int t = base + xcd * pl + loc;
+        return (loc < pl && xcd * pl + loc < rem) ? t : -1;
+    };
+    constexpr int NVA = Stager<BM, NT, A_KC, true>::NV, NVB = Stager<BN, NT, B_KC, true>::NV;
+    static_assert(NVA + NVB <= 8, "one staged float4 per k step and slot");
+    Stager<BM, NT, A_KC, true> sa;
+    Stager<BN, NT, B_KC, true> sb;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, (int)p.b_bytes, 0x00020000);
+    const uint32_t a_kbytes = (uint32_t)((A_KC ? (size_t)BK : (size_t)BK * p.lda) * sizeof(float));
+    const uint32_t b_kbytes = (uint32_t)((B_KC ? (size_t)BK : (size_t)BK * p.ldb) * sizeof(float));
+    uint32_t voff_a[NVA], voff_b[NVB];
+
+    int round = 0;
+    int tile = tile_of(0);
+    bool pre = false;               // the first K tile of `tile` is already in the staging registers
+    while (tile >= 0) {
+        const int mt = tile / p.tilesN, nt = tile - mt * p.tilesN;
+        const int m0 = mt * BM, n0 = nt * BN;
+#pragma unroll
+        for (int e = 0; e < NVA; ++e) voff_a[e] = sa.voffset(e, p.lda, m0, p.M);
+#pragma unroll
+        for (int e = 0; e < NVB; ++e) voff_b[e] = sb.voffset(e, p.ldb, n0, p.N);
+        floatx16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        if (!pre) {
+#pragma unroll
+            for (int e = 0; e < NVA; ++e) sa.load_buf(e, rsrc_a, voff_a[e], 0u);
+#pragma unroll
+            for (int e = 0; e < NVB; ++e) sb.load_buf(e, rsrc_b, voff_b[e], 0u);
+        }
+        __syncthreads();                       // every LDS read of the previous tile is complete
+        sa.store(As);
+        sb.store(Bs);
+#pragma unroll
+        for (int e = 0; e < NVA; ++e) sa.load_buf(e, rsrc_a, voff_a[e], a_kbytes);
+#pragma unroll
+        for (int e = 0; e < NVB; ++e) sb.load_buf(e, rsrc_b, voff_b[e], b_kbytes);
+        __syncthreads();
+        float fa0[TM][8], fb0[TN][8], fa1[TM][8], fb1[TN][8];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) read_frag<BM, A_KC>(As, wm * WTM + i * 32 + l31, h, 0, fa0[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) read_frag<BN, B_KC>(Bs, wn * WTN + j * 32 + l31, h, 0, fb0[j]);
+
+        // one K tile: the hand-interleaved PIPE 5 body (SMODE 1: tiles it+1, it+2 exist; 2: only it+1; 3: last tile)
+        auto tile_step = [&](int it, auto steady_tag, auto cur_tag) {
+            constexpr int SMODE = decltype(steady_tag)::value;
+            constexpr bool HAS1 = SMODE == 1 || SMODE == 2, HAS2 = SMODE == 1;
+            constexpr int CC = decltype(cur_tag)::value;
+            const int cur = CC >= 0 ? CC : (it & 1);
+            const float* a_lds = As + cur * A_ST;
+            const float* b_lds = Bs + cur * B_ST;
+            float* a_st = As + (cur ^ 1) * A_ST;
+            float* b_st = Bs + (cur ^ 1) * B_ST;
+            const uint32_t soff_a = (uint32_t)(it + 2) * a_kbytes, soff_b = (uint32_t)(it + 2) * b_kbytes;
+            if constexpr (HAS1) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the staged tile it+1 has landed
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int e = (kk & 3) * 2 + q;
+                    if (kk < 4) {
+                        if constexpr (HAS1) {
+                            if (e < NVA) sa.store_one(e, a_st);
+                            else if (e - NVA < NVB) sb.store_one(e - NVA, b_st);
+                        }
+                    } else if constexpr (HAS2) {
+                        if (e < NVA) sa.load_buf(e, rsrc_a, voff_a[e < NVA ? e : 0], soff_a);
+                        else if (e - NVA < NVB) sb.load_buf(e - NVA, rsrc_b, voff_b[e - NVA < NVB ? e - NVA : 0], soff_b);
+                    }
+                }
+                if (kk < TM) read_frag<BM, A_KC>(a_lds, wm * WTM + kk * 32 + l31, h, 1, fa1[kk < TM ? kk : 0]);
+                else if (kk - TM < TN) read_frag<BN, B_KC>(b_lds, wn * WTN + (kk - TM) * 32 + l31, h, 1, fb1[kk - TM < TN ? kk - TM : 0]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][kk], fb0[j][kk], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                if constexpr (HAS1) {
+                    if (kk < TM) read_frag<BM, A_KC>(a_st, wm * WTM + kk * 32 + l31, h, 0, fa0[kk < TM ? kk : 0]);
+                    else if (kk - TM < TN) read_frag<BN, B_KC>(b_st, wn * WTN + (kk - TM) * 32 + l31, h, 0, fb0[kk - TM < TN ? kk - TM : 0]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[i][kk], fb1[j][kk], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        using dyn = std::integral_constant<int, -1>;
+        using full = std::integral_constant<int, 1>;
+        int it = 0;
+        const int full_end = nkt - 2;
+        for (; it + 1 < full_end; it += 2) {
+            tile_step(it, full{}, std::integral_constant<int, 0>{});
+            tile_step(it + 1, full{}, std::integral_constant<int, 1>{});
+        }
+        for (; it < full_end; ++it) tile_step(it, full{}, dyn{});
+        tile_step(it, std::integral_constant<int, 2>{}, dyn{}); ++it;
+        tile_step(it, std::integral_constant<int, 3>{}, dyn{});
+
+        // ---- the next tile's first K tile is requested before this tile's epilogue
+        ++round;
+        const int next = tile_of(round);
+        pre = false;
+        if (next >= 0) {
+            const int mtn = next / p.tilesN, ntn = next - mtn * p.tilesN;
+#pragma unroll
+            for (int e = 0; e < NVA; ++e) sa.load_buf(e, rsrc_a, sa.voffset(e, p.lda, mtn * BM, p.M), 0u);
+#pragma unroll
+            for (int e = 0; e < NVB; ++e) sb.load_buf(e, rsrc_b, sb.voffset(e, p.ldb, ntn * BN, p.N), 0u);
+            pre = true;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        epilogue_f4<TM, TN, AUX>(LSTC_EPI_ARGS(p), acc, m0 + wm * WTM, n0 + wn * WTN, lane);
+        tile = next;
+    }
+}
+
+template <bool A_KC, bool B_KC>
+int launch_persist(const GemmParams& p, hipStream_t st) {
+    constexpr size_t lds = (size_t)(2 * stage_floats<128, A_KC>() + 2 * stage_floats<128, B_KC>()) * sizeof(float);
+    static std::atomic<int> slots_dev[64];
+    static LstcDevOnce once;
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) cur = 0;
+    const int dev_ = once.begin();
+    if (dev_ >= 0) {
+        hipDeviceProp_t prop;
+        int n = 0;
+        if (hipGetDeviceProperties(&prop, dev_) == hipSuccess) n = prop.multiProcessorCount;
+        slots_dev[dev_ & 63].store(n > 0 ? 2 * n : 512, std::memory_order_relaxed);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_persist_kernel<A_KC, B_KC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_persist_kernel<A_KC, B_KC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        once.end(dev_);
+    }
+    int G = slots_dev[cur & 63].load(std::memory_order_relaxed);
+    const int ntiles = p.tilesM * p.tilesN;
+    if (G > ntiles) G = ntiles;
+    G &= ~7;
+    if (G < 8) return LSTC_E_UNSUPPORTED;
+    // per-element operand of the epilogue: at most one of residual / ReLU-mask source / accumulate target on this kernel
+    if (p.epi_f4 == 2) hipLaunchKernelGGL((gemm_f32_persist_kernel<A_KC, B_KC, true>), dim3(G), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((gemm_f32_persist_kernel<A_KC, B_KC, false>), dim3(G), dim3(256), lds, st, p);
+    return lstc_launch_status();
 }
 
 template <int BM, int BN, int WGM, int WGN, int PIPE, bool A_KC, bool B_KC>
@@ -720,6 +1015,16 @@ int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipS
     switch (variant) {
         case 1: return launch_cfg<128, 128, 2, 2, 0, A_KC, B_KC>(p, va, vb, splits, st);
         case 11: return launch_cfg<64, 64, 2, 2, 0, A_KC, B_KC>(p, va, vb, splits, st);    // small tile: the tail rows of a row-split product
+#ifndef LSTC_TUNING     // (12-15 are timing ablations in the tuning build)
+        //  12 = persistent PIPE 5 (gemm_f32_persist_kernel): next tile's first loads before the epilogue, float4 epilogue
+        case 12: if (va && vb && p.a_bytes && p.b_bytes && splits == 1 && p.batch == 1 && p.K % BK == 0 && p.ktiles >= 4 && p.epi_f4)
+                 {
+                     const int rc_ = launch_persist<A_KC, B_KC>(p, st);
+                     if (rc_ != LSTC_E_UNSUPPORTED) return rc_;
+                 }
+                 if (va && vb && p.a_bytes && p.b_bytes) return launch_cfg<128, 128, 2, 2, 5, A_KC, B_KC>(p, true, true, splits, st);
+                 return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);
+#endif
         case 3: return launch_cfg<128, 128, 2, 2, 2, A_KC, B_KC>(p, va, vb, splits, st);
         case 6: return launch_cfg<256, 128, 4, 2, 2, A_KC, B_KC>(p, va, vb, splits, st);
         case 2: return launch_cfg<256, 128, 4, 2, 1, A_KC, B_KC>(p, va, vb, splits, st);
@@ -772,7 +1077,7 @@ int lstc_gemm_f32_impl(const LstcGemmDesc* d, hipStream_t st) {
 #else
     // the production library accepts the documented tile variants only: garbage in this public field must not select a
     // timing ablation or an undefined tile (LstcGemmDesc.variant, include/lstc_hip.h)
-    if (d->variant < 0 || d->variant > 11) return LSTC_E_UNSUPPORTED;
+    if (d->variant < 0 || d->variant > 12) return LSTC_E_UNSUPPORTED;
     p.debug = 0;
 #endif
     const size_t a_ext = ((size_t)((d->transA ? d->K : d->M) - 1) * d->lda + (d->transA ? d->M : d->K)) * sizeof(float) + p.batch_stride_a * sizeof(float) * (size_t)(p.batch - 1) * 0;
@@ -788,6 +1093,15 @@ int lstc_gemm_f32_impl(const LstcGemmDesc* d, hipStream_t st) {
     const bool vb = aligned16(d->B) && (d->ldb % 4 == 0) && ((d->transB ? d->K : d->N) % 4 == 0) &&
                     (p.batch <= 1 || d->batch_stride_b % 4 == 0);
     p.row_off = 0;
+    // float4 epilogue (epilogue_f4): one row-contiguous float4 per lane and store, operands as float4 loads - needs 16-B aligned rows
+    // everywhere and at most ONE per-element operand (residual | ReLU-mask source | accumulate target)
+    {
+        const int naux = ((d->flags & LSTC_EPI_RESIDUAL) ? 1 : 0) + ((d->flags & LSTC_EPI_RELU_MASK) ? 1 : 0) + ((d->flags & LSTC_EPI_ACCUM) ? 1 : 0);
+        const bool al = d->N % 4 == 0 && d->N >= 4 && d->ldc % 4 == 0 && aligned16(d->C) && (!(d->flags & LSTC_EPI_BIAS) || aligned16(d->bias)) &&
+                        (!(d->flags & LSTC_EPI_RESIDUAL) || (d->ldr % 4 == 0 && aligned16(d->residual))) &&
+                        (!(d->flags & LSTC_EPI_RELU_MASK) || (d->ld_relu % 4 == 0 && aligned16(d->relu_src)));
+        p.epi_f4 = (al && naux <= 1 && p.batch <= 1 && eff_splits == 1) ? (naux ? 2 : 1) : 0;
+    }
     auto launch = [&](GemmParams& q, int variant) {
         if (!d->transA && d->transB) return launch_layout<true, true>(q, va, vb, eff_splits, variant, st);
         if (!d->transA && !d->transB) return launch_layout<true, false>(q, va, vb, eff_splits, variant, st);
@@ -798,6 +1112,7 @@ int lstc_gemm_f32_impl(const LstcGemmDesc* d, hipStream_t st) {
     // job) pays a whole extra round.  The rows of that last round go to the 64x64-tile variant instead (4x the workgroups,
     // 4 resident per CU): every output element keeps the same k order, so the result is bit-identical to the one-launch
     // product (tests/test_hip_parity.py::test_row_split_f32_product_is_bitwise_the_single_launch_product).
+    int v_main = d->variant;
     if (d->variant == 0 && eff_splits == 1 && p.batch <= 1 && !d->transA) {
         static int slots = 0;
         if (slots == 0) {
@@ -808,6 +1123,8 @@ int lstc_gemm_f32_impl(const LstcGemmDesc* d, hipStream_t st) {
         }
         const int tM = (d->M + 127) / 128, tN = (d->N + 127) / 128;
         const long long tiles = (long long)tM * tN;
+        // (The persistent walk of the same loop, variant 12, is NOT the default: with the float4 epilogue on both, one tile per workgroup
+        // is faster - tools/gemm_check, 100352 x 2048 x 2048 NT: 149.6 vs 146.3 TFLOP/s plain, 146.1 vs 141.7 with dropout + residual.)
         const long long full = tiles / slots, rem = tiles % slots;
         const int main_rows = (int)((full * slots) / tN);              // whole tile rows inside the full rounds
         // (measured: a tail round up to ~30 % full gains - 4 pairs per rank 41.2 -> 40.1 ms per step; a half-full one does not)
@@ -821,10 +1138,10 @@ int lstc_gemm_f32_impl(const LstcGemmDesc* d, hipStream_t st) {
             pt.C += (size_t)M_main * d->ldc;
             if (pt.res) pt.res += (size_t)M_main * d->ldr;
             if (pt.relu_src) pt.relu_src += (size_t)M_main * d->ld_relu;
-            int rc = launch(pm, 0);
+            int rc = launch(pm, v_main);
             if (rc) return rc;
             return launch(pt, 11);
         }
     }
-    return launch(p, d->variant);
+    return launch(p, v_main);
 }

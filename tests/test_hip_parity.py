@@ -1663,6 +1663,34 @@ def test_row_split_f32_product_is_bitwise_the_single_launch_product(M, N, K, tb)
     assert max_abs_diff(split, ref * keep + res.double()) < 1e-4 * (K ** 0.5)
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb", [(12544, 2048, 2048, False, True), (12544, 2048, 2048, False, False), (6221, 2052, 256, False, True),
+                                         (9000, 4096, 160, False, False), (2048, 2048, 12544, True, False), (70000, 2048, 128, False, True)])
+def test_float4_epilogue_and_persistent_walk_are_bitwise_the_scalar_epilogue_product(M, N, K, ta, tb):
+    """Exact-f32 GEMM, round 3: (a) the default kernel's epilogue transposes each 4-register group across its lane quad so a
+    lane stores one row-contiguous float4 (16 stores of 8 full lines per wave instead of 64 two-segment ones; operands as
+    float4 loads); (b) variant 12 walks the tiles with persistent workgroups and requests the next tile's first K tile before
+    that epilogue.  Same K loop, same k order, same epilogue arithmetic: both must equal variant 8 (PIPE 3, the scalar
+    epilogue, one tile per workgroup) bit for bit - plain, with bias + ReLU + dropout + residual, with a ReLU mask and alpha,
+    with a residual only, and accumulating; ragged M, N = 2052 (not a tile multiple), NT / NN / TN."""
+    from lstc_vad_amd import functional as Fn
+    g = torch.Generator(device=DEV).manual_seed(3)
+    a = torch.randn((K, M) if ta else (M, K), device=DEV, generator=g)
+    b = torch.randn((N, K) if tb else (K, N), device=DEV, generator=g) * 0.1
+    bias = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g)
+    msk = torch.randn(M, N, device=DEV, generator=g)
+    for kw in (dict(), dict(bias=bias, relu=True, dropout=(0.2, 0xABCDEF12345), residual=res), dict(relu_mask=msk, alpha=0.5), dict(residual=res)):
+        want = Fn.gemm(a, b, trans_a=ta, trans_b=tb, variant=8, **kw)
+        for v in (12, 4, 0):
+            assert torch.equal(Fn.gemm(a, b, trans_a=ta, trans_b=tb, variant=v, **kw), want), (v, list(kw))
+    acc0 = torch.randn(M, N, device=DEV, generator=g)
+    want = Fn.gemm(a, b, trans_a=ta, trans_b=tb, variant=8, out=acc0.clone(), accumulate=True)
+    for v in (12, 0):
+        assert torch.equal(Fn.gemm(a, b, trans_a=ta, trans_b=tb, variant=v, out=acc0.clone(), accumulate=True), want), v
+    ref = a.double().T @ b.double() if ta else a.double() @ (b.double().T if tb else b.double())
+    assert max_abs_diff(Fn.gemm(a, b, trans_a=ta, trans_b=tb), ref) < 1e-4 * (K ** 0.5)
+
+
 @pytest.mark.parametrize("S", [49, 17, 81, 19])
 def test_attention_backward_packed_gradients_equal_the_packed_f32_gradients(S):
     """lstc_attn_fwd with O_pack and lstc_attn_bwd with dQ_pack / dK_pack / dV_pack (bf16 mode): the packed bf16 results are
