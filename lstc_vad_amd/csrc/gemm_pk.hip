@@ -167,6 +167,7 @@ struct PkParams {
     const float* inv_b;
     long long split_stride;   // elements between the outputs of consecutive K splits (0: add into one C with atomics)
     int fbA, fbB;        // TR mode: 32-feature blocks per token row-block of the A / B packs (= ceil(M/32), ceil(N/32))
+    int epi_f4;          // 0: scalar epilogue; 1 / 2: float4 epilogue (lstc_common.h, epilogue_f4) without / with one per-element operand
 };
 
 // plane pairs by decreasing magnitude: q = 0: hh, 1: hl, 2: lh
@@ -338,7 +339,14 @@ __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
     const int flags = p.flags;
     const bool atomic = gridDim.y > 1 && p.split_stride == 0;      // split_stride != 0: split z owns C + z * split_stride
     float* const Cz = p.C + (size_t)blockIdx.y * p.split_stride;
-    const float alpha = p.alpha * p.inv_a[0] * p.inv_b[0];       // undo the operands' power-of-two scales (exact)
+    const float alpha = p.alpha * p.inv_a[0] * p.inv_b[0];
+    if (p.epi_f4 && !atomic) {                 // float4 form (host checked alignment and the operand count)
+        EpiArgs ea = make_epi_args(nullptr, Cz, p.bias, p.res, p.relu_src, p.M, p.N, p.ldc, p.ldr, p.ld_relu, flags, 0, alpha, dkn);
+        if (flags & LSTC_EPI_ACCUM) ea.aux = ea.aux == p.C ? Cz : ea.aux;      // accumulate target of this split
+        if (p.epi_f4 == 2) epilogue_f4<2, 2, true>(ea, acc, mb * 128 + wm * 64, nb * 128 + wn * 64, lane);
+        else epilogue_f4<2, 2, false>(ea, acc, mb * 128 + wm * 64, nb * 128 + wn * 64, lane);
+        return;
+    }       // undo the operands' power-of-two scales (exact)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = nb * 128 + wn * 64 + j * 32 + l31;
@@ -516,6 +524,13 @@ __global__ void __launch_bounds__(NT, 2) gemm_pk2s_kernel(const PkParams p) {
     const bool atomic = gridDim.y > 1 && p.split_stride == 0;      // split_stride != 0: split z owns C + z * split_stride
     float* const Cz = p.C + (size_t)blockIdx.y * p.split_stride;
     const float alpha = p.alpha * p.inv_a[0] * p.inv_b[0];
+    if (p.epi_f4 && !atomic) {                 // float4 form (host checked alignment and the operand count)
+        EpiArgs ea = make_epi_args(nullptr, Cz, p.bias, p.res, p.relu_src, p.M, p.N, p.ldc, p.ldr, p.ld_relu, flags, 0, alpha, dkn);
+        if (flags & LSTC_EPI_ACCUM) ea.aux = ea.aux == p.C ? Cz : ea.aux;      // accumulate target of this split
+        if (p.epi_f4 == 2) epilogue_f4<2, 2, true>(ea, acc, mb * 128 + wm * 64, nb * 128 + wn * 64, lane);
+        else epilogue_f4<2, 2, false>(ea, acc, mb * 128 + wm * 64, nb * 128 + wn * 64, lane);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = nb * 128 + wn * 64 + j * 32 + l31;
@@ -699,6 +714,13 @@ __global__ void __launch_bounds__(NT, 1) gemm_pkw_kernel(const PkParams p) {
     const bool atomic = gridDim.y > 1 && p.split_stride == 0;      // split_stride != 0: split z owns C + z * split_stride
     float* const Cz = p.C + (size_t)blockIdx.y * p.split_stride;
     const float alpha = p.alpha * p.inv_a[0] * p.inv_b[0];
+    if (p.epi_f4 && !atomic) {                 // float4 form (host checked alignment and the operand count)
+        EpiArgs ea = make_epi_args(nullptr, Cz, p.bias, p.res, p.relu_src, p.M, p.N, p.ldc, p.ldr, p.ld_relu, flags, 0, alpha, dkn);
+        if (flags & LSTC_EPI_ACCUM) ea.aux = ea.aux == p.C ? Cz : ea.aux;      // accumulate target of this split
+        if (p.epi_f4 == 2) epilogue_f4<4, 2, true>(ea, acc, mb * 256 + wm * 128, nb * 128 + wn * 64, lane);
+        else epilogue_f4<4, 2, false>(ea, acc, mb * 256 + wm * 128, nb * 128 + wn * 64, lane);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = nb * 128 + wn * 64 + j * 32 + l31;
@@ -752,6 +774,13 @@ int lstc_gemm_f32x3_impl(const LstcGemmDesc* d, hipStream_t st) {
     p.bias = d->bias; p.res = (const float*)d->residual; p.relu_src = (const float*)d->relu_src;
     p.M = d->M; p.N = d->N; p.ldc = d->ldc; p.ldr = d->ldr; p.ld_relu = d->ld_relu; p.flags = d->flags; p.alpha = d->alpha;
     p.dk = make_drop_key(d->dropout_p, d->dropout_seed);
+    {
+        const int naux = ((d->flags & LSTC_EPI_RESIDUAL) ? 1 : 0) + ((d->flags & LSTC_EPI_RELU_MASK) ? 1 : 0) + ((d->flags & LSTC_EPI_ACCUM) ? 1 : 0);
+        const bool al = d->N % 4 == 0 && d->N >= 4 && d->ldc % 4 == 0 && aligned16(d->C) && (!(d->flags & LSTC_EPI_BIAS) || aligned16(d->bias)) &&
+                        (!(d->flags & LSTC_EPI_RESIDUAL) || (d->ldr % 4 == 0 && aligned16(d->residual))) &&
+                        (!(d->flags & LSTC_EPI_RELU_MASK) || (d->ld_relu % 4 == 0 && aligned16(d->relu_src))) && (p.split_stride % 4 == 0);
+        p.epi_f4 = (al && naux <= 1) ? (naux ? 2 : 1) : 0;
+    }
     // (transA, transB) = (0, 1): A, B are packs of [M, K], [N, K];  (1, 0): packs of the k-major sources [K, M], [K, N]
     const bool tr = d->transA != 0 && d->transB == 0;
     if (!tr && !(d->transA == 0 && d->transB != 0)) return LSTC_E_UNSUPPORTED;

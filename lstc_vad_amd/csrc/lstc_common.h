@@ -115,3 +115,101 @@ struct LstcDevOnce {
 };
 
 __host__ __device__ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ---------------------------------------------------------------------------------- float4 GEMM epilogue (32x32 f32 accumulators)
+// Shared by gemm_f32.hip and gemm_pk.hip.  A v_mfma_*_32x32 accumulator register r of a lane holds row (r & 3) + 8 (r >> 2) + 4 h,
+// column l31: stored as it lies, every lane writes 4 bytes per store and a wave-level store touches two 128-B segments (64 store
+// instructions per 128x128 tile and lane; 12 us of a 235-us tile on the exact-f32 kernel).  Transposing each 4-register group
+// across its lane quad (two DPP quad_perm steps) gives a lane four consecutive columns of ONE row: 16 global_store_dwordx4
+// per lane, every wave-level store = 8 rows x 128-B full lines, bias / residual / ReLU-mask operands as float4 loads.
+#ifdef __HIPCC__
+template <int CTRL>
+__device__ __forceinline__ float quad_dpp(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+// 4 x 4 transpose across (4 registers) x (the 4 lanes of a quad): afterwards register k of lane c holds what register c of lane k held
+__device__ __forceinline__ void quad_transpose(float& r0, float& r1, float& r2, float& r3, int c) {
+    { const float x = (c & 1) ? r0 : r1; const float y = quad_dpp<0xB1>(x); if (c & 1) r0 = y; else r1 = y; }    // quad_perm [1,0,3,2]
+    { const float x = (c & 1) ? r2 : r3; const float y = quad_dpp<0xB1>(x); if (c & 1) r2 = y; else r3 = y; }
+    { const float x = (c & 2) ? r0 : r2; const float y = quad_dpp<0x4E>(x); if (c & 2) r0 = y; else r2 = y; }    // quad_perm [2,3,0,1]
+    { const float x = (c & 2) ? r1 : r3; const float y = quad_dpp<0x4E>(x); if (c & 2) r1 = y; else r3 = y; }
+}
+
+// Epilogue of one wave's (32 TM) x (32 TN) block whose top-left element is (mw0, nw0): quad-transposed float4 form (see
+// gemm_f32_persist_kernel).  Needs N, ldc (and the operand's ld) multiples of 4 and 16-B aligned pointers; AUX = the launch has
+// exactly one per-element operand (residual | ReLU-mask source | accumulate target).
+struct EpiArgs {       // passed BY VALUE: a reference to the kernel's (modified) parameter copy would pin that struct in scratch memory
+    float* C;
+    const float* bias;
+    const float* aux;  // the one per-element operand: residual | ReLU-mask source | accumulate target (AUX)
+    int M, N, ldc, ldaux, flags, row_off;
+    float alpha;
+    DropKey dk;
+};
+__device__ __forceinline__ EpiArgs make_epi_args(const float* A_unused, float* C, const float* bias, const float* res, const float* relu_src,
+                                                  int M, int N, int ldc, int ldr, int ld_relu, int flags, int row_off, float alpha, DropKey dk) {
+    EpiArgs e;
+    e.C = C; e.bias = bias;
+    e.aux = (flags & LSTC_EPI_RESIDUAL) ? res : (flags & LSTC_EPI_RELU_MASK) ? relu_src : C;
+    e.ldaux = (flags & LSTC_EPI_RESIDUAL) ? ldr : (flags & LSTC_EPI_RELU_MASK) ? ld_relu : ldc;
+    e.M = M; e.N = N; e.ldc = ldc; e.flags = flags; e.row_off = row_off; e.alpha = alpha; e.dk = dk;
+    return e;
+}
+#define LSTC_EPI_ARGS(p) make_epi_args(nullptr, (p).C, (p).bias, (p).res, (p).relu_src, (p).M, (p).N, (p).ldc, (p).ldr, (p).ld_relu, (p).flags, (p).row_off, (p).alpha, (p).dk)
+
+template <int TM, int TN, bool AUX>
+__device__ __forceinline__ void epilogue_f4(const EpiArgs p, floatx16 (&acc)[TM][TN], int mw0, int nw0, int lane) {
+    const int l31 = lane & 31, h = lane >> 5;
+    // ---- epilogue: quad-transposed, one float4 of a row per lane and register group.  Straight-line code: the per-element
+    // operand (AUX: residual, ReLU-mask source or the accumulate target - at most one of them on this kernel) is loaded
+    // unconditionally from clamped addresses, four groups ahead of its use, and only the store is predicated - a load inside
+    // a flag branch makes the compiler drain vmcnt(0) at every join (16 serialized store round trips per tile, and the next
+    // tile's prefetch with them).
+    const int flags = p.flags;
+    const int c = lane & 3, q = l31 >> 2;
+    const float* aux = p.aux;
+    const int ldaux = p.ldaux;
+    const bool f_relu = flags & LSTC_EPI_RELU, f_drop = flags & LSTC_EPI_DROPOUT, f_mask = flags & LSTC_EPI_RELU_MASK;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = nw0 + j * 32 + 4 * q;
+        const int colc = min(col, p.N - 4);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (flags & LSTC_EPI_BIAS) bv = *reinterpret_cast<const float4*>(p.bias + colc);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rbase = mw0 + i * 32 + 4 * h + c;
+            float4 ax[4];
+            if constexpr (AUX) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    ax[g] = *reinterpret_cast<const float4*>(aux + (size_t)min(rbase + 8 * g, p.M - 1) * ldaux + colc);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float r0 = acc[i][j][4 * g + 0], r1 = acc[i][j][4 * g + 1], r2 = acc[i][j][4 * g + 2], r3 = acc[i][j][4 * g + 3];
+                quad_transpose(r0, r1, r2, r3, c);
+                const int row = rbase + 8 * g;
+                float4 v = make_float4(r0 * p.alpha + bv.x, r1 * p.alpha + bv.y, r2 * p.alpha + bv.z, r3 * p.alpha + bv.w);
+                if (f_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (f_drop) {
+                    const uint32_t idx = (uint32_t)(row + p.row_off) * (uint32_t)p.N + (uint32_t)col;
+                    v.x = drop_keep(idx, p.dk) ? v.x * p.dk.scale : 0.f;
+                    v.y = drop_keep(idx + 1, p.dk) ? v.y * p.dk.scale : 0.f;
+                    v.z = drop_keep(idx + 2, p.dk) ? v.z * p.dk.scale : 0.f;
+                    v.w = drop_keep(idx + 3, p.dk) ? v.w * p.dk.scale : 0.f;
+                }
+                if constexpr (AUX) {
+                    const float4 x = ax[g];
+                    if (f_mask) {
+                        v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f; v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
+                    } else {                                 // residual or accumulate: both add the operand
+                        v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                    }
+                }
+                if (row < p.M && col < p.N) *reinterpret_cast<float4*>(p.C + (size_t)row * p.ldc + col) = v;
+            }
+        }
+    }
+}
+#endif
