@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401  (must be imported first so its libamdhip64.so.7 is the one the library binds to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblstc_hip.so")
+# LSTC_LIBRARY: another build of the same library (tools/build_variant.sh -> build/<name>/liblstc_hip.so) for same-box A/B timings
+LIB_PATH = os.environ.get("LSTC_LIBRARY") or os.path.join(_HERE, "liblstc_hip.so")
 
 F32, BF16, F32X3, BF16P = 0, 1, 2, 3
 EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_RESIDUAL, EPI_RELU_MASK, EPI_ACCUM, EPI_OUT_F32 = 1, 2, 4, 8, 16, 32, 64
