@@ -1664,14 +1664,16 @@ def test_row_split_f32_product_is_bitwise_the_single_launch_product(M, N, K, tb)
 
 
 @pytest.mark.parametrize("M,N,K,ta,tb", [(12544, 2048, 2048, False, True), (12544, 2048, 2048, False, False), (6221, 2052, 256, False, True),
-                                         (9000, 4096, 160, False, False), (2048, 2048, 12544, True, False), (70000, 2048, 128, False, True)])
+                                         (9000, 4096, 160, False, False), (2048, 2048, 12544, True, False), (70000, 2048, 128, False, True),
+                                         (5000, 2050, 192, False, True)])
 def test_float4_epilogue_and_persistent_walk_are_bitwise_the_scalar_epilogue_product(M, N, K, ta, tb):
     """Exact-f32 GEMM, round 3: (a) the default kernel's epilogue transposes each 4-register group across its lane quad so a
     lane stores one row-contiguous float4 (16 stores of 8 full lines per wave instead of 64 two-segment ones; operands as
     float4 loads); (b) variant 12 walks the tiles with persistent workgroups and requests the next tile's first K tile before
     that epilogue.  Same K loop, same k order, same epilogue arithmetic: both must equal variant 8 (PIPE 3, the scalar
     epilogue, one tile per workgroup) bit for bit - plain, with bias + ReLU + dropout + residual, with a ReLU mask and alpha,
-    with a residual only, and accumulating; ragged M, N = 2052 (not a tile multiple), NT / NN / TN."""
+    with a residual only, and accumulating; ragged M, N = 2052 (not a tile multiple), N = 2050 (not a multiple of 4: the scalar
+    form must take over), NT / NN / TN, and outputs / residuals that are column slices of wider buffers."""
     from lstc_vad_amd import functional as Fn
     g = torch.Generator(device=DEV).manual_seed(3)
     a = torch.randn((K, M) if ta else (M, K), device=DEV, generator=g)
@@ -1689,6 +1691,14 @@ def test_float4_epilogue_and_persistent_walk_are_bitwise_the_scalar_epilogue_pro
         assert torch.equal(Fn.gemm(a, b, trans_a=ta, trans_b=tb, variant=v, out=acc0.clone(), accumulate=True), want), v
     ref = a.double().T @ b.double() if ta else a.double() @ (b.double().T if tb else b.double())
     assert max_abs_diff(Fn.gemm(a, b, trans_a=ta, trans_b=tb), ref) < 1e-4 * (K ** 0.5)
+    if N % 8 == 0:
+        # output and residual as column slices of wider buffers (the fused Q|K|V projection writes such slices): leading dimension
+        # != N, 16-B aligned column offset -> still the float4 form; an offset of 2 columns breaks the alignment -> scalar form
+        wide, rw = torch.zeros(M, 2 * N + 8, device=DEV), torch.randn(M, 2 * N + 8, device=DEV, generator=g)
+        for off in (N // 2, 2):
+            got = Fn.gemm(a, b, trans_a=ta, trans_b=tb, out=wide[:, off:off + N], residual=rw[:, off:off + N])
+            want = Fn.gemm(a, b, trans_a=ta, trans_b=tb, variant=8, residual=rw[:, off:off + N].contiguous())
+            assert torch.equal(got, want), off
 
 
 @pytest.mark.parametrize("S", [49, 17, 81, 19])
