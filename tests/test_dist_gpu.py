@@ -129,3 +129,80 @@ def test_two_rank_hip_step_over_gloo_matches_reference_golden(name, compute):
             lr = 1e-4 if k.startswith("enc.") else 1e-2
             assert float((diff > 5e-5).float().mean()) <= (1e-3 if k.startswith("enc.") else 1e-2), (k, float(diff.max()))
             assert float(diff.max()) <= 4 * lr + 1e-6, (k, float(diff.max()))
+
+
+def _mixed_rank(rank, world, port, q):
+    """BASELINE config 5 per rank: engine.MixedStep over a UBnormal-shaped pair (S = 81, d_k = 32) and an SHT-shaped pair (S = 49) -
+    all forwards / backwards issued first, every model's gradient buckets reduced as its backward produces them, then the waits
+    and the Adagrad steps."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from argparse import Namespace
+        from lstc_vad_amd.engine import MixedStep, TrainStep
+        from lstc_vad_amd.models import Classifier, Encoder
+        from util import load_case, sub
+        dev = torch.device("cuda", 0)
+        steps, shards, zs = [], [], []
+        for name in ("ltn_ubnormal_dk32", "ltn_sht"):
+            z, mode, ekw, skw = load_case(name)
+            d, h = ekw["d_model"], skw["batch_size"] // world
+            enc = Encoder(n_layers=3, MHA_attn_dropout=0.0, MHA_fc_dropout=0.0, FFN_dropout=0.0, position_dropout=0.0, weight_init=False, **ekw)
+            head = Classifier(d, 0.0, weight_init=False)
+            enc.load_state_dict(sub(z, "enc_init."), strict=True)
+            head.load_state_dict(sub(z, "head_init."), strict=True)
+            args = Namespace(batch_size=h, part_num=skw["part_num"], part_len=skw["part_len"], n_patch=skw["n_patch"], lambda_1=0.01,
+                             lambda_MIL=1.0, lambda_CE=0.8, temporal_only=False, clip_grad=False)
+            steps.append(TrainStep(args, mode, enc.to(dev).train(), head.to(dev).train(), 1e-4, 1e-2, 1e-3, fuse_qkv="off"))
+            sl = slice(rank * h, (rank + 1) * h)
+            shards.append(tuple(torch.from_numpy(z[k])[sl].to(dev) for k in ("norm_feats", "abnorm_feats", "abnorm_labs")))
+            zs.append(name)
+        ms = MixedStep(steps)
+        out = {}
+        for it in range(2):
+            scs = ms.step(shards)
+            for name, sc in zip(zs, scs):
+                sc = sc.clone(); dist.all_reduce(sc)
+                out[f"{name}.scalars{it}"] = sc.cpu().double().numpy()
+        torch.cuda.synchronize()
+        for name, ts in zip(zs, steps):
+            out[name + ".weights"] = {k: v.detach().cpu().numpy().copy() for k, v in ts.encoder.state_dict().items() if v.is_floating_point()}
+        if rank == 0:
+            q.put(out)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_mixed_step_over_gloo_matches_both_reference_goldens():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from util import load_case, sub
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mixed_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = q.get(timeout=420)
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    for name in ("ltn_ubnormal_dk32", "ltn_sht"):
+        z, mode, ekw, skw = load_case(name)
+        assert np.max(np.abs(res[name + ".scalars0"] - z["scalars"])) < 2e-5, name
+        assert np.max(np.abs(res[name + ".scalars1"] - z["scalars_step2"])) < 1e-4, name
+        ref_w = {k: v for k, v in sub(z, "enc_after2.").items() if v.is_floating_point()}
+        for k, v in res[name + ".weights"].items():
+            diff = (torch.from_numpy(v) - ref_w[k]).abs()
+            assert float((diff > 5e-5).float().mean()) <= 1e-3 and float(diff.max()) <= 4e-4 + 1e-6, (name, k, float(diff.max()))
