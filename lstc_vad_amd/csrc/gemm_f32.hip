@@ -1011,10 +1011,7 @@ int lstc_gemm_f32_impl(const LstcGemmDesc* d, hipStream_t st) {
                         (!(d->flags & LSTC_EPI_RESIDUAL) || (d->ldr % 4 == 0 && aligned16(d->residual))) &&
                         (!(d->flags & LSTC_EPI_RELU_MASK) || (d->ld_relu % 4 == 0 && aligned16(d->relu_src)));
         // (batched launches - the split-K partials of the weight gradients - qualify when every problem's C stays 16-B aligned)
-#ifndef LSTC_F4_BATCH
-#define LSTC_F4_BATCH 1
-#endif
-        p.epi_f4 = (al && naux <= 1 && (p.batch <= 1 || (LSTC_F4_BATCH && d->batch_stride_c % 4 == 0)) && eff_splits == 1) ? (naux ? 2 : 1) : 0;
+        p.epi_f4 = (al && naux <= 1 && (p.batch <= 1 || d->batch_stride_c % 4 == 0) && eff_splits == 1) ? (naux ? 2 : 1) : 0;
     }
     auto launch = [&](GemmParams& q, int variant) {
         if (!d->transA && d->transB) return launch_layout<true, true>(q, va, vb, eff_splits, variant, st);

@@ -341,8 +341,7 @@ __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
     float* const Cz = p.C + (size_t)blockIdx.y * p.split_stride;
     const float alpha = p.alpha * p.inv_a[0] * p.inv_b[0];
     if (p.epi_f4 && !atomic) {                 // float4 form (host checked alignment and the operand count)
-        EpiArgs ea = make_epi_args(nullptr, Cz, p.bias, p.res, p.relu_src, p.M, p.N, p.ldc, p.ldr, p.ld_relu, flags, 0, alpha, dkn);
-        if (flags & LSTC_EPI_ACCUM) ea.aux = ea.aux == p.C ? Cz : ea.aux;      // accumulate target of this split
+        EpiArgs ea = make_epi_args(Cz, p.bias, p.res, p.relu_src, p.M, p.N, p.ldc, p.ldr, p.ld_relu, flags, 0, alpha, dkn);
         if (p.epi_f4 == 2) epilogue_f4<2, 2, true>(ea, acc, mb * 128 + wm * 64, nb * 128 + wn * 64, lane);
         else epilogue_f4<2, 2, false>(ea, acc, mb * 128 + wm * 64, nb * 128 + wn * 64, lane);
         return;
@@ -525,8 +524,7 @@ __global__ void __launch_bounds__(NT, 2) gemm_pk2s_kernel(const PkParams p) {
     float* const Cz = p.C + (size_t)blockIdx.y * p.split_stride;
     const float alpha = p.alpha * p.inv_a[0] * p.inv_b[0];
     if (p.epi_f4 && !atomic) {                 // float4 form (host checked alignment and the operand count)
-        EpiArgs ea = make_epi_args(nullptr, Cz, p.bias, p.res, p.relu_src, p.M, p.N, p.ldc, p.ldr, p.ld_relu, flags, 0, alpha, dkn);
-        if (flags & LSTC_EPI_ACCUM) ea.aux = ea.aux == p.C ? Cz : ea.aux;      // accumulate target of this split
+        EpiArgs ea = make_epi_args(Cz, p.bias, p.res, p.relu_src, p.M, p.N, p.ldc, p.ldr, p.ld_relu, flags, 0, alpha, dkn);
         if (p.epi_f4 == 2) epilogue_f4<2, 2, true>(ea, acc, mb * 128 + wm * 64, nb * 128 + wn * 64, lane);
         else epilogue_f4<2, 2, false>(ea, acc, mb * 128 + wm * 64, nb * 128 + wn * 64, lane);
         return;
@@ -715,8 +713,7 @@ __global__ void __launch_bounds__(NT, 1) gemm_pkw_kernel(const PkParams p) {
     float* const Cz = p.C + (size_t)blockIdx.y * p.split_stride;
     const float alpha = p.alpha * p.inv_a[0] * p.inv_b[0];
     if (p.epi_f4 && !atomic) {                 // float4 form (host checked alignment and the operand count)
-        EpiArgs ea = make_epi_args(nullptr, Cz, p.bias, p.res, p.relu_src, p.M, p.N, p.ldc, p.ldr, p.ld_relu, flags, 0, alpha, dkn);
-        if (flags & LSTC_EPI_ACCUM) ea.aux = ea.aux == p.C ? Cz : ea.aux;      // accumulate target of this split
+        EpiArgs ea = make_epi_args(Cz, p.bias, p.res, p.relu_src, p.M, p.N, p.ldc, p.ldr, p.ld_relu, flags, 0, alpha, dkn);
         if (p.epi_f4 == 2) epilogue_f4<4, 2, true>(ea, acc, mb * 256 + wm * 128, nb * 128 + wn * 64, lane);
         else epilogue_f4<4, 2, false>(ea, acc, mb * 256 + wm * 128, nb * 128 + wn * 64, lane);
         return;

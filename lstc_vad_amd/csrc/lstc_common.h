@@ -146,7 +146,7 @@ struct EpiArgs {       // passed BY VALUE: a reference to the kernel's (modified
     float alpha;
     DropKey dk;
 };
-__device__ __forceinline__ EpiArgs make_epi_args(const float* A_unused, float* C, const float* bias, const float* res, const float* relu_src,
+__device__ __forceinline__ EpiArgs make_epi_args(float* C, const float* bias, const float* res, const float* relu_src,
                                                   int M, int N, int ldc, int ldr, int ld_relu, int flags, int row_off, float alpha, DropKey dk) {
     EpiArgs e;
     e.C = C; e.bias = bias;
@@ -155,7 +155,7 @@ __device__ __forceinline__ EpiArgs make_epi_args(const float* A_unused, float* C
     e.M = M; e.N = N; e.ldc = ldc; e.flags = flags; e.row_off = row_off; e.alpha = alpha; e.dk = dk;
     return e;
 }
-#define LSTC_EPI_ARGS(p) make_epi_args(nullptr, (p).C, (p).bias, (p).res, (p).relu_src, (p).M, (p).N, (p).ldc, (p).ldr, (p).ld_relu, (p).flags, (p).row_off, (p).alpha, (p).dk)
+#define LSTC_EPI_ARGS(p) make_epi_args((p).C, (p).bias, (p).res, (p).relu_src, (p).M, (p).N, (p).ldc, (p).ldr, (p).ld_relu, (p).flags, (p).row_off, (p).alpha, (p).dk)
 
 template <int TM, int TN, bool AUX>
 __device__ __forceinline__ void epilogue_f4(const EpiArgs p, floatx16 (&acc)[TM][TN], int mw0, int nw0, int lane) {
