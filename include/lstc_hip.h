@@ -197,6 +197,16 @@ typedef struct LstcAttnDesc {
      * packed products of the output projection fc (models/MultiHeadAttention.py:122-123) and of its weight gradient.  N*S a
      * multiple of 256, H*dv a multiple of 64, d_v a multiple of 32; else LSTC_E_UNSUPPORTED. */
     void* O_pack;
+    /* bf16 mode, PACKED INPUTS (third-generation kernels): in_pack_cols > 0 says that Q, K, V point at lstc_pack1 buffers of
+     * a [N*S, in_pack_cols] matrix - normally all three at ONE pack, the fused Q|K|V projection written with LSTC_EPI_OUT_PACK
+     * (models/MultiHeadAttention.py:97-99) - whose columns Q_col0 / K_col0 / V_col0 .. + H*dk|dv hold the projections (multiples
+     * of 32; in_pack_cols a multiple of 64); ldq / ldk / ldv are ignored.  Backward: dO_pack_cols > 0 likewise makes dO a pack of
+     * [N*S, dO_pack_cols], columns dO_col0 .. + H*dv (the packed input gradient of fc, :123).  Packed inputs come with packed
+     * outputs only: the forward needs O_pack, the backward dQ_pack / dK_pack / dV_pack and both packed inputs.  dtype LSTC_BF16,
+     * S <= 96, d_k a multiple of 32, d_v of 64, N*S of 256; else LSTC_E_UNSUPPORTED.  No f32 copy of Q, K, V, O, dO, dQ, dK or dV
+     * exists in this form: the attention core moves 2 bytes per element each way. */
+    int32_t in_pack_cols, Q_col0, K_col0, V_col0;
+    int32_t dO_pack_cols, dO_col0;
 } LstcAttnDesc;
 
 int lstc_attn_fwd(const LstcAttnDesc* d, void* stream);

@@ -53,7 +53,9 @@ class AttnDesc(C.Structure):
                 ("dtable", C.c_void_p), ("dtable_chunks", C.c_int32), ("variant", C.c_int32),
                 ("dQ_pack", C.c_void_p), ("dK_pack", C.c_void_p), ("dV_pack", C.c_void_p),
                 ("pack_cols", C.c_int32), ("dQ_col0", C.c_int32), ("dK_col0", C.c_int32), ("dV_col0", C.c_int32),
-                ("O_pack", C.c_void_p)]
+                ("O_pack", C.c_void_p),
+                ("in_pack_cols", C.c_int32), ("Q_col0", C.c_int32), ("K_col0", C.c_int32), ("V_col0", C.c_int32),
+                ("dO_pack_cols", C.c_int32), ("dO_col0", C.c_int32)]
 
 
 class AdagradItem(C.Structure):

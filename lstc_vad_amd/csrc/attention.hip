@@ -42,6 +42,11 @@ struct AttnParams {
     int tq0, tk0, tv0;      // first k tile of the dQ / dK / dV columns inside their pack (one fused pack: column offsets / 32)
     void* Op;               // forward, bf16 mode: O written as a packed bf16 operand [N*S, H*dv] instead of f32
     int kbo;
+    // bf16 mode, packed INPUTS (third-generation kernels): Q / K / V / dO are lstc_pack1 buffers; 32-k tiles per 128-row block of
+    // each pack and the first tile of head 0's columns inside it
+    const __bf16 *Qi, *Ki, *Vi, *dOi;
+    int kiq, kik, kiv, kido;
+    int iq0, ik0, iv0, ido0;
 };
 
 __device__ __forceinline__ void load16(const float* __restrict__ p, int k0, int kdim, bool vec, float (&f)[16]) {
@@ -794,6 +799,476 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) attn_fwd2_kernel(con
 #undef RTL_LOAD
 #undef RTL_COMPUTE
 
+// =====================================================================================================
+// Third generation (bf16 mode, PACKED operands; S <= 96, d_k a multiple of 32, d_v of 64).  Q | K | V (and dO) arrive as the
+// lstc_pack1 buffers the projection GEMMs write with LSTC_EPI_OUT_PACK (2 B per element, 64-B rows of 32 features, 16-B chunk
+// index XOR (row >> 2) & 3), O / dQ | dK | dV leave as packs: no f32 activation of the attention core touches HBM.
+//   * T = ceil(S / 32) waves per (sequence, head); wave w owns the 32 QUERIES 32 w .. 32 w + 31 through the whole item.
+//   * Every product is SWAPPED so that the query index sits on the lane: logits^T[j][i] = K Q^T (A = K rows, B = Q rows) leaves
+//     lane = i, registers = 16 T keys j -> the softmax is lane-local plus ONE exchange with lane ^ 32, and the dropped
+//     probabilities, rounded to bf16 pairwise, ARE the A operand of O = Pd V (MFMA accumulator layout = A-operand layout with a
+//     permuted k order; the B operand follows the same order).  No logit / probability tile in LDS at all.
+//   * Operands are staged by LDS-DMA exactly as they lie in the packs (16 rows x 64 B per wave instruction).  The swizzle key of
+//     a row is that of its GLOBAL row, so readers XOR with ((n S + row) >> 2) & 3.  Feature contractions read fragments with
+//     ds_read_b128 (conflict-free for any row offset), token contractions read the SAME image with ds_read_b64_tr_b16 (4
+//     consecutive rows x 64 B per half-wave: conflict-free by construction).
+//   * One ring of NB slots carries every staged unit of a workgroup - {Q chunk, K chunk} x d_k/32, then {V tile, V tile} x
+//     d_v/64 - across the sequences a workgroup walks, so the next item's first chunks are in flight under the current item's
+//     P V.  One barrier per unit; s_waitcnt vmcnt counts DMA pieces only (stores are younger or complete earlier: loads return
+//     in order among themselves, which is all the count relies on).
+// =====================================================================================================
+typedef short a3_s4 __attribute__((ext_vector_type(4)));
+typedef short a3_s8 __attribute__((ext_vector_type(8)));
+typedef float a3_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef a3_s4 __attribute__((address_space(3))) * a3_lds4;
+constexpr int A3_NB = 4;
+
+__device__ __forceinline__ void a3_dma(const __bf16* tile, uint32_t voff, uint32_t lds_bytes) {
+    const uint32_t lb = __builtin_amdgcn_readfirstlane(lds_bytes);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(tile), "s"(lb) : "memory");
+}
+// byte offset, inside tile column 0 of a pack with `kb` tiles per row block, of this lane's 16-B piece of global row g
+__device__ __forceinline__ uint32_t a3_row_off(uint32_t g, uint32_t kb, uint32_t lane) {
+    return ((g >> 7) * kb * 4096u + (g & 127u) * 32u) * 2u + (lane & 3u) * 16u;
+}
+__device__ __forceinline__ attn_h8 a3_tr(const char* p0, const char* p1) {
+    const a3_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((a3_lds4)p0);
+    const a3_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((a3_lds4)p1);
+    a3_s8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return __builtin_bit_cast(attn_h8, f);
+}
+__device__ __forceinline__ attn_h8 a3_row(const char* p) { return *reinterpret_cast<const attn_h8*>(p); }
+#define A3_LDS_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)   /* lgkmcnt(0) only: the ring's DMA stays in flight */
+#define A3_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (0 << 8) | (((N) >> 4) << 14))     /* vmcnt(N), lgkmcnt(0) */
+
+template <int T>
+__global__ void __launch_bounds__(64 * T) attn_fwd3_kernel(const AttnParams p) {
+    const DropKey dkn = drop_key_now(p.dkey);
+    constexpr int SP = 32 * T, HALF = SP * 64, SLOT = 2 * HALF, NB = A3_NB;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const char* ring = reinterpret_cast<const char*>(sm);
+    const int h = blockIdx.y, S = p.S;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, h2 = lane >> 5;
+    const int n_begin = blockIdx.x * p.n_per_wg, n_end = min(p.N, n_begin + p.n_per_wg);
+    const int nq = p.dk >> 5, nvp = p.dv >> 6, U = nq + nvp;
+    const int total = (n_end - n_begin) * U;
+    const int tq = p.iq0 + ((h * p.dk) >> 5), tk = p.ik0 + ((h * p.dk) >> 5), tv = p.iv0 + ((h * p.dv) >> 5);
+    const int i = 32 * wave + l31;
+    // relative-position bias of this lane's (i, j) pairs: two dependent loads per element, once per workgroup
+    float biasr[T][16];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = 32 * t + 8 * (r >> 2) + 4 * h2 + (r & 3);
+            biasr[t][r] = (p.index_ld > 0 && i >= 1 && j >= 1 && i < S && j < S)
+                              ? p.table[(size_t)p.index[(size_t)(i - 1) * p.index_ld + (j - 1)] * p.H + h] : (j < S ? 0.f : -INFINITY);
+        }
+    // (keys j >= S carry a bias of -inf: their logits, exponentials and probabilities come out as -inf, 0, 0 with no predicate)
+    // ---- the staged-unit stream
+    int is_n = n_begin, is_u = 0, is_slot = 0, issued = 0;
+    auto issue_next = [&]() {
+        if (issued >= total) return;
+        const __bf16 *b0, *b1;
+        uint32_t kb0, kb1;
+        if (is_u < nq) {
+            b0 = p.Qi + (size_t)(tq + is_u) * 4096; kb0 = (uint32_t)p.kiq;
+            b1 = p.Ki + (size_t)(tk + is_u) * 4096; kb1 = (uint32_t)p.kik;
+        } else {
+            b0 = p.Vi + (size_t)(tv + 2 * (is_u - nq)) * 4096; kb0 = kb1 = (uint32_t)p.kiv;
+            b1 = b0 + 4096;
+        }
+        const uint32_t lb = (uint32_t)(is_slot * SLOT + (32 * wave) * 64);
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            const uint32_t g = (uint32_t)is_n * (uint32_t)S + (uint32_t)min(32 * wave + 16 * pc + (lane >> 2), S - 1);
+            a3_dma(b0, a3_row_off(g, kb0, lane), lb + pc * 1024);
+            a3_dma(b1, a3_row_off(g, kb1, lane), lb + HALF + pc * 1024);
+        }
+        ++issued;
+        if (++is_u == U) { is_u = 0; ++is_n; }
+        if (++is_slot == NB) is_slot = 0;
+    };
+#pragma unroll
+    for (int k = 0; k < NB - 1; ++k) issue_next();
+    const __amdgpu_buffer_rsrc_t r_Op = __builtin_amdgcn_make_buffer_rsrc(p.Op, 0, (int)0x7fffffff, 0x00020000);
+    const int q4 = (lane >> 2) & 3, p4 = lane & 3, gg = (lane >> 4) & 1;
+    int g = 0, cslot = 0;
+    floatx16 acc[T];
+    attn_h8 pf[T][2];
+#pragma unroll 1
+    for (int n = n_begin; n < n_end; ++n) {
+        const uint32_t r0 = (uint32_t)n * (uint32_t)S;
+        const uint32_t keyq = ((r0 + (uint32_t)i) >> 2) & 3u, keyk = ((r0 + (uint32_t)l31) >> 2) & 3u;
+        const int offq0 = i * 64 + (int)(((0 + h2) ^ keyq) << 4), offq1 = i * 64 + (int)(((2 + h2) ^ keyq) << 4);
+        const int offk0 = l31 * 64 + (int)(((0 + h2) ^ keyk) << 4), offk1 = l31 * 64 + (int)(((2 + h2) ^ keyk) << 4);
+        int troff[2];
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const uint32_t row = (uint32_t)(4 * h2 + 8 * rd + q4);
+            troff[rd] = (int)(row * 64u + ((((uint32_t)(2 * gg + (p4 >> 1))) ^ (((r0 + row) >> 2) & 3u)) << 4) + 8u * (uint32_t)(p4 & 1));
+        }
+#pragma unroll 1
+        for (int u = 0; u < U; ++u) {
+            if (total - 1 - g >= NB - 2) A3_WAIT_VM(4 * (NB - 2)); else A3_WAIT_VM(0);
+            __builtin_amdgcn_s_barrier();
+            issue_next();
+            const char* slot = ring + cslot * SLOT;
+            if (u < nq) {
+                if (u == 0) {
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+                }
+                const attn_h8 fq0 = a3_row(slot + offq0), fq1 = a3_row(slot + offq1);
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const attn_h8 fk0 = a3_row(slot + HALF + t * 2048 + offk0), fk1 = a3_row(slot + HALF + t * 2048 + offk1);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk0, fq0, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk1, fq1, acc[t], 0, 0, 0);
+                }
+                if (u == nq - 1) {
+                    // ---- softmax of row i over this lane's 16 T keys and those of lane ^ 32
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float x = acc[t][r] * p.scale + biasr[t][r];
+                            acc[t][r] = x;
+                            m = fmaxf(m, x);
+                        }
+                    m = fmaxf(m, __shfl_xor(m, 32, 64));
+                    float sum = 0.f;
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float e = expf(acc[t][r] - m);
+                            acc[t][r] = e;
+                            sum += e;
+                        }
+                    sum += __shfl_xor(sum, 32, 64);
+                    float* pr_row = p.probs + (((size_t)n * p.H + h) * S + (size_t)min(i, S - 1)) * S;
+                    const uint32_t flat_i = ((uint32_t)n * p.H + h) * (uint32_t)(S * S) + (uint32_t)(i * S);
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int j0 = 32 * t + 8 * g4 + 4 * h2;
+                            a3_f4u pv;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pv[e] = acc[t][4 * g4 + e] / sum;
+                            if (i < S) {
+                                if (j0 + 3 < S) *reinterpret_cast<a3_f4u*>(pr_row + j0) = pv;
+                                else {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        if (j0 + e < S) pr_row[j0 + e] = pv[e];
+                                }
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float v = pv[e];
+                                if (p.has_drop) v = drop_keep(flat_i + (uint32_t)(j0 + e), dkn) ? v * dkn.scale : 0.f;
+                                acc[t][4 * g4 + e] = v;
+                            }
+                        }
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) pf[t][s2][e] = (__bf16)acc[t][8 * s2 + e];
+                    }
+                }
+            } else {
+                // ---- O[i-tile, two 32-column tiles] = Pd V
+                const int ct = 2 * (u - nq);
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const char* Vs = slot + hf * HALF;
+                    floatx16 o[1];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[0][r] = 0.f;
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const attn_h8 fv = a3_tr(Vs + t * 2048 + s2 * 1024 + troff[0], Vs + t * 2048 + s2 * 1024 + troff[1]);
+                            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[t][s2], fv, o[0], 0, 0, 0);
+                        }
+                    store_rows_packed<1>(o, 1.f, r_Op, r0 + 32u * (uint32_t)wave, (uint32_t)(((h * p.dv) >> 5) + ct + hf), (uint32_t)p.kbo,
+                                         max(S - 32 * wave, 0), l31, h2);
+                }
+            }
+            ++g;
+            if (++cslot == NB) cslot = 0;
+        }
+    }
+}
+
+// Third-generation backward.  Same ownership (wave w = queries 32 w ..), same ring, per item:
+//   A   {dO chunk, V chunk} x d_v/32 : dP^T[j][i] = V dO^T on the lane-=-query layout; then in registers
+//       dA = P (dP keep - rowsum(dP keep P)), Pd = P keep; the bias-table gradient goes to a per-wave LDS table by ds_add_f32;
+//       dA (bf16) is the A operand of dQ as it stands; Pd and dA cross the lanes ONCE each through a [key tile][query][32 keys]
+//       image with 72-B rows (8-B stores conflict-free, transposed reads 2-way at worst) and come back as the A operands of
+//       dV and dK with the KEY on the lane: wave w then owns the 32 keys 32 w .. of those two products;
+//   C1  {K tile, K tile} x d_k/64    : dQ[queries of w] = scale dA K       (B operand by transposed reads, accumulator k order)
+//   C2  {dO tile, dO tile} x d_v/64  : dV[keys of w]    = Pd^T dO          (natural k order)
+//   C3  {Q tile, Q tile} x d_k/64    : dK[keys of w]    = scale dA^T Q
+template <int T>
+__global__ void __launch_bounds__(64 * T) attn_bwd3_kernel(const AttnParams p) {
+    const DropKey dkn = drop_key_now(p.dkey);
+    constexpr int SP = 32 * T, HALF = SP * 64, SLOT = 2 * HALF, NB = A3_NB;
+    constexpr int ILD = 72, IMG = T * SP * ILD;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    char* ring = reinterpret_cast<char*>(sm);
+    char* img = ring + NB * SLOT;
+    float* tacc = reinterpret_cast<float*>(img + IMG);
+    const int h = blockIdx.y, S = p.S;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, h2 = lane >> 5;
+    const int n_begin = blockIdx.x * p.n_per_wg, n_end = min(p.N, n_begin + p.n_per_wg);
+    const int nv = p.dv >> 5, nq2 = p.dk >> 6, nv2 = p.dv >> 6;
+    const int u_c1 = nv, u_c2 = nv + nq2, u_c3 = nv + nq2 + nv2, U = nv + 2 * nq2 + nv2;
+    const int total = (n_end - n_begin) * U;
+    const int tq = p.iq0 + ((h * p.dk) >> 5), tk = p.ik0 + ((h * p.dk) >> 5), tv = p.iv0 + ((h * p.dv) >> 5), tdo = p.ido0 + ((h * p.dv) >> 5);
+    const int i = 32 * wave + l31;
+    const bool has_bias = p.index_ld > 0 && p.dtable != nullptr;
+    if (has_bias)
+        for (int x = threadIdx.x; x < T * p.table_rows; x += 64 * T) tacc[x] = 0.f;
+    float* const tw = tacc + wave * p.table_rows;
+    // bias-table rows of this lane's (i, j) pairs, two per register (0xFFFF: none)
+    uint32_t idxp[T][8];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r2 = 0; r2 < 8; ++r2) {
+            uint32_t w2 = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int r = 2 * r2 + e;
+                const int j = 32 * t + 8 * (r >> 2) + 4 * h2 + (r & 3);
+                const uint32_t v = (has_bias && i >= 1 && j >= 1 && i < S && j < S) ? (uint32_t)p.index[(size_t)(i - 1) * p.index_ld + (j - 1)] : 0xFFFFu;
+                w2 |= (v & 0xFFFFu) << (16 * e);
+            }
+            idxp[t][r2] = w2;
+        }
+    int is_n = n_begin, is_u = 0, is_slot = 0, issued = 0;
+    auto issue_next = [&]() {
+        if (issued >= total) return;
+        const __bf16 *b0, *b1;
+        uint32_t kb0, kb1;
+        if (is_u < u_c1) {
+            b0 = p.dOi + (size_t)(tdo + is_u) * 4096; kb0 = (uint32_t)p.kido;
+            b1 = p.Vi + (size_t)(tv + is_u) * 4096; kb1 = (uint32_t)p.kiv;
+        } else if (is_u < u_c2) {
+            b0 = p.Ki + (size_t)(tk + 2 * (is_u - u_c1)) * 4096; kb0 = kb1 = (uint32_t)p.kik; b1 = b0 + 4096;
+        } else if (is_u < u_c3) {
+            b0 = p.dOi + (size_t)(tdo + 2 * (is_u - u_c2)) * 4096; kb0 = kb1 = (uint32_t)p.kido; b1 = b0 + 4096;
+        } else {
+            b0 = p.Qi + (size_t)(tq + 2 * (is_u - u_c3)) * 4096; kb0 = kb1 = (uint32_t)p.kiq; b1 = b0 + 4096;
+        }
+        const uint32_t lb = (uint32_t)(is_slot * SLOT + (32 * wave) * 64);
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            const uint32_t g = (uint32_t)is_n * (uint32_t)S + (uint32_t)min(32 * wave + 16 * pc + (lane >> 2), S - 1);
+            a3_dma(b0, a3_row_off(g, kb0, lane), lb + pc * 1024);
+            a3_dma(b1, a3_row_off(g, kb1, lane), lb + HALF + pc * 1024);
+        }
+        ++issued;
+        if (++is_u == U) { is_u = 0; ++is_n; }
+        if (++is_slot == NB) is_slot = 0;
+    };
+#pragma unroll
+    for (int k = 0; k < NB - 1; ++k) issue_next();
+    const __amdgpu_buffer_rsrc_t r_dQ = __builtin_amdgcn_make_buffer_rsrc(p.dQp, 0, (int)0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_dK = __builtin_amdgcn_make_buffer_rsrc(p.dKp, 0, (int)0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_dV = __builtin_amdgcn_make_buffer_rsrc(p.dVp, 0, (int)0x7fffffff, 0x00020000);
+    const int q4 = (lane >> 2) & 3, p4 = lane & 3, gg = (lane >> 4) & 1;
+    // image addresses: 8-B store of keys 8 g4 + 4 h2 .. + 3 of query i (panel = key tile); transposed read of queries
+    // 8 h2 + 4 rd + q4 (+ 32 ti + 16 s2), keys 16 gg + 4 p4 .. of this wave's key panel
+    char* const img_w = img + i * ILD + 8 * h2;
+    const char* const img_r = img + wave * (SP * ILD) + (8 * h2 + q4) * ILD + 32 * gg + 8 * p4;
+    int g = 0, cslot = 0;
+    floatx16 acc[T];
+    float prr[T][16];
+    attn_h8 dAf[T][2], PdTf[T][2], dATf[T][2];
+    __syncthreads();          // tacc zeroed
+#pragma unroll 1
+    for (int n = n_begin; n < n_end; ++n) {
+        const uint32_t r0 = (uint32_t)n * (uint32_t)S;
+        const uint32_t keyq = ((r0 + (uint32_t)i) >> 2) & 3u, keyk = ((r0 + (uint32_t)l31) >> 2) & 3u;
+        const int offq0 = i * 64 + (int)(((0 + h2) ^ keyq) << 4), offq1 = i * 64 + (int)(((2 + h2) ^ keyq) << 4);
+        const int offk0 = l31 * 64 + (int)(((0 + h2) ^ keyk) << 4), offk1 = l31 * 64 + (int)(((2 + h2) ^ keyk) << 4);
+        int troff[2], trnat[2];
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const uint32_t row = (uint32_t)(4 * h2 + 8 * rd + q4), rown = (uint32_t)(8 * h2 + 4 * rd + q4);
+            troff[rd] = (int)(row * 64u + ((((uint32_t)(2 * gg + (p4 >> 1))) ^ (((r0 + row) >> 2) & 3u)) << 4) + 8u * (uint32_t)(p4 & 1));
+            trnat[rd] = (int)(rown * 64u + ((((uint32_t)(2 * gg + (p4 >> 1))) ^ (((r0 + rown) >> 2) & 3u)) << 4) + 8u * (uint32_t)(p4 & 1));
+        }
+        const uint32_t prow = r0 + 32u * (uint32_t)wave;
+        const int s_eff = max(S - 32 * wave, 0);
+#pragma unroll 1
+        for (int u = 0; u < U; ++u) {
+            if (total - 1 - g >= NB - 2) A3_WAIT_VM(4 * (NB - 2)); else A3_WAIT_VM(0);
+            __builtin_amdgcn_s_barrier();
+            issue_next();
+            const char* slot = ring + cslot * SLOT;
+            if (u < u_c1) {
+                if (u == 0) {
+                    // the saved probabilities of this lane's pairs land under phase A
+                    const float* pr_row = p.probs + (((size_t)n * p.H + h) * S + (size_t)min(i, S - 1)) * S;
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int j0 = 32 * t + 8 * g4 + 4 * h2;
+                            a3_f4u v = {0.f, 0.f, 0.f, 0.f};
+                            if (i < S) {
+                                if (j0 + 3 < S) v = *reinterpret_cast<const a3_f4u*>(pr_row + j0);
+                                else {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        if (j0 + e < S) v[e] = pr_row[j0 + e];
+                                }
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) prr[t][4 * g4 + e] = v[e];
+                        }
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+                }
+                const attn_h8 fo0 = a3_row(slot + offq0), fo1 = a3_row(slot + offq1);
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const attn_h8 fv0 = a3_row(slot + HALF + t * 2048 + offk0), fv1 = a3_row(slot + HALF + t * 2048 + offk1);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv0, fo0, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv1, fo1, acc[t], 0, 0, 0);
+                }
+                if (u == u_c1 - 1) {
+                    const uint32_t flat_i = ((uint32_t)n * p.H + h) * (uint32_t)(S * S) + (uint32_t)(i * S);
+                    float rs = 0.f;
+                    // Pd = P keep goes to the image at once (its values die here); acc <- dP keep
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            typedef __bf16 h4v __attribute__((ext_vector_type(4)));
+                            h4v pd;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int r = 4 * g4 + e;
+                                const int j = 32 * t + 8 * g4 + 4 * h2 + e;
+                                const float keep = p.has_drop ? (drop_keep(flat_i + (uint32_t)j, dkn) ? dkn.scale : 0.f) : 1.f;
+                                const float dpk = acc[t][r] * keep;
+                                rs += dpk * prr[t][r];
+                                acc[t][r] = dpk;
+                                pd[e] = (__bf16)(prr[t][r] * keep);
+                            }
+                            *reinterpret_cast<h4v*>(img_w + t * (SP * ILD) + 16 * g4) = pd;
+                        }
+                    rs += __shfl_xor(rs, 32, 64);
+                    // dA = P (dP keep - rs): bias-table gradient, then bf16 as the A operand of dQ
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float da = prr[t][r] * (acc[t][r] - rs);
+                            acc[t][r] = da;
+                            const uint32_t ix = (idxp[t][r >> 1] >> (16 * (r & 1))) & 0xFFFFu;
+                            if (ix != 0xFFFFu) atomicAdd(&tw[ix], da);
+                        }
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) dAf[t][s2][e] = (__bf16)acc[t][8 * s2 + e];
+                    }
+                    A3_LDS_BARRIER();
+#pragma unroll
+                    for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+                            PdTf[ti][s2] = a3_tr(img_r + (32 * ti + 16 * s2) * ILD, img_r + (32 * ti + 16 * s2 + 4) * ILD);
+                    A3_LDS_BARRIER();
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            typedef __bf16 h4v __attribute__((ext_vector_type(4)));
+                            h4v da4;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) da4[e] = dAf[t][g4 >> 1][4 * (g4 & 1) + e];
+                            *reinterpret_cast<h4v*>(img_w + t * (SP * ILD) + 16 * g4) = da4;
+                        }
+                    A3_LDS_BARRIER();
+#pragma unroll
+                    for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+                            dATf[ti][s2] = a3_tr(img_r + (32 * ti + 16 * s2) * ILD, img_r + (32 * ti + 16 * s2 + 4) * ILD);
+                }
+            } else {
+                // ---- token contractions: two 32-column tiles of dQ (u < u_c2), dV (u < u_c3) or dK
+                const int ph = u < u_c2 ? 0 : (u < u_c3 ? 1 : 2);
+                const int ct = 2 * (u - (ph == 0 ? u_c1 : (ph == 1 ? u_c2 : u_c3)));
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const char* Bs = slot + hf * HALF;
+                    floatx16 o[1];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[0][r] = 0.f;
+                    if (ph == 0) {
+#pragma unroll
+                        for (int t = 0; t < T; ++t)
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2) {
+                                const attn_h8 fb = a3_tr(Bs + t * 2048 + s2 * 1024 + troff[0], Bs + t * 2048 + s2 * 1024 + troff[1]);
+                                o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dAf[t][s2], fb, o[0], 0, 0, 0);
+                            }
+                        store_rows_packed<1>(o, p.scale, r_dQ, prow, (uint32_t)(p.tq0 + ((h * p.dk) >> 5) + ct + hf), (uint32_t)p.kbq, s_eff, l31, h2);
+                    } else if (ph == 1) {
+#pragma unroll
+                        for (int t = 0; t < T; ++t)
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2) {
+                                const attn_h8 fb = a3_tr(Bs + t * 2048 + s2 * 1024 + trnat[0], Bs + t * 2048 + s2 * 1024 + trnat[1]);
+                                o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PdTf[t][s2], fb, o[0], 0, 0, 0);
+                            }
+                        store_rows_packed<1>(o, 1.f, r_dV, prow, (uint32_t)(p.tv0 + ((h * p.dv) >> 5) + ct + hf), (uint32_t)p.kbv, s_eff, l31, h2);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < T; ++t)
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2) {
+                                const attn_h8 fb = a3_tr(Bs + t * 2048 + s2 * 1024 + trnat[0], Bs + t * 2048 + s2 * 1024 + trnat[1]);
+                                o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dATf[t][s2], fb, o[0], 0, 0, 0);
+                            }
+                        store_rows_packed<1>(o, p.scale, r_dK, prow, (uint32_t)(p.tk0 + ((h * p.dk) >> 5) + ct + hf), (uint32_t)p.kbk, s_eff, l31, h2);
+                    }
+                }
+            }
+            ++g;
+            if (++cslot == NB) cslot = 0;
+        }
+    }
+    if (has_bias) {
+        __syncthreads();
+        for (int x = threadIdx.x; x < p.table_rows; x += 64 * T) {
+            float v = tacc[x];
+#pragma unroll
+            for (int w = 1; w < T; ++w) v += tacc[w * p.table_rows + x];
+            if (p.table_partials) p.dtable[((size_t)blockIdx.x * p.table_rows + x) * p.H + h] = v;
+            else atomicAdd(&p.dtable[(size_t)x * p.H + h], v);
+        }
+    }
+}
+
 int fill_params(const LstcAttnDesc* d, AttnParams& p, bool bwd) {
     if (!d) return LSTC_E_NULL;
     if (d->dtype != LSTC_F32 && d->dtype != LSTC_BF16) return LSTC_E_UNSUPPORTED;
@@ -803,7 +1278,9 @@ int fill_params(const LstcAttnDesc* d, AttnParams& p, bool bwd) {
     if (bwd && (!d->dO || (!gpk && (!d->dQ || !d->dK || !d->dV)))) return LSTC_E_NULL;
     if (d->N <= 0 || d->S < 1 || d->H <= 0 || d->dk <= 0 || d->dv <= 0) return LSTC_E_SHAPE;
     if (d->S > 128) return LSTC_E_RANGE;
-    if (d->ldq < d->H * d->dk || d->ldk < d->H * d->dk || d->ldv < d->H * d->dv || d->ldo < d->H * d->dv) return LSTC_E_SHAPE;
+    if (d->in_pack_cols < 0 || d->dO_pack_cols < 0) return LSTC_E_SHAPE;
+    if (d->in_pack_cols == 0 && (d->ldq < d->H * d->dk || d->ldk < d->H * d->dk || d->ldv < d->H * d->dv)) return LSTC_E_SHAPE;
+    if (!(d->O_pack && !bwd) && !(bwd && d->dO_pack_cols > 0) && d->ldo < d->H * d->dv) return LSTC_E_SHAPE;
     if ((uint64_t)d->N * d->H * d->S * d->S > 0xffffffffull) return LSTC_E_RANGE;
     if (d->index_ld > 0 && (!d->table || !d->index || d->index_ld < d->S - 1)) return LSTC_E_NULL;
     p.Q = (const float*)d->Q; p.K = (const float*)d->K; p.V = (const float*)d->V; p.O = (float*)d->O;
@@ -822,6 +1299,32 @@ int fill_params(const LstcAttnDesc* d, AttnParams& p, bool bwd) {
     p.kbq = p.kbk = p.kbv = 0;
     p.tq0 = p.tk0 = p.tv0 = 0;
     p.Op = nullptr; p.kbo = 0;
+    p.Qi = p.Ki = p.Vi = p.dOi = nullptr;
+    p.kiq = p.kik = p.kiv = p.kido = 0;
+    p.iq0 = p.ik0 = p.iv0 = p.ido0 = 0;
+    return 0;
+}
+
+// Packed-input form (LstcAttnDesc.in_pack_cols > 0): shape / alignment checks shared by forward and backward, pack geometry.
+int fill_packed_inputs(const LstcAttnDesc* d, AttnParams& p, bool bwd) {
+    const int64_t M = (int64_t)p.N * p.S;
+    if (d->dtype != LSTC_BF16 || p.S > 96 || p.dk % 32 || p.dv % 64 || M % 256) return LSTC_E_UNSUPPORTED;
+    if (d->in_pack_cols % 64 || d->Q_col0 % 32 || d->K_col0 % 32 || d->V_col0 % 32 || d->Q_col0 < 0 || d->K_col0 < 0 || d->V_col0 < 0 ||
+        d->Q_col0 + p.H * p.dk > d->in_pack_cols || d->K_col0 + p.H * p.dk > d->in_pack_cols || d->V_col0 + p.H * p.dv > d->in_pack_cols ||
+        M * (int64_t)d->in_pack_cols * 2 > 0x7fffffffLL) return LSTC_E_SHAPE;
+    if (!aligned16(d->Q) || !aligned16(d->K) || !aligned16(d->V)) return LSTC_E_ALIGN;
+    p.Qi = (const __bf16*)d->Q; p.Ki = (const __bf16*)d->K; p.Vi = (const __bf16*)d->V;
+    p.kiq = p.kik = p.kiv = d->in_pack_cols / 32;
+    p.iq0 = d->Q_col0 / 32; p.ik0 = d->K_col0 / 32; p.iv0 = d->V_col0 / 32;
+    if (bwd) {
+        if (d->dO_pack_cols <= 0) return LSTC_E_UNSUPPORTED;
+        if (d->dO_pack_cols % 64 || d->dO_col0 % 32 || d->dO_col0 < 0 || d->dO_col0 + p.H * p.dv > d->dO_pack_cols ||
+            M * (int64_t)d->dO_pack_cols * 2 > 0x7fffffffLL) return LSTC_E_SHAPE;
+        if (!aligned16(d->dO)) return LSTC_E_ALIGN;
+        p.dOi = (const __bf16*)d->dO;
+        p.kido = d->dO_pack_cols / 32;
+        p.ido0 = d->dO_col0 / 32;
+    }
     return 0;
 }
 
@@ -848,6 +1351,27 @@ int lstc_attn_fwd(const LstcAttnDesc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const bool bf = d->dtype == LSTC_BF16;
     const int T = (p.S + 31) / 32;
+    if (d->in_pack_cols > 0) {      // third generation: packed bf16 inputs and output
+        if (!d->O_pack) return LSTC_E_UNSUPPORTED;
+        rc = fill_packed_inputs(d, p, false);
+        if (rc) return rc;
+        int npw = (int)(((int64_t)p.N * p.H + 8191) / 8192);
+        if (d->variant >= 100) npw = d->variant - 100;          // measurement hook: sequences per workgroup
+        npw = npw < 1 ? 1 : (npw > 16 ? 16 : npw);
+        p.n_per_wg = npw;
+        dim3 grid3((p.N + npw - 1) / npw, p.H);
+        const size_t lds3 = (size_t)A3_NB * 2 * (32 * T) * 64;
+#define LSTC_FWD3(TT)                                                                      \
+    do {                                                                                   \
+        static LstcDevOnce once3;                                                          \
+        const int dev3_ = once3.begin();                                                   \
+        if (dev3_ >= 0) { set_lds(attn_fwd3_kernel<TT>, 160 * 1024); once3.end(dev3_); }    \
+        hipLaunchKernelGGL((attn_fwd3_kernel<TT>), grid3, 64 * TT, lds3, st, p);            \
+    } while (0)
+        if (T == 1) LSTC_FWD3(1); else if (T == 2) LSTC_FWD3(2); else LSTC_FWD3(3);
+#undef LSTC_FWD3
+        return lstc_launch_status();
+    }
     const size_t lds = (size_t)(32 * T) * (32 * T + 1) * sizeof(float);
     dim3 grid(p.N, p.H);
     if ((T == 1 || T == 3 || (bf && T == 2)) && p.vec_qk && p.vec_v && (p.dk % 32) == 0 && (p.dv % 32) == 0 && d->variant == 0) {
@@ -897,6 +1421,11 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
     const int T = (p.S + 31) / 32;
     p.table_rows = (d->index_ld > 0 && d->dtable) ? d->table_rows : 0;
     if (d->index_ld > 0 && d->dtable && d->table_rows <= 0) return LSTC_E_SHAPE;
+    if (d->in_pack_cols > 0) {
+        rc = fill_packed_inputs(d, p, true);
+        if (rc) return rc;
+        if (p.dk % 64 || p.table_rows >= 0xFFFF) return LSTC_E_UNSUPPORTED;
+    } else if (d->dO_pack_cols > 0) return LSTC_E_UNSUPPORTED;
     const size_t lds = ((size_t)2 * (32 * T) * (32 * T + 1) + (size_t)(NT / 64) * p.table_rows) * sizeof(float);
     if (lds > 160 * 1024) return LSTC_E_RANGE;
     // enough workgroups to fill the chip (>= ~2048) while amortising the bias-table flush over a few sequences
@@ -919,7 +1448,7 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
     if (d->dQ_pack || d->dK_pack || d->dV_pack) {
         // packed bf16 gradients: the staged kernel only, token rows and head columns filling the packs' even tile grid exactly
         const int64_t M = (int64_t)p.N * p.S;
-        if (!(d->dQ_pack && d->dK_pack && d->dV_pack) || !v2 || M % 256 || (p.H * p.dk) % 64 || (p.H * p.dv) % 64 ||
+        if (!(d->dQ_pack && d->dK_pack && d->dV_pack) || (!v2 && d->in_pack_cols <= 0) || M % 256 || (p.H * p.dk) % 64 || (p.H * p.dv) % 64 ||
             M * (int64_t)(p.H * (p.dk > p.dv ? p.dk : p.dv)) * 2 > 0x7fffffffLL) return LSTC_E_UNSUPPORTED;
         if (!aligned16(d->dQ_pack) || !aligned16(d->dK_pack) || !aligned16(d->dV_pack)) return LSTC_E_ALIGN;
         p.dQp = d->dQ_pack; p.dKp = d->dK_pack; p.dVp = d->dV_pack;
@@ -932,6 +1461,21 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
             p.kbq = p.kbk = p.kbv = d->pack_cols / 32;
             p.tq0 = d->dQ_col0 / 32; p.tk0 = d->dK_col0 / 32; p.tv0 = d->dV_col0 / 32;
         }
+    }
+    if (d->in_pack_cols > 0) {      // third generation: packed bf16 inputs and outputs
+        if (!p.dQp) return LSTC_E_UNSUPPORTED;
+        const size_t lds3 = (size_t)A3_NB * 2 * (32 * T) * 64 + (size_t)T * (32 * T) * 72 + (size_t)T * p.table_rows * sizeof(float);
+        if (lds3 > 160 * 1024) return LSTC_E_RANGE;
+#define LSTC_BWD3(TT)                                                                      \
+    do {                                                                                   \
+        static LstcDevOnce once3;                                                          \
+        const int dev3_ = once3.begin();                                                   \
+        if (dev3_ >= 0) { set_lds(attn_bwd3_kernel<TT>, 160 * 1024); once3.end(dev3_); }    \
+        hipLaunchKernelGGL((attn_bwd3_kernel<TT>), grid, 64 * TT, lds3, st, p);             \
+    } while (0)
+        if (T == 1) LSTC_BWD3(1); else if (T == 2) LSTC_BWD3(2); else LSTC_BWD3(3);
+#undef LSTC_BWD3
+        return lstc_launch_status();
     }
     if (v2) {
         const int SP = 32 * T, NW = T == 3 ? 8 : 4;      // 64 < S <= 96: 138 KB of LDS = one workgroup per CU, so that one runs 8 waves

@@ -113,6 +113,8 @@ _memo_stack = []           # activation packs made inside one autograd-node body
 _x3_min = (256, 256, 1 << 30)   # min(M, N), K, M*N*K from which a product goes to the packed kernel
 _ATTN_F32 = os.environ.get("LSTC_ATTN_F32", "0") == "1"          # bf16 mode: keep the attention products on the exact-f32 MFMA
 _ATTN_VARIANT = int(os.environ.get("LSTC_ATTN_VARIANT", "0"))     # 1: first-generation attention kernels (A/B measurements)
+_attn3_bwd_ready = True
+_ATTN_PACKED_IN = os.environ.get("LSTC_ATTN_PACKED_IN", "1") != "0"   # bf16 mode: Q | K | V / dO reach the attention core as packs
 _DETERMINISTIC_WGRAD = os.environ.get("LSTC_ATOMIC_SPLITK", "0") != "1"   # split-K weight gradients: partials + ordered sum, not atomics
 
 
@@ -589,18 +591,38 @@ def attn_fwd_pack(N, S, H, dv) -> bool:
             M * H * dv * max(_x3_min[0], 256) >= _x3_min[2])
 
 
+def _qkv_pack_desc(d, qkv: "Packed", H, dk, dv):
+    """Packed-input form of LstcAttnDesc: Q | K | V are the column blocks of ONE pack (the fused projection's output)."""
+    assert qkv.kind == _lib.BF16P and qkv.K == H * (2 * dk + dv)
+    d.in_pack_cols, d.Q_col0, d.K_col0, d.V_col0 = qkv.K, 0, H * dk, 2 * H * dk
+    d.Q = d.K = d.V = dev_ptr(qkv.buf)
+
+
+def attn_packed_inputs(N, S, H, dk, dv) -> bool:
+    """bf16 mode: the attention core can read Q | K | V (and dO) as packed bf16 operands (include/lstc_hip.h, in_pack_cols)."""
+    return (attn_fwd_pack(N, S, H, dv) and attn_bwd_packs(N, S, H, dk, dv) and _ATTN_PACKED_IN and not _ATTN_F32 and S <= 96 and
+            dk % 64 == 0 and dv % 64 == 0 and N * S * H * (2 * dk + dv) * 2 < 2 ** 31)
+
+
 def attn_fwd(q, k, v, N, S, H, dk, dv, table, index, p_drop, seed, packed=False):
-    """``packed``: O comes back ONLY as a ``Packed`` bf16 operand (returns (Packed, probs)) - see ``attn_fwd_pack``."""
+    """``packed``: O comes back ONLY as a ``Packed`` bf16 operand (returns (Packed, probs)) - see ``attn_fwd_pack``.
+    ``q`` may be the ``Packed`` fused Q | K | V projection (``k``, ``v`` None): the packed-input kernels, ``packed`` implied."""
     M = N * S
+    in_pack = isinstance(q, Packed)
+    dev = q.buf.device if in_pack else q.device
+    packed = packed or in_pack
     if packed:
         o = None
-        obuf = torch.empty((int(_lib.load().lstc_pack1_bytes(M, H * dv)),), device=q.device, dtype=torch.uint8)
+        obuf = torch.empty((int(_lib.load().lstc_pack1_bytes(M, H * dv)),), device=dev, dtype=torch.uint8)
     else:
-        o = torch.empty((M, H * dv), device=q.device, dtype=torch.float32)
-    probs = torch.empty((N, H, S, S), device=q.device, dtype=torch.float32)
+        o = torch.empty((M, H * dv), device=dev, dtype=torch.float32)
+    probs = torch.empty((N, H, S, S), device=dev, dtype=torch.float32)
     d = AttnDesc()
     d.N, d.S, d.H, d.dk, d.dv = N, S, H, dk, dv
-    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), (H * dv if packed else o.stride(0))
+    if in_pack:
+        d.ldo = H * dv
+    else:
+        d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), (H * dv if packed else o.stride(0))
     d.dtype = _attn_dtype()
     if table is not None:
         d.index_ld, d.table_rows = index.shape[1], table.shape[0]
@@ -608,7 +630,11 @@ def attn_fwd(q, k, v, N, S, H, dk, dv, table, index, p_drop, seed, packed=False)
     d.scale = 1.0 / (dk ** 0.5)
     d.dropout_p, d.dropout_seed = float(p_drop), int(seed)
     d.variant = _ATTN_VARIANT
-    d.Q, d.K, d.V, d.probs = dev_ptr(q), dev_ptr(k), dev_ptr(v), dev_ptr(probs)
+    d.probs = dev_ptr(probs)
+    if in_pack:
+        _qkv_pack_desc(d, q, H, dk, dv)
+    else:
+        d.Q, d.K, d.V = dev_ptr(q), dev_ptr(k), dev_ptr(v)
     if packed:
         d.O_pack = dev_ptr(obuf)
     else:
@@ -629,12 +655,18 @@ def attn_bwd_packs(N, S, H, dk, dv) -> bool:
 
 def attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, p_drop, seed, out=None, packed=False):
     """``packed``: return dQ, dK, dV as ``Packed`` bf16 operands (no f32 copies) - see ``attn_bwd_packs``; ``packed="fused"``:
-    ONE Packed [N*S, H*(2 dk + dv)] with the column blocks dQ | dK | dV (gradient of the fused Q|K|V projection)."""
+    ONE Packed [N*S, H*(2 dk + dv)] with the column blocks dQ | dK | dV (gradient of the fused Q|K|V projection).
+    ``q`` and ``do`` may be ``Packed`` (the fused Q | K | V projection, the packed input gradient of fc; ``k``, ``v`` None): the
+    packed-input kernel, ``packed="fused"`` implied."""
+    in_pack = isinstance(q, Packed)
+    if in_pack:
+        assert isinstance(do, Packed) and do.K == H * dv and do.kind == _lib.BF16P
+        packed = "fused"
     if packed:
         lib = _lib.load()
         M = N * S
         widths = (H * (2 * dk + dv),) if packed == "fused" else (H * dk, H * dk, H * dv)
-        bufs = [torch.empty((int(lib.lstc_pack1_bytes(M, w)),), device=q.device, dtype=torch.uint8) for w in widths]
+        bufs = [torch.empty((int(lib.lstc_pack1_bytes(M, w)),), device=probs.device, dtype=torch.uint8) for w in widths]
         if packed == "fused":
             if M * widths[0] * 2 >= 2 ** 31:
                 raise RuntimeError("attn_bwd(packed='fused'): pack larger than a buffer descriptor addresses")
@@ -644,7 +676,8 @@ def attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, p_drop, seed, ou
         dq, dk_, dv_ = out if out is not None else (torch.empty_like(q), torch.empty_like(k), torch.empty_like(v))
     d = AttnDesc()
     d.N, d.S, d.H, d.dk, d.dv = N, S, H, dk, dv
-    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), do.stride(0)
+    if not in_pack:
+        d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), do.stride(0)
     assert packed or (dq.stride(0) == q.stride(0) and dk_.stride(0) == k.stride(0) and dv_.stride(0) == v.stride(0))
     d.dtype = _attn_dtype()
     dtable = parts = None
@@ -653,13 +686,17 @@ def attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, p_drop, seed, ou
         npw = min(8, max(1, (N * H + 4095) // 4096))
         chunks = (N + npw - 1) // npw
         chunks = (N + ((N + chunks - 1) // chunks) - 1) // ((N + chunks - 1) // chunks)
-        parts = torch.empty((chunks, table.shape[0] * H), device=q.device, dtype=torch.float32)
+        parts = torch.empty((chunks, table.shape[0] * H), device=probs.device, dtype=torch.float32)
         d.index_ld, d.table_rows, d.dtable_chunks = index.shape[1], table.shape[0], chunks
         d.table, d.index, d.dtable = dev_ptr(table), dev_ptr(index), dev_ptr(parts)
     d.scale = 1.0 / (dk ** 0.5)
     d.dropout_p, d.dropout_seed = float(p_drop), int(seed)
-    d.Q, d.K, d.V, d.probs = dev_ptr(q), dev_ptr(k), dev_ptr(v), dev_ptr(probs)
-    d.dO = dev_ptr(do)
+    d.probs = dev_ptr(probs)
+    if in_pack:
+        _qkv_pack_desc(d, q, H, dk, dv)
+        d.dO, d.dO_pack_cols, d.dO_col0 = dev_ptr(do.buf), do.K, 0
+    else:
+        d.Q, d.K, d.V, d.dO = dev_ptr(q), dev_ptr(k), dev_ptr(v), dev_ptr(do)
     if packed:
         d.dQ_pack, d.dK_pack, d.dV_pack = (dev_ptr(b) for b in bufs)
         if packed == "fused":
