@@ -207,6 +207,10 @@ typedef struct LstcAttnDesc {
      * exists in this form: the attention core moves 2 bytes per element each way. */
     int32_t in_pack_cols, Q_col0, K_col0, V_col0;
     int32_t dO_pack_cols, dO_col0;
+    /* row pitch of `probs` in floats: 0 or S = dense [N,H,S,S].  The packed-input kernels need a multiple of 4 (>= S; `probs`
+     * 16-B aligned): they move the probabilities as 16-B groups, the forward writes zeros into the padding columns and the
+     * backward expects them there. */
+    int32_t probs_ld;
 } LstcAttnDesc;
 
 int lstc_attn_fwd(const LstcAttnDesc* d, void* stream);

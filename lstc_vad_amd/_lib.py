@@ -55,7 +55,7 @@ class AttnDesc(C.Structure):
                 ("pack_cols", C.c_int32), ("dQ_col0", C.c_int32), ("dK_col0", C.c_int32), ("dV_col0", C.c_int32),
                 ("O_pack", C.c_void_p),
                 ("in_pack_cols", C.c_int32), ("Q_col0", C.c_int32), ("K_col0", C.c_int32), ("V_col0", C.c_int32),
-                ("dO_pack_cols", C.c_int32), ("dO_col0", C.c_int32)]
+                ("dO_pack_cols", C.c_int32), ("dO_col0", C.c_int32), ("probs_ld", C.c_int32)]
 
 
 class AdagradItem(C.Structure):

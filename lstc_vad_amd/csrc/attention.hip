@@ -47,6 +47,8 @@ struct AttnParams {
     const __bf16 *Qi, *Ki, *Vi, *dOi;
     int kiq, kik, kiv, kido;
     int iq0, ik0, iv0, ido0;
+    int dbg;
+    int pld;                // row pitch of `probs` in floats (packed-input kernels: a multiple of 4, >= S; else S)
 };
 
 __device__ __forceinline__ void load16(const float* __restrict__ p, int k0, int kdim, bool vec, float (&f)[16]) {
@@ -820,8 +822,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) attn_fwd2_kernel(con
 typedef short a3_s4 __attribute__((ext_vector_type(4)));
 typedef short a3_s8 __attribute__((ext_vector_type(8)));
 typedef float a3_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t a3_u4 __attribute__((ext_vector_type(4)));
 typedef a3_s4 __attribute__((address_space(3))) * a3_lds4;
-constexpr int A3_NB = 4;
+constexpr int A3_NB = 4;       // A3_WAIT_UNIT's history is three steps deep: NB - 1
 
 __device__ __forceinline__ void a3_dma(const __bf16* tile, uint32_t voff, uint32_t lds_bytes) {
     const uint32_t lb = __builtin_amdgcn_readfirstlane(lds_bytes);
@@ -840,6 +843,16 @@ __device__ __forceinline__ attn_h8 a3_tr(const char* p0, const char* p1) {
 }
 __device__ __forceinline__ attn_h8 a3_row(const char* p) { return *reinterpret_cast<const attn_h8*>(p); }
 #define A3_LDS_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)   /* lgkmcnt(0) only: the ring's DMA stays in flight */
+// s_waitcnt takes an immediate: the count of vector-memory operations younger than the awaited unit - 4 DMA pieces for each of the
+// NB - 2 units behind it plus the loads / stores of the last NB - 1 steps (multiples of 4, each step's count known exactly because
+// every such operation is an unconditional buffer instruction) - selects one of the instantiated waits
+#define A3_CASE_VM(N) case N: A3_WAIT_VM(N); break;
+#define A3_WAIT_UNIT(x)                                                                                          \
+    switch (x) {                                                                                                 \
+        A3_CASE_VM(8) A3_CASE_VM(12) A3_CASE_VM(16) A3_CASE_VM(20) A3_CASE_VM(24) A3_CASE_VM(28) A3_CASE_VM(32)  \
+        A3_CASE_VM(36) A3_CASE_VM(40) A3_CASE_VM(44) A3_CASE_VM(48) A3_CASE_VM(52) A3_CASE_VM(56) A3_CASE_VM(60) \
+        default: A3_WAIT_VM(0); break;                                                                           \
+    }
 #define A3_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (0 << 8) | (((N) >> 4) << 14))     /* vmcnt(N), lgkmcnt(0) */
 
 template <int T>
@@ -857,14 +870,24 @@ __global__ void __launch_bounds__(64 * T) attn_fwd3_kernel(const AttnParams p) {
     const int tq = p.iq0 + ((h * p.dk) >> 5), tk = p.ik0 + ((h * p.dk) >> 5), tv = p.iv0 + ((h * p.dv) >> 5);
     const int i = 32 * wave + l31;
     // relative-position bias of this lane's (i, j) pairs: two dependent loads per element, once per workgroup
+    const bool has_bias = p.index_ld > 0 && S > 1;
+    const __amdgpu_buffer_rsrc_t r_index = __builtin_amdgcn_make_buffer_rsrc(const_cast<int64_t*>(p.index), 0,
+        has_bias ? (S - 1) * p.index_ld * 8 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_table = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.table), 0,
+        has_bias ? (p.table_rows > 0 ? p.table_rows * p.H * 4 : 0x7fffffff) : 0, 0x00020000);
     float biasr[T][16];
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = 32 * t + 8 * (r >> 2) + 4 * h2 + (r & 3);
-            biasr[t][r] = (p.index_ld > 0 && i >= 1 && j >= 1 && i < S && j < S)
-                              ? p.table[(size_t)p.index[(size_t)(i - 1) * p.index_ld + (j - 1)] * p.H + h] : (j < S ? 0.f : -INFINITY);
+            // buffer loads whose offset is out of range where no bias applies (they return 0): a plain load under a lane-dependent
+            // condition is waited for on the spot - 16 T exposed double latencies per workgroup
+            const bool pair = i >= 1 && j >= 1 && i < S && j < S;
+            const uint32_t ix = __builtin_amdgcn_raw_buffer_load_b32(r_index, pair ? (uint32_t)((i - 1) * p.index_ld + (j - 1)) * 8u : 0xFFFFFFFFu, 0, 0);
+            // (the OR keeps the first load's result in use on every lane: a select would let the compiler sink that load into a branch)
+            const float b = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_table, ((ix * (uint32_t)p.H + (uint32_t)h) * 4u) | (pair ? 0u : 0xFFFFFFFFu), 0, 0));
+            biasr[t][r] = b + (j < S ? 0.f : -INFINITY);
         }
     // (keys j >= S carry a bias of -inf: their logits, exponentials and probabilities come out as -inf, 0, 0 with no predicate)
     // ---- the staged-unit stream
@@ -895,7 +918,7 @@ __global__ void __launch_bounds__(64 * T) attn_fwd3_kernel(const AttnParams p) {
     for (int k = 0; k < NB - 1; ++k) issue_next();
     const __amdgpu_buffer_rsrc_t r_Op = __builtin_amdgcn_make_buffer_rsrc(p.Op, 0, (int)0x7fffffff, 0x00020000);
     const int q4 = (lane >> 2) & 3, p4 = lane & 3, gg = (lane >> 4) & 1;
-    int g = 0, cslot = 0;
+    int g = 0, cslot = 0, oh1 = 0, oh2 = 0, oh3 = 0;
     floatx16 acc[T];
     attn_h8 pf[T][2];
 #pragma unroll 1
@@ -912,9 +935,10 @@ __global__ void __launch_bounds__(64 * T) attn_fwd3_kernel(const AttnParams p) {
         }
 #pragma unroll 1
         for (int u = 0; u < U; ++u) {
-            if (total - 1 - g >= NB - 2) A3_WAIT_VM(4 * (NB - 2)); else A3_WAIT_VM(0);
+            { int x = (total - 1 - g >= NB - 2) ? 4 * (NB - 2) + oh1 + oh2 + oh3 : 0; if (p.dbg & 1) x = min(x, 8); A3_WAIT_UNIT(x); }
             __builtin_amdgcn_s_barrier();
             issue_next();
+            oh3 = oh2; oh2 = oh1; oh1 = u < nq - 1 ? 0 : (u == nq - 1 ? 4 * T : 16);
             const char* slot = ring + cslot * SLOT;
             if (u < nq) {
                 if (u == 0) {
@@ -952,7 +976,9 @@ __global__ void __launch_bounds__(64 * T) attn_fwd3_kernel(const AttnParams p) {
                             sum += e;
                         }
                     sum += __shfl_xor(sum, 32, 64);
-                    float* pr_row = p.probs + (((size_t)n * p.H + h) * S + (size_t)min(i, S - 1)) * S;
+                    // probabilities: 4 T unconditional 16-B buffer stores (rows >= S, padding groups: dropped by the range check)
+                    const __amdgpu_buffer_rsrc_t r_pr = __builtin_amdgcn_make_buffer_rsrc(
+                        p.probs + ((size_t)n * p.H + h) * S * p.pld, 0, S * p.pld * 4, 0x00020000);
                     const uint32_t flat_i = ((uint32_t)n * p.H + h) * (uint32_t)(S * S) + (uint32_t)(i * S);
 #pragma unroll
                     for (int t = 0; t < T; ++t) {
@@ -962,14 +988,8 @@ __global__ void __launch_bounds__(64 * T) attn_fwd3_kernel(const AttnParams p) {
                             a3_f4u pv;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) pv[e] = acc[t][4 * g4 + e] / sum;
-                            if (i < S) {
-                                if (j0 + 3 < S) *reinterpret_cast<a3_f4u*>(pr_row + j0) = pv;
-                                else {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e)
-                                        if (j0 + e < S) pr_row[j0 + e] = pv[e];
-                                }
-                            }
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(a3_u4, pv), r_pr,
+                                (i < S && j0 < p.pld) ? (uint32_t)(i * p.pld + j0) * 4u : 0xFFFFFFFFu, 0, 0);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 float v = pv[e];
@@ -1041,6 +1061,8 @@ __global__ void __launch_bounds__(64 * T) attn_bwd3_kernel(const AttnParams p) {
         for (int x = threadIdx.x; x < T * p.table_rows; x += 64 * T) tacc[x] = 0.f;
     float* const tw = tacc + wave * p.table_rows;
     // bias-table rows of this lane's (i, j) pairs, two per register (0xFFFF: none)
+    const __amdgpu_buffer_rsrc_t r_index = __builtin_amdgcn_make_buffer_rsrc(const_cast<int64_t*>(p.index), 0,
+        (has_bias && S > 1) ? (S - 1) * p.index_ld * 8 : 0, 0x00020000);
     uint32_t idxp[T][8];
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -1051,7 +1073,9 @@ __global__ void __launch_bounds__(64 * T) attn_bwd3_kernel(const AttnParams p) {
             for (int e = 0; e < 2; ++e) {
                 const int r = 2 * r2 + e;
                 const int j = 32 * t + 8 * (r >> 2) + 4 * h2 + (r & 3);
-                const uint32_t v = (has_bias && i >= 1 && j >= 1 && i < S && j < S) ? (uint32_t)p.index[(size_t)(i - 1) * p.index_ld + (j - 1)] : 0xFFFFu;
+                const bool pair = has_bias && i >= 1 && j >= 1 && i < S && j < S;      // out-of-range offset reads 0 (see the forward)
+                const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(r_index, pair ? (uint32_t)((i - 1) * p.index_ld + (j - 1)) * 8u : 0xFFFFFFFFu, 0, 0)
+                                   | (pair ? 0u : 0xFFFFu);
                 w2 |= (v & 0xFFFFu) << (16 * e);
             }
             idxp[t][r2] = w2;
@@ -1092,7 +1116,7 @@ __global__ void __launch_bounds__(64 * T) attn_bwd3_kernel(const AttnParams p) {
     // 8 h2 + 4 rd + q4 (+ 32 ti + 16 s2), keys 16 gg + 4 p4 .. of this wave's key panel
     char* const img_w = img + i * ILD + 8 * h2;
     const char* const img_r = img + wave * (SP * ILD) + (8 * h2 + q4) * ILD + 32 * gg + 8 * p4;
-    int g = 0, cslot = 0;
+    int g = 0, cslot = 0, oh1 = 0, oh2 = 0, oh3 = 0;
     floatx16 acc[T];
     float prr[T][16];
     attn_h8 dAf[T][2], PdTf[T][2], dATf[T][2];
@@ -1114,30 +1138,27 @@ __global__ void __launch_bounds__(64 * T) attn_bwd3_kernel(const AttnParams p) {
         const int s_eff = max(S - 32 * wave, 0);
 #pragma unroll 1
         for (int u = 0; u < U; ++u) {
-            if (total - 1 - g >= NB - 2) A3_WAIT_VM(4 * (NB - 2)); else A3_WAIT_VM(0);
+            { int x = (total - 1 - g >= NB - 2) ? 4 * (NB - 2) + oh1 + oh2 + oh3 : 0; if (p.dbg & 1) x = min(x, 8); A3_WAIT_UNIT(x); }
             __builtin_amdgcn_s_barrier();
             issue_next();
+            oh3 = oh2; oh2 = oh1; oh1 = u == 0 ? 4 * T : (u < u_c1 ? 0 : 16);
             const char* slot = ring + cslot * SLOT;
             if (u < u_c1) {
                 if (u == 0) {
                     // the saved probabilities of this lane's pairs land under phase A
-                    const float* pr_row = p.probs + (((size_t)n * p.H + h) * S + (size_t)min(i, S - 1)) * S;
+                    // 4 T unconditional 16-B loads (clamped address, result masked: the count A3_WAIT_UNIT relies on is exact;
+                    // __builtin_amdgcn_raw_buffer_load_b128 of this toolchain loads ONE dword and splats it)
+                    const float* pr_item = p.probs + ((size_t)n * p.H + h) * S * p.pld;
 #pragma unroll
                     for (int t = 0; t < T; ++t)
 #pragma unroll
                         for (int g4 = 0; g4 < 4; ++g4) {
                             const int j0 = 32 * t + 8 * g4 + 4 * h2;
-                            a3_f4u v = {0.f, 0.f, 0.f, 0.f};
-                            if (i < S) {
-                                if (j0 + 3 < S) v = *reinterpret_cast<const a3_f4u*>(pr_row + j0);
-                                else {
+                            const bool ok = i < S && j0 < p.pld;
+                            const a3_u4 v = *reinterpret_cast<const a3_u4*>(pr_item + (ok ? i * p.pld + j0 : 0));
+                            const uint32_t mask = ok ? 0xFFFFFFFFu : 0u;
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e)
-                                        if (j0 + e < S) v[e] = pr_row[j0 + e];
-                                }
-                            }
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) prr[t][4 * g4 + e] = v[e];
+                            for (int e = 0; e < 4; ++e) prr[t][4 * g4 + e] = __builtin_bit_cast(float, v[e] & mask);     // padding columns hold the forward's zeros
                         }
 #pragma unroll
                     for (int t = 0; t < T; ++t)
@@ -1302,6 +1323,9 @@ int fill_params(const LstcAttnDesc* d, AttnParams& p, bool bwd) {
     p.Qi = p.Ki = p.Vi = p.dOi = nullptr;
     p.kiq = p.kik = p.kiv = p.kido = 0;
     p.iq0 = p.ik0 = p.iv0 = p.ido0 = 0;
+    p.pld = d->S;
+    { const char* e_ = getenv("LSTC_A3_DEBUG"); p.dbg = e_ ? atoi(e_) : 0; }
+    if (d->probs_ld != 0 && d->probs_ld != d->S && d->in_pack_cols <= 0) return LSTC_E_UNSUPPORTED;
     return 0;
 }
 
@@ -1312,7 +1336,9 @@ int fill_packed_inputs(const LstcAttnDesc* d, AttnParams& p, bool bwd) {
     if (d->in_pack_cols % 64 || d->Q_col0 % 32 || d->K_col0 % 32 || d->V_col0 % 32 || d->Q_col0 < 0 || d->K_col0 < 0 || d->V_col0 < 0 ||
         d->Q_col0 + p.H * p.dk > d->in_pack_cols || d->K_col0 + p.H * p.dk > d->in_pack_cols || d->V_col0 + p.H * p.dv > d->in_pack_cols ||
         M * (int64_t)d->in_pack_cols * 2 > 0x7fffffffLL) return LSTC_E_SHAPE;
-    if (!aligned16(d->Q) || !aligned16(d->K) || !aligned16(d->V)) return LSTC_E_ALIGN;
+    if (!aligned16(d->Q) || !aligned16(d->K) || !aligned16(d->V) || !aligned16(d->probs)) return LSTC_E_ALIGN;
+    if (d->probs_ld < p.S || d->probs_ld % 4 || (int64_t)p.S * d->probs_ld * 4 > 0x7fffffffLL) return LSTC_E_SHAPE;
+    p.pld = d->probs_ld;
     p.Qi = (const __bf16*)d->Q; p.Ki = (const __bf16*)d->K; p.Vi = (const __bf16*)d->V;
     p.kiq = p.kik = p.kiv = d->in_pack_cols / 32;
     p.iq0 = d->Q_col0 / 32; p.ik0 = d->K_col0 / 32; p.iv0 = d->V_col0 / 32;

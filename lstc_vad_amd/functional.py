@@ -113,7 +113,6 @@ _memo_stack = []           # activation packs made inside one autograd-node body
 _x3_min = (256, 256, 1 << 30)   # min(M, N), K, M*N*K from which a product goes to the packed kernel
 _ATTN_F32 = os.environ.get("LSTC_ATTN_F32", "0") == "1"          # bf16 mode: keep the attention products on the exact-f32 MFMA
 _ATTN_VARIANT = int(os.environ.get("LSTC_ATTN_VARIANT", "0"))     # 1: first-generation attention kernels (A/B measurements)
-_attn3_bwd_ready = True
 _ATTN_PACKED_IN = os.environ.get("LSTC_ATTN_PACKED_IN", "1") != "0"   # bf16 mode: Q | K | V / dO reach the attention core as packs
 _DETERMINISTIC_WGRAD = os.environ.get("LSTC_ATOMIC_SPLITK", "0") != "1"   # split-K weight gradients: partials + ordered sum, not atomics
 
@@ -616,9 +615,13 @@ def attn_fwd(q, k, v, N, S, H, dk, dv, table, index, p_drop, seed, packed=False)
         obuf = torch.empty((int(_lib.load().lstc_pack1_bytes(M, H * dv)),), device=dev, dtype=torch.uint8)
     else:
         o = torch.empty((M, H * dv), device=dev, dtype=torch.float32)
-    probs = torch.empty((N, H, S, S), device=dev, dtype=torch.float32)
+    if in_pack:      # rows padded to whole 16-B groups (include/lstc_hip.h, probs_ld); callers see the [N, H, S, S] view
+        probs = torch.empty((N, H, S, (S + 3) // 4 * 4), device=dev, dtype=torch.float32)[..., :S]
+    else:
+        probs = torch.empty((N, H, S, S), device=dev, dtype=torch.float32)
     d = AttnDesc()
     d.N, d.S, d.H, d.dk, d.dv = N, S, H, dk, dv
+    d.probs_ld = probs.stride(2)
     if in_pack:
         d.ldo = H * dv
     else:
@@ -691,7 +694,8 @@ def attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, p_drop, seed, ou
         d.table, d.index, d.dtable = dev_ptr(table), dev_ptr(index), dev_ptr(parts)
     d.scale = 1.0 / (dk ** 0.5)
     d.dropout_p, d.dropout_seed = float(p_drop), int(seed)
-    d.probs = dev_ptr(probs)
+    d.probs, d.probs_ld = dev_ptr(probs), probs.stride(2)
+    assert probs.stride(3) == 1 and probs.stride(1) == S * probs.stride(2) and probs.stride(0) == H * S * probs.stride(2)
     if in_pack:
         _qkv_pack_desc(d, q, H, dk, dv)
         d.dO, d.dO_pack_cols, d.dO_col0 = dev_ptr(do.buf), do.K, 0
@@ -748,7 +752,14 @@ class MHAFunction(torch.autograd.Function):
         xp = maybe_pack(x2)            # f32x3: one pack of X feeds Q, K, V now and the three weight gradients later
         xa = xp if xp is not None else x2
         wqkv = _fused_qkv_weight(wq, wk, wv)
-        if wqkv is not None:       # w_qs / w_ks / w_vs live in one buffer (MultiHeadAttention.fuse_qkv_): one GEMM, X read once
+        qkv_p = None
+        if (xp is not None and wqkv is not None and wqkv.shape[0] == H * (2 * dk + dv) and attn_packed_inputs(N, S, H, dk, dv) and
+                packed_out_shape(N * S, wqkv.shape[0]) and packed_out_shape(N * S, H * dv) and wfc.shape[0] >= max(_x3_min[0], 1)):
+            # bf16 mode: Q | K | V exist only as ONE packed bf16 operand - the projection writes it (LSTC_EPI_OUT_PACK), the attention
+            # core reads it (forward and backward) and writes O / dQ | dK | dV as packs: no f32 activation between the two GEMMs
+            qkv_p = gemm(xa, wqkv, trans_b=True, out_pack=True)
+            q = k = v = None
+        elif wqkv is not None:       # w_qs / w_ks / w_vs live in one buffer (MultiHeadAttention.fuse_qkv_): one GEMM, X read once
             qkv = gemm(xa, wqkv, trans_b=True)
             q, k, v = qkv[:, : H * dk], qkv[:, H * dk: 2 * H * dk], qkv[:, 2 * H * dk:]
         else:
@@ -761,7 +772,10 @@ class MHAFunction(torch.autograd.Function):
             _note(cfg["site"] + "attn_dropout", p_attn, seed_a, (N, H, S, S))
         if p_fc > 0:
             _note(cfg["site"] + "dropout", p_fc, seed_f, (N, S, dm))
-        if xp is not None and attn_fwd_pack(N, S, H, dv) and wfc.shape[0] >= max(_x3_min[0], 1):
+        if qkv_p is not None:
+            op, probs = attn_fwd(qkv_p, None, None, N, S, H, dk, dv, table, index, p_attn, seed_a)
+            o = None
+        elif xp is not None and attn_fwd_pack(N, S, H, dv) and wfc.shape[0] >= max(_x3_min[0], 1):
             # bf16 mode: the attention output exists only as the packed bf16 operand of fc (and of fc's weight gradient)
             op, probs = attn_fwd(q, k, v, N, S, H, dk, dv, table, index, p_attn, seed_a, packed=True)
             o = None
@@ -774,6 +788,7 @@ class MHAFunction(torch.autograd.Function):
         else:
             z, mean, rstd = y, None, None
         ctx.packs = (xp, op) if (training or o is None) else (None, None)
+        ctx.qkv_p = qkv_p
         ctx.cfg = dict(cfg, N=N, S=S, p_attn=p_attn, p_fc=p_fc, seed_a=seed_a, seed_f=seed_f)
         ctx.save_for_backward(x2, wq, wk, wv, wfc, ln_w, table, index, q, k, v, o, probs,
                               y if cfg["layer_norm"] else None, mean, rstd)
@@ -789,12 +804,15 @@ class MHAFunction(torch.autograd.Function):
         dy, df, dln_w, dln_b, _ = layernorm_bwd_branch(dz2, y, ln_w, mean, rstd, c["p_fc"], c["seed_f"], c["layer_norm"], False)
         xp, op = ctx.packs
         dwfc = wgrad(df, o, op)
-        do = gemm(df, wfc)                                   # [M, H*dv]
+        qkv_p = ctx.qkv_p
+        do = gemm(df, wfc, out_pack=qkv_p is not None)       # [M, H*dv]; packed-input attention: as a packed bf16 operand only
         wqkv = _fused_qkv_weight(wq, wk, wv)
         dx = None
         if wqkv is not None:
             rq, rk = wq.shape[0], wk.shape[0]
-            if xp is not None and attn_bwd_packs(N, S, H, dk, dv) and N * S * wqkv.shape[0] * 2 < 2 ** 31:
+            if qkv_p is not None:
+                dqkv, _, _, dtable = attn_bwd(do, qkv_p, None, None, probs, N, S, H, dk, dv, table, index, c["p_attn"], c["seed_a"])
+            elif xp is not None and attn_bwd_packs(N, S, H, dk, dv) and N * S * wqkv.shape[0] * 2 < 2 ** 31:
                 # bf16 mode: the attention backward writes dQ | dK | dV straight into ONE packed bf16 operand
                 dqkv, _, _, dtable = attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, c["p_attn"], c["seed_a"], packed="fused")
             else:

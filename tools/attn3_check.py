@@ -58,9 +58,9 @@ def main():
         nbad = ((o_ref - o_new).abs() > 0.02 * o_ref.abs() + 1e-3).sum().item()
         print(f"FWD3 S={S} dk={dk}: probs max|d|={dp:.3e} (max {pr_ref.max().item():.3f}), O max|d|={do_:.3e} (max {o_ref.abs().max().item():.3f}), "
               f"O beyond 2%: {nbad} of {o_ref.numel()}, nan: {torch.isnan(o_new).sum().item()}", flush=True)
-        if hasattr(Fn, "_attn3_bwd_ready"):
+        if True:
             ref = Fn.attn_bwd(do, q, k, v, pr_ref, N, S, H, dk, dk, tab, idx, pdrop, 7, packed="fused")
-            new = Fn.attn_bwd(do_p, qkv_p, None, None, pr_ref, N, S, H, dk, dk, tab, idx, pdrop, 7)
+            new = Fn.attn_bwd(do_p, qkv_p, None, None, pr_new, N, S, H, dk, dk, tab, idx, pdrop, 7)
             torch.cuda.synchronize()
             g_ref, g_new = unpack1(ref[0].buf, M, 3 * H * dk), unpack1(new[0].buf, M, 3 * H * dk)
             for nm, c0 in (("dQ", 0), ("dK", H * dk), ("dV", 2 * H * dk)):
@@ -75,9 +75,9 @@ def main():
                 t2, _ = timeit(lambda: Fn.attn_fwd(q, k, v, N, S, H, dk, dk, tab, idx, pdrop, 7, packed=True))
                 t3, _ = timeit(lambda: Fn.attn_fwd(qkv_p, None, None, N, S, H, dk, dk, tab, idx, pdrop, 7))
                 line = f"TIME S={S} N={N}: fwd f32-in {t2:.3f} ms, packed-in {t3:.3f} ms"
-                if hasattr(Fn, "_attn3_bwd_ready"):
+                if True:
                     b2, _ = timeit(lambda: Fn.attn_bwd(do, q, k, v, pr_ref, N, S, H, dk, dk, tab, idx, pdrop, 7, packed="fused"))
-                    b3, _ = timeit(lambda: Fn.attn_bwd(do_p, qkv_p, None, None, pr_ref, N, S, H, dk, dk, tab, idx, pdrop, 7))
+                    b3, _ = timeit(lambda: Fn.attn_bwd(do_p, qkv_p, None, None, pr_new, N, S, H, dk, dk, tab, idx, pdrop, 7))
                     line += f"; bwd f32-in {b2:.3f} ms, packed-in {b3:.3f} ms"
                 print(line, flush=True)
             for npw in (1, 2, 4, 8):
