@@ -47,7 +47,6 @@ struct AttnParams {
     const __bf16 *Qi, *Ki, *Vi, *dOi;
     int kiq, kik, kiv, kido;
     int iq0, ik0, iv0, ido0;
-    int dbg;
     int pld;                // row pitch of `probs` in floats (packed-input kernels: a multiple of 4, >= S; else S)
 };
 
@@ -802,10 +801,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) attn_fwd2_kernel(con
 #undef RTL_COMPUTE
 
 // =====================================================================================================
-// Third generation (bf16 mode, PACKED operands; S <= 96, d_k a multiple of 32, d_v of 64).  Q | K | V (and dO) arrive as the
+// Third generation (bf16 mode, PACKED operands; S <= 96, d_k and d_v multiples of 64).  Q | K | V (and dO) arrive as the
 // lstc_pack1 buffers the projection GEMMs write with LSTC_EPI_OUT_PACK (2 B per element, 64-B rows of 32 features, 16-B chunk
 // index XOR (row >> 2) & 3), O / dQ | dK | dV leave as packs: no f32 activation of the attention core touches HBM.
-//   * T = ceil(S / 32) waves per (sequence, head); wave w owns the 32 QUERIES 32 w .. 32 w + 31 through the whole item.
+//   * T = ceil(S / 32) CONSUMER waves per (sequence, head) plus ONE PRODUCER wave.  Consumer w owns the 32 QUERIES
+//     32 w .. 32 w + 31 through the whole item.
 //   * Every product is SWAPPED so that the query index sits on the lane: logits^T[j][i] = K Q^T (A = K rows, B = Q rows) leaves
 //     lane = i, registers = 16 T keys j -> the softmax is lane-local plus ONE exchange with lane ^ 32, and the dropped
 //     probabilities, rounded to bf16 pairwise, ARE the A operand of O = Pd V (MFMA accumulator layout = A-operand layout with a
@@ -816,15 +816,19 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) attn_fwd2_kernel(con
 //     consecutive rows x 64 B per half-wave: conflict-free by construction).
 //   * One ring of NB slots carries every staged unit of a workgroup - {Q chunk, K chunk} x d_k/32, then {V tile, V tile} x
 //     d_v/64 - across the sequences a workgroup walks, so the next item's first chunks are in flight under the current item's
-//     P V.  One barrier per unit; s_waitcnt vmcnt counts DMA pieces only (stores are younger or complete earlier: loads return
-//     in order among themselves, which is all the count relies on).
+//     P V.  The producer wave issues ALL the DMA and nothing else: its vmcnt counts DMA pieces only, so "unit g has landed" is
+//     one s_waitcnt with a known count however many stores the consumers have in flight (first version: every wave issued its
+//     share and had to count its own stores into the wait - correct only while the compiler emits exactly the expected memory
+//     instructions, and limited to 4 slots by the 6-bit counter).  Per unit: producer waits, ONE barrier (data visible to the
+//     consumers, slot g - 1 free), producer refills slot g - 1 with unit g + NB - 1, consumers compute unit g.
+//     What the kernels need is BYTES IN FLIGHT: measured bandwidth followed (NB - 1) x slot x workgroups per CU (72 KB: 2.4-2.8
+//     TB/s, 96 KB: 4.8 TB/s), so NB is chosen per instantiation to fill the LDS the resident workgroups can share.
 // =====================================================================================================
 typedef short a3_s4 __attribute__((ext_vector_type(4)));
 typedef short a3_s8 __attribute__((ext_vector_type(8)));
-typedef float a3_f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t a3_u4 __attribute__((ext_vector_type(4)));
+typedef float a3_f4 __attribute__((ext_vector_type(4)));
 typedef a3_s4 __attribute__((address_space(3))) * a3_lds4;
-constexpr int A3_NB = 4;       // A3_WAIT_UNIT's history is three steps deep: NB - 1
 
 __device__ __forceinline__ void a3_dma(const __bf16* tile, uint32_t voff, uint32_t lds_bytes) {
     const uint32_t lb = __builtin_amdgcn_readfirstlane(lds_bytes);
@@ -842,32 +846,115 @@ __device__ __forceinline__ attn_h8 a3_tr(const char* p0, const char* p1) {
     return __builtin_bit_cast(attn_h8, f);
 }
 __device__ __forceinline__ attn_h8 a3_row(const char* p) { return *reinterpret_cast<const attn_h8*>(p); }
-#define A3_LDS_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)   /* lgkmcnt(0) only: the ring's DMA stays in flight */
-// s_waitcnt takes an immediate: the count of vector-memory operations younger than the awaited unit - 4 DMA pieces for each of the
-// NB - 2 units behind it plus the loads / stores of the last NB - 1 steps (multiples of 4, each step's count known exactly because
-// every such operation is an unconditional buffer instruction) - selects one of the instantiated waits
-#define A3_CASE_VM(N) case N: A3_WAIT_VM(N); break;
-#define A3_WAIT_UNIT(x)                                                                                          \
-    switch (x) {                                                                                                 \
-        A3_CASE_VM(8) A3_CASE_VM(12) A3_CASE_VM(16) A3_CASE_VM(20) A3_CASE_VM(24) A3_CASE_VM(28) A3_CASE_VM(32)  \
-        A3_CASE_VM(36) A3_CASE_VM(40) A3_CASE_VM(44) A3_CASE_VM(48) A3_CASE_VM(52) A3_CASE_VM(56) A3_CASE_VM(60) \
-        default: A3_WAIT_VM(0); break;                                                                           \
+// A 32 x 32 result tile held TRANSPOSED - lane = token row, registers = columns (r & 3) + 8 (r >> 2) + 4 h2 of the tile - written, rounded
+// to bf16, into a pack.  One v_permlane32_swap per dword hands the lower lanes the 16-B chunks 0 and 1 of their row and the upper
+// lanes chunks 2 and 3, so a tile leaves as TWO 16-B stores per lane.  (First version: lane = column, eight 4-B stores per tile and
+// lane - the same bytes for 4x the address-unit cycles, a quarter of a millisecond per S = 81 backward launch.)
+// rowb: byte offset of the lane's row inside tile column 0 of the pack; key: its swizzle key (row >> 2) & 3; valid: row < S.
+__device__ __forceinline__ void a3_store_tile(const floatx16& o, float scale, __amdgpu_buffer_rsrc_t rs, uint32_t rowb, uint32_t key,
+                                              bool valid, uint32_t tile, int h2) {
+    uint32_t d[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            attn_f2 f;
+            f[0] = o[4 * g + 2 * k] * scale;
+            f[1] = o[4 * g + 2 * k + 1] * scale;
+            d[g][k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, attn_h2));
+        }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const auto x = __builtin_amdgcn_permlane32_swap(d[0][k], d[2][k], false, false);
+        d[0][k] = x[0]; d[2][k] = x[1];
+        const auto y = __builtin_amdgcn_permlane32_swap(d[1][k], d[3][k], false, false);
+        d[1][k] = y[0]; d[3][k] = y[1];
     }
-#define A3_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (0 << 8) | (((N) >> 4) << 14))     /* vmcnt(N), lgkmcnt(0) */
+    const uint32_t base = rowb + tile * 8192u;
+    const a3_u4 ca = {d[0][0], d[0][1], d[2][0], d[2][1]}, cb = {d[1][0], d[1][1], d[3][0], d[3][1]};
+    __builtin_amdgcn_raw_buffer_store_b128(ca, rs, valid ? base + ((((uint32_t)(2 * h2)) ^ key) << 4) : 0xFFFFFFFFu, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(cb, rs, valid ? base + ((((uint32_t)(2 * h2 + 1)) ^ key) << 4) : 0xFFFFFFFFu, 0, 0);
+}
+// lgkmcnt(0) + barrier: the wave's LDS reads / writes are done; vmcnt untouched (the ring's DMA and the stores stay in flight)
+#define A3_LDS_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#define A3_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (15 << 8) | (((N) >> 4) << 14))     /* vmcnt(N) */
 
-template <int T>
-__global__ void __launch_bounds__(64 * T) attn_fwd3_kernel(const AttnParams p) {
+// One unit of the ring: two [SP rows][64 B] halves, each a column tile of a pack.
+struct A3Unit { const __bf16 *b0, *b1; uint32_t kb0, kb1; };
+
+// Producer wave: `total` units, unit k described by unit_of(item, u); P = 4 T DMA pieces per unit.  `extra(u)`: barriers the
+// consumers run inside step u beyond the ring's own (the backward's transposition image).
+template <int T, int NB, typename UnitOf, typename Extra>
+__device__ __forceinline__ void a3_producer(int n_begin, int n_end, int U, int S, UnitOf unit_of, Extra extra) {
+    constexpr int SP = 32 * T, HALF = SP * 64, SLOT = 2 * HALF, P = 4 * T;
+    static_assert(P * (NB - 2) <= 63, "vmcnt is a 6-bit counter");
+    const int lane = threadIdx.x & 63;
+    const int total = (n_end - n_begin) * U;
+    int is_n = n_begin, is_u = 0, is_slot = 0, issued = 0;
+    auto issue_next = [&]() {
+        if (issued >= total) return;
+        const A3Unit un = unit_of(is_u);
+        const uint32_t lb = (uint32_t)(is_slot * SLOT);
+#pragma unroll
+        for (int pc = 0; pc < 2 * T; ++pc) {
+            const uint32_t g = (uint32_t)is_n * (uint32_t)S + (uint32_t)min(16 * pc + (lane >> 2), S - 1);
+            a3_dma(un.b0, a3_row_off(g, un.kb0, lane), lb + pc * 1024);
+            a3_dma(un.b1, a3_row_off(g, un.kb1, lane), lb + HALF + pc * 1024);
+        }
+        ++issued;
+        if (++is_u == U) { is_u = 0; ++is_n; }
+        if (++is_slot == NB) is_slot = 0;
+    };
+#pragma unroll 1
+    for (int k = 0; k < NB - 1; ++k) issue_next();
+    int g = 0;
+#pragma unroll 1
+    for (int n = n_begin; n < n_end; ++n)
+#pragma unroll 1
+        for (int u = 0; u < U; ++u) {
+            // units younger than unit g: min(NB - 2, total - 1 - g), P pieces each
+            const int rem = min(NB - 2, total - 1 - g);
+            if (rem >= NB - 2) A3_WAIT_VM(P * (NB - 2));
+            else if (NB > 3 && rem == NB - 3) A3_WAIT_VM(P * (NB > 3 ? NB - 3 : 0));
+            else if (NB > 4 && rem == NB - 4) A3_WAIT_VM(P * (NB > 4 ? NB - 4 : 0));
+            else A3_WAIT_VM(0);
+            __builtin_amdgcn_s_barrier();
+            issue_next();
+            const int nx = extra(u);
+            for (int x = 0; x < nx; ++x) __builtin_amdgcn_s_barrier();
+            ++g;
+        }
+}
+
+template <int T, int NB>
+__global__ void __launch_bounds__(64 * (T + 1)) attn_fwd3_kernel(const AttnParams p) {
     const DropKey dkn = drop_key_now(p.dkey);
-    constexpr int SP = 32 * T, HALF = SP * 64, SLOT = 2 * HALF, NB = A3_NB;
+    constexpr int SP = 32 * T, HALF = SP * 64, SLOT = 2 * HALF;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const char* ring = reinterpret_cast<const char*>(sm);
-    const int h = blockIdx.y, S = p.S;
+    // 1-D grid, head fastest: the workgroups resident together read the SAME token rows (adjacent column tiles of the packs)
+    const int h = (int)(blockIdx.x % (unsigned)p.H), chunk = (int)(blockIdx.x / (unsigned)p.H), S = p.S;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, h2 = lane >> 5;
-    const int n_begin = blockIdx.x * p.n_per_wg, n_end = min(p.N, n_begin + p.n_per_wg);
+    const int n_begin = chunk * p.n_per_wg, n_end = min(p.N, n_begin + p.n_per_wg);
     const int nq = p.dk >> 5, nvp = p.dv >> 6, U = nq + nvp;
-    const int total = (n_end - n_begin) * U;
-    const int tq = p.iq0 + ((h * p.dk) >> 5), tk = p.ik0 + ((h * p.dk) >> 5), tv = p.iv0 + ((h * p.dv) >> 5);
+    if (wave == T) {
+        const int tq = p.iq0 + ((h * p.dk) >> 5), tk = p.ik0 + ((h * p.dk) >> 5), tv = p.iv0 + ((h * p.dv) >> 5);
+        a3_producer<T, NB>(n_begin, n_end, U, S,
+            [&](int u) -> A3Unit {
+                A3Unit un;
+                if (u < nq) {
+                    un.b0 = p.Qi + (size_t)(tq + u) * 4096; un.kb0 = (uint32_t)p.kiq;
+                    un.b1 = p.Ki + (size_t)(tk + u) * 4096; un.kb1 = (uint32_t)p.kik;
+                } else {
+                    un.b0 = p.Vi + (size_t)(tv + 2 * (u - nq)) * 4096; un.kb0 = un.kb1 = (uint32_t)p.kiv;
+                    un.b1 = un.b0 + 4096;
+                }
+                return un;
+            },
+            [](int) { return 0; });
+        return;
+    }
     const int i = 32 * wave + l31;
     // relative-position bias of this lane's (i, j) pairs: two dependent loads per element, once per workgroup
     const bool has_bias = p.index_ld > 0 && S > 1;
@@ -890,35 +977,9 @@ __global__ void __launch_bounds__(64 * T) attn_fwd3_kernel(const AttnParams p) {
             biasr[t][r] = b + (j < S ? 0.f : -INFINITY);
         }
     // (keys j >= S carry a bias of -inf: their logits, exponentials and probabilities come out as -inf, 0, 0 with no predicate)
-    // ---- the staged-unit stream
-    int is_n = n_begin, is_u = 0, is_slot = 0, issued = 0;
-    auto issue_next = [&]() {
-        if (issued >= total) return;
-        const __bf16 *b0, *b1;
-        uint32_t kb0, kb1;
-        if (is_u < nq) {
-            b0 = p.Qi + (size_t)(tq + is_u) * 4096; kb0 = (uint32_t)p.kiq;
-            b1 = p.Ki + (size_t)(tk + is_u) * 4096; kb1 = (uint32_t)p.kik;
-        } else {
-            b0 = p.Vi + (size_t)(tv + 2 * (is_u - nq)) * 4096; kb0 = kb1 = (uint32_t)p.kiv;
-            b1 = b0 + 4096;
-        }
-        const uint32_t lb = (uint32_t)(is_slot * SLOT + (32 * wave) * 64);
-#pragma unroll
-        for (int pc = 0; pc < 2; ++pc) {
-            const uint32_t g = (uint32_t)is_n * (uint32_t)S + (uint32_t)min(32 * wave + 16 * pc + (lane >> 2), S - 1);
-            a3_dma(b0, a3_row_off(g, kb0, lane), lb + pc * 1024);
-            a3_dma(b1, a3_row_off(g, kb1, lane), lb + HALF + pc * 1024);
-        }
-        ++issued;
-        if (++is_u == U) { is_u = 0; ++is_n; }
-        if (++is_slot == NB) is_slot = 0;
-    };
-#pragma unroll
-    for (int k = 0; k < NB - 1; ++k) issue_next();
     const __amdgpu_buffer_rsrc_t r_Op = __builtin_amdgcn_make_buffer_rsrc(p.Op, 0, (int)0x7fffffff, 0x00020000);
     const int q4 = (lane >> 2) & 3, p4 = lane & 3, gg = (lane >> 4) & 1;
-    int g = 0, cslot = 0, oh1 = 0, oh2 = 0, oh3 = 0;
+    int cslot = 0;
     floatx16 acc[T];
     attn_h8 pf[T][2];
 #pragma unroll 1
@@ -933,12 +994,10 @@ __global__ void __launch_bounds__(64 * T) attn_fwd3_kernel(const AttnParams p) {
             const uint32_t row = (uint32_t)(4 * h2 + 8 * rd + q4);
             troff[rd] = (int)(row * 64u + ((((uint32_t)(2 * gg + (p4 >> 1))) ^ (((r0 + row) >> 2) & 3u)) << 4) + 8u * (uint32_t)(p4 & 1));
         }
+        const uint32_t orow = a3_row_off(r0 + (uint32_t)i, (uint32_t)p.kbo, 0);      // this lane's row of the O pack
 #pragma unroll 1
         for (int u = 0; u < U; ++u) {
-            { int x = (total - 1 - g >= NB - 2) ? 4 * (NB - 2) + oh1 + oh2 + oh3 : 0; if (p.dbg & 1) x = min(x, 8); A3_WAIT_UNIT(x); }
-            __builtin_amdgcn_s_barrier();
-            issue_next();
-            oh3 = oh2; oh2 = oh1; oh1 = u < nq - 1 ? 0 : (u == nq - 1 ? 4 * T : 16);
+            A3_LDS_BARRIER();
             const char* slot = ring + cslot * SLOT;
             if (u < nq) {
                 if (u == 0) {
@@ -976,7 +1035,8 @@ __global__ void __launch_bounds__(64 * T) attn_fwd3_kernel(const AttnParams p) {
                             sum += e;
                         }
                     sum += __shfl_xor(sum, 32, 64);
-                    // probabilities: 4 T unconditional 16-B buffer stores (rows >= S, padding groups: dropped by the range check)
+                    const float inv = 1.f / sum;
+                    // probabilities: 16-B buffer stores (rows >= S, groups beyond the row pitch: dropped by the range check)
                     const __amdgpu_buffer_rsrc_t r_pr = __builtin_amdgcn_make_buffer_rsrc(
                         p.probs + ((size_t)n * p.H + h) * S * p.pld, 0, S * p.pld * 4, 0x00020000);
                     const uint32_t flat_i = ((uint32_t)n * p.H + h) * (uint32_t)(S * S) + (uint32_t)(i * S);
@@ -985,9 +1045,9 @@ __global__ void __launch_bounds__(64 * T) attn_fwd3_kernel(const AttnParams p) {
 #pragma unroll
                         for (int g4 = 0; g4 < 4; ++g4) {
                             const int j0 = 32 * t + 8 * g4 + 4 * h2;
-                            a3_f4u pv;
+                            a3_f4 pv;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) pv[e] = acc[t][4 * g4 + e] / sum;
+                            for (int e = 0; e < 4; ++e) pv[e] = acc[t][4 * g4 + e] * inv;
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(a3_u4, pv), r_pr,
                                 (i < S && j0 < p.pld) ? (uint32_t)(i * p.pld + j0) * 4u : 0xFFFFFFFFu, 0, 0);
 #pragma unroll
@@ -1017,48 +1077,66 @@ __global__ void __launch_bounds__(64 * T) attn_fwd3_kernel(const AttnParams p) {
 #pragma unroll
                         for (int s2 = 0; s2 < 2; ++s2) {
                             const attn_h8 fv = a3_tr(Vs + t * 2048 + s2 * 1024 + troff[0], Vs + t * 2048 + s2 * 1024 + troff[1]);
-                            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[t][s2], fv, o[0], 0, 0, 0);
+                            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv, pf[t][s2], o[0], 0, 0, 0);      // O^T: lane = query
                         }
-                    store_rows_packed<1>(o, 1.f, r_Op, r0 + 32u * (uint32_t)wave, (uint32_t)(((h * p.dv) >> 5) + ct + hf), (uint32_t)p.kbo,
-                                         max(S - 32 * wave, 0), l31, h2);
+                    a3_store_tile(o[0], 1.f, r_Op, orow, keyq, i < S, (uint32_t)(((h * p.dv) >> 5) + ct + hf), h2);
                 }
             }
-            ++g;
             if (++cslot == NB) cslot = 0;
         }
     }
 }
 
-// Third-generation backward.  Same ownership (wave w = queries 32 w ..), same ring, per item:
+// Third-generation backward.  Same ownership (consumer w = queries 32 w ..), same ring and producer, per item:
 //   A   {dO chunk, V chunk} x d_v/32 : dP^T[j][i] = V dO^T on the lane-=-query layout; then in registers
 //       dA = P (dP keep - rowsum(dP keep P)), Pd = P keep; the bias-table gradient goes to a per-wave LDS table by ds_add_f32;
-//       dA (bf16) is the A operand of dQ as it stands; Pd and dA cross the lanes ONCE each through a [key tile][query][32 keys]
-//       image with 72-B rows (8-B stores conflict-free, transposed reads 2-way at worst) and come back as the A operands of
-//       dV and dK with the KEY on the lane: wave w then owns the 32 keys 32 w .. of those two products;
+//       dA (bf16) is the A operand of dQ as it stands; Pd and dA cross the lanes ONCE each through a [query][32 keys] LDS image
+//       with 72-B rows (8-B stores conflict-free, transposed reads 2-way at worst) and come back as the A operands of dV and
+//       dK with the KEY on the lane: wave w then owns the 32 keys 32 w .. of those two products.  The image holds ONE key
+//       panel (SP x 72 B): panel t is written by every wave and read by wave t, T rounds per matrix;
 //   C1  {K tile, K tile} x d_k/64    : dQ[queries of w] = scale dA K       (B operand by transposed reads, accumulator k order)
 //   C2  {dO tile, dO tile} x d_v/64  : dV[keys of w]    = Pd^T dO          (natural k order)
 //   C3  {Q tile, Q tile} x d_k/64    : dK[keys of w]    = scale dA^T Q
-template <int T>
-__global__ void __launch_bounds__(64 * T) attn_bwd3_kernel(const AttnParams p) {
+template <int T, int NB>
+__global__ void __launch_bounds__(64 * (T + 1)) attn_bwd3_kernel(const AttnParams p) {
     const DropKey dkn = drop_key_now(p.dkey);
-    constexpr int SP = 32 * T, HALF = SP * 64, SLOT = 2 * HALF, NB = A3_NB;
-    constexpr int ILD = 72, IMG = T * SP * ILD;
+    constexpr int SP = 32 * T, HALF = SP * 64, SLOT = 2 * HALF;
+    constexpr int ILD = 72, IMG = SP * ILD;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     char* ring = reinterpret_cast<char*>(sm);
     char* img = ring + NB * SLOT;
     float* tacc = reinterpret_cast<float*>(img + IMG);
-    const int h = blockIdx.y, S = p.S;
+    // 1-D grid, head fastest: the workgroups resident together read the SAME token rows (adjacent column tiles of the packs)
+    const int h = (int)(blockIdx.x % (unsigned)p.H), chunk = (int)(blockIdx.x / (unsigned)p.H), S = p.S;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, h2 = lane >> 5;
-    const int n_begin = blockIdx.x * p.n_per_wg, n_end = min(p.N, n_begin + p.n_per_wg);
+    const int n_begin = chunk * p.n_per_wg, n_end = min(p.N, n_begin + p.n_per_wg);
     const int nv = p.dv >> 5, nq2 = p.dk >> 6, nv2 = p.dv >> 6;
     const int u_c1 = nv, u_c2 = nv + nq2, u_c3 = nv + nq2 + nv2, U = nv + 2 * nq2 + nv2;
-    const int total = (n_end - n_begin) * U;
-    const int tq = p.iq0 + ((h * p.dk) >> 5), tk = p.ik0 + ((h * p.dk) >> 5), tv = p.iv0 + ((h * p.dv) >> 5), tdo = p.ido0 + ((h * p.dv) >> 5);
-    const int i = 32 * wave + l31;
     const bool has_bias = p.index_ld > 0 && p.dtable != nullptr;
     if (has_bias)
-        for (int x = threadIdx.x; x < T * p.table_rows; x += 64 * T) tacc[x] = 0.f;
+        for (int x = threadIdx.x; x < T * p.table_rows; x += 64 * (T + 1)) tacc[x] = 0.f;
+    __syncthreads();          // tacc zeroed (before any DMA is in flight)
+    if (wave == T) {
+        const int tq = p.iq0 + ((h * p.dk) >> 5), tk = p.ik0 + ((h * p.dk) >> 5), tv = p.iv0 + ((h * p.dv) >> 5), tdo = p.ido0 + ((h * p.dv) >> 5);
+        a3_producer<T, NB>(n_begin, n_end, U, S,
+            [&](int u) -> A3Unit {
+                A3Unit un;
+                if (u < u_c1) {
+                    un.b0 = p.dOi + (size_t)(tdo + u) * 4096; un.kb0 = (uint32_t)p.kido;
+                    un.b1 = p.Vi + (size_t)(tv + u) * 4096; un.kb1 = (uint32_t)p.kiv;
+                } else if (u < u_c2) {
+                    un.b0 = p.Ki + (size_t)(tk + 2 * (u - u_c1)) * 4096; un.kb0 = un.kb1 = (uint32_t)p.kik; un.b1 = un.b0 + 4096;
+                } else if (u < u_c3) {
+                    un.b0 = p.dOi + (size_t)(tdo + 2 * (u - u_c2)) * 4096; un.kb0 = un.kb1 = (uint32_t)p.kido; un.b1 = un.b0 + 4096;
+                } else {
+                    un.b0 = p.Qi + (size_t)(tq + 2 * (u - u_c3)) * 4096; un.kb0 = un.kb1 = (uint32_t)p.kiq; un.b1 = un.b0 + 4096;
+                }
+                return un;
+            },
+            [&](int u) { return u == u_c1 - 1 ? 4 * T : 0; });
+    } else {
+    const int i = 32 * wave + l31;
     float* const tw = tacc + wave * p.table_rows;
     // bias-table rows of this lane's (i, j) pairs, two per register (0xFFFF: none)
     const __amdgpu_buffer_rsrc_t r_index = __builtin_amdgcn_make_buffer_rsrc(const_cast<int64_t*>(p.index), 0,
@@ -1080,47 +1158,25 @@ __global__ void __launch_bounds__(64 * T) attn_bwd3_kernel(const AttnParams p) {
             }
             idxp[t][r2] = w2;
         }
-    int is_n = n_begin, is_u = 0, is_slot = 0, issued = 0;
-    auto issue_next = [&]() {
-        if (issued >= total) return;
-        const __bf16 *b0, *b1;
-        uint32_t kb0, kb1;
-        if (is_u < u_c1) {
-            b0 = p.dOi + (size_t)(tdo + is_u) * 4096; kb0 = (uint32_t)p.kido;
-            b1 = p.Vi + (size_t)(tv + is_u) * 4096; kb1 = (uint32_t)p.kiv;
-        } else if (is_u < u_c2) {
-            b0 = p.Ki + (size_t)(tk + 2 * (is_u - u_c1)) * 4096; kb0 = kb1 = (uint32_t)p.kik; b1 = b0 + 4096;
-        } else if (is_u < u_c3) {
-            b0 = p.dOi + (size_t)(tdo + 2 * (is_u - u_c2)) * 4096; kb0 = kb1 = (uint32_t)p.kido; b1 = b0 + 4096;
-        } else {
-            b0 = p.Qi + (size_t)(tq + 2 * (is_u - u_c3)) * 4096; kb0 = kb1 = (uint32_t)p.kiq; b1 = b0 + 4096;
-        }
-        const uint32_t lb = (uint32_t)(is_slot * SLOT + (32 * wave) * 64);
-#pragma unroll
-        for (int pc = 0; pc < 2; ++pc) {
-            const uint32_t g = (uint32_t)is_n * (uint32_t)S + (uint32_t)min(32 * wave + 16 * pc + (lane >> 2), S - 1);
-            a3_dma(b0, a3_row_off(g, kb0, lane), lb + pc * 1024);
-            a3_dma(b1, a3_row_off(g, kb1, lane), lb + HALF + pc * 1024);
-        }
-        ++issued;
-        if (++is_u == U) { is_u = 0; ++is_n; }
-        if (++is_slot == NB) is_slot = 0;
-    };
-#pragma unroll
-    for (int k = 0; k < NB - 1; ++k) issue_next();
     const __amdgpu_buffer_rsrc_t r_dQ = __builtin_amdgcn_make_buffer_rsrc(p.dQp, 0, (int)0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_dK = __builtin_amdgcn_make_buffer_rsrc(p.dKp, 0, (int)0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_dV = __builtin_amdgcn_make_buffer_rsrc(p.dVp, 0, (int)0x7fffffff, 0x00020000);
     const int q4 = (lane >> 2) & 3, p4 = lane & 3, gg = (lane >> 4) & 1;
-    // image addresses: 8-B store of keys 8 g4 + 4 h2 .. + 3 of query i (panel = key tile); transposed read of queries
-    // 8 h2 + 4 rd + q4 (+ 32 ti + 16 s2), keys 16 gg + 4 p4 .. of this wave's key panel
+    // image addresses: 8-B store of keys 8 g4 + 4 h2 .. + 3 (of the panel's 32) of query i; transposed read of queries
+    // 8 h2 + 4 rd + q4 (+ 32 ti + 16 s2), keys 16 gg + 4 p4 ..
     char* const img_w = img + i * ILD + 8 * h2;
-    const char* const img_r = img + wave * (SP * ILD) + (8 * h2 + q4) * ILD + 32 * gg + 8 * p4;
-    int g = 0, cslot = 0, oh1 = 0, oh2 = 0, oh3 = 0;
+    const char* const img_r = img + (8 * h2 + q4) * ILD + 32 * gg + 8 * p4;
+    int cslot = 0;
     floatx16 acc[T];
     float prr[T][16];
     attn_h8 dAf[T][2], PdTf[T][2], dATf[T][2];
-    __syncthreads();          // tacc zeroed
+    // the pair's table row depends on (i, j) only: one LDS atomic per pair and WORKGROUP, not per sequence (first version:
+    // 48 ds_add_f32 per lane and item kept the CU's LDS pipe busy for 0.6 ms of a 2.1-ms S = 81 launch)
+    float dsum[T][16];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dsum[t][r] = 0.f;
 #pragma unroll 1
     for (int n = n_begin; n < n_end; ++n) {
         const uint32_t r0 = (uint32_t)n * (uint32_t)S;
@@ -1134,20 +1190,14 @@ __global__ void __launch_bounds__(64 * T) attn_bwd3_kernel(const AttnParams p) {
             troff[rd] = (int)(row * 64u + ((((uint32_t)(2 * gg + (p4 >> 1))) ^ (((r0 + row) >> 2) & 3u)) << 4) + 8u * (uint32_t)(p4 & 1));
             trnat[rd] = (int)(rown * 64u + ((((uint32_t)(2 * gg + (p4 >> 1))) ^ (((r0 + rown) >> 2) & 3u)) << 4) + 8u * (uint32_t)(p4 & 1));
         }
-        const uint32_t prow = r0 + 32u * (uint32_t)wave;
-        const int s_eff = max(S - 32 * wave, 0);
 #pragma unroll 1
         for (int u = 0; u < U; ++u) {
-            { int x = (total - 1 - g >= NB - 2) ? 4 * (NB - 2) + oh1 + oh2 + oh3 : 0; if (p.dbg & 1) x = min(x, 8); A3_WAIT_UNIT(x); }
-            __builtin_amdgcn_s_barrier();
-            issue_next();
-            oh3 = oh2; oh2 = oh1; oh1 = u == 0 ? 4 * T : (u < u_c1 ? 0 : 16);
+            A3_LDS_BARRIER();
             const char* slot = ring + cslot * SLOT;
             if (u < u_c1) {
                 if (u == 0) {
-                    // the saved probabilities of this lane's pairs land under phase A
-                    // 4 T unconditional 16-B loads (clamped address, result masked: the count A3_WAIT_UNIT relies on is exact;
-                    // __builtin_amdgcn_raw_buffer_load_b128 of this toolchain loads ONE dword and splats it)
+                    // the saved probabilities of this lane's pairs land under phase A: 16-B loads at a clamped address, result
+                    // masked (__builtin_amdgcn_raw_buffer_load_b128 of this toolchain loads ONE dword and splats it)
                     const float* pr_item = p.probs + ((size_t)n * p.H + h) * S * p.pld;
 #pragma unroll
                     for (int t = 0; t < T; ++t)
@@ -1173,15 +1223,16 @@ __global__ void __launch_bounds__(64 * T) attn_bwd3_kernel(const AttnParams p) {
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv1, fo1, acc[t], 0, 0, 0);
                 }
                 if (u == u_c1 - 1) {
+                    typedef __bf16 h4v __attribute__((ext_vector_type(4)));
                     const uint32_t flat_i = ((uint32_t)n * p.H + h) * (uint32_t)(S * S) + (uint32_t)(i * S);
                     float rs = 0.f;
-                    // Pd = P keep goes to the image at once (its values die here); acc <- dP keep
+                    // Pd = P keep (bf16, kept packed for the image rounds: prr <- its bits would cost registers, so it is
+                    // recomputed per round from prr and the keep factor folded into acc's sign-free companion below)
+                    h4v pdp[T][4];
 #pragma unroll
                     for (int t = 0; t < T; ++t)
 #pragma unroll
                         for (int g4 = 0; g4 < 4; ++g4) {
-                            typedef __bf16 h4v __attribute__((ext_vector_type(4)));
-                            h4v pd;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const int r = 4 * g4 + e;
@@ -1190,9 +1241,8 @@ __global__ void __launch_bounds__(64 * T) attn_bwd3_kernel(const AttnParams p) {
                                 const float dpk = acc[t][r] * keep;
                                 rs += dpk * prr[t][r];
                                 acc[t][r] = dpk;
-                                pd[e] = (__bf16)(prr[t][r] * keep);
+                                pdp[t][g4][e] = (__bf16)(prr[t][r] * keep);
                             }
-                            *reinterpret_cast<h4v*>(img_w + t * (SP * ILD) + 16 * g4) = pd;
                         }
                     rs += __shfl_xor(rs, 32, 64);
                     // dA = P (dP keep - rs): bias-table gradient, then bf16 as the A operand of dQ
@@ -1202,37 +1252,47 @@ __global__ void __launch_bounds__(64 * T) attn_bwd3_kernel(const AttnParams p) {
                         for (int r = 0; r < 16; ++r) {
                             const float da = prr[t][r] * (acc[t][r] - rs);
                             acc[t][r] = da;
-                            const uint32_t ix = (idxp[t][r >> 1] >> (16 * (r & 1))) & 0xFFFFu;
-                            if (ix != 0xFFFFu) atomicAdd(&tw[ix], da);
+                            dsum[t][r] += da;          // bias-table gradient: summed per (i, j) pair over this workgroup's sequences first
                         }
 #pragma unroll
                         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                             for (int e = 0; e < 8; ++e) dAf[t][s2][e] = (__bf16)acc[t][8 * s2 + e];
                     }
-                    A3_LDS_BARRIER();
+                    // 2 T image rounds: key panel t of Pd, then of dA, written by every wave, read back transposed by wave t
 #pragma unroll
-                    for (int ti = 0; ti < T; ++ti)
+                    for (int t = 0; t < T; ++t) {
 #pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2)
-                            PdTf[ti][s2] = a3_tr(img_r + (32 * ti + 16 * s2) * ILD, img_r + (32 * ti + 16 * s2 + 4) * ILD);
-                    A3_LDS_BARRIER();
+                        for (int g4 = 0; g4 < 4; ++g4) *reinterpret_cast<h4v*>(img_w + 16 * g4) = pdp[t][g4];
+                        A3_LDS_BARRIER();
+                        if (wave == t) {
 #pragma unroll
-                    for (int t = 0; t < T; ++t)
+                            for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+                                for (int s2 = 0; s2 < 2; ++s2)
+                                    PdTf[ti][s2] = a3_tr(img_r + (32 * ti + 16 * s2) * ILD, img_r + (32 * ti + 16 * s2 + 4) * ILD);
+                        }
+                        A3_LDS_BARRIER();
+                    }
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
 #pragma unroll
                         for (int g4 = 0; g4 < 4; ++g4) {
-                            typedef __bf16 h4v __attribute__((ext_vector_type(4)));
                             h4v da4;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) da4[e] = dAf[t][g4 >> 1][4 * (g4 & 1) + e];
-                            *reinterpret_cast<h4v*>(img_w + t * (SP * ILD) + 16 * g4) = da4;
+                            *reinterpret_cast<h4v*>(img_w + 16 * g4) = da4;
                         }
-                    A3_LDS_BARRIER();
+                        A3_LDS_BARRIER();
+                        if (wave == t) {
 #pragma unroll
-                    for (int ti = 0; ti < T; ++ti)
+                            for (int ti = 0; ti < T; ++ti)
 #pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2)
-                            dATf[ti][s2] = a3_tr(img_r + (32 * ti + 16 * s2) * ILD, img_r + (32 * ti + 16 * s2 + 4) * ILD);
+                                for (int s2 = 0; s2 < 2; ++s2)
+                                    dATf[ti][s2] = a3_tr(img_r + (32 * ti + 16 * s2) * ILD, img_r + (32 * ti + 16 * s2 + 4) * ILD);
+                        }
+                        A3_LDS_BARRIER();
+                    }
                 }
             } else {
                 // ---- token contractions: two 32-column tiles of dQ (u < u_c2), dV (u < u_c3) or dK
@@ -1250,41 +1310,50 @@ __global__ void __launch_bounds__(64 * T) attn_bwd3_kernel(const AttnParams p) {
 #pragma unroll
                             for (int s2 = 0; s2 < 2; ++s2) {
                                 const attn_h8 fb = a3_tr(Bs + t * 2048 + s2 * 1024 + troff[0], Bs + t * 2048 + s2 * 1024 + troff[1]);
-                                o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dAf[t][s2], fb, o[0], 0, 0, 0);
+                                o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, dAf[t][s2], o[0], 0, 0, 0);
                             }
-                        store_rows_packed<1>(o, p.scale, r_dQ, prow, (uint32_t)(p.tq0 + ((h * p.dk) >> 5) + ct + hf), (uint32_t)p.kbq, s_eff, l31, h2);
+                        a3_store_tile(o[0], p.scale, r_dQ, a3_row_off(r0 + (uint32_t)i, (uint32_t)p.kbq, 0), keyq, i < S, (uint32_t)(p.tq0 + ((h * p.dk) >> 5) + ct + hf), h2);
                     } else if (ph == 1) {
 #pragma unroll
                         for (int t = 0; t < T; ++t)
 #pragma unroll
                             for (int s2 = 0; s2 < 2; ++s2) {
                                 const attn_h8 fb = a3_tr(Bs + t * 2048 + s2 * 1024 + trnat[0], Bs + t * 2048 + s2 * 1024 + trnat[1]);
-                                o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PdTf[t][s2], fb, o[0], 0, 0, 0);
+                                o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, PdTf[t][s2], o[0], 0, 0, 0);
                             }
-                        store_rows_packed<1>(o, 1.f, r_dV, prow, (uint32_t)(p.tv0 + ((h * p.dv) >> 5) + ct + hf), (uint32_t)p.kbv, s_eff, l31, h2);
+                        a3_store_tile(o[0], 1.f, r_dV, a3_row_off(r0 + (uint32_t)i, (uint32_t)p.kbv, 0), keyq, i < S, (uint32_t)(p.tv0 + ((h * p.dv) >> 5) + ct + hf), h2);
                     } else {
 #pragma unroll
                         for (int t = 0; t < T; ++t)
 #pragma unroll
                             for (int s2 = 0; s2 < 2; ++s2) {
                                 const attn_h8 fb = a3_tr(Bs + t * 2048 + s2 * 1024 + trnat[0], Bs + t * 2048 + s2 * 1024 + trnat[1]);
-                                o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dATf[t][s2], fb, o[0], 0, 0, 0);
+                                o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, dATf[t][s2], o[0], 0, 0, 0);
                             }
-                        store_rows_packed<1>(o, p.scale, r_dK, prow, (uint32_t)(p.tk0 + ((h * p.dk) >> 5) + ct + hf), (uint32_t)p.kbk, s_eff, l31, h2);
+                        a3_store_tile(o[0], p.scale, r_dK, a3_row_off(r0 + (uint32_t)i, (uint32_t)p.kbk, 0), keyq, i < S, (uint32_t)(p.tk0 + ((h * p.dk) >> 5) + ct + hf), h2);
                     }
                 }
             }
-            ++g;
             if (++cslot == NB) cslot = 0;
         }
     }
     if (has_bias) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t ix = (idxp[t][r >> 1] >> (16 * (r & 1))) & 0xFFFFu;
+                if (ix != 0xFFFFu) atomicAdd(&tw[ix], dsum[t][r]);
+            }
+    }
+    }
+    if (has_bias) {
         __syncthreads();
-        for (int x = threadIdx.x; x < p.table_rows; x += 64 * T) {
+        for (int x = threadIdx.x; x < p.table_rows; x += 64 * (T + 1)) {
             float v = tacc[x];
 #pragma unroll
             for (int w = 1; w < T; ++w) v += tacc[w * p.table_rows + x];
-            if (p.table_partials) p.dtable[((size_t)blockIdx.x * p.table_rows + x) * p.H + h] = v;
+            if (p.table_partials) p.dtable[((size_t)chunk * p.table_rows + x) * p.H + h] = v;
             else atomicAdd(&p.dtable[(size_t)x * p.H + h], v);
         }
     }
@@ -1324,7 +1393,6 @@ int fill_params(const LstcAttnDesc* d, AttnParams& p, bool bwd) {
     p.kiq = p.kik = p.kiv = p.kido = 0;
     p.iq0 = p.ik0 = p.iv0 = p.ido0 = 0;
     p.pld = d->S;
-    { const char* e_ = getenv("LSTC_A3_DEBUG"); p.dbg = e_ ? atoi(e_) : 0; }
     if (d->probs_ld != 0 && d->probs_ld != d->S && d->in_pack_cols <= 0) return LSTC_E_UNSUPPORTED;
     return 0;
 }
@@ -1386,15 +1454,15 @@ int lstc_attn_fwd(const LstcAttnDesc* d, void* stream) {
         npw = npw < 1 ? 1 : (npw > 16 ? 16 : npw);
         p.n_per_wg = npw;
         dim3 grid3((p.N + npw - 1) / npw, p.H);
-        const size_t lds3 = (size_t)A3_NB * 2 * (32 * T) * 64;
-#define LSTC_FWD3(TT)                                                                      \
+        // ring depth per instantiation: (NB - 1) x slot x resident workgroups ~ 120 KB in flight per CU (kernel comment)
+#define LSTC_FWD3(TT, NBB)                                                                 \
     do {                                                                                   \
         static LstcDevOnce once3;                                                          \
         const int dev3_ = once3.begin();                                                   \
-        if (dev3_ >= 0) { set_lds(attn_fwd3_kernel<TT>, 160 * 1024); once3.end(dev3_); }    \
-        hipLaunchKernelGGL((attn_fwd3_kernel<TT>), grid3, 64 * TT, lds3, st, p);            \
+        if (dev3_ >= 0) { set_lds(attn_fwd3_kernel<TT, NBB>, 160 * 1024); once3.end(dev3_); } \
+        hipLaunchKernelGGL((attn_fwd3_kernel<TT, NBB>), dim3(grid3.x * grid3.y), 64 * (TT + 1), (size_t)NBB * 2 * (32 * TT) * 64, st, p); \
     } while (0)
-        if (T == 1) LSTC_FWD3(1); else if (T == 2) LSTC_FWD3(2); else LSTC_FWD3(3);
+        if (T == 1) LSTC_FWD3(1, 6); else if (T == 2) LSTC_FWD3(2, 9); else LSTC_FWD3(3, 6);
 #undef LSTC_FWD3
         return lstc_launch_status();
     }
@@ -1490,16 +1558,16 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
     }
     if (d->in_pack_cols > 0) {      // third generation: packed bf16 inputs and outputs
         if (!p.dQp) return LSTC_E_UNSUPPORTED;
-        const size_t lds3 = (size_t)A3_NB * 2 * (32 * T) * 64 + (size_t)T * (32 * T) * 72 + (size_t)T * p.table_rows * sizeof(float);
-        if (lds3 > 160 * 1024) return LSTC_E_RANGE;
-#define LSTC_BWD3(TT)                                                                      \
+#define LSTC_BWD3(TT, NBB)                                                                 \
     do {                                                                                   \
+        const size_t lds3 = (size_t)NBB * 2 * (32 * TT) * 64 + (size_t)(32 * TT) * 72 + (size_t)TT * p.table_rows * sizeof(float); \
+        if (lds3 > 160 * 1024) return LSTC_E_RANGE;                                        \
         static LstcDevOnce once3;                                                          \
         const int dev3_ = once3.begin();                                                   \
-        if (dev3_ >= 0) { set_lds(attn_bwd3_kernel<TT>, 160 * 1024); once3.end(dev3_); }    \
-        hipLaunchKernelGGL((attn_bwd3_kernel<TT>), grid, 64 * TT, lds3, st, p);             \
+        if (dev3_ >= 0) { set_lds(attn_bwd3_kernel<TT, NBB>, 160 * 1024); once3.end(dev3_); } \
+        hipLaunchKernelGGL((attn_bwd3_kernel<TT, NBB>), dim3(grid.x * grid.y), 64 * (TT + 1), lds3, st, p);  \
     } while (0)
-        if (T == 1) LSTC_BWD3(1); else if (T == 2) LSTC_BWD3(2); else LSTC_BWD3(3);
+        if (T == 1) LSTC_BWD3(1, 9); else if (T == 2) LSTC_BWD3(2, 8); else LSTC_BWD3(3, 5);
 #undef LSTC_BWD3
         return lstc_launch_status();
     }
