@@ -1449,8 +1449,11 @@ int lstc_attn_fwd(const LstcAttnDesc* d, void* stream) {
         if (!d->O_pack) return LSTC_E_UNSUPPORTED;
         rc = fill_packed_inputs(d, p, false);
         if (rc) return rc;
-        int npw = (int)(((int64_t)p.N * p.H + 8191) / 8192);
-        if (d->variant >= 100) npw = d->variant - 100;          // measurement hook: sequences per workgroup
+        // sequences per workgroup: a workgroup's ring runs across them (no cold start per sequence); ~2 rounds of the 512
+        // resident workgroups at T >= 2 (measured, 16384 items: S = 81 0.81 / 0.71 / 0.65 / 0.63 ms at 1 / 2 / 4 / 8), more and
+        // smaller workgroups at T = 1 (1536 resident; S = 17 0.113 / 0.119 / 0.134 ms at 1 / 2 / 8)
+        int npw = (int)(((int64_t)p.N * p.H) / (T == 1 ? 8192 : 1024));
+        if (d->variant >= 100) npw = d->variant - 100;          // measurement hook
         npw = npw < 1 ? 1 : (npw > 16 ? 16 : npw);
         p.n_per_wg = npw;
         dim3 grid3((p.N + npw - 1) / npw, p.H);
@@ -1530,6 +1533,10 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
     if (p.table_rows > 0 && d->dtable_chunks > 0) {          // the caller fixes the chunking and gets one partial table per chunk
         npw = (p.N + d->dtable_chunks - 1) / d->dtable_chunks;
         p.table_partials = 1;
+    }
+    if (d->in_pack_cols > 0 && !p.table_partials) {      // packed-input kernel: as its forward (measured: S = 81 1.72 / 1.50 / 1.38 / 1.33 ms at 2 / 4 / 8 / 16)
+        npw = (int)(((int64_t)p.N * p.H) / (T == 1 ? 8192 : 1024));
+        npw = npw < 1 ? 1 : (npw > 16 ? 16 : npw);
     }
     p.n_per_wg = npw;
     dim3 grid((p.N + npw - 1) / npw, p.H);

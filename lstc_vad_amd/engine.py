@@ -57,6 +57,9 @@ class TrainStep:
             M, Hd = n_seq * (1 + tokens), attn.n_head * attn.d_k
         except Exception:
             return False
+        if (Fn.get_compute_dtype() == "bf16" and Fn.attn_packed_inputs(n_seq, 1 + tokens, attn.n_head, attn.d_k, attn.d_v) and
+                Fn.packed_out_shape(M, attn.n_head * (2 * attn.d_k + attn.d_v))):
+            return True        # bf16 mode: the fused projection writes Q | K | V as ONE packed operand that the attention core reads
         tile, slots = (256, 256) if Fn.get_compute_dtype() == "bf16" else (128, 512)
         tiles = -(-M // tile) * -(-Hd // tile)
         eff = lambda t: (t / slots) / -(-t // slots)

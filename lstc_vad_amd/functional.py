@@ -113,6 +113,7 @@ _memo_stack = []           # activation packs made inside one autograd-node body
 _x3_min = (256, 256, 1 << 30)   # min(M, N), K, M*N*K from which a product goes to the packed kernel
 _ATTN_F32 = os.environ.get("LSTC_ATTN_F32", "0") == "1"          # bf16 mode: keep the attention products on the exact-f32 MFMA
 _ATTN_VARIANT = int(os.environ.get("LSTC_ATTN_VARIANT", "0"))     # 1: first-generation attention kernels (A/B measurements)
+_BWD_NPW = int(os.environ.get("LSTC_ATTN_BWD_NPW", "0"))       # measurement hook: sequences per workgroup of the attention backward
 _ATTN_PACKED_IN = os.environ.get("LSTC_ATTN_PACKED_IN", "1") != "0"   # bf16 mode: Q | K | V / dO reach the attention core as packs
 _DETERMINISTIC_WGRAD = os.environ.get("LSTC_ATOMIC_SPLITK", "0") != "1"   # split-K weight gradients: partials + ordered sum, not atomics
 
@@ -687,6 +688,10 @@ def attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, p_drop, seed, ou
     if table is not None:
         # one partial table per chunk of sequences, summed in a fixed order afterwards: no float atomics anywhere
         npw = min(8, max(1, (N * H + 4095) // 4096))
+        if in_pack:        # the packed-input kernel's ring runs across a workgroup's sequences: fewer, longer workgroups (csrc/attention.hip)
+            npw = min(16, max(1, (N * H) // (8192 if S <= 32 else 1024)))
+        if _BWD_NPW:
+            npw = _BWD_NPW
         chunks = (N + npw - 1) // npw
         chunks = (N + ((N + chunks - 1) // chunks) - 1) // ((N + chunks - 1) // chunks)
         parts = torch.empty((chunks, table.shape[0] * H), device=probs.device, dtype=torch.float32)

@@ -94,6 +94,30 @@ def test_host_side_validation_error_codes(lib):
     a.N, a.S, a.H, a.dk, a.dv = 1, 200, 1, 8, 8
     a.ldq = a.ldk = a.ldv = a.ldo = 8
     assert lib.lstc_attn_fwd(C.byref(a), None) == -5                  # S > 128
+    # packed-input form (LstcAttnDesc.in_pack_cols, include/lstc_hip.h): every broken precondition is refused before any launch
+    def packed_in():
+        p = AttnDesc()
+        p.Q = p.K = p.V = p.probs = p.O_pack = p.dO = p.dQ_pack = p.dK_pack = p.dV_pack = 4096
+        p.N, p.S, p.H, p.dk, p.dv, p.dtype, p.scale = 256, 49, 4, 64, 64, 1, 0.125
+        p.in_pack_cols, p.K_col0, p.V_col0, p.probs_ld = 768, 256, 512, 52
+        p.dO_pack_cols, p.pack_cols, p.dK_col0, p.dV_col0 = 256, 768, 256, 512
+        return p
+    for field, value, fwd_rc, bwd_rc in (("dtype", 0, -4, -4), ("probs_ld", 49, -2, -2), ("probs_ld", 48, -2, -2), ("K_col0", 16, -2, -2),
+                                         ("in_pack_cols", 800, -2, -2), ("V_col0", 640, -2, -2), ("O_pack", None, -1, None),
+                                         ("dv", 32, -4, -4), ("S", 97, -4, -4), ("N", 255, -4, -4), ("Q", 4104, -3, -3), ("probs", 4100, -3, -3),
+                                         ("dO_pack_cols", 0, None, -2), ("dO_pack_cols", 288, None, -2), ("dO", 4104, None, -3),
+                                         ("dQ_pack", None, None, -1), ("dk", 96, None, -4)):
+        p = packed_in()
+        setattr(p, field, value)
+        if fwd_rc is not None:
+            assert lib.lstc_attn_fwd(C.byref(p), None) == fwd_rc, (field, value)
+        if bwd_rc is not None:
+            assert lib.lstc_attn_bwd(C.byref(p), None) == bwd_rc, (field, value)
+    p = packed_in()
+    p.in_pack_cols, p.probs_ld = 0, 52            # a padded probability pitch belongs to the packed-input kernels only
+    p.O = 4096
+    p.ldq = p.ldk = p.ldv = p.ldo = 256
+    assert lib.lstc_attn_fwd(C.byref(p), None) == -4
     l = LossDesc()
     l.out = 16
     l.phase = 2

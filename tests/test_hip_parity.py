@@ -1736,3 +1736,129 @@ def test_attention_backward_packed_gradients_equal_the_packed_f32_gradients(S):
         torch.cuda.synchronize()
     finally:
         Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
+
+
+def _unpack1(buf, rows, K):
+    """f32 [rows, K] of an lstc_pack1 buffer (csrc/lstc_common.h p1_offset): 128-row x 32-k tiles, 64-B rows, 16-B chunk index
+    XOR (row >> 2) & 3."""
+    h = buf.view(torch.bfloat16)
+    r = torch.arange(rows, device=buf.device).view(-1, 1)
+    k = torch.arange(K, device=buf.device).view(1, -1)
+    kbp = ((K + 63) // 64) * 2
+    rr, kb, ch = r & 127, k >> 5, (k & 31) >> 3
+    off = ((r >> 7) * kbp + kb) * 4096 + rr * 32 + ((ch ^ ((rr >> 2) & 3)) << 3) + (k & 7)
+    return h[off.reshape(-1)].view(rows, K).float()
+
+
+@pytest.mark.parametrize("S,L,dk,H", [(49, 3, 256, 8), (17, 1, 256, 8), (81, 5, 256, 8), (19, 2, 64, 4), (33, 2, 64, 4), (81, 5, 64, 4), (96, 6, 64, 4)])
+def test_packed_input_attention_matches_the_f32_input_kernels_and_f64(S, L, dk, H):
+    """LstcAttnDesc.in_pack_cols > 0 (bf16 mode): Q | K | V and dO read from lstc_pack1 buffers, O and dQ | dK | dV written as
+    packs, probabilities with a padded row pitch.  On bf16-representable operands the results are those of the f32-input
+    bf16-mode kernels up to the summation order of the softmax (probabilities to 1e-6, packed outputs to one bf16 rounding);
+    S = 49 and 81 also against an f64 evaluation of models/MultiHeadAttention.py:103-122.  Workgroups walk several sequences
+    (the staging ring runs across them); S = 33 repeats both launches with 3 sequences per workgroup, which leaves the last
+    workgroup a partial chunk; S = 96: no padding rows at all."""
+    from lstc_vad_amd import functional as Fn
+    N = 256 if S != 81 else 512
+    M = N * S
+    g = torch.Generator(device=DEV).manual_seed(100 + S + dk)
+    qkv = torch.randn(M, 3 * H * dk, device=DEV, generator=g).bfloat16().float()
+    do = torch.randn(M, H * dk, device=DEV, generator=g).bfloat16().float()
+    q, k, v = qkv[:, :H * dk], qkv[:, H * dk:2 * H * dk], qkv[:, 2 * H * dk:]
+    index = orc.relative_position_index_3d(L, 4).to(DEV) if S != 17 else None
+    table = torch.randn((2 * L - 1) * 49, H, device=DEV, generator=g) * 0.3 if S != 17 else None
+    p_drop = 0.2
+    Fn.set_compute_dtype("bf16"); Fn.set_x3_threshold(0, 0, 0)
+    try:
+        assert Fn.attn_packed_inputs(N, S, H, dk, dk)
+        qkv_p, do_p = Fn.pack3(qkv, False), Fn.pack3(do, False)
+        o_ref, pr_ref = Fn.attn_fwd(q, k, v, N, S, H, dk, dk, table, index, p_drop, 7, packed=True)
+        o_new, pr_new = Fn.attn_fwd(qkv_p, None, None, N, S, H, dk, dk, table, index, p_drop, 7)
+        assert pr_new.shape == pr_ref.shape and pr_new.stride(2) % 4 == 0
+        assert max_abs_diff(pr_new, pr_ref) < 2e-6
+        assert float(pr_new.sum(-1).sub(1).abs().max()) < 1e-5
+        if pr_new.stride(2) > S:        # padding columns: the forward's zeros
+            assert float(torch.as_strided(pr_new, (N, H, S, pr_new.stride(2) - S), pr_new.stride(), S).abs().max()) == 0.0
+        a, b = _unpack1(o_ref.buf, M, H * dk), _unpack1(o_new.buf, M, H * dk)
+        # (a probability that rounds to the other bf16 neighbour moves an output by 2^-9 p |v|: a few 1e-3 absolute)
+        assert float(((a - b).abs() - (2.0 ** -7) * a.abs()).max()) < 2e-3 * float(a.abs().max())
+        ref = Fn.attn_bwd(do, q, k, v, pr_ref, N, S, H, dk, dk, table, index, p_drop, 7, packed="fused")
+        new = Fn.attn_bwd(do_p, qkv_p, None, None, pr_new, N, S, H, dk, dk, table, index, p_drop, 7)
+        a, b = _unpack1(ref[0].buf, M, 3 * H * dk), _unpack1(new[0].buf, M, 3 * H * dk)
+        assert not torch.isnan(b).any()
+        assert float(((a - b).abs() - (2.0 ** -6) * a.abs()).max()) < 4e-3 * float(a.abs().max())
+        if table is not None:
+            assert max_abs_diff(new[3], ref[3]) < 1e-5 * float(ref[3].abs().max())
+            again = Fn.attn_bwd(do_p, qkv_p, None, None, pr_new, N, S, H, dk, dk, table, index, p_drop, 7)
+            assert torch.equal(again[3], new[3]) and torch.equal(_unpack1(again[0].buf, M, 3 * H * dk), b)       # run-to-run bit-identical
+        if S == 33:
+            Fn._ATTN_VARIANT, Fn._BWD_NPW = 103, 3
+            try:
+                o3, pr3 = Fn.attn_fwd(qkv_p, None, None, N, S, H, dk, dk, table, index, p_drop, 7)
+                new3 = Fn.attn_bwd(do_p, qkv_p, None, None, pr_new, N, S, H, dk, dk, table, index, p_drop, 7)
+            finally:
+                Fn._ATTN_VARIANT, Fn._BWD_NPW = 0, 0
+            assert torch.equal(pr3, pr_new) and torch.equal(_unpack1(o3.buf, M, H * dk), _unpack1(o_new.buf, M, H * dk))
+            assert torch.equal(_unpack1(new3[0].buf, M, 3 * H * dk), b)
+            assert max_abs_diff(new3[3], new[3]) < 1e-5 * float(new[3].abs().max())
+        if S in (49, 81):
+            # f64 evaluation with the SAME dropout mask (elements where the kernels kept the probability)
+            n_chk = 8
+            qd, kd, vd, dod = (t[: n_chk * S].double().view(n_chk, S, H, dk).transpose(1, 2) for t in (q, k, v, do))
+            att = qd @ kd.transpose(-1, -2) / dk ** 0.5
+            att[:, :, 1:, 1:] += table.double()[index[: S - 1, : S - 1].reshape(-1)].view(S - 1, S - 1, H).permute(2, 0, 1)
+            pr = att.softmax(-1)
+            assert max_abs_diff(pr_new[:n_chk], pr.float()) < 2e-3        # bf16 products of Q K^T
+            keep = Fn.dropout_mask((N, H, S, S), p_drop, 7, DEV)[:n_chk].double() / (1 - p_drop)
+            o64 = ((pr * keep) @ vd).transpose(1, 2).reshape(n_chk * S, H * dk)
+            assert max_abs_diff(_unpack1(o_new.buf, M, H * dk)[: n_chk * S], o64.float()) < 3e-2
+    finally:
+        Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
+
+
+def test_bf16_encoder_step_with_packed_attention_operands_is_as_close_to_fp32_as_the_f32_operand_path():
+    """bf16 mode, fused Q|K|V projection, 256 sequences x 49 tokens x d = 512 (H = 8, d_k = 64), same dropout seeds: the encoder
+    step with Q | K | V / dO handed to the attention core as packed bf16 operands (default) and with LSTC_ATTN_PACKED_IN=0 (f32 Q,
+    K, V, dO; the same bf16 products inside the kernels), both against the fp32-mode step.  The two bf16 paths round the same
+    values at the same places, so they sit at the same distance from the fp32 step (within 10 % of each other, tensor by tensor -
+    the attention gradients of a randomly initialised encoder are heavily cancelling sums, 6-20 % away from fp32 in either
+    path) and their outputs agree to 1e-3; the packed path is the one that ran (attn_fwd saw a Packed operand)."""
+    from lstc_vad_amd import functional as Fn
+    from lstc_vad_amd.models import Encoder
+    torch.manual_seed(5)
+    enc = Encoder(n_layers=2, n_head=8, d_k=64, d_v=64, d_model=512, d_inner=1024, MHA_attn_dropout=0.1, MHA_fc_dropout=0.1,
+                  FFN_dropout=0.1, MHA_layerNorm=True, FFN_layerNorm=True, relative_pe=True, window_size=4, window_depth=3).to(DEV).train()
+    for layer in enc.layer_stack:
+        layer.slf_attn.fuse_qkv_()
+    x = torch.randn(256, 48, 512, device=DEV)
+    res, seen = {}, []
+    real = Fn.attn_fwd
+    def spy(q, *a, **kw):
+        seen.append(isinstance(q, Fn.Packed))
+        return real(q, *a, **kw)
+    Fn.attn_fwd = spy
+    try:
+        for name, mode, packed_in in (("fp32", "fp32", True), ("packed", "bf16", True), ("f32ops", "bf16", False)):
+            Fn.set_compute_dtype(mode)
+            if mode == "bf16":
+                Fn.set_x3_threshold(0, 0, 0)
+            Fn._ATTN_PACKED_IN = packed_in
+            torch.manual_seed(17); Fn.reset_rng()
+            enc.zero_grad(set_to_none=True)
+            y = enc(x)
+            y.square().mean().backward()
+            torch.cuda.synchronize()
+            res[name] = (y.detach().clone(), {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None})
+            Fn.bump_weight_epoch()
+            Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
+    finally:
+        Fn.attn_fwd = real
+        Fn._ATTN_PACKED_IN = True
+        Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
+    assert seen == [False, False, True, True, False, False]
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    assert rel(res["packed"][0], res["f32ops"][0]) < 2e-3 and rel(res["packed"][0], res["fp32"][0]) < 1e-2
+    gp, gf, g32 = res["packed"][1], res["f32ops"][1], res["fp32"][1]
+    assert gp.keys() == g32.keys() and len(gp) >= 20
+    for k in g32:
+        assert rel(gp[k], g32[k]) < 1.1 * rel(gf[k], g32[k]) + 2e-3, (k, rel(gp[k], g32[k]), rel(gf[k], g32[k]))

@@ -37,7 +37,8 @@ def main():
     Fn.set_compute_dtype("bf16"); Fn.set_x3_threshold(0, 0, 0)
     for S in Ss:
         L, dk = shapes[S]
-        H = 8 if dk == 256 else 4
+        dk = int(os.environ.get("A3_DK", dk))
+        H = int(os.environ.get("A3_H", 8 if dk == 256 else 4))
         N = 2048 if mode == "time" else 256
         M = N * S
         g = torch.Generator(device=dev).manual_seed(5 + S)
@@ -85,6 +86,11 @@ def main():
                 t3, _ = timeit(lambda: Fn.attn_fwd(qkv_p, None, None, N, S, H, dk, dk, tab, idx, pdrop, 7))
                 print(f"TIME S={S} fwd packed-in, {npw} sequences per workgroup: {t3:.3f} ms", flush=True)
             Fn._ATTN_VARIANT = 0
+            for npw in (2, 4, 8, 16):
+                Fn._BWD_NPW = npw
+                b3, _ = timeit(lambda: Fn.attn_bwd(do_p, qkv_p, None, None, pr_new, N, S, H, dk, dk, tab, idx, pdrop, 7))
+                print(f"TIME S={S} bwd packed-in, {npw} sequences per workgroup: {b3:.3f} ms", flush=True)
+            Fn._BWD_NPW = 0
 
 
 main()
