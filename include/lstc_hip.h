@@ -184,7 +184,10 @@ typedef struct LstcAttnDesc {
     int32_t dtable_chunks;
     int32_t variant;                /* 0 = default kernels; 1 = first-generation kernels (operands straight from global in
                                        MFMA lane layout) - kept for A/B measurements and as the fallback for shapes the
-                                       staged kernels do not take (d_k or d_v not a multiple of 32, unaligned operands, S > 96) */
+                                       staged kernels do not take (d_k or d_v not a multiple of 32, unaligned operands, S > 96).
+                                       Packed-input forward only (in_pack_cols > 0): 100 + n = n sequences per workgroup
+                                       (1 <= n <= 16; the default picks n from N * H), a measurement hook - results do not
+                                       depend on it */
     /* backward, bf16 mode: when all three are non-NULL, dQ / dK / dV are written ONLY as packed bf16 operands [N*S, H*dk|dv]
      * (lstc_pack1 layout, lstc_pack1_bytes(N*S, H*dk|dv) bytes each; dQ / dK / dV may be NULL) - they feed the packed weight- and
      * input-gradient products of the projections (autograd of models/MultiHeadAttention.py:97-99).  Needs the staged kernel
