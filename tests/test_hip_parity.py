@@ -1750,14 +1750,15 @@ def _unpack1(buf, rows, K):
     return h[off.reshape(-1)].view(rows, K).float()
 
 
-@pytest.mark.parametrize("S,L,dk,H", [(49, 3, 256, 8), (17, 1, 256, 8), (81, 5, 256, 8), (19, 2, 64, 4), (33, 2, 64, 4), (81, 5, 64, 4), (96, 6, 64, 4)])
+@pytest.mark.parametrize("S,L,dk,H", [(49, 3, 256, 8), (17, 1, 256, 8), (81, 5, 256, 8), (19, 2, 64, 4), (33, 2, 64, 4), (81, 5, 64, 4), (96, 6, 64, 4),
+                                      (32, 2, 64, 4), (64, 4, 128, 2)])
 def test_packed_input_attention_matches_the_f32_input_kernels_and_f64(S, L, dk, H):
     """LstcAttnDesc.in_pack_cols > 0 (bf16 mode): Q | K | V and dO read from lstc_pack1 buffers, O and dQ | dK | dV written as
     packs, probabilities with a padded row pitch.  On bf16-representable operands the results are those of the f32-input
     bf16-mode kernels up to the summation order of the softmax (probabilities to 1e-6, packed outputs to one bf16 rounding);
     S = 49 and 81 also against an f64 evaluation of models/MultiHeadAttention.py:103-122.  Workgroups walk several sequences
     (the staging ring runs across them); S = 33 repeats both launches with 3 sequences per workgroup, which leaves the last
-    workgroup a partial chunk; S = 96: no padding rows at all."""
+    workgroup a partial chunk; S = 32, 64, 96: no padding rows in the last query tile (S = 32 and 64 run without dropout)."""
     from lstc_vad_amd import functional as Fn
     N = 256 if S != 81 else 512
     M = N * S
@@ -1767,7 +1768,7 @@ def test_packed_input_attention_matches_the_f32_input_kernels_and_f64(S, L, dk, 
     q, k, v = qkv[:, :H * dk], qkv[:, H * dk:2 * H * dk], qkv[:, 2 * H * dk:]
     index = orc.relative_position_index_3d(L, 4).to(DEV) if S != 17 else None
     table = torch.randn((2 * L - 1) * 49, H, device=DEV, generator=g) * 0.3 if S != 17 else None
-    p_drop = 0.2
+    p_drop = 0.0 if S in (32, 64) else 0.2
     Fn.set_compute_dtype("bf16"); Fn.set_x3_threshold(0, 0, 0)
     try:
         assert Fn.attn_packed_inputs(N, S, H, dk, dk)
@@ -1775,20 +1776,25 @@ def test_packed_input_attention_matches_the_f32_input_kernels_and_f64(S, L, dk, 
         o_ref, pr_ref = Fn.attn_fwd(q, k, v, N, S, H, dk, dk, table, index, p_drop, 7, packed=True)
         o_new, pr_new = Fn.attn_fwd(qkv_p, None, None, N, S, H, dk, dk, table, index, p_drop, 7)
         assert pr_new.shape == pr_ref.shape and pr_new.stride(2) % 4 == 0
-        assert max_abs_diff(pr_new, pr_ref) < 2e-6
+        # 1 / sqrt(d_k) a power of two: scaling commutes with the bf16 rounding of Q, the two generations differ by summation order
+        # only.  d_k = 128: the f32-input kernels round Q * scale, the packed-input ones scale the f32 logits of the rounded Q -
+        # two different bf16 roundings of the same product (2^-9 relative on a logit), both checked against f64 below
+        pow2 = dk in (64, 256)
+        loose = 1.0 if pow2 else 12.0
+        assert max_abs_diff(pr_new, pr_ref) < (2e-6 if pow2 else 4e-3)
         assert float(pr_new.sum(-1).sub(1).abs().max()) < 1e-5
         if pr_new.stride(2) > S:        # padding columns: the forward's zeros
             assert float(torch.as_strided(pr_new, (N, H, S, pr_new.stride(2) - S), pr_new.stride(), S).abs().max()) == 0.0
         a, b = _unpack1(o_ref.buf, M, H * dk), _unpack1(o_new.buf, M, H * dk)
         # (a probability that rounds to the other bf16 neighbour moves an output by 2^-9 p |v|: a few 1e-3 absolute)
-        assert float(((a - b).abs() - (2.0 ** -7) * a.abs()).max()) < 2e-3 * float(a.abs().max())
+        assert float(((a - b).abs() - (2.0 ** -7) * a.abs()).max()) < loose * 2e-3 * float(a.abs().max())
         ref = Fn.attn_bwd(do, q, k, v, pr_ref, N, S, H, dk, dk, table, index, p_drop, 7, packed="fused")
         new = Fn.attn_bwd(do_p, qkv_p, None, None, pr_new, N, S, H, dk, dk, table, index, p_drop, 7)
         a, b = _unpack1(ref[0].buf, M, 3 * H * dk), _unpack1(new[0].buf, M, 3 * H * dk)
         assert not torch.isnan(b).any()
-        assert float(((a - b).abs() - (2.0 ** -6) * a.abs()).max()) < 4e-3 * float(a.abs().max())
+        assert float(((a - b).abs() - (2.0 ** -6) * a.abs()).max()) < loose * 4e-3 * float(a.abs().max())
         if table is not None:
-            assert max_abs_diff(new[3], ref[3]) < 1e-5 * float(ref[3].abs().max())
+            assert max_abs_diff(new[3], ref[3]) < (1e-5 if pow2 else 2e-2) * float(ref[3].abs().max())
             again = Fn.attn_bwd(do_p, qkv_p, None, None, pr_new, N, S, H, dk, dk, table, index, p_drop, 7)
             assert torch.equal(again[3], new[3]) and torch.equal(_unpack1(again[0].buf, M, 3 * H * dk), b)       # run-to-run bit-identical
         if S == 33:
@@ -1801,7 +1807,7 @@ def test_packed_input_attention_matches_the_f32_input_kernels_and_f64(S, L, dk, 
             assert torch.equal(pr3, pr_new) and torch.equal(_unpack1(o3.buf, M, H * dk), _unpack1(o_new.buf, M, H * dk))
             assert torch.equal(_unpack1(new3[0].buf, M, 3 * H * dk), b)
             assert max_abs_diff(new3[3], new[3]) < 1e-5 * float(new[3].abs().max())
-        if S in (49, 81):
+        if S in (49, 81, 64):
             # f64 evaluation with the SAME dropout mask (elements where the kernels kept the probability)
             n_chk = 8
             qd, kd, vd, dod = (t[: n_chk * S].double().view(n_chk, S, H, dk).transpose(1, 2) for t in (q, k, v, do))
@@ -1809,7 +1815,7 @@ def test_packed_input_attention_matches_the_f32_input_kernels_and_f64(S, L, dk, 
             att[:, :, 1:, 1:] += table.double()[index[: S - 1, : S - 1].reshape(-1)].view(S - 1, S - 1, H).permute(2, 0, 1)
             pr = att.softmax(-1)
             assert max_abs_diff(pr_new[:n_chk], pr.float()) < 2e-3        # bf16 products of Q K^T
-            keep = Fn.dropout_mask((N, H, S, S), p_drop, 7, DEV)[:n_chk].double() / (1 - p_drop)
+            keep = Fn.dropout_mask((N, H, S, S), p_drop, 7, DEV)[:n_chk].double() / (1 - p_drop) if p_drop > 0 else 1.0
             o64 = ((pr * keep) @ vd).transpose(1, 2).reshape(n_chk * S, H * dk)
             assert max_abs_diff(_unpack1(o_new.buf, M, H * dk)[: n_chk * S], o64.float()) < 3e-2
     finally:
