@@ -10,7 +10,7 @@ HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Werror=return-typ
 
 all: $(LIB)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/lstc_common.h include/lstc_hip.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/lstc_common.h $(CSRC)/attention_common.h include/lstc_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)
@@ -21,7 +21,7 @@ tools/gemm_check: tools/gemm_check.cpp $(LIB)
 
 # tuning build (timing ablations compiled in; NEVER the product): tools/tuning/liblstc_hip.so + tools/tuning/gemm_check
 TOBJS := $(patsubst $(CSRC)/%.hip,tools/tuning/%.o,$(SRCS))
-tools/tuning/%.o: $(CSRC)/%.hip $(CSRC)/lstc_common.h include/lstc_hip.h
+tools/tuning/%.o: $(CSRC)/%.hip $(CSRC)/lstc_common.h $(CSRC)/attention_common.h include/lstc_hip.h
 	@mkdir -p tools/tuning
 	$(HIPCC) $(HIPFLAGS) -DLSTC_TUNING -c $< -o $@
 tools/tuning/liblstc_hip.so: $(TOBJS)

@@ -688,7 +688,7 @@ def attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, p_drop, seed, ou
     if table is not None:
         # one partial table per chunk of sequences, summed in a fixed order afterwards: no float atomics anywhere
         npw = min(8, max(1, (N * H + 4095) // 4096))
-        if in_pack:        # the packed-input kernel's ring runs across a workgroup's sequences: fewer, longer workgroups (csrc/attention.hip)
+        if in_pack:        # the packed-input kernel's ring runs across a workgroup's sequences: fewer, longer workgroups (csrc/attention_pk.hip)
             npw = min(16, max(1, (N * H) // (8192 if S <= 32 else 1024)))
         if _BWD_NPW:
             npw = _BWD_NPW
