@@ -402,6 +402,45 @@ __global__ void __launch_bounds__(NT) cls_concat_fwd_kernel(const float* __restr
     if (packed) packed[p1_offset(n * S, c, KBp)] = (__bf16)cv;
 }
 
+// The same with FOUR columns per thread (d a multiple of 4, 16-B aligned operands): 16-B loads / stores, 8-B pack stores, the
+// token loop unrolled so that several rows are in flight per lane.  Same per-column arithmetic in the same order (the mean CLS
+// token is a sequential sum over the tokens), so the results are bitwise those of the scalar kernel, which took 569 us for the
+// headline batch in bf16 mode (2.0 GB moved: 3.6 TB/s) with its 4-B loads and 2-B pack stores.
+__global__ void __launch_bounds__(NT) cls_concat_fwd_vec4_kernel(const float4* __restrict__ x, const float4* __restrict__ x_hi,
+                                                                  int64_t n_lo, const float4* __restrict__ cls,
+                                                                  const float4* __restrict__ pos, float4* __restrict__ y, int S,
+                                                                  int d4, __bf16* __restrict__ packed, int KBp) {
+    const int64_t n = blockIdx.x;
+    const int c4 = blockIdx.y * NT + threadIdx.x;
+    if (c4 >= d4) return;
+    const float4* xr = (x_hi && n >= n_lo ? x_hi + (n - n_lo) * (int64_t)(S - 1) * d4 : x + n * (int64_t)(S - 1) * d4) + c4;
+    float4* yr = y + n * (int64_t)S * d4 + c4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto emit = [&](int64_t row, const float4& w) {
+        bf16x4v h;
+        h[0] = (__bf16)w.x; h[1] = (__bf16)w.y; h[2] = (__bf16)w.z; h[3] = (__bf16)w.w;
+        *reinterpret_cast<bf16x4v*>(packed + p1_offset(row, 4 * c4, KBp)) = h;
+    };
+#pragma unroll 4
+    for (int t = 0; t < S - 1; ++t) {
+        const float4 v = xr[(int64_t)t * d4];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        float4 w = v;
+        if (pos) {
+            const float4 pv = pos[(int64_t)(t + 1) * d4 + c4];
+            w.x += pv.x; w.y += pv.y; w.z += pv.z; w.w += pv.w;
+        }
+        yr[(int64_t)(t + 1) * d4] = w;
+        if (packed) emit(n * S + t + 1, w);
+    }
+    float4 cv;
+    if (cls) cv = cls[c4];
+    else { const float r = (float)(S - 1); cv = make_float4(s.x / r, s.y / r, s.z / r, s.w / r); }
+    if (pos) { const float4 pv = pos[c4]; cv.x += pv.x; cv.y += pv.y; cv.z += pv.z; cv.w += pv.w; }
+    yr[0] = cv;
+    if (packed) emit(n * S, cv);
+}
+
 // dx[n,t,:] = dy[n,t+1,:] + (mean_cls ? dy[n,0,:]/(S-1) : 0)
 __global__ void __launch_bounds__(NT) cls_concat_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int S,
                                                              int d, int mean_cls) {
@@ -832,12 +871,23 @@ int lstc_layernorm_bwd_drop(const float* dy, const float* x, const float* gamma,
     return lstc_launch_status();
 }
 
+static void launch_cls_concat_fwd(const float* x, const float* x_hi, int64_t n_lo, const float* cls_token, const float* pos, float* y,
+                                  int64_t N, int32_t S, int32_t d, __bf16* packed, int KBp, hipStream_t st) {
+    if (d % 4 == 0 && aligned16(x) && aligned16(y) && (!x_hi || aligned16(x_hi)) && (!cls_token || aligned16(cls_token)) &&
+        (!pos || aligned16(pos))) {
+        hipLaunchKernelGGL(cls_concat_fwd_vec4_kernel, dim3((unsigned)N, (d / 4 + NT - 1) / NT), NT, 0, st, (const float4*)x,
+                           (const float4*)x_hi, n_lo, (const float4*)cls_token, (const float4*)pos, (float4*)y, S, d / 4, packed, KBp);
+        return;
+    }
+    hipLaunchKernelGGL(cls_concat_fwd_kernel, dim3((unsigned)N, (d + NT - 1) / NT), NT, 0, st, x, x_hi, n_lo, cls_token, pos, y, S, d,
+                       packed, KBp);
+}
+
 int lstc_cls_concat_fwd(const float* x, const float* x_hi, int64_t n_lo, const float* cls_token, const float* pos,
                         float* y, int64_t N, int32_t S, int32_t d, void* stream) {
     if (!x || !y) return LSTC_E_NULL;
     if (N <= 0 || S < 2 || d <= 0 || (x_hi && (n_lo < 0 || n_lo > N))) return LSTC_E_SHAPE;
-    hipLaunchKernelGGL(cls_concat_fwd_kernel, dim3((unsigned)N, (d + NT - 1) / NT), NT, 0, (hipStream_t)stream, x, x_hi,
-                       n_lo, cls_token, pos, y, S, d, (__bf16*)nullptr, 0);
+    launch_cls_concat_fwd(x, x_hi, n_lo, cls_token, pos, y, N, S, d, nullptr, 0, (hipStream_t)stream);
     return lstc_launch_status();
 }
 
@@ -847,8 +897,7 @@ int lstc_cls_concat_fwd_pack(const float* x, const float* x_hi, int64_t n_lo, co
     if (N <= 0 || S < 2 || d <= 0 || (x_hi && (n_lo < 0 || n_lo > N))) return LSTC_E_SHAPE;
     if ((N * S) % 256 != 0 || d % 64 != 0) return LSTC_E_UNSUPPORTED;      // the rows fill the pack's even tile grid exactly
     if (!aligned16(packed)) return LSTC_E_ALIGN;
-    hipLaunchKernelGGL(cls_concat_fwd_kernel, dim3((unsigned)N, (d + NT - 1) / NT), NT, 0, (hipStream_t)stream, x, x_hi,
-                       n_lo, cls_token, pos, y, S, d, (__bf16*)packed, d / 32);
+    launch_cls_concat_fwd(x, x_hi, n_lo, cls_token, pos, y, N, S, d, (__bf16*)packed, d / 32, (hipStream_t)stream);
     return lstc_launch_status();
 }
 

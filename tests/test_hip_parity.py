@@ -1868,3 +1868,45 @@ def test_bf16_encoder_step_with_packed_attention_operands_is_as_close_to_fp32_as
     assert gp.keys() == g32.keys() and len(gp) >= 20
     for k in g32:
         assert rel(gp[k], g32[k]) < 1.1 * rel(gf[k], g32[k]) + 2e-3, (k, rel(gp[k], g32[k]), rel(gf[k], g32[k]))
+
+
+@pytest.mark.parametrize("learned,with_pos,split", [(False, False, True), (True, True, False), (False, True, True)])
+def test_cls_concat_vector_kernel_is_bitwise_the_scalar_kernel(learned, with_pos, split):
+    """lstc_cls_concat_fwd[_pack]: the four-columns-per-thread kernel (16-B aligned operands) against the one-column kernel
+    (reached with an input that starts 4 bytes off a 16-B boundary) and against the reference's cat([cls, x], 1) [+ pos]
+    (models/Encoder.py:52-61): bit-identical, mean or learned CLS token, one or two input tensors, with and without the packed
+    bf16 copy."""
+    from lstc_vad_amd import _lib
+    from lstc_vad_amd.functional import dev_ptr, stream_ptr, check
+    lib = _lib.load()
+    N, S, d = 256, 17, 192
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(N, S - 1, d, device=DEV, generator=g)
+    cls = torch.randn(d, device=DEV, generator=g) if learned else None
+    pos = torch.randn(S, d, device=DEV, generator=g) if with_pos else None
+    n_lo = N // 2 if split else N
+    lo, hi = x[:n_lo].contiguous(), (x[n_lo:].contiguous() if split else None)
+    want = torch.cat([(cls.expand(N, 1, d) if learned else x.sum(1, keepdim=True) / (S - 1)), x], 1)
+    # the kernel sums the tokens one after another; torch.sum uses another order: compare row 0 with a tolerance, the rest exactly
+    if with_pos:
+        want = want + pos
+    def run(xlo, xhi, packed):
+        y = torch.empty(N, S, d, device=DEV)
+        args = (dev_ptr(xlo), dev_ptr(xhi) if xhi is not None else None, n_lo, dev_ptr(cls) if learned else None,
+                dev_ptr(pos) if with_pos else None, dev_ptr(y), N, S, d)
+        if packed:
+            buf = torch.zeros(int(lib.lstc_pack1_bytes(N * S, d)), device=DEV, dtype=torch.uint8)
+            check(lib.lstc_cls_concat_fwd_pack(*args, dev_ptr(buf), stream_ptr()), "lstc_cls_concat_fwd_pack")
+            return y, buf
+        check(lib.lstc_cls_concat_fwd(*args, stream_ptr()), "lstc_cls_concat_fwd")
+        return y, None
+    off = torch.empty(lo.numel() + 1, device=DEV)[1:].view_as(lo)       # 4 bytes past a 16-B boundary: the scalar kernel
+    off.copy_(lo)
+    assert dev_ptr(off) % 16 == 4 and dev_ptr(lo) % 16 == 0
+    y_vec, p_vec = run(lo, hi, True)
+    y_sca, p_sca = run(off, hi, True)
+    y_plain, _ = run(lo, hi, False)
+    torch.cuda.synchronize()
+    assert torch.equal(y_vec, y_sca) and torch.equal(y_vec, y_plain) and torch.equal(p_vec, p_sca)
+    assert torch.equal(y_vec[:, 1:], want[:, 1:]) and max_abs_diff(y_vec[:, 0], want[:, 0]) < 1e-5
+    assert torch.equal(_unpack1(p_vec, N * S, d), y_vec.view(N * S, d).bfloat16().float())
