@@ -1910,3 +1910,38 @@ def test_cls_concat_vector_kernel_is_bitwise_the_scalar_kernel(learned, with_pos
     assert torch.equal(y_vec, y_sca) and torch.equal(y_vec, y_plain) and torch.equal(p_vec, p_sca)
     assert torch.equal(y_vec[:, 1:], want[:, 1:]) and max_abs_diff(y_vec[:, 0], want[:, 0]) < 1e-5
     assert torch.equal(_unpack1(p_vec, N * S, d), y_vec.view(N * S, d).bfloat16().float())
+
+
+@pytest.mark.parametrize("S", [2, 3, 5, 16, 31, 32, 33, 48, 63, 64, 65, 80, 95, 96])
+def test_packed_input_attention_sequence_length_sweep(S):
+    """Every boundary of the packed-input kernels' tiling - S = 2 (one key besides CLS), the last row of a 32-query tile, the
+    first row of the next one, S = 96 - against the f32-input bf16-mode kernels (first or second generation, whichever the
+    shape takes): 256 sequences, H = 4, d_k = 64, relative bias read through the top-left (S-1) x (S-1) of a larger index,
+    dropout 0.15."""
+    from lstc_vad_amd import functional as Fn
+    N, H, dk = 256, 4, 64
+    M = N * S
+    L = max(1, (S - 1 + 15) // 16)
+    g = torch.Generator(device=DEV).manual_seed(1000 + S)
+    qkv = torch.randn(M, 3 * H * dk, device=DEV, generator=g).bfloat16().float()
+    do = torch.randn(M, H * dk, device=DEV, generator=g).bfloat16().float()
+    q, k, v = qkv[:, :H * dk], qkv[:, H * dk:2 * H * dk], qkv[:, 2 * H * dk:]
+    index = orc.relative_position_index_3d(L, 4).to(DEV)
+    table = torch.randn((2 * L - 1) * 49, H, device=DEV, generator=g) * 0.3
+    Fn.set_compute_dtype("bf16"); Fn.set_x3_threshold(0, 0, 0)
+    try:
+        assert Fn.attn_packed_inputs(N, S, H, dk, dk)
+        qkv_p, do_p = Fn.pack3(qkv, False), Fn.pack3(do, False)
+        o_ref, pr_ref = Fn.attn_fwd(q, k, v, N, S, H, dk, dk, table, index, 0.15, 11, packed=True)
+        o_new, pr_new = Fn.attn_fwd(qkv_p, None, None, N, S, H, dk, dk, table, index, 0.15, 11)
+        assert max_abs_diff(pr_new, pr_ref) < 2e-6
+        a, b = _unpack1(o_ref.buf, M, H * dk), _unpack1(o_new.buf, M, H * dk)
+        assert float(((a - b).abs() - (2.0 ** -7) * a.abs()).max()) < 2e-3 * float(a.abs().max())
+        ref = Fn.attn_bwd(do, q, k, v, pr_ref, N, S, H, dk, dk, table, index, 0.15, 11, packed="fused")
+        new = Fn.attn_bwd(do_p, qkv_p, None, None, pr_new, N, S, H, dk, dk, table, index, 0.15, 11)
+        a, b = _unpack1(ref[0].buf, M, 3 * H * dk), _unpack1(new[0].buf, M, 3 * H * dk)
+        assert not torch.isnan(b).any()
+        assert float(((a - b).abs() - (2.0 ** -6) * a.abs()).max()) < 4e-3 * float(a.abs().max())
+        assert max_abs_diff(new[3], ref[3]) < 1e-5 * float(ref[3].abs().max()) + 1e-6
+    finally:
+        Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
