@@ -184,7 +184,10 @@ typedef struct LstcAttnDesc {
     int32_t dtable_chunks;
     int32_t variant;                /* 0 = default kernels; 1 = first-generation kernels (operands straight from global in
                                        MFMA lane layout) - kept for A/B measurements and as the fallback for shapes the
-                                       staged kernels do not take (d_k or d_v not a multiple of 32, unaligned operands, S > 96).
+                                       staged kernels do not take (d_k or d_v not a multiple of 32, unaligned operands, S > 96);
+                                       forward only: 2 = the second-generation (LDS-logit) kernel where the default is the
+                                       lane-=-query f32 kernel (LSTC_F32, S <= 32 or 64 < S <= 96, d_v a multiple of 64),
+                                       3 = that kernel also for 32 < S <= 64 (A/B measurements; same results to rounding).
                                        Packed-input forward only (in_pack_cols > 0): 100 + n = n sequences per workgroup
                                        (1 <= n <= 16; the default picks n from N * H), a measurement hook - results do not
                                        depend on it */

@@ -868,9 +868,18 @@ int lstc_attn_fwd(const LstcAttnDesc* d, void* stream) {
         dim3 grid3((p.N + npw - 1) / npw, p.H);
         return attn3_fwd_launch(p, T, (int)grid3.x, st);
     }
+    if (!bf && (d->variant == 3 || (d->variant == 0 && T != 2)) && d->O && T <= 3 && p.vec_qk && p.vec_v && p.dk % 32 == 0 && p.dv % 64 == 0) {
+        // third-generation structure on the exact-f32 MFMA (csrc/attention_pk.hip, attn_fwd3f_kernel).  Same box, N = 2048, H = 8,
+        // d_k = 256 (tools/attn3f_check.py): S = 81 2.85 -> 1.89 ms, S = 96 3.1 -> 2.1, S = 17 0.30 -> 0.27; S = 49 1.13 vs 1.17 and
+        // S = 33 0.97 vs 1.1 (the padded 64-key tiles cost MFMA time the first generation skips): 32 < S <= 64 stays where it was
+        int npw = (int)(((int64_t)p.N * p.H) / (T == 1 ? 8192 : 1024));
+        npw = npw < 1 ? 1 : (npw > 16 ? 16 : npw);
+        p.n_per_wg = npw;
+        return attn3f_fwd_launch(p, T, (p.N + npw - 1) / npw, st);
+    }
     const size_t lds = (size_t)(32 * T) * (32 * T + 1) * sizeof(float);
     dim3 grid(p.N, p.H);
-    if ((T == 1 || T == 3 || (bf && T == 2)) && p.vec_qk && p.vec_v && (p.dk % 32) == 0 && (p.dv % 32) == 0 && d->variant == 0) {
+    if ((T == 1 || T == 3 || (bf && T == 2)) && p.vec_qk && p.vec_v && (p.dk % 32) == 0 && (p.dv % 32) == 0 && (d->variant == 0 || d->variant == 2)) {
         // second-generation kernel (LDS-DMA staged Q K^T, register-resident V rows).  Interleaved A/B on one MI355X
         // (tools/attn_time.py): S = 17 0.283 vs 0.350 ms; S = 49 with exact-f32 products 1.10 vs 1.02 ms (the first generation's 4
         // waves per SIMD hide more latency than this kernel's 2) - stays on the first generation; with bf16 products (LSTC_BF16)
@@ -944,7 +953,7 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
     // S = 49: 1.63 vs 2.75 ms, S = 17: 0.53 vs 1.19 ms per LTN / STN layer (interleaved A/B); S = 81 (T = 3): 138 KB of LDS =
     // one workgroup per CU; with 4 waves that was no faster than the first generation (193 spilled registers, 7.3 vs 7.1 ms),
     // the 8-wave instantiation (two waves per SIMD, 12 rows / 3 DMA pieces / <= 2 jobs per wave) runs 4.3 ms
-    const bool v2 = T <= 3 && p.vec_qk && p.vec_v && (p.dk % 32) == 0 && (p.dv % 32) == 0 && d->variant == 0;
+    const bool v2 = T <= 3 && p.vec_qk && p.vec_v && (p.dk % 32) == 0 && (p.dv % 32) == 0 && d->variant != 1;
     if (d->dQ_pack || d->dK_pack || d->dV_pack) {
         // packed bf16 gradients: the staged kernel only, token rows and head columns filling the packs' even tile grid exactly
         const int64_t M = (int64_t)p.N * p.S;

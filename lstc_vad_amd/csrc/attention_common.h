@@ -45,5 +45,7 @@ typedef __bf16 attn_h2 __attribute__((ext_vector_type(2)));
 // (internal to the library: not part of the C ABI, hidden from the dynamic symbol table)
 __attribute__((visibility("hidden"))) int attn3_fwd_launch(const AttnParams& p, int T, int chunks, hipStream_t st);
 __attribute__((visibility("hidden"))) int attn3_bwd_launch(const AttnParams& p, int T, int chunks, hipStream_t st);
+// exact-f32 forward on the same structure (f32 operands, dense probs): csrc/attention_pk.hip
+__attribute__((visibility("hidden"))) int attn3f_fwd_launch(const AttnParams& p, int T, int chunks, hipStream_t st);
 
 }  // namespace lstc_attn

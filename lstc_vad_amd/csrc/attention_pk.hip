@@ -564,6 +564,224 @@ __global__ void __launch_bounds__(64 * (T + 1)) attn_bwd3_kernel(const AttnParam
     }
 }
 
+// =====================================================================================================
+// The same lane-=-query structure on the EXACT-f32 MFMA (fp32 mode; f32 Q, K, V, O in the token-major [M, H d] layout of the
+// projection GEMMs): logits^T = K (Q scale)^T leaves lane = query, the softmax is lane-local, the dropped probabilities ARE the
+// B operand of O^T = V^T Pd^T (v_mfma_f32_32x32x2_f32 contracts k = lane half: accumulator register r of the two lane halves holds
+// the key pair (j, j + 4), and the A operand reads V[j][c] / V[j + 4][c] with plain ds_read_b32 - no transposed read is needed for
+// 4-byte elements).  Staging: 32-feature chunks of 128-B rows, 8 rows x 128 B per LDS-DMA instruction, 16-B chunk index XOR
+// (row >> 1) & 7 on the source side (conflict-free ds_read_b128, as the second generation), the producer-wave ring of the
+// packed-operand kernels.  O leaves as 16-B stores (4 consecutive columns of the lane's row per accumulator register group).
+// =====================================================================================================
+struct A3UnitF { const float *b0, *b1; uint32_t ld0, ld1; };      // two [SP rows][32 floats] halves: base of (row 0, column 0), row pitch
+
+template <int T, int NB, typename UnitOf>
+__device__ __forceinline__ void a3f_producer(int n_begin, int n_end, int U, int S, UnitOf unit_of) {
+    constexpr int SP = 32 * T, HALF = SP * 128, SLOT = 2 * HALF, P = 8 * T;
+    static_assert(P * (NB - 2) <= 63, "vmcnt is a 6-bit counter");
+    const int lane = threadIdx.x & 63;
+    const int total = (n_end - n_begin) * U;
+    int is_n = n_begin, is_u = 0, is_slot = 0, issued = 0;
+    auto issue_next = [&]() {
+        if (issued >= total) return;
+        const A3UnitF un = unit_of(is_n, is_u);
+        const uint32_t lb = (uint32_t)(is_slot * SLOT);
+#pragma unroll
+        for (int pc = 0; pc < 4 * T; ++pc) {
+            const uint32_t r = (uint32_t)min(8 * pc + (lane >> 3), S - 1);
+            const uint32_t sw = ((((uint32_t)lane & 7u) ^ ((r >> 1) & 7u)) << 4);
+            const uint32_t lb0 = __builtin_amdgcn_readfirstlane(lb + pc * 1024), lb1 = __builtin_amdgcn_readfirstlane(lb + HALF + pc * 1024);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(r * un.ld0 * 4u + sw), "s"(un.b0), "s"(lb0) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(r * un.ld1 * 4u + sw), "s"(un.b1), "s"(lb1) : "memory");
+        }
+        ++issued;
+        if (++is_u == U) { is_u = 0; ++is_n; }
+        if (++is_slot == NB) is_slot = 0;
+    };
+#pragma unroll 1
+    for (int k = 0; k < NB - 1; ++k) issue_next();
+    int g = 0;
+#pragma unroll 1
+    for (int n = n_begin; n < n_end; ++n)
+#pragma unroll 1
+        for (int u = 0; u < U; ++u) {
+            const int rem = min(NB - 2, total - 1 - g);
+            if (rem >= NB - 2) A3_WAIT_VM(P * (NB - 2));
+            else if (NB > 3 && rem == NB - 3) A3_WAIT_VM(P * (NB > 3 ? NB - 3 : 0));
+            else A3_WAIT_VM(0);
+            __builtin_amdgcn_s_barrier();
+            issue_next();
+            ++g;
+        }
+}
+
+// (second launch-bound argument: waves per SIMD the register budget must allow - 3 workgroups per CU at T = 2, 6 and more at T = 1)
+template <int T, int NB>
+__global__ void __launch_bounds__(64 * (T + 1), T == 1 ? 4 : (T == 2 ? 3 : 2)) attn_fwd3f_kernel(const AttnParams p) {
+    const DropKey dkn = drop_key_now(p.dkey);
+    constexpr int SP = 32 * T, HALF = SP * 128, SLOT = 2 * HALF;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const char* ring = reinterpret_cast<const char*>(sm);
+    const int h = (int)(blockIdx.x % (unsigned)p.H), chunk = (int)(blockIdx.x / (unsigned)p.H), S = p.S;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, h2 = lane >> 5;
+    const int n_begin = chunk * p.n_per_wg, n_end = min(p.N, n_begin + p.n_per_wg);
+    const int nq = p.dk >> 5, nvp = p.dv >> 6, U = nq + nvp;
+    if (wave == T) {
+        a3f_producer<T, NB>(n_begin, n_end, U, S, [&](int n, int u) -> A3UnitF {
+            A3UnitF un;
+            if (u < nq) {
+                un.b0 = p.Q + (size_t)n * S * p.ldq + (size_t)h * p.dk + 32 * u; un.ld0 = (uint32_t)p.ldq;
+                un.b1 = p.K + (size_t)n * S * p.ldk + (size_t)h * p.dk + 32 * u; un.ld1 = (uint32_t)p.ldk;
+            } else {
+                un.b0 = p.V + (size_t)n * S * p.ldv + (size_t)h * p.dv + 64 * (u - nq); un.ld0 = un.ld1 = (uint32_t)p.ldv;
+                un.b1 = un.b0 + 32;
+            }
+            return un;
+        });
+        return;
+    }
+    const int i = 32 * wave + l31;
+    const bool has_bias = p.index_ld > 0 && S > 1;
+    const __amdgpu_buffer_rsrc_t r_index = __builtin_amdgcn_make_buffer_rsrc(const_cast<int64_t*>(p.index), 0,
+        has_bias ? (S - 1) * p.index_ld * 8 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_table = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.table), 0,
+        has_bias ? (p.table_rows > 0 ? p.table_rows * p.H * 4 : 0x7fffffff) : 0, 0x00020000);
+    float biasr[T][16];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = 32 * t + 8 * (r >> 2) + 4 * h2 + (r & 3);
+            const bool pair = i >= 1 && j >= 1 && i < S && j < S;
+            const uint32_t ix = __builtin_amdgcn_raw_buffer_load_b32(r_index, pair ? (uint32_t)((i - 1) * p.index_ld + (j - 1)) * 8u : 0xFFFFFFFFu, 0, 0);
+            const float b = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_table, ((ix * (uint32_t)p.H + (uint32_t)h) * 4u) | (pair ? 0u : 0xFFFFFFFFu), 0, 0));
+            biasr[t][r] = b + (j < S ? 0.f : -INFINITY);
+        }
+    // fragment offsets: this lane half's 16-float run of row r of a staged chunk; V[j][c] of a staged tile
+    const int keyq = (i >> 1) & 7, keyk = (l31 >> 1) & 7;
+    int offq[4], offk[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        offq[q] = i * 128 + (((4 * h2 + q) ^ keyq) << 4);
+        offk[q] = l31 * 128 + (((4 * h2 + q) ^ keyk) << 4);
+    }
+    int cslot = 0;
+    floatx16 acc[T];
+#pragma unroll 1
+    for (int n = n_begin; n < n_end; ++n) {
+#pragma unroll 1
+        for (int u = 0; u < U; ++u) {
+            A3_LDS_BARRIER();
+            const char* slot = ring + cslot * SLOT;
+            if (u < nq) {
+                if (u == 0) {
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+                }
+                float fq[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const a3_f4 v = *reinterpret_cast<const a3_f4*>(slot + offq[q]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fq[4 * q + e] = v[e] * p.scale;
+                }
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    float fk[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const a3_f4 v = *reinterpret_cast<const a3_f4*>(slot + HALF + t * 4096 + offk[q]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) fk[4 * q + e] = v[e];
+                    }
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fk[s], fq[s], acc[t], 0, 0, 0);
+                }
+                if (u == nq - 1) {
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float x = acc[t][r] + biasr[t][r];
+                            acc[t][r] = x;
+                            m = fmaxf(m, x);
+                        }
+                    m = fmaxf(m, __shfl_xor(m, 32, 64));
+                    float sum = 0.f;
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float e = expf(acc[t][r] - m);
+                            acc[t][r] = e;
+                            sum += e;
+                        }
+                    sum += __shfl_xor(sum, 32, 64);
+                    float* pr_row = p.probs + (((size_t)n * p.H + h) * S + (size_t)min(i, S - 1)) * S;
+                    const uint32_t flat_i = ((uint32_t)n * p.H + h) * (uint32_t)(S * S) + (uint32_t)(i * S);
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int j0 = 32 * t + 8 * g4 + 4 * h2;
+                            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                            f4u pv;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pv[e] = acc[t][4 * g4 + e] / sum;
+                            if (i < S) {          // dense [S][S] rows (the backward kernels read that layout): 4-B aligned 16-B stores
+                                if (j0 + 3 < S) *reinterpret_cast<f4u*>(pr_row + j0) = pv;
+                                else {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        if (j0 + e < S) pr_row[j0 + e] = pv[e];
+                                }
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float v = pv[e];
+                                if (p.has_drop) v = drop_keep(flat_i + (uint32_t)(j0 + e), dkn) ? v * dkn.scale : 0.f;
+                                acc[t][4 * g4 + e] = v;
+                            }
+                        }
+                }
+            } else {
+                // ---- O^T[two 32-column tiles][queries of this wave] = V^T Pd^T
+                const int ct = 2 * (u - nq);
+                float* o_row = p.O + ((size_t)n * S + (size_t)min(i, S - 1)) * p.ldo + (size_t)h * p.dv;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const char* Vs = slot + hf * HALF;
+                    floatx16 o;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int jl = (r & 3) + 8 * (r >> 2) + 4 * h2;                    // key row inside the 32-key tile
+                            const float a = *reinterpret_cast<const float*>(Vs + t * 4096 + jl * 128 + ((((l31 >> 2)) ^ ((jl >> 1) & 7)) << 4) + (l31 & 3) * 4);
+                            o = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[t][r], o, 0, 0, 0);
+                        }
+                    if (i < S) {
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            a3_f4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = o[4 * g4 + e];
+                            *reinterpret_cast<a3_f4*>(o_row + 32 * (ct + hf) + 8 * g4 + 4 * h2) = v;
+                        }
+                    }
+                }
+            }
+            if (++cslot == NB) cslot = 0;
+        }
+    }
+}
+
 template <typename Kern>
 void set_lds(Kern k, size_t lds) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -585,6 +803,20 @@ int attn3_fwd_launch(const AttnParams& p, int T, int chunks, hipStream_t st) {
     } while (0)
     if (T == 1) LSTC_FWD3(1, 6); else if (T == 2) LSTC_FWD3(2, 9); else if (T == 3) LSTC_FWD3(3, 6); else return LSTC_E_RANGE;
 #undef LSTC_FWD3
+    return lstc_launch_status();
+}
+
+int attn3f_fwd_launch(const AttnParams& p, int T, int chunks, hipStream_t st) {
+#define LSTC_FWD3F(TT, NBB)                                                                \
+    do {                                                                                   \
+        static LstcDevOnce once3;                                                          \
+        const int dev3_ = once3.begin();                                                   \
+        if (dev3_ >= 0) { set_lds(attn_fwd3f_kernel<TT, NBB>, 160 * 1024); once3.end(dev3_); } \
+        hipLaunchKernelGGL((attn_fwd3f_kernel<TT, NBB>), dim3((unsigned)chunks * (unsigned)p.H), 64 * (TT + 1), \
+                           (size_t)NBB * 2 * (32 * TT) * 128, st, p);                      \
+    } while (0)
+    if (T == 1) LSTC_FWD3F(1, 3); else if (T == 2) LSTC_FWD3F(2, 3); else if (T == 3) LSTC_FWD3F(3, 3); else return LSTC_E_RANGE;
+#undef LSTC_FWD3F
     return lstc_launch_status();
 }
 

@@ -1945,3 +1945,38 @@ def test_packed_input_attention_sequence_length_sweep(S):
         assert max_abs_diff(new[3], ref[3]) < 1e-5 * float(ref[3].abs().max()) + 1e-6
     finally:
         Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
+
+
+@pytest.mark.parametrize("S,dk,H", [(17, 256, 8), (81, 256, 8), (2, 64, 4), (19, 64, 4), (32, 64, 4), (33, 64, 4), (49, 128, 2), (64, 64, 4),
+                                    (65, 64, 4), (96, 64, 4)])
+def test_f32_lane_query_attention_forward_matches_the_first_generation(S, dk, H):
+    """fp32 mode: attn_fwd3f_kernel (lane = query, exact-f32 MFMA, producer-wave ring; the default for S <= 32 and 64 < S <= 96,
+    LstcAttnDesc.variant = 3 elsewhere) against the first-generation kernel (variant 1): probabilities and O to f32 summation
+    order, with relative bias (read through the top-left of a larger index), dropout, partial last workgroup chunk (N = 300 is
+    not a multiple of the sequences per workgroup)."""
+    from lstc_vad_amd import functional as Fn
+    N = 300
+    M = N * S
+    L = max(1, (S - 1 + 15) // 16)
+    g = torch.Generator(device=DEV).manual_seed(2000 + S)
+    q, k, v = (torch.randn(M, H * dk, device=DEV, generator=g) for _ in range(3))
+    index = orc.relative_position_index_3d(L, 4).to(DEV)
+    table = torch.randn((2 * L - 1) * 49, H, device=DEV, generator=g) * 0.3
+    try:
+        Fn._ATTN_VARIANT = 1
+        o1, p1 = Fn.attn_fwd(q, k, v, N, S, H, dk, dk, table, index, 0.2, 5)
+        Fn._ATTN_VARIANT = 3
+        o3, p3 = Fn.attn_fwd(q, k, v, N, S, H, dk, dk, table, index, 0.2, 5)
+        o3n, p3n = Fn.attn_fwd(q, k, v, N, S, H, dk, dk, None, None, 0.0, 0)          # no bias, no dropout
+        Fn._ATTN_VARIANT = 0
+        o0, p0 = Fn.attn_fwd(q, k, v, N, S, H, dk, dk, table, index, 0.2, 5)
+        Fn._ATTN_VARIANT = 1
+        o1n, p1n = Fn.attn_fwd(q, k, v, N, S, H, dk, dk, None, None, 0.0, 0)
+    finally:
+        Fn._ATTN_VARIANT = 0
+    torch.cuda.synchronize()
+    assert max_abs_diff(p3, p1) < 2e-6 and max_abs_diff(o3, o1) < 2e-5 * max(1.0, float(o1.abs().max()))
+    assert max_abs_diff(p0, p1) < 2e-6 and max_abs_diff(o0, o1) < 2e-5 * max(1.0, float(o1.abs().max()))
+    assert max_abs_diff(p3n, p1n) < 2e-6 and max_abs_diff(o3n, o1n) < 2e-5 * max(1.0, float(o1n.abs().max()))
+    if S <= 32 or S > 64:
+        assert torch.equal(o0, o3) and torch.equal(p0, p3)          # the default IS the lane-=-query kernel there
