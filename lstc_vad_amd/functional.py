@@ -593,7 +593,8 @@ def attn_fwd_pack(N, S, H, dv) -> bool:
 
 def _qkv_pack_desc(d, qkv: "Packed", H, dk, dv):
     """Packed-input form of LstcAttnDesc: Q | K | V are the column blocks of ONE pack (the fused projection's output)."""
-    assert qkv.kind == _lib.BF16P and qkv.K == H * (2 * dk + dv)
+    if not (qkv.kind == _lib.BF16P and qkv.K == H * (2 * dk + dv)):
+        raise RuntimeError(f"packed Q | K | V operand: expected a bf16 pack of {H * (2 * dk + dv)} columns, got kind {qkv.kind}, {qkv.K} columns")
     d.in_pack_cols, d.Q_col0, d.K_col0, d.V_col0 = qkv.K, 0, H * dk, 2 * H * dk
     d.Q = d.K = d.V = dev_ptr(qkv.buf)
 
@@ -664,7 +665,8 @@ def attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, p_drop, seed, ou
     packed-input kernel, ``packed="fused"`` implied."""
     in_pack = isinstance(q, Packed)
     if in_pack:
-        assert isinstance(do, Packed) and do.K == H * dv and do.kind == _lib.BF16P
+        if not (isinstance(do, Packed) and do.K == H * dv and do.kind == _lib.BF16P):
+            raise RuntimeError("attn_bwd: a packed Q | K | V operand needs dO as a packed bf16 operand [N*S, H*d_v] too")
         packed = "fused"
     if packed:
         lib = _lib.load()
@@ -700,7 +702,8 @@ def attn_bwd(do, q, k, v, probs, N, S, H, dk, dv, table, index, p_drop, seed, ou
     d.scale = 1.0 / (dk ** 0.5)
     d.dropout_p, d.dropout_seed = float(p_drop), int(seed)
     d.probs, d.probs_ld = dev_ptr(probs), probs.stride(2)
-    assert probs.stride(3) == 1 and probs.stride(1) == S * probs.stride(2) and probs.stride(0) == H * S * probs.stride(2)
+    if not (probs.stride(3) == 1 and probs.stride(1) == S * probs.stride(2) and probs.stride(0) == H * S * probs.stride(2)):
+        raise RuntimeError(f"attn_bwd: probs must be [N, H, S, S] rows of one pitch (strides {probs.stride()})")
     if in_pack:
         _qkv_pack_desc(d, q, H, dk, dv)
         d.dO, d.dO_pack_cols, d.dO_col0 = dev_ptr(do.buf), do.K, 0
