@@ -1,10 +1,10 @@
 // C-ABI front door: dtype dispatch, version, error strings.
 #include "lstc_common.h"
 
-int lstc_gemm_f32_impl(const LstcGemmDesc* d, hipStream_t st);
-int lstc_gemm_bf16_impl(const LstcGemmDesc* d, hipStream_t st) __attribute__((weak));
-int lstc_gemm_f32x3_impl(const LstcGemmDesc* d, hipStream_t st);
-int lstc_gemm_bf16p_impl(const LstcGemmDesc* d, hipStream_t st);
+__attribute__((visibility("hidden"))) int lstc_gemm_f32_impl(const LstcGemmDesc* d, hipStream_t st);
+__attribute__((visibility("hidden"))) int lstc_gemm_bf16_impl(const LstcGemmDesc* d, hipStream_t st) __attribute__((weak));
+__attribute__((visibility("hidden"))) int lstc_gemm_f32x3_impl(const LstcGemmDesc* d, hipStream_t st);
+__attribute__((visibility("hidden"))) int lstc_gemm_bf16p_impl(const LstcGemmDesc* d, hipStream_t st);
 
 static std::atomic<const uint64_t*> g_seed_dev{nullptr};
 const uint64_t* lstc_seed_dev_current() { return g_seed_dev.load(std::memory_order_acquire); }

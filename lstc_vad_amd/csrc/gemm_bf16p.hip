@@ -794,7 +794,7 @@ inline int64_t p1_kbp(int64_t K) { const int64_t kb = (K + 31) / 32; return kb +
 }  // namespace
 
 // Packed-operand bf16 GEMM behind lstc_gemm (dtype LSTC_BF16P): d->A / d->B point to lstc_pack1 outputs.
-int lstc_gemm_bf16p_impl(const LstcGemmDesc* d, hipStream_t st) {
+__attribute__((visibility("hidden"))) int lstc_gemm_bf16p_impl(const LstcGemmDesc* d, hipStream_t st) {
     if (!d->A || !d->B || !d->C) return LSTC_E_NULL;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (!(d->flags & LSTC_EPI_OUT_PACK) && d->ldc < d->N)) return LSTC_E_SHAPE;
     if (d->batch > 1) return LSTC_E_UNSUPPORTED;

@@ -958,7 +958,7 @@ int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipS
 
 }  // namespace
 
-int lstc_gemm_f32_impl(const LstcGemmDesc* d, hipStream_t st) {
+__attribute__((visibility("hidden"))) int lstc_gemm_f32_impl(const LstcGemmDesc* d, hipStream_t st) {
     if (!d->A || !d->B || !d->C) return LSTC_E_NULL;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return LSTC_E_SHAPE;
     const int a_min = d->transA ? d->M : d->K, b_min = d->transB ? d->K : d->N;

@@ -754,7 +754,7 @@ __global__ void __launch_bounds__(NT, 1) gemm_pkw_kernel(const PkParams p) {
 }  // namespace
 
 // Packed-operand GEMM behind lstc_gemm (dtype LSTC_F32X3): d->A / d->B point to lstc_pack3 outputs for [M, K] / [N, K].
-int lstc_gemm_f32x3_impl(const LstcGemmDesc* d, hipStream_t st) {
+__attribute__((visibility("hidden"))) int lstc_gemm_f32x3_impl(const LstcGemmDesc* d, hipStream_t st) {
     if (!d->A || !d->B || !d->C) return LSTC_E_NULL;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->ldc < d->N) return LSTC_E_SHAPE;
     if (d->batch > 1) return LSTC_E_UNSUPPORTED;

@@ -27,7 +27,8 @@ __host__ __device__ inline void drop_key_mix(DropKey& k, uint64_t seed) {
 
 // lstc_dropout_seed_device (api.hip): while set, every launch of this process that draws a dropout mask carries the pointer
 // and re-derives its key from seed + *pointer ON THE DEVICE - a captured (hipGraph) step replays with fresh masks.
-const uint64_t* lstc_seed_dev_current();
+// (library-internal cross-unit symbols are hidden from the dynamic symbol table: the C ABI is include/lstc_hip.h)
+__attribute__((visibility("hidden"))) const uint64_t* lstc_seed_dev_current();
 
 inline DropKey make_drop_key(float p, uint64_t seed) {
     DropKey k;
