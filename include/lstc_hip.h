@@ -137,6 +137,13 @@ int lstc_pack3(const float* src, int64_t rows, int64_t K, int64_t ld, int32_t k_
  * 16-B aligned.  Same nn.Linear products as lstc_gemm (models/MultiHeadAttention.py:97-99,123; models/FFN.py:17). */
 int64_t lstc_pack1_bytes(int64_t rows, int64_t K);
 int lstc_pack1(const float* src, int64_t rows, int64_t K, int64_t ld, int32_t k_major, void* dst, void* stream);
+/* Several operands in ONE launch - the weights of a model after an optimizer step (models/MultiHeadAttention.py:97-99,123 and
+ * models/FFN.py:17,19 each need their nn.Linear weight in both layouts: ~35 launches of 10-20 us otherwise).  Each item as
+ * lstc_pack1's arguments; results are bit for bit those of `count` lstc_pack1 calls. */
+typedef struct LstcPackItem {
+    const float* src; int64_t rows, K, ld; int32_t k_major; void* dst;
+} LstcPackItem;
+int lstc_pack1_multi(const LstcPackItem* items, int32_t count, void* stream);
 /* out[k] (+)= sum over rows of the packed [rows, K] operand (bf16 values added in f32; two passes through `partial`
  * [n_partial, K]): the bias gradient db1 = column sums of the hidden's gradient (autograd of models/FFN.py:17) when that
  * gradient exists only as the packed output of a LSTC_EPI_OUT_PACK product. */

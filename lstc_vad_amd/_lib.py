@@ -25,7 +25,7 @@ EXPORTS = (
     "lstc_layernorm_bwd_drop_pack", "lstc_layernorm_bwd_drop",
     "lstc_cls_concat_fwd", "lstc_cls_concat_fwd_pack", "lstc_cls_concat_bwd", "lstc_colsum", "lstc_dropout_apply", "lstc_dropout_mask", "lstc_dropout_seed_device",
     "lstc_head_out_fwd", "lstc_head_out_bwd", "lstc_vad_loss", "lstc_adagrad_step", "lstc_adagrad_multi", "lstc_sqnorm_accum", "lstc_scale",
-    "lstc_gather_rows", "lstc_cast_f32_bf16", "lstc_cast_bf16_f32", "lstc_pack3", "lstc_pack3_bytes", "lstc_pack1", "lstc_pack1_bytes", "lstc_colsum_pack1", "lstc_gemm_splits",
+    "lstc_gather_rows", "lstc_cast_f32_bf16", "lstc_cast_bf16_f32", "lstc_pack3", "lstc_pack3_bytes", "lstc_pack1", "lstc_pack1_multi", "lstc_pack1_bytes", "lstc_colsum_pack1", "lstc_gemm_splits",
     "lstc_version", "lstc_strerror",
 )
 
@@ -56,6 +56,11 @@ class AttnDesc(C.Structure):
                 ("O_pack", C.c_void_p),
                 ("in_pack_cols", C.c_int32), ("Q_col0", C.c_int32), ("K_col0", C.c_int32), ("V_col0", C.c_int32),
                 ("dO_pack_cols", C.c_int32), ("dO_col0", C.c_int32), ("probs_ld", C.c_int32)]
+
+
+class PackItem(C.Structure):
+    """LstcPackItem (include/lstc_hip.h)."""
+    _fields_ = [("src", C.c_void_p), ("rows", C.c_int64), ("K", C.c_int64), ("ld", C.c_int64), ("k_major", C.c_int32), ("dst", C.c_void_p)]
 
 
 class AdagradItem(C.Structure):
@@ -121,6 +126,7 @@ def load():
         "lstc_pack3": [vp, i64, i64, i64, C.c_int32, vp, vp],
         "lstc_pack3_bytes": [i64, i64],
         "lstc_pack1": [vp, i64, i64, i64, C.c_int32, vp, vp],
+        "lstc_pack1_multi": [vp, C.c_int32, vp],
         "lstc_colsum_pack1": [vp, i64, i32, vp, i32, vp, i32, vp],
         "lstc_pack1_bytes": [i64, i64],
         "lstc_gemm_splits": [i32, i32, i32],

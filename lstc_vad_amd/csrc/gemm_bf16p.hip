@@ -45,10 +45,10 @@ constexpr int P1_SLACK = 65536;          // bytes after the tiles (TR feature-bl
 
 // ---- pack, K-contiguous source [rows, K] (ld): one workgroup per row block and 4 consecutive k tiles.
 constexpr int P1_KPB = 4;
-__global__ void __launch_bounds__(256) pack1_kc_kernel(const float* __restrict__ x, int rows, int K, long long ld,
-                                                       bf16_t* __restrict__ out, int KBp) {
+__device__ __forceinline__ void pack1_kc_block(const float* __restrict__ x, int rows, int K, long long ld, bf16_t* __restrict__ out, int KBp,
+                                               int block) {
     const int kgroups = (KBp + P1_KPB - 1) / P1_KPB;
-    const int kb0 = (blockIdx.x % kgroups) * P1_KPB, rb = blockIdx.x / kgroups;
+    const int kb0 = (block % kgroups) * P1_KPB, rb = block / kgroups;
     const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     float4 va[P1_KPB][2], vb[P1_KPB][2];
 #pragma unroll
@@ -88,11 +88,16 @@ __global__ void __launch_bounds__(256) pack1_kc_kernel(const float* __restrict__
     }
 }
 
-// ---- pack, k-major source [K, rows] (ld): the packed operand's row index runs along the source's contiguous dimension.
-__global__ void __launch_bounds__(256) pack1_km_kernel(const float* __restrict__ x, int rows, int K, long long ld,
+__global__ void __launch_bounds__(256) pack1_kc_kernel(const float* __restrict__ x, int rows, int K, long long ld,
                                                        bf16_t* __restrict__ out, int KBp) {
-    const int kb = blockIdx.x % KBp, rb = blockIdx.x / KBp;
-    bf16x8* o = reinterpret_cast<bf16x8*>(out) + (size_t)blockIdx.x * 512;
+    pack1_kc_block(x, rows, K, ld, out, KBp, (int)blockIdx.x);
+}
+
+// ---- pack, k-major source [K, rows] (ld): the packed operand's row index runs along the source's contiguous dimension.
+__device__ __forceinline__ void pack1_km_block(const float* __restrict__ x, int rows, int K, long long ld, bf16_t* __restrict__ out, int KBp,
+                                               int block) {
+    const int kb = block % KBp, rb = block / KBp;
+    bf16x8* o = reinterpret_cast<bf16x8*>(out) + (size_t)block * 512;
     const int r = threadIdx.x & 127, half = threadIdx.x >> 7;
     const int row = rb * 128 + r;
 #pragma unroll
@@ -103,6 +108,30 @@ __global__ void __launch_bounds__(256) pack1_km_kernel(const float* __restrict__
         for (int j = 0; j < 8; ++j) hh[j] = (bf16_t)((row < rows && k0 + j < K) ? x[(size_t)(k0 + j) * ld + row] : 0.f);
         o[r * 4 + (c ^ ((r >> 2) & 3))] = hh;
     }
+}
+__global__ void __launch_bounds__(256) pack1_km_kernel(const float* __restrict__ x, int rows, int K, long long ld,
+                                                       bf16_t* __restrict__ out, int KBp) {
+    pack1_km_block(x, rows, K, ld, out, KBp, (int)blockIdx.x);
+}
+
+// ---- several operands in ONE launch (lstc_pack1_multi: the weights of a model after an optimizer step - ~35 launches of 10-20 us,
+// most of them ramp-up and drain, become one).  The items ride in the kernel arguments; a workgroup finds its item by a wave-uniform
+// scan of the block offsets and runs the single-operand code on its local block index: results are those of lstc_pack1, bit for bit.
+constexpr int P1_MULTI_MAX = 56;
+struct P1Multi {
+    const float* src[P1_MULTI_MAX];
+    bf16_t* dst[P1_MULTI_MAX];
+    long long ld[P1_MULTI_MAX];
+    int rows[P1_MULTI_MAX], K[P1_MULTI_MAX], KBp[P1_MULTI_MAX], k_major[P1_MULTI_MAX];
+    int first_block[P1_MULTI_MAX + 1];
+    int count;
+};
+__global__ void __launch_bounds__(256) pack1_multi_kernel(const P1Multi b) {
+    int t = 0;
+    while (t + 1 < b.count && (int)blockIdx.x >= b.first_block[t + 1]) ++t;
+    const int block = (int)blockIdx.x - b.first_block[t];
+    if (b.k_major[t]) pack1_km_block(b.src[t], b.rows[t], b.K[t], b.ld[t], b.dst[t], b.KBp[t], block);
+    else pack1_kc_block(b.src[t], b.rows[t], b.K[t], b.ld[t], b.dst[t], b.KBp[t], block);
 }
 
 struct P1Params {
@@ -904,6 +933,37 @@ int lstc_pack1(const float* src, int64_t rows, int64_t K, int64_t ld, int32_t k_
         hipLaunchKernelGGL(pack1_kc_kernel, dim3((unsigned)(RBp * ((KBp + P1_KPB - 1) / P1_KPB))), dim3(256), 0, st, src, (int)rows, (int)K,
                            (long long)ld, out, (int)KBp);
     return lstc_launch_status();
+}
+
+int lstc_pack1_multi(const LstcPackItem* items, int32_t count, void* stream) {
+    if (!items) return LSTC_E_NULL;
+    if (count <= 0) return LSTC_E_SHAPE;
+    for (int32_t i = 0; i < count; ++i) {
+        const LstcPackItem& it = items[i];
+        if (!it.src || !it.dst) return LSTC_E_NULL;
+        if (it.rows <= 0 || it.K <= 0 || it.ld < (it.k_major ? it.rows : it.K)) return LSTC_E_SHAPE;
+        if (!aligned16(it.dst)) return LSTC_E_ALIGN;
+        if (p1_rbp(it.rows) * p1_kbp(it.K) > 0x7fffffffLL || it.rows > 0x7fffffffLL || it.K > 0x7fffffffLL) return LSTC_E_RANGE;
+    }
+    for (int32_t base = 0; base < count; base += P1_MULTI_MAX) {
+        P1Multi b;
+        b.count = count - base < P1_MULTI_MAX ? count - base : P1_MULTI_MAX;
+        int64_t blocks = 0;
+        for (int i = 0; i < b.count; ++i) {
+            const LstcPackItem& it = items[base + i];
+            const int64_t RBp = p1_rbp(it.rows), KBp = p1_kbp(it.K);
+            b.src[i] = it.src; b.dst[i] = reinterpret_cast<bf16_t*>(it.dst); b.ld[i] = it.ld;
+            b.rows[i] = (int)it.rows; b.K[i] = (int)it.K; b.KBp[i] = (int)KBp; b.k_major[i] = it.k_major ? 1 : 0;
+            b.first_block[i] = (int)blocks;
+            blocks += it.k_major ? RBp * KBp : RBp * ((KBp + P1_KPB - 1) / P1_KPB);
+            if (blocks > 0x7fffffffLL) return LSTC_E_RANGE;
+        }
+        for (int i = b.count; i <= P1_MULTI_MAX; ++i) b.first_block[i] = (int)blocks;
+        hipLaunchKernelGGL(pack1_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, b);
+        const int rc = lstc_launch_status();
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 }  // extern "C"

@@ -45,8 +45,12 @@ class Adagrad(torch.optim.Optimizer):
         if items:           # every parameter in ONE launch (lstc_adagrad_multi; element arithmetic of lstc_adagrad_step)
             arr = (_lib.AdagradItem * len(items))(*items)
             check(lib.lstc_adagrad_multi(arr, len(items), stream_ptr()), "lstc_adagrad_multi")
-        from .functional import bump_weight_epoch
-        bump_weight_epoch()          # weights changed through raw pointers: packed copies (f32x3 GEMM) are stale
+        from .functional import bump_weight_epoch, repack_weights
+        bump_weight_epoch()          # weights changed through raw pointers: packed copies (f32x3 / bf16 GEMM) are stale
+        if items and not torch.cuda.is_current_stream_capturing():
+            # bf16 mode: every packed weight copy of the finished step rebuilt in one launch (a captured step keeps the
+            # lazily issued packs of its forward instead: the graph replays those)
+            repack_weights([p for group in self.param_groups for p in group["params"]])
         return None
 
 

@@ -1980,3 +1980,70 @@ def test_f32_lane_query_attention_forward_matches_the_first_generation(S, dk, H)
     assert max_abs_diff(p3n, p1n) < 2e-6 and max_abs_diff(o3n, o1n) < 2e-5 * max(1.0, float(o1n.abs().max()))
     if S <= 32 or S > 64:
         assert torch.equal(o0, o3) and torch.equal(p0, p3)          # the default IS the lane-=-query kernel there
+
+
+def test_weights_repacked_in_one_launch_after_the_optimizer_step_give_the_same_training_run():
+    """bf16 mode: after Adagrad.step every packed weight copy the step used is rebuilt by ONE lstc_pack1_multi launch (leaf weights
+    in both layouts and the fused Q|K|V view); the next step issues no lstc_pack1 for a weight.  Three steps with and without
+    (LSTC_NO_REPACK behaviour): bit-identical weights; the multi launch equals per-item lstc_pack1 byte for byte."""
+    from argparse import Namespace
+    from lstc_vad_amd import functional as Fn, _lib
+    from lstc_vad_amd.engine import TrainStep
+    from lstc_vad_amd.models import Classifier, Encoder
+    lib = _lib.load()
+    # (a) the kernel: three operands, both layouts, ragged sizes
+    g = torch.Generator(device=DEV).manual_seed(3)
+    srcs = [torch.randn(300, 200, device=DEV, generator=g), torch.randn(512, 1024, device=DEV, generator=g), torch.randn(130, 70, device=DEV, generator=g)]
+    items, singles, multis = [], [], []
+    for t in srcs:
+        for km in (0, 1):
+            rows, K = (t.shape[1], t.shape[0]) if km else t.shape
+            n = int(lib.lstc_pack1_bytes(rows, K))
+            a, b = torch.zeros(n, device=DEV, dtype=torch.uint8), torch.zeros(n, device=DEV, dtype=torch.uint8)
+            _lib.check(lib.lstc_pack1(_lib.dev_ptr(t), rows, K, t.stride(0), km, _lib.dev_ptr(a), _lib.stream_ptr()), "lstc_pack1")
+            items.append(_lib.PackItem(t.data_ptr(), rows, K, t.stride(0), km, b.data_ptr()))
+            singles.append(a); multis.append(b)
+    _lib.check(lib.lstc_pack1_multi((_lib.PackItem * len(items))(*items), len(items), _lib.stream_ptr()), "lstc_pack1_multi")
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(singles, multis))
+    # (b) the training loop
+    def run(repack):
+        torch.manual_seed(11)
+        enc = Encoder(n_layers=3, n_head=4, d_k=64, d_v=64, d_model=256, d_inner=512, MHA_attn_dropout=0.1, MHA_fc_dropout=0.1,
+                      FFN_dropout=0.1, MHA_layerNorm=True, FFN_layerNorm=True, relative_pe=True, window_size=4, window_depth=3).to(DEV).train()
+        head = Classifier(256, 0.3).to(DEV).train()
+        args = Namespace(batch_size=4, part_num=32, part_len=3, n_patch=16, lambda_1=0.01, lambda_MIL=1.0, lambda_CE=0.8, lambda_BCE=1.0,
+                         lambda_normal=0.2, lambda_abnormal=2.0, temporal_only=False, clip_grad=False)
+        Fn._REPACK_WEIGHTS = repack
+        Fn.reset_rng()
+        ts = TrainStep(args, "LTN", enc, head, 1e-4, 1e-2, 1e-3, fuse_qkv="on")
+        gg = torch.Generator(device=DEV).manual_seed(1)
+        nf = 0.5 * torch.relu(torch.randn(4, 96, 16, 256, device=DEV, generator=gg)); af = 0.5 * torch.relu(torch.randn(4, 96, 16, 256, device=DEV, generator=gg))
+        al = torch.rand(4, 96, 1, device=DEV, generator=gg)
+        calls = []
+        real = lib.lstc_pack1
+        for step in range(3):
+            n0 = len(_pack_log)
+            ts.step(nf, af, al)
+            calls.append(len(_pack_log) - n0)
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in enc.state_dict().items()}, calls
+    _pack_log = []
+    real_pack3 = Fn.pack3
+    def spy(t, k_major=False, kind=None):
+        _pack_log.append((tuple(t.shape), k_major))
+        return real_pack3(t, k_major, kind)
+    Fn.set_compute_dtype("bf16"); Fn.set_x3_threshold(0, 0, 0)
+    Fn.pack3 = spy
+    try:
+        w1, c1 = run(True)
+        w0, c0 = run(False)
+    finally:
+        Fn.pack3 = real_pack3
+        Fn._REPACK_WEIGHTS = True
+        Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
+    assert c1[0] == c0[0] and c1[1] < c0[1] and c1[2] < c0[2], (c1, c0)      # first step packs lazily either way
+    assert c0[1] - c1[1] >= 10, (c1, c0)                                      # every weight pack of steps 2, 3 came from the one launch
+    assert w1.keys() == w0.keys()
+    for k in w1:
+        assert torch.equal(w1[k], w0[k]), k
