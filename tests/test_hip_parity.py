@@ -1214,24 +1214,36 @@ def test_f32x3_wgrad_with_uneven_k_splits(T):
     assert max_abs_diff(dw, ref) < 2e-4 * (T ** 0.5) * 0.05
 
 
-@pytest.mark.parametrize("name", FULL_NAMES)
-def test_full_width_bf16_step_tracks_reference(name):
+@pytest.mark.parametrize("name,fused", [(n, False) for n in FULL_NAMES] + [("stn_full", True), ("ltn_ucf_full", True)])
+def test_full_width_bf16_step_tracks_reference(name, fused):
     """bf16 GEMM mode (packed bf16 kernel on every large product incl. TR weight gradients, bf16c on the heads) at BASELINE
     widths against the reference's fp32 run: scores within 2e-2, loss within 2e-2, every large gradient tensor's direction
-    (cosine on the sampled entries) > 0.98."""
+    (cosine on the sampled entries) > 0.98.  ``fused`` (the two cases whose token count fills whole 256-row pack tiles): the Q, K, V
+    projections share one buffer as engine.TrainStep arranges it, so the attention core runs on PACKED operands (Q|K|V and dO
+    read as packs, csrc/attention_pk.hip) - with the sliced relative-bias index of the UCF case and without bias (STN)."""
     from cases import sample_index
     from lstc_vad_amd import functional as Fn
     z, mode, skw, d, enc, head, nf, af, al = _full_width_models(name)
     enc, head = enc.to(DEV).train(), head.to(DEV).train()
+    if fused:
+        for layer in list(enc.layer_stack)[:-1]:
+            layer.slf_attn.fuse_qkv_()
     args = _args(mode, skw)
     nf, af, al = (torch.from_numpy(x).to(DEV) for x in (nf, af, al))
+    seen, real = [], Fn.attn_fwd
+    def spy(q, *a, **kw):
+        seen.append(isinstance(q, Fn.Packed))
+        return real(q, *a, **kw)
     Fn.set_compute_dtype("bf16")
+    Fn.attn_fwd = spy
     try:
         enc_out, outputs, loss, sc = _step(enc, head, mode, args, nf, af, al, d, cls_only=True)
         loss.backward()
         torch.cuda.synchronize()
     finally:
+        Fn.attn_fwd = real
         Fn.set_compute_dtype("fp32")
+    assert seen and all(seen) == fused, seen
     assert max_abs_diff(outputs.reshape(z["outputs"].shape), z["outputs"]) < 2e-2
     assert abs(float(sc[0]) - float(z["scalars"][0])) < 2e-2
     for k, p in enc.named_parameters():
