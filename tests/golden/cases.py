@@ -57,6 +57,17 @@ FULL_CASES = {
                                       FFN_layerNorm=True, relative_pe=True, window_size=4, window_depth=5),
                           dict(batch_size=2, part_num=16, part_len=5, n_patch=16), 34),   # 64 sequences, S = 81, 5184 tokens
 }
+# Full-width cases whose token count fills whole 256-row pack tiles (256 sequences): with the Q | K | V projections fused, the
+# bf16 mode runs its attention core on PACKED operands (csrc/attention_pk.hip) at S = 49 (two query tiles) and S = 81 (three).
+# Same recipe and fixture format as FULL_CASES; used by the GPU tests only (the CPU oracle suite keeps the smaller FULL_CASES).
+PACKED_CASES = {
+    "ltn_full_256": ("LTN", dict(d_model=2048, n_head=8, d_k=256, d_v=256, d_inner=4096, MHA_layerNorm=True,
+                                 FFN_layerNorm=True, relative_pe=True, window_size=4, window_depth=3),
+                     dict(batch_size=8, part_num=16, part_len=3, n_patch=16), 35),    # 256 sequences, S = 49, 12544 tokens
+    "ltn_ubnormal_full_256": ("LTN", dict(d_model=1024, n_head=8, d_k=256, d_v=256, d_inner=4096, MHA_layerNorm=True,
+                                          FFN_layerNorm=True, relative_pe=True, window_size=4, window_depth=5),
+                              dict(batch_size=8, part_num=16, part_len=5, n_patch=16), 36),   # 256 sequences, S = 81, 20736 tokens
+}
 N_SAMPLE = 256
 
 

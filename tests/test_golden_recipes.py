@@ -75,3 +75,13 @@ def test_make_golden_full_width_reproduces_committed_fixtures(tmp_path):
     _run("make_golden.py", tmp_path, "--only", ",".join(FULL_CASES))
     for name in FULL_CASES:
         _same(os.path.join(tmp_path, name + ".npz"), os.path.join(GOLD, name + ".npz"))
+
+
+@pytest.mark.skipif(os.environ.get("LSTC_SLOW_GOLDEN", "0") != "1", reason="several minutes of reference CPU time: LSTC_SLOW_GOLDEN=1")
+def test_make_golden_packed_cases_reproduce_committed_fixtures(tmp_path):
+    """cases.PACKED_CASES (256 sequences at S = 49 / S = 81, the shapes on which the bf16 mode's attention core runs on packed
+    operands): same generator, opt-in because the reference needs minutes of CPU time for them."""
+    from cases import PACKED_CASES
+    _run("make_golden.py", tmp_path, "--only", ",".join(PACKED_CASES))
+    for name in PACKED_CASES:
+        _same(os.path.join(tmp_path, name + ".npz"), os.path.join(GOLD, name + ".npz"))
