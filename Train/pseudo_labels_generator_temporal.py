@@ -1,12 +1,26 @@
 #!/usr/bin/env python3
-"""MI355X drop-in for the reference's Train/pseudo_labels_generator_temporal.py: same flags (lstc_vad_amd/cli_flags.json), same loop,
-HIP kernels underneath.  See lstc_vad_amd/cli.py."""
+"""MI355X drop-in for the reference's Train/pseudo_labels_generator_temporal.py: same flags (lstc_vad_amd/cli_flags.json), same loop, HIP kernels
+underneath (lstc_vad_amd/cli.py).  The module exports what the reference's module exports (generator :22, parser_arg :148),
+so ``from Train.pseudo_labels_generator_temporal import generator`` written against the reference keeps working."""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from lstc_vad_amd.cli import main  # noqa: E402
+from lstc_vad_amd import cli, losses  # noqa: E402
+
+SCRIPT = "pseudo_labels_generator_temporal"
+
+
+def parser_arg():
+    """Train/pseudo_labels_generator_temporal.py:148: the script's flags parsed from sys.argv."""
+    return cli.complete_args(SCRIPT)
+
+
+def generator(args):
+    """Train/pseudo_labels_generator_temporal.py:22: score every training video and write the pseudo-label file."""
+    return cli.generate_pseudo_labels(SCRIPT, args=args)
+
 
 if __name__ == "__main__":
-    main("pseudo_labels_generator_temporal")
+    cli.main(SCRIPT)

@@ -1,12 +1,37 @@
 #!/usr/bin/env python3
-"""MI355X drop-in for the reference's Train/temporal_transformer_shanghaitech.py: same flags (lstc_vad_amd/cli_flags.json), same loop,
-HIP kernels underneath.  See lstc_vad_amd/cli.py."""
+"""MI355X drop-in for the reference's Train/temporal_transformer_shanghaitech.py: same flags (lstc_vad_amd/cli_flags.json), same loop, HIP kernels
+underneath (lstc_vad_amd/cli.py).  The module exports what the reference's module exports (get_CE_loss :21, get_MIL_loss :25, train :38, parser_arg :257),
+so ``from Train.temporal_transformer_shanghaitech import get_MIL_loss`` written against the reference keeps working."""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from lstc_vad_amd.cli import main  # noqa: E402
+from lstc_vad_amd import cli, losses  # noqa: E402
+
+SCRIPT = "temporal_transformer_shanghaitech"
+
+
+def parser_arg():
+    """Train/temporal_transformer_shanghaitech.py:257: the script's flags parsed from sys.argv."""
+    return cli.complete_args(SCRIPT)
+
+
+def get_CE_loss(args, outputs, labs):
+    """Train/temporal_transformer_shanghaitech.py:21-23: ``F.cross_entropy`` of the softmax OUTPUTS against soft targets."""
+    return losses.get_CE_loss(args, outputs, labs)
+
+
+def get_MIL_loss(args, y_pred):
+    """Train/temporal_transformer_shanghaitech.py:25-36: ``(loss, err, l1)`` of part scores ``y_pred`` [2*bs*part_num] - bag score = max over parts; l1 on the
+    flat slice ``y_pred[bs:]`` exactly as upstream spells it."""
+    return losses.get_MIL_loss(args, y_pred, 1)
+
+
+def train(args):
+    """Train/temporal_transformer_shanghaitech.py:38: the training loop on a parsed (or caller-built) argument namespace."""
+    return cli.train(SCRIPT, args=args)
+
 
 if __name__ == "__main__":
-    main("temporal_transformer_shanghaitech")
+    cli.main(SCRIPT)

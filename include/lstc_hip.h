@@ -95,11 +95,12 @@ typedef struct LstcGemmDesc {
                                        into C, which the caller must have zeroed (only alpha epilogue allowed).
                                        LSTC_F32X3 with batch_stride_c != 0: split z writes its partial product to
                                        C + z*batch_stride_c instead (no atomics; the caller sums the partials) */
-    int32_t variant;                /* 0 = library default tile (LSTC_F32: 128x128, the rows of a mostly empty last tile round on the
-                                       64x64 variant, K <= 2048 / N <= 2048 products on the persistent walk of the same loop - bit-identical
-                                       results); 1..12 select a documented tile variant (tuning / tests; 12 = the persistent kernel);
-                                       anything else -> LSTC_E_UNSUPPORTED.  Timing-only ablation variants exist only in
-                                       -DLSTC_TUNING builds (tools/gemm_check), never in the production library */
+    int32_t variant;                /* 0 = library default tile (LSTC_F32: 128x128 tiles, one tile per workgroup, with the rows of a
+                                       mostly empty last tile round on the 64x64 variant - bit-identical results; the default NEVER
+                                       selects the persistent kernel); 1..12 select a documented tile variant (tuning / tests;
+                                       12 = the persistent walk of the default loop, bit-identical, measured slower - in every
+                                       build); anything else -> LSTC_E_UNSUPPORTED.  Timing-only ablation variants (13-15) exist
+                                       only in -DLSTC_TUNING builds (tools/gemm_check), never in the production library */
     int32_t batch;                  /* 0/1 = single problem; >1: `batch` independent problems of identical shape, problem z
                                        uses A + z*batch_stride_a etc. (elements).  Per-head products of the last layer's
                                        CLS attention (q_h W_k,h etc.).  Only alpha / ACCUM epilogues. */
@@ -387,6 +388,23 @@ typedef struct LstcAdagradItem {
 int lstc_adagrad_multi(const LstcAdagradItem* items, int32_t count, void* stream);
 /* out[0] += sum(x^2) (f32 atomics over workgroup partials; caller zeroes) — for clip_grad_norm_. */
 int lstc_sqnorm_accum(const float* x, int64_t n, float* out, void* stream);
+
+/* torch.nn.utils.clip_grad_norm_(parameters, max_norm) (Train/temporal_transformer_shanghaitech.py:139-141) over a whole
+ * parameter list without a host read-back, so a captured step (HIP graph) can contain it:
+ *   lstc_sqnorm_multi      out[0] = sum over every tensor of sum(x^2), out[1] = its square root (the total norm the reference
+ *                          logs): one launch over all tensors (48 per launch) writing one
+ *                          partial per 8192-element slice into `scratch` (>= lstc_sqnorm_multi_scratch(items, count) floats),
+ *                          then one workgroup adds the partials in index order - bit-reproducible, no float atomics;
+ *   lstc_clip_scale_multi  x *= max_norm / (sqrt(sqnorm[0]) + 1e-6) for every tensor when that coefficient is < 1 (torch's
+ *                          clamp to 1), the coefficient formed ON THE DEVICE from the value lstc_sqnorm_multi left there.
+ * `items` is a HOST array (it rides in the kernel arguments). */
+typedef struct LstcVecItem {
+    float* x;
+    int64_t n;
+} LstcVecItem;
+int64_t lstc_sqnorm_multi_scratch(const LstcVecItem* items, int32_t count);
+int lstc_sqnorm_multi(const LstcVecItem* items, int32_t count, float* scratch, int64_t scratch_floats, float* out, void* stream);
+int lstc_clip_scale_multi(const LstcVecItem* items, int32_t count, const float* sqnorm, float max_norm, void* stream);
 
 /* x *= alpha in place: applies the clip_grad_norm_ coefficient to a gradient tensor. */
 int lstc_scale(float* x, int64_t n, float alpha, void* stream);

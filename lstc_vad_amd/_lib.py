@@ -25,6 +25,7 @@ EXPORTS = (
     "lstc_layernorm_bwd_drop_pack", "lstc_layernorm_bwd_drop",
     "lstc_cls_concat_fwd", "lstc_cls_concat_fwd_pack", "lstc_cls_concat_bwd", "lstc_colsum", "lstc_dropout_apply", "lstc_dropout_mask", "lstc_dropout_seed_device",
     "lstc_head_out_fwd", "lstc_head_out_bwd", "lstc_vad_loss", "lstc_adagrad_step", "lstc_adagrad_multi", "lstc_sqnorm_accum", "lstc_scale",
+    "lstc_sqnorm_multi_scratch", "lstc_sqnorm_multi", "lstc_clip_scale_multi",
     "lstc_gather_rows", "lstc_cast_f32_bf16", "lstc_cast_bf16_f32", "lstc_pack3", "lstc_pack3_bytes", "lstc_pack1", "lstc_pack1_multi", "lstc_pack1_bytes", "lstc_colsum_pack1", "lstc_gemm_splits",
     "lstc_version", "lstc_strerror",
 )
@@ -67,6 +68,11 @@ class AdagradItem(C.Structure):
     """LstcAdagradItem (include/lstc_hip.h)."""
     _fields_ = [("w", C.c_void_p), ("grad", C.c_void_p), ("state", C.c_void_p), ("n", C.c_int64),
                 ("lr", C.c_float), ("weight_decay", C.c_float), ("eps", C.c_float), ("grad_scale", C.c_float)]
+
+
+class VecItem(C.Structure):
+    """LstcVecItem (include/lstc_hip.h)."""
+    _fields_ = [("x", C.c_void_p), ("n", C.c_int64)]
 
 
 class LossDesc(C.Structure):
@@ -120,6 +126,9 @@ def load():
         "lstc_adagrad_multi": [C.POINTER(AdagradItem), i32, vp],
         "lstc_sqnorm_accum": [vp, i64, vp, vp],
         "lstc_scale": [vp, i64, f32, vp],
+        "lstc_sqnorm_multi_scratch": [C.POINTER(VecItem), i32],
+        "lstc_sqnorm_multi": [C.POINTER(VecItem), i32, vp, i64, vp, vp],
+        "lstc_clip_scale_multi": [C.POINTER(VecItem), i32, vp, f32, vp],
         "lstc_gather_rows": [vp, i64, vp, vp, i64, i64, vp],
         "lstc_cast_f32_bf16": [vp, vp, i64, vp],
         "lstc_cast_bf16_f32": [vp, vp, i64, vp],
@@ -138,6 +147,7 @@ def load():
         fn.restype = C.c_int
     lib.lstc_pack3_bytes.restype = C.c_int64
     lib.lstc_pack1_bytes.restype = C.c_int64
+    lib.lstc_sqnorm_multi_scratch.restype = C.c_int64
     lib.lstc_strerror.argtypes = [C.c_int]
     lib.lstc_strerror.restype = C.c_char_p
     _lib = lib

@@ -126,6 +126,20 @@ def build_parser(script: str) -> argparse.ArgumentParser:
     return p
 
 
+def complete_args(script: str, args=None, argv=None) -> Namespace:
+    """The argument namespace of ``script``: parsed from ``argv`` (``None`` = sys.argv), or - when a caller hands over the
+    Namespace it built itself, as code written against the reference's ``train(args)`` / ``generator(args)`` /
+    ``evaluation(args)`` does - that namespace on top of the script's flag defaults (so the flags this build adds, e.g.
+    ``--steps``, ``--compute_dtype``, need not be present)."""
+    parser = build_parser(script)
+    if args is None:
+        return parser.parse_args(argv)
+    full = parser.parse_args([])
+    for k, v in vars(args).items():
+        setattr(full, k, v)
+    return full
+
+
 def _apply_compute_dtype(args):
     from . import functional as Fn
     Fn.set_compute_dtype(getattr(args, "compute_dtype", "fp32"))
@@ -148,9 +162,9 @@ def _logger(args, script):
     return lg, log_dir
 
 
-def train(script: str, argv=None):
+def train(script: str, argv=None, args=None):
     mode, head_kind, pre = SCRIPTS[script]
-    args = build_parser(script).parse_args(argv)
+    args = complete_args(script, args, argv)
     if "LOCAL_RANK" not in os.environ:                      # single process: honour --gpu like the reference does
         os.environ.setdefault("HIP_VISIBLE_DEVICES", str(getattr(args, "gpu", 0)))
     import numpy as np
@@ -422,11 +436,11 @@ def score_video(enc, head, mode, feats, part_len):
     return torch.cat(out)
 
 
-def generate_pseudo_labels(script: str, argv=None):
+def generate_pseudo_labels(script: str, argv=None, args=None):
     """Train/pseudo_labels_generator_{spatio,temporal}.py: score every training video, keep ``score > threshold``
     (else 0), save ``{key: [n_clips, 1]}`` with ``np.save`` (the pickled-dict format utils/load_dataset.py:20 reads)."""
     mode = "LTN" if script.endswith("temporal") else "STN"
-    args = build_parser(script).parse_args(argv)
+    args = complete_args(script, args, argv)
     os.environ.setdefault("HIP_VISIBLE_DEVICES", str(getattr(args, "gpu", 0)))
     import numpy as np
     import torch
@@ -476,13 +490,13 @@ def generate_pseudo_labels(script: str, argv=None):
     return out
 
 
-def evaluate_cli(script: str, argv=None):
+def evaluate_cli(script: str, argv=None, args=None):
     """Test/evaluation_shanghaitech_ubnormal.py (:69-96) and Test/evaluation_UCF.py (:47-88): frame-level AUC of a
     trained LTN.  SHT/UBnormal: consecutive parts of ``part_len`` clips, a short tail is RE-WINDOWED to the video's last
     ``part_len`` clips (:83-84; unlike the pseudo-label generators, which feed the short tail as a shorter sequence).
     UCF: every video is averaged into 32 bins (linspace :54), parts of part_len = 2 bins (:42), features L2-normalised
     (:77).  All full parts of a video are scored in one launch sequence instead of one part per launch."""
-    args = build_parser(script).parse_args(argv)
+    args = complete_args(script, args, argv)
     os.environ.setdefault("HIP_VISIBLE_DEVICES", str(getattr(args, "gpu", 0)))
     import numpy as np
     import torch

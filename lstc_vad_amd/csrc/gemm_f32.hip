@@ -917,7 +917,8 @@ int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipS
     //       the swizzled per-lane source addresses of K-contiguous operands and the one-iteration latency budget cost
     //       more than the ds_write + staging registers they remove)
     //   2, 6, 5 = 256x128 with 8 waves (PIPE 1 / 2 / 0)                           115-126, never the best
-    //  12-15 = timing-only ablations of variant 8 (NT): no loads 142, no loads/LDS writes 146, +no barrier 146.5
+    //  13-15 = (-DLSTC_TUNING builds only) timing-only ablations of variant 8 (NT): no loads 142, no loads/LDS writes 146,
+    //          +no barrier 146.5.  12 is the persistent kernel in EVERY build.
     if (variant == 0) variant = 4;
     const int BM = (variant == 2 || variant == 5 || variant == 6 || variant == 9) ? 256 : variant == 11 ? 64 : 128, BN = variant == 11 ? 64 : 128;
     p.tilesM = (p.M + BM - 1) / BM;
@@ -925,7 +926,6 @@ int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipS
     switch (variant) {
         case 1: return launch_cfg<128, 128, 2, 2, 0, A_KC, B_KC>(p, va, vb, splits, st);
         case 11: return launch_cfg<64, 64, 2, 2, 0, A_KC, B_KC>(p, va, vb, splits, st);    // small tile: the tail rows of a row-split product
-#ifndef LSTC_TUNING     // (12-15 are timing ablations in the tuning build)
         //  12 = persistent PIPE 5 (gemm_f32_persist_kernel): next tile's first loads before the epilogue, float4 epilogue
         case 12: if (va && vb && p.a_bytes && p.b_bytes && splits == 1 && p.batch == 1 && p.K % BK == 0 && p.ktiles >= 4 && p.epi_f4)
                  {
@@ -934,7 +934,6 @@ int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipS
                  }
                  if (va && vb && p.a_bytes && p.b_bytes) return launch_cfg<128, 128, 2, 2, 5, A_KC, B_KC>(p, true, true, splits, st);
                  return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);
-#endif
         case 3: return launch_cfg<128, 128, 2, 2, 2, A_KC, B_KC>(p, va, vb, splits, st);
         case 6: return launch_cfg<256, 128, 4, 2, 2, A_KC, B_KC>(p, va, vb, splits, st);
         case 2: return launch_cfg<256, 128, 4, 2, 1, A_KC, B_KC>(p, va, vb, splits, st);
@@ -947,10 +946,9 @@ int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipS
         case 10: if (va && vb && p.K % BK == 0) return launch_cfg<128, 128, 2, 2, 4, A_KC, B_KC>(p, true, true, splits, st);
                  return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // LDS-DMA needs aligned rows, full K tiles
 #ifdef LSTC_TUNING      // timing-only ablations: products are WRONG by construction; never in the production library
-        case 12: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 1, A_KC, B_KC>(p, va, vb, splits, st); return LSTC_E_UNSUPPORTED;
-        case 13: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 3, A_KC, B_KC>(p, va, vb, splits, st); return LSTC_E_UNSUPPORTED;
-        case 14: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 7, A_KC, B_KC>(p, va, vb, splits, st); return LSTC_E_UNSUPPORTED;
-        case 15: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 4, A_KC, B_KC>(p, va, vb, splits, st); return LSTC_E_UNSUPPORTED;
+        case 13: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 1, A_KC, B_KC>(p, va, vb, splits, st); return LSTC_E_UNSUPPORTED;
+        case 14: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 3, A_KC, B_KC>(p, va, vb, splits, st); return LSTC_E_UNSUPPORTED;
+        case 15: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 7, A_KC, B_KC>(p, va, vb, splits, st); return LSTC_E_UNSUPPORTED;
 #endif
         default: return LSTC_E_UNSUPPORTED;
     }

@@ -20,9 +20,18 @@ struct DropKey {
     const uint64_t* seed_dev;      // device word ADDED to the seed when the kernel runs (lstc_dropout_seed_device), or NULL
 };
 
+// Seeds are LINEAR in the host's call counter (functional.next_seed: a captured step replays with seed + device word), so the
+// avalanche happens here: splitmix64's finaliser over the whole 64-bit seed, k0 / k1 = its two halves.  Consecutive seeds - the
+// dropout sites of one step, the steps of one run - get unrelated (k0, k1) pairs, hence independent masks (with k1 taken from the
+// seed's high word alone it was constant over a run and every mask was an XOR-shifted window of one table: ADVICE r3).
+// Wave-uniform scalar work, once per kernel (drop_key_now) or on the host (make_drop_key).
 __host__ __device__ inline void drop_key_mix(DropKey& k, uint64_t seed) {
-    k.k0 = (uint32_t)(seed & 0xffffffffu) * 0x9E3779B1u + 0x7F4A7C15u;
-    k.k1 = (uint32_t)(seed >> 32) * 0x85EBCA77u + 0x165667B1u;
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    k.k0 = (uint32_t)z;
+    k.k1 = (uint32_t)(z >> 32);
 }
 
 // lstc_dropout_seed_device (api.hip): while set, every launch of this process that draws a dropout mask carries the pointer

@@ -725,6 +725,70 @@ __global__ void __launch_bounds__(NT) sqnorm_kernel(const float* __restrict__ x,
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
 
+// clip_grad_norm_ over a parameter LIST in two launches and without a host read-back (the reference: one norm kernel per tensor, a
+// stack, a norm of norms and a python comparison, Train/temporal_transformer_shanghaitech.py:139-141).  Items ride in the kernel
+// arguments like adagrad_multi_kernel's; workgroup w owns one ADA_PER_WG-element slice of one tensor and writes ONE partial
+// (fixed slice -> workgroup map, fixed tree inside the workgroup), a single workgroup then adds the partials in index order:
+// the norm is run-to-run bit-identical (no float atomics).
+struct VecBatch {
+    float* x[ADA_MAX];
+    long long n[ADA_MAX];
+    int first_wg[ADA_MAX + 1];
+    int count;
+};
+__global__ void __launch_bounds__(NT) sqnorm_multi_kernel(const VecBatch b, float* __restrict__ partials) {
+    __shared__ float red[NT / 64];
+    int t = 0;
+    while (t + 1 < b.count && (int)blockIdx.x >= b.first_wg[t + 1]) ++t;
+    const float* __restrict__ x = b.x[t];
+    const int64_t n = b.n[t];
+    const int64_t e0 = (int64_t)((int)blockIdx.x - b.first_wg[t]) * ADA_PER_WG;
+    const int64_t e1 = min(n, e0 + ADA_PER_WG);
+    float s = 0.f;
+    if (aligned16(x)) {          // e0 is a multiple of 4: float4 over the whole quads, then the tensor's last 0-3 elements
+        const int64_t v1 = e1 >> 2;
+        for (int64_t i = (e0 >> 2) + threadIdx.x; i < v1; i += NT) {
+            const float4 v = reinterpret_cast<const float4*>(x)[i];
+            s += v.x * v.x; s += v.y * v.y; s += v.z * v.z; s += v.w * v.w;
+        }
+        for (int64_t i = (v1 << 2) + threadIdx.x; i < e1; i += NT) s += x[i] * x[i];
+    } else {
+        for (int64_t i = e0 + threadIdx.x; i < e1; i += NT) s += x[i] * x[i];
+    }
+    s = block_sum<NT>(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(NT) sum_partials_kernel(const float* __restrict__ partials, int64_t n, float* __restrict__ out) {
+    __shared__ float red[NT / 64];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += NT) s += partials[i];
+    s = block_sum<NT>(s, red);
+    if (threadIdx.x == 0) { out[0] = s; out[1] = sqrtf(s); }
+}
+// x *= min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) for every tensor of the list, the coefficient formed on the device
+// (torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1); coefficient 1 leaves the data untouched.
+__global__ void __launch_bounds__(NT) clip_scale_multi_kernel(const VecBatch b, const float* __restrict__ sqnorm, float max_norm) {
+    const float coef = max_norm / (sqrtf(sqnorm[0]) + 1e-6f);
+    if (!(coef < 1.0f)) return;
+    int t = 0;
+    while (t + 1 < b.count && (int)blockIdx.x >= b.first_wg[t + 1]) ++t;
+    float* __restrict__ x = b.x[t];
+    const int64_t n = b.n[t];
+    const int64_t e0 = (int64_t)((int)blockIdx.x - b.first_wg[t]) * ADA_PER_WG;
+    const int64_t e1 = min(n, e0 + ADA_PER_WG);
+    if (aligned16(x)) {
+        const int64_t v1 = e1 >> 2;
+        for (int64_t i = (e0 >> 2) + threadIdx.x; i < v1; i += NT) {
+            float4 v = reinterpret_cast<float4*>(x)[i];
+            v.x *= coef; v.y *= coef; v.z *= coef; v.w *= coef;
+            reinterpret_cast<float4*>(x)[i] = v;
+        }
+        for (int64_t i = (v1 << 2) + threadIdx.x; i < e1; i += NT) x[i] *= coef;
+    } else {
+        for (int64_t i = e0 + threadIdx.x; i < e1; i += NT) x[i] *= coef;
+    }
+}
+
 __global__ void __launch_bounds__(NT) scale_kernel(float* __restrict__ x, int64_t n, float alpha) {
     const int64_t stride = (int64_t)gridDim.x * NT;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) x[i] *= alpha;
@@ -1003,6 +1067,71 @@ int lstc_adagrad_multi(const LstcAdagradItem* items, int32_t count, void* stream
         b.first_wg[b.count] = wg;
         for (int i = b.count + 1; i <= ADA_MAX; ++i) b.first_wg[i] = wg;
         hipLaunchKernelGGL(adagrad_multi_kernel, dim3((unsigned)wg), NT, 0, (hipStream_t)stream, b);
+        const int rc = lstc_launch_status();
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+static int vec_batch(const LstcVecItem* items, int32_t base, int32_t count, VecBatch& b) {
+    b.count = count - base < ADA_MAX ? count - base : ADA_MAX;
+    int wg = 0;
+    for (int i = 0; i < b.count; ++i) {
+        b.x[i] = items[base + i].x; b.n[i] = items[base + i].n;
+        b.first_wg[i] = wg;
+        const int64_t nwg = (items[base + i].n + ADA_PER_WG - 1) / ADA_PER_WG;
+        if (nwg > 0x7fffffff - wg) return -1;
+        wg += (int)nwg;
+    }
+    for (int i = b.count; i <= ADA_MAX; ++i) b.first_wg[i] = wg;
+    return wg;
+}
+
+int64_t lstc_sqnorm_multi_scratch(const LstcVecItem* items, int32_t count) {
+    if (!items || count <= 0) return 0;
+    int64_t wg = 0;
+    for (int32_t i = 0; i < count; ++i) {
+        if (items[i].n <= 0) return 0;
+        wg += (items[i].n + ADA_PER_WG - 1) / ADA_PER_WG;
+    }
+    return wg;
+}
+
+int lstc_sqnorm_multi(const LstcVecItem* items, int32_t count, float* scratch, int64_t scratch_floats, float* out, void* stream) {
+    if (!items || !scratch || !out) return LSTC_E_NULL;
+    if (count <= 0) return LSTC_E_SHAPE;
+    for (int32_t i = 0; i < count; ++i) {
+        if (!items[i].x) return LSTC_E_NULL;
+        if (items[i].n <= 0) return LSTC_E_SHAPE;
+    }
+    const int64_t need = lstc_sqnorm_multi_scratch(items, count);
+    if (scratch_floats < need) return LSTC_E_SHAPE;
+    int64_t off = 0;
+    for (int32_t base = 0; base < count; base += ADA_MAX) {
+        VecBatch b;
+        const int wg = vec_batch(items, base, count, b);
+        if (wg < 0) return LSTC_E_RANGE;
+        hipLaunchKernelGGL(sqnorm_multi_kernel, dim3((unsigned)wg), NT, 0, (hipStream_t)stream, b, scratch + off);
+        const int rc = lstc_launch_status();
+        if (rc) return rc;
+        off += wg;
+    }
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), NT, 0, (hipStream_t)stream, scratch, need, out);
+    return lstc_launch_status();
+}
+
+int lstc_clip_scale_multi(const LstcVecItem* items, int32_t count, const float* sqnorm, float max_norm, void* stream) {
+    if (!items || !sqnorm) return LSTC_E_NULL;
+    if (count <= 0 || !(max_norm > 0.f)) return LSTC_E_SHAPE;
+    for (int32_t i = 0; i < count; ++i) {
+        if (!items[i].x) return LSTC_E_NULL;
+        if (items[i].n <= 0) return LSTC_E_SHAPE;
+    }
+    for (int32_t base = 0; base < count; base += ADA_MAX) {
+        VecBatch b;
+        const int wg = vec_batch(items, base, count, b);
+        if (wg < 0) return LSTC_E_RANGE;
+        hipLaunchKernelGGL(clip_scale_multi_kernel, dim3((unsigned)wg), NT, 0, (hipStream_t)stream, b, sqnorm, max_norm);
         const int rc = lstc_launch_status();
         if (rc) return rc;
     }

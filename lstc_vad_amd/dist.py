@@ -26,9 +26,14 @@ import torch.distributed as dist
 
 class GradAllReducer:
     def __init__(self, param_groups: Sequence[Iterable[torch.nn.Parameter]], group=None, overlap: bool = True,
-                 force: bool = False, reduce_dtype: str = "fp32"):
+                 force: bool = False, reduce_dtype: str = "fp32", direct: Iterable[torch.nn.Parameter] = ()):
         """``param_groups``: lists of parameters, one per bucket, ordered the way backward produces them
-        (head first, last encoder layer next, ...).  Every listed parameter MUST receive a gradient each step."""
+        (head first, last encoder layer next, ...).  Every listed parameter MUST receive a gradient each step.
+        ``direct``: parameters whose backward WRITES the gradient into the bucket itself (``functional.grad_sink`` /
+        ``deliver``: the weight-gradient GEMM's output, or the ordered sum of its split-K partials, lands in the bucket - no
+        fill, no accumulate pass; ``direct_grad_parameters`` lists them for an Encoder + head pair).  They are laid out first
+        in their bucket; only the remainder (biases, LayerNorms, bias tables: a few hundred KB) is zero-filled per step and
+        accumulated into by autograd."""
         self.group = group
         self.overlap = overlap
         # reduce_dtype "bf16": a bucket is rounded to bf16 (lstc_cast_f32_bf16), summed by RCCL at half the bytes and widened
@@ -46,22 +51,30 @@ class GradAllReducer:
         self._sizes: List[int] = []
         self._handles = []
         self._bucket_of = {}
+        self._accum_from: List[int] = []           # per bucket: first element of the autograd-accumulated (zero-filled) tail
+        direct_ids = {id(p) for p in direct}
         for bi, params in enumerate(param_groups):
             params = [p for p in params if p.requires_grad]
+            params = [p for p in params if id(p) in direct_ids] + [p for p in params if id(p) not in direct_ids]   # stable
             n = sum(p.numel() for p in params)
             if n == 0:
                 continue
             flat = torch.zeros(n, device=params[0].device, dtype=params[0].dtype)
             off = 0
             views = []
+            self._accum_from.append(sum(p.numel() for p in params if id(p) in direct_ids))
             for p in params:
                 v = flat[off:off + p.numel()].view_as(p)
-                p.grad = v                       # autograd accumulates in place into the bucket
+                p.grad = v                       # the optimizer reads the gradient here either way
                 views.append((p, v))
                 off += p.numel()
                 self._bucket_of[p] = len(self.buckets)
-                if self.active and overlap:
-                    p.register_post_accumulate_grad_hook(self._hook)
+                if id(p) in direct_ids:
+                    # the producing kernel writes into ``v`` and the Function calls back (functional.deliver): always installed -
+                    # also on one rank without a process group - so the single-rank bucket path runs what N ranks run
+                    p.__dict__["_lstc_grad_sink"] = (v, self._sink_done)
+                elif self.active and overlap:
+                    p.register_post_accumulate_grad_hook(self._hook)    # autograd accumulates in place into the bucket
             self.buckets.append(flat)
             if reduce_dtype == "bf16":
                 self._half.append(torch.empty(n, device=flat.device, dtype=torch.bfloat16))
@@ -73,12 +86,18 @@ class GradAllReducer:
     def zero_grad(self):
         """Replaces ``optimizer.zero_grad()``: clears the flat buckets and re-arms the hooks."""
         for bi, flat in enumerate(self.buckets):
-            flat.zero_()
+            if self._accum_from[bi] < flat.numel():
+                flat[self._accum_from[bi]:].zero_()        # direct gradients are overwritten by their kernels: no fill
             self._pending[bi] = self._sizes[bi]
             for p, v in self._views[bi]:
                 if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                     p.grad = v
         self._handles = []
+
+    def _sink_done(self, p):
+        """A direct gradient has been issued into its slot (called from the Function's backward, on the launch stream)."""
+        if self.active and self.overlap:
+            self._hook(p)
 
     def _hook(self, p):
         bi = self._bucket_of[p]
@@ -126,6 +145,22 @@ class GradAllReducer:
     def payload_bytes(self) -> int:
         src = self._half if self.reduce_dtype == "bf16" else self.buckets
         return sum(b.numel() * b.element_size() for b in src)
+
+
+def direct_grad_parameters(encoder, head) -> List[torch.nn.Parameter]:
+    """The weights of an ``Encoder`` + head pair whose gradient kernels write into a gradient sink (lstc_vad_amd.functional:
+    MHAFunction / MHAClsFunction / MHAClsAssocFunction / FFNFunction / HeadFunction): the four attention projections and the two
+    FFN matrices of every layer and the head's first Linear - 99.9 % of the gradient bytes."""
+    out = []
+    for layer in encoder.layer_stack:
+        a = layer.slf_attn
+        out += [a.w_qs.weight, a.w_ks.weight, a.w_vs.weight, a.fc.weight]
+        if getattr(layer, "FFN_need", True):
+            out += [layer.pos_ffn.w_1.weight, layer.pos_ffn.w_2.weight]
+    seq = getattr(head, "classifier", None) or getattr(head, "regressor", None)
+    if seq is not None:
+        out.append(seq[0].weight)
+    return out
 
 
 def encoder_head_buckets(encoder, head) -> List[List[torch.nn.Parameter]]:

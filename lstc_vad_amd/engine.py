@@ -13,7 +13,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from .dist import GradAllReducer, encoder_head_buckets
+from .dist import GradAllReducer, direct_grad_parameters, encoder_head_buckets
 from .losses import training_loss
 from .optim import Adagrad, clip_grad_norm_
 
@@ -44,7 +44,8 @@ class TrainStep:
                                   {"params": head.parameters(), "lr": lr_head}], weight_decay=weight_decay)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         force = os.environ.get("LSTC_FORCE_DIST", "0") == "1" and dist.is_available() and dist.is_initialized()
-        self.reducer = (GradAllReducer(encoder_head_buckets(encoder, head), group, force=force, reduce_dtype=grad_reduce_dtype)
+        self.reducer = (GradAllReducer(encoder_head_buckets(encoder, head), group, force=force, reduce_dtype=grad_reduce_dtype,
+                                       direct=direct_grad_parameters(encoder, head))
                         if (self.world > 1 or force) else None)
 
     @staticmethod
@@ -118,16 +119,19 @@ class GraphedStep:
       * inputs live in static buffers (``step`` copies the batch in); gradients, activations and split-K partials come out
         of the graph's private memory pool; the optimizer's one launch carries the parameter pointers, which never move;
       * no host sync and no host-dependent control flow inside a step (the five scalars stay on the device).
-    Not captured: the gradient all-reduce / bag exchange of a multi-rank job and ``clip_grad`` (it reads the norm back on
-    the host like upstream) - ``GraphedStep`` refuses those and the caller keeps ``TrainStep.step``."""
+      * ``--clip_grad`` (Train/temporal_transformer_shanghaitech.py:139-141) is two multi-tensor launches per parameter list
+        with the clip coefficient formed on the device (optim.clip_grad_norm_): captured like everything else.
+    Not captured: the gradient all-reduce / bag exchange of a multi-rank job - ``GraphedStep`` refuses that and the caller
+    keeps ``TrainStep.step``.
+
+    While the capture is open ``lstc_dropout_seed_device`` points EVERY dropout-drawing launch of the process at the seed word:
+    no other thread or stream may launch dropout kernels during construction (evaluation / feeder threads must be idle)."""
 
     def __init__(self, ts: TrainStep, norm_feats, abnorm_feats, abnorm_labs, warmup: int = 1):
         from . import _lib
         from . import functional as Fn
         if ts.reducer is not None or ts.world > 1 or ts.loss_exchange is not None:
             raise RuntimeError("GraphedStep: the multi-rank step (gradient all-reduce, bag exchange) is not captured")
-        if getattr(ts.args, "clip_grad", False):
-            raise RuntimeError("GraphedStep: --clip_grad reads the gradient norm on the host; not capturable")
         self.ts = ts
         dev = norm_feats.device
         self.nf, self.af, self.al = (torch.empty_like(t) for t in (norm_feats, abnorm_feats, abnorm_labs))
@@ -167,16 +171,24 @@ class GraphedStep:
             with torch.cuda.graph(self.graph):
                 loss, scalars, _ = ts.forward_loss(self.nf, self.af, self.al)
                 loss.backward()
+                if getattr(ts.args, "clip_grad", False):
+                    clip_grad_norm_(ts.encoder.parameters(), 10)
+                    clip_grad_norm_(ts.head.parameters(), 10)
                 ts.optimizer.step()
                 self.seed_word.add_(self.seeds_per_step)
         finally:
             _lib.check(lib.lstc_dropout_seed_device(None), "lstc_dropout_seed_device")
         self.scalars = scalars
-        assert Fn._counter - c0 == self.seeds_per_step, "a step must draw the same number of dropout seeds every time"
+        if Fn._counter - c0 != self.seeds_per_step:
+            raise RuntimeError("GraphedStep: a step must draw the same number of dropout seeds every time")
         Fn.reset_rng(c0)                      # nothing ran: the first replay IS the step with these seeds
         for p, n in zip(params, keep_n):
             ts.optimizer.state[p]["step"] = n
-        self._params = params
+        # eager Adagrad.step skips parameters without a gradient (LayerNorms the reference builds but never calls): only the
+        # ones the captured step really updates get their ``step`` count bumped per replay (state_dict parity with eager runs)
+        self._params = [p for p in params if p.grad is not None]
+        self._word_host = 0                   # host mirror of the device seed word (the graph's last node adds seeds_per_step)
+        self._c0 = c0                         # host seed counter the baked seeds were drawn at: word = Fn._counter - c0 at replay
 
     def step(self, norm_feats, abnorm_feats, abnorm_labs):
         """One optimisation step on this batch (shapes as at construction).  Returns the five scalars (a fresh device
@@ -186,7 +198,13 @@ class GraphedStep:
             self.nf.copy_(norm_feats.reshape(self.nf.shape))
             self.af.copy_(abnorm_feats.reshape(self.af.shape))
             self.al.copy_(abnorm_labs.reshape(self.al.shape))
+        # the graph's seeds are (baked seed + *word): keep the device word in step with the host counter, so eager seed draws
+        # between replays (an evaluation pass with dropout, another TrainStep) never make two steps share a mask
+        want = Fn._counter - self._c0
+        if want != self._word_host:
+            self.seed_word.fill_(want)
         self.graph.replay()
+        self._word_host = want + self.seeds_per_step
         Fn.reset_rng(Fn._counter + self.seeds_per_step)
         for p in self._params:
             self.ts.optimizer.state[p]["step"] += 1

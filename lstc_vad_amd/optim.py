@@ -30,7 +30,7 @@ class Adagrad(torch.optim.Optimizer):
     def step(self, closure=None, grad_scales=None):
         """``grad_scales``: optional {group index: device-or-host scale} from ``clip_grad_norm_`` below."""
         lib = _lib.load()
-        items, keep = [], []
+        items, keep, updated = [], [], []
         for gi, group in enumerate(self.param_groups):
             gs = 1.0 if not grad_scales else float(grad_scales.get(gi, 1.0))
             for p in group["params"]:
@@ -40,38 +40,41 @@ class Adagrad(torch.optim.Optimizer):
                 state = self.state[p]
                 state["step"] += 1
                 keep.append(g)
+                updated.append(p)
                 items.append((dev_ptr(p.data), dev_ptr(g), dev_ptr(state["sum"]), p.numel(), float(group["lr"]),
                               float(group["weight_decay"]), float(group["eps"]), gs))
         if items:           # every parameter in ONE launch (lstc_adagrad_multi; element arithmetic of lstc_adagrad_step)
             arr = (_lib.AdagradItem * len(items))(*items)
             check(lib.lstc_adagrad_multi(arr, len(items), stream_ptr()), "lstc_adagrad_multi")
         from .functional import bump_weight_epoch, repack_weights
-        bump_weight_epoch()          # weights changed through raw pointers: packed copies (f32x3 / bf16 GEMM) are stale
+        bump_weight_epoch(updated)   # THESE weights changed through raw pointers: their packed copies (f32x3 / bf16 GEMM) are stale
         if items and not torch.cuda.is_current_stream_capturing():
             # bf16 mode: every packed weight copy of the finished step rebuilt in one launch (a captured step keeps the
             # lazily issued packs of its forward instead: the graph replays those)
-            repack_weights([p for group in self.param_groups for p in group["params"]])
+            repack_weights(updated)
         return None
 
 
 def clip_grad_norm_(parameters, max_norm: float, norm_type: float = 2.0) -> torch.Tensor:
-    """``torch.nn.utils.clip_grad_norm_(params, 10)`` (Train/temporal_transformer_shanghaitech.py:139-141):
-    total L2 norm over the given parameters' grads via ``lstc_sqnorm_accum``; grads are scaled in place by
-    ``max_norm / (total + 1e-6)`` clamped to 1 (torch semantics).  Returns the total norm (device scalar)."""
+    """``torch.nn.utils.clip_grad_norm_(params, 10)`` (Train/temporal_transformer_shanghaitech.py:139-141): total L2 norm over
+    the given parameters' grads and an in-place scale by ``max_norm / (total + 1e-6)`` clamped to 1 (torch semantics) - as TWO
+    launches over the whole list (``lstc_sqnorm_multi`` + ``lstc_clip_scale_multi``, the coefficient formed on the device)
+    instead of upstream's kernel per tensor and host comparison.  No host sync, so a captured step may contain it.  Returns
+    the total norm as a 0-dim device tensor (torch returns a device tensor too)."""
     if norm_type != 2.0:
-        raise NotImplementedError
+        raise NotImplementedError("clip_grad_norm_: only the L2 norm the LSTC_VAD scripts use")
     params = [p for p in parameters if p.grad is not None]
     if not params:
         return torch.zeros(())
-    lib = _lib.load()
-    acc = torch.zeros((1,), device=params[0].grad.device, dtype=torch.float32)
     for p in params:
-        assert p.grad.is_contiguous()
-        check(lib.lstc_sqnorm_accum(dev_ptr(p.grad), p.grad.numel(), dev_ptr(acc), stream_ptr()),
-              "lstc_sqnorm_accum")
-    total = float(acc.sqrt().item())            # the reference syncs here too (python float compare inside torch)
-    coef = min(1.0, max_norm / (total + 1e-6))
-    if coef < 1.0:
-        for p in params:
-            check(lib.lstc_scale(dev_ptr(p.grad), p.grad.numel(), coef, stream_ptr()), "lstc_scale")
-    return torch.tensor(total)
+        if not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
+            raise RuntimeError("clip_grad_norm_: gradients must be contiguous float32 tensors")
+    lib = _lib.load()
+    dev = params[0].grad.device
+    items = (_lib.VecItem * len(params))(*[(dev_ptr(p.grad), p.grad.numel()) for p in params])
+    need = int(lib.lstc_sqnorm_multi_scratch(items, len(params)))
+    scratch = torch.empty((need + 2,), device=dev, dtype=torch.float32)       # [partials..., sum of squares, total norm]
+    sq = scratch[need:]
+    check(lib.lstc_sqnorm_multi(items, len(params), dev_ptr(scratch), need, dev_ptr(sq), stream_ptr()), "lstc_sqnorm_multi")
+    check(lib.lstc_clip_scale_multi(items, len(params), dev_ptr(sq), float(max_norm), stream_ptr()), "lstc_clip_scale_multi")
+    return sq[1]

@@ -56,6 +56,11 @@ FULL_CASES = {
     "ltn_ubnormal_full": ("LTN", dict(d_model=1024, n_head=8, d_k=256, d_v=256, d_inner=4096, MHA_layerNorm=True,
                                       FFN_layerNorm=True, relative_pe=True, window_size=4, window_depth=5),
                           dict(batch_size=2, part_num=16, part_len=5, n_patch=16), 34),   # 64 sequences, S = 81, 5184 tokens
+    # BASELINE config 3's third stage (Train/spatio_transformer_MIL_CE.py:23-44,156-181) at the width it is quoted on: the STN
+    # (F = 3027, Regressor head) under the co-teaching loss - MIL with the flat-slice l1 quirk + the weighted BCE of the
+    # part-mean scores against the pseudo labels (lambda_normal / lambda_abnormal, 1e-8 inside the logs)
+    "stn_mil_ce_full": ("STN_MIL_CE", dict(d_model=2048, n_head=8, d_k=256, d_v=256, d_inner=3027, FFN_layerNorm=True),
+                        dict(batch_size=2, part_num=16, part_len=4, n_patch=16), 37),   # 256 sequences, S = 17, 4352 tokens
 }
 # Full-width cases whose token count fills whole 256-row pack tiles (256 sequences): with the Q | K | V projections fused, the
 # bf16 mode runs its attention core on PACKED operands (csrc/attention_pk.hip) at S = 49 (two query tiles) and S = 81 (three).

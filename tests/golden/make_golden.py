@@ -182,6 +182,8 @@ def run_case(name, mode, enc_kw, st_kw, seed):
 
 
 RELU_EDGE = 4e-6     # |W1 x + b1| below which a ReLU decision is treated as summation-order dependent (f32, K = 2048, |x| ~ 1)
+HEAD_EDGE_FACTOR = 4 # the head's first Linear (models/Classifier.py:8-10, models/Regressor.py:7-9) sits behind three encoder layers:
+                     # its input already carries their accumulated f32 noise, so its band is 4x the FFN band
 
 
 def run_full_case(name, mode, enc_kw, st_kw, seed, relu_edge=None):
@@ -219,6 +221,27 @@ def run_full_case(name, mode, enc_kw, st_kw, seed, relu_edge=None):
             t, j = torch.nonzero(pre.abs() < (relu_edge or RELU_EDGE), as_tuple=True)
             edges[li] = (torch.stack([t, j], 1).numpy().astype(np.int64), pre[t, j].numpy().copy())
         hooks.append(layer.pos_ffn.w_1.register_forward_hook(grab))
+
+    # the head's hidden Linear(d, 512) + ReLU (models/Classifier.py:8-10, models/Regressor.py:7-9): same recording, key "head";
+    # row = row of the head's [-1, d] input view
+    def grab_head(mod, inp, outp):
+        if "head" in edges:
+            return
+        pre = outp.detach().reshape(-1, outp.shape[-1])
+        t, j = torch.nonzero(pre.abs() < HEAD_EDGE_FACTOR * (relu_edge or RELU_EDGE), as_tuple=True)
+        edges["head"] = (torch.stack([t, j], 1).numpy().astype(np.int64), pre[t, j].numpy().copy())
+    hooks.append((head.classifier if mode == "LTN" else head.regressor)[0].register_forward_hook(grab_head))
+    if mode == "LTN":
+        # inference on the initial weights, as the pseudo-label generator feeds it (Train/pseudo_labels_generator_temporal.py:
+        # 110-146: full parts of part_len clips, then the video's short tail as a SHORTER sequence - S = 1 + (L-1) P and 1 + P;
+        # for L = 3 that is S = 33 and S = 17): P(abnormal) of the first 8 sequences of the normal batch
+        enc.eval(); head.eval()
+        with torch.no_grad():
+            x = tnf.float().view([bs * pn, L * P, d])[:8]
+            for tag, xs in (("full", x), ("tail", x[:, :(L - 1) * P]), ("tail1", x[:, :P])):
+                out["eval_scores_" + tag] = head(enc(xs)[:, 0, :]).numpy().copy()
+        enc.train(); head.train()
+        edges.clear()                                   # the hooks fired on these passes too: record the TRAINING step's units
     for step in range(2):
         enc_out, outputs, score, loss, mil, err, l1, aux = ref_forward_loss(mode, args, enc, head, tnf, taf, tal)
         opt.zero_grad()

@@ -171,29 +171,31 @@ def test_no_cpu_fallback(lib):
 
 
 def test_dropout_hash_matches_host_restatement():
-    """The counter-based keep/drop rule is part of the ABI contract (masks are replayed by tests): restate it in
-    numpy and check basic statistics."""
-    def key(p, seed):
-        k0 = ((seed & 0xffffffff) * 0x9E3779B1 + 0x7F4A7C15) & 0xffffffff
-        k1 = ((seed >> 32) * 0x85EBCA77 + 0x165667B1) & 0xffffffff
-        return k0, k1, min(int(p * 4294967296.0), 0xffffffff)
+    """The counter-based keep/drop rule is part of the ABI contract (masks are replayed by tests): restated in numpy
+    (tests/util.py; the GPU suite compares lstc_dropout_mask with it bit for bit) - basic statistics here."""
+    from util import host_dropout_keep as keep
 
-    def keep(i, p, seed):
-        k0, k1, thr = key(p, seed)
-        h = (i.astype(np.uint64) ^ np.uint64(k0)) & np.uint64(0xffffffff)
-        h = (h * np.uint64(0x9E3779B1)) & np.uint64(0xffffffff)
-        h ^= h >> np.uint64(15)
-        h = (h + np.uint64(k1)) & np.uint64(0xffffffff)
-        h = (h * np.uint64(0x85EBCA77)) & np.uint64(0xffffffff)
-        h ^= h >> np.uint64(13)
-        h = (h * np.uint64(0xC2B2AE3D)) & np.uint64(0xffffffff)
-        h ^= h >> np.uint64(16)
-        return h >= np.uint64(thr)
+    def key(p, seed):
+        m = (1 << 64) - 1                               # splitmix64 finaliser over the 64-bit seed (csrc/lstc_common.h: drop_key_mix)
+        zz = (seed + 0x9E3779B97F4A7C15) & m
+        zz = ((zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9) & m
+        zz = ((zz ^ (zz >> 27)) * 0x94D049BB133111EB) & m
+        zz ^= zz >> 31
+        return zz & 0xffffffff, zz >> 32, min(int(p * 4294967296.0), 0xffffffff)
     i = np.arange(1 << 20)
     for p in (0.1, 0.5, 0.6):
         m = keep(i, p, 0x1234567890ABCDEF)
         assert abs(m.mean() - (1 - p)) < 2e-3
         assert abs(np.corrcoef(m[:-1], m[1:])[0, 1]) < 5e-3
+    # consecutive seeds (the sites of a step, the steps of a run: functional.next_seed is linear in its counter) give
+    # independent masks - no two of them are shifted / XOR-permuted copies of one table (ADVICE r3): different (k0, k1) pairs
+    # in BOTH words, and uncorrelated keep decisions at equal element indices
+    base = 0x1234567890ABCDEF
+    keys = [key(0.5, base + c)[:2] for c in range(64)]
+    assert len({k[0] for k in keys}) == 64 and len({k[1] for k in keys}) == 64
+    m0 = keep(i, 0.5, base)
+    for c in (1, 2, 3, 17):
+        assert abs(np.corrcoef(m0, keep(i, 0.5, base + c))[0, 1]) < 5e-3
 
 
 def test_bf16p_epilogue_never_spills_a_register_with_a_load_in_flight():

@@ -198,3 +198,91 @@ def test_mixed_step_two_models_one_reduction_stream():
         p.join(60)
         assert p.exitcode == 0
     assert worst < 1e-6
+
+
+def _direct_worker(rank, world, port, q):
+    """Gradient sinks on gloo: a Function that honours functional.grad_sink / deliver (what the HIP Functions do) writes its weight
+    gradient INTO the all-reduce bucket and returns None to autograd; biases travel through autograd's accumulate.  The bucket
+    starts every step poisoned with NaN in its direct region (nothing fills it: a gradient that is not written shows up)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from lstc_vad_amd import functional as Fn
+    from lstc_vad_amd.dist import GradAllReducer
+
+    class Lin(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, b):
+            ctx.save_for_backward(x, w)
+            return x @ w.t() + b
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w = ctx.saved_tensors
+            out = Fn.grad_sink(w)
+            dw = torch.mm(dy.t(), x, out=out) if out is not None else dy.t() @ x
+            return dy @ w, Fn.deliver(w, dw), dy.sum(0)
+
+    def make(seed):
+        g = torch.Generator().manual_seed(seed)
+        ws = [torch.nn.Parameter(torch.randn(6, 5, generator=g)), torch.nn.Parameter(torch.randn(4, 6, generator=g))]
+        bs = [torch.nn.Parameter(torch.randn(6, generator=g)), torch.nn.Parameter(torch.randn(4, generator=g))]
+        return ws, bs
+
+    def loss_of(ws, bs, x):
+        h = torch.tanh(Lin.apply(x, ws[0], bs[0]))
+        return (Lin.apply(h, ws[1], bs[1]) ** 2).sum()
+
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(8, 5, generator=g) for _ in range(2)]
+    ws, bs = make(1)
+    red = GradAllReducer([[bs[1], ws[1]], [bs[0], ws[0]]], direct=ws)           # weights are laid out FIRST in their bucket
+    assert red.buckets[0].numel() == 28 and red._accum_from == [24, 30]
+    assert ws[1].grad.data_ptr() == red.buckets[0].data_ptr() and Fn.grad_sink(ws[1]) is not None
+    rws, rbs = make(1)                                                           # single-process reference on the full batch
+    worst, launched_early = 0.0, True
+    for step in range(2):
+        red.zero_grad()
+        for bi, flat in enumerate(red.buckets):
+            flat[:red._accum_from[bi]] = float("nan")                            # the direct region is never filled by the reducer
+        h = 8 // world
+        loss_of(ws, bs, xs[step][rank * h:(rank + 1) * h]).backward()
+        launched_early &= len(red._handles) == 2                                 # both buckets went out from inside backward
+        red.finish()
+        for p in rws + rbs:
+            p.grad = None
+        loss_of(rws, rbs, xs[step]).backward()
+        for p, r in zip(ws + bs, rws + rbs):
+            assert p.grad is not None and torch.isfinite(p.grad).all()
+            worst = max(worst, float((p.grad - r.grad).abs().max()))
+        with torch.no_grad():
+            for p, r in zip(ws + bs, rws + rbs):
+                p -= 0.05 * p.grad
+                r -= 0.05 * r.grad
+    # a model reused WITHOUT its reducer: once somebody else owns .grad the sink is ignored and autograd delivers the gradient
+    for p in ws + bs:
+        p.grad = None
+    assert Fn.grad_sink(ws[0]) is None
+    loss_of(ws, bs, xs[0]).backward()
+    assert all(p.grad is not None and p.grad.data_ptr() != red.buckets[1].data_ptr() for p in ws)
+    if rank == 0:
+        q.put((worst, launched_early))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_direct_gradient_sinks_write_into_the_bucket_without_fill_or_accumulate():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_direct_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    worst, launched_early = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert worst < 1e-5 and launched_early

@@ -107,7 +107,7 @@ def test_param_shapes_match_reference_counts_and_keys():
     assert sorted(z["stn_state_keys"].tolist()) == sorted(orc.encoder_param_shapes(stn))
 
 
-@pytest.mark.parametrize("name", ["ltn_full", "stn_full", "ltn_ucf_full", "ltn_ubnormal_full"])
+@pytest.mark.parametrize("name", ["ltn_full", "stn_full", "ltn_ucf_full", "ltn_ubnormal_full", "stn_mil_ce_full"])
 def test_full_width_step_against_reference_samples(name):
     """The oracle at BASELINE widths (d=2048, 8x256 heads, F=4096 / 3027) against the reference's own full-width run:
     scores, scalars, sampled gradient entries, gradient norms (tests/golden/make_golden.py ``run_full_case``)."""

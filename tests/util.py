@@ -37,3 +37,25 @@ def max_abs_diff(a, b):
     b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
     assert a.shape == b.shape, (a.shape, b.shape)
     return float(np.max(np.abs(a - b))) if a.size else 0.0
+
+
+def host_dropout_keep(i, p, seed):
+    """numpy restatement of the library's counter-based keep/drop rule (csrc/lstc_common.h: drop_key_mix = splitmix64's
+    finaliser over the 64-bit seed, drop_hash = two-multiply avalanche of the flat element index): True where element ``i``
+    is kept.  Part of the ABI contract - masks are replayed by tests."""
+    m = (1 << 64) - 1
+    zz = (int(seed) + 0x9E3779B97F4A7C15) & m
+    zz = ((zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9) & m
+    zz = ((zz ^ (zz >> 27)) * 0x94D049BB133111EB) & m
+    zz ^= zz >> 31
+    k0, k1, thr = zz & 0xffffffff, zz >> 32, min(int(p * 4294967296.0), 0xffffffff)
+    u, lo = np.uint64, np.uint64(0xffffffff)
+    h = (np.asarray(i).astype(np.uint64) ^ u(k0)) & lo
+    h = (h * u(0x9E3779B1)) & lo
+    h ^= h >> u(15)
+    h = (h + u(k1)) & lo
+    h = (h * u(0x85EBCA77)) & lo
+    h ^= h >> u(13)
+    h = (h * u(0xC2B2AE3D)) & lo
+    h ^= h >> u(16)
+    return h >= u(thr)
