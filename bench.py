@@ -301,6 +301,10 @@ def main():
                     "the rank's token count leaves the three separate products with badly filled tile rounds, engine.TrainStep)")
     ap.add_argument("--grad_reduce_dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient all-reduce "
                     "(bf16: buckets rounded by lstc_cast_f32_bf16, half the xGMI bytes; default fp32 = the reference's numerics)")
+    ap.add_argument("--buckets", type=int, default=0, help="gradient all-reduce buckets per model (0 = default: head + one per encoder "
+                    "layer, backward order; 1 = one all-reduce after the backward; up to 8 = FFN / attention halves of every layer)")
+    ap.add_argument("--nccl_algo", default="", help="sets NCCL_ALGO for RCCL (e.g. Ring, Tree) before the communicator is created; recorded in config")
+    ap.add_argument("--nccl_proto", default="", help="sets NCCL_PROTO for RCCL (e.g. Simple, LL, LL128); recorded in config")
     ap.add_argument("--graph", action="store_true", help="run the step as ONE captured HIP graph (lstc_vad_amd.engine.GraphedStep; N=1 "
                     "only): removes the ~340-launch train that small per-rank batches cannot hide")
     ap.add_argument("--no-dropout", action="store_true")
@@ -308,6 +312,10 @@ def main():
     ap.add_argument("--no-gemm-events", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the N=1 sub-objects (static_batch, stn_headline, bf16, f32x3)")
     a = ap.parse_args()
+    if a.nccl_algo:
+        os.environ["NCCL_ALGO"] = a.nccl_algo            # inherited by the rank processes launch_ranks starts
+    if a.nccl_proto:
+        os.environ["NCCL_PROTO"] = a.nccl_proto
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a.gpus, sys.argv[1:], rank_timeout_s=a.rank_timeout_s))   # before anything initialises the GPU here
@@ -365,7 +373,8 @@ def main():
                       FFN_dropout=drops[2], weight_init=(mode != "LTN"), **ekw).to(dev).train()
         head = (Classifier(d, drops[3]) if mode == "LTN" else Regressor(d, drops[3])).to(dev).train()
         ts = TrainStep(args, mode, enc, head, lr_encoder=1e-4 * a.lr_scale, lr_head=1e-2 * a.lr_scale, weight_decay=1e-3,
-                       cls_only=not a.naive_last_layer, fuse_qkv=a.fuse_qkv, grad_reduce_dtype=a.grad_reduce_dtype)
+                       cls_only=not a.naive_last_layer, fuse_qkv=a.fuse_qkv, grad_reduce_dtype=a.grad_reduce_dtype,
+                       n_buckets=a.buckets or None)
         feed = feed or a.feed
         if feed == "resident":
             src = SyntheticResidentPairs(cfg_name, bs_g, pn, dev, rank if strong else 0, world if strong else 1,
@@ -410,6 +419,9 @@ def main():
         for _ in range(warmup):
             run_step()
         sync()
+        if world > 1 or force_dist:
+            for t in tss:                                          # backward / exposed-communication events of the timed steps
+                t.comm_events = []
         want_events = gemm_events and not a.no_gemm_events and not a.graph      # a replayed graph records no per-GEMM events
         # exact-f32 steps are long (280 ms): the events around every GEMM ride inside the timed region.  In the 16-bit modes a
         # step is 5x shorter and the ~360 event records per step cost the HOST 2-5 ms of it (bf16, 8 pairs: 23.1 vs 17.8 ms per
@@ -428,6 +440,20 @@ def main():
         sync()
         dt = time.perf_counter() - t0
         step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+        comm = None
+        if any(t.comm_events for t in tss):
+            # per step: backward = first event -> after backward; exposed = after backward -> after reducer.finish() on the launch
+            # stream (the buckets' reductions started inside the backward; what is left here is what the backward did not hide)
+            bw = sum(e[0].elapsed_time(e[1]) for t in tss for e in (t.comm_events or [])) / steps
+            ex = sum(e[1].elapsed_time(e[2]) for t in tss for e in (t.comm_events or [])) / steps
+            cm = torch.tensor([bw, ex], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(cm, op=dist.ReduceOp.MAX)
+            comm = {"backward_ms_per_step": round(float(cm[0]), 3), "comm_exposed_ms_per_step": round(float(cm[1]), 3),
+                    "allreduce_buckets": [len(t.reducer.buckets) for t in tss if t.reducer is not None],
+                    "bucket_MB": [[round(b.numel() * 4 / 1e6, 1) for b in t.reducer.buckets] for t in tss if t.reducer is not None]}
+            for t in tss:
+                t.comm_events = None
         Fn.set_gemm_profiling(None)
         pprof, prof_steps = None, steps
         if want_events and not inline_events:
@@ -453,7 +479,7 @@ def main():
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             med = float(tm.item())
         res = {"dt": dt, "steps": steps, "step_ms_median": med, "step_ms_min": step_ms[0], "step_ms_max": step_ms[-1], "prof": prof, "pprof": pprof, "prof_steps": prof_steps, "events_inline": inline_events, "loss_first": float(first[0]), "loss_last": float(last[0]),
-               "hbm": torch.cuda.max_memory_allocated(dev),
+               "hbm": torch.cuda.max_memory_allocated(dev), "comm": comm,
                "allreduce_MB": round(sum(t.reducer.payload_bytes() for t in tss if t.reducer is not None) / 1e6, 1),
                "bank_GB": None if mixed or src is None else round(src.bank_GB, 2)}
         del tss, run_step
@@ -534,9 +560,25 @@ def main():
              "loss_last_timed_step": res["loss_last"], "hbm_peak_GB": round(res["hbm"] / 1e9, 2)}
         r = roofline_of(res, dtype, cfg)
         if r:
-            r["traffic"] = pmc_traffic(cfg, dtype)
+            t = pmc_traffic(cfg, dtype)
+            if t is not None:
+                r["traffic"] = t
+            else:
+                del r["traffic"]               # sub-objects carry the key only with a counter figure behind it (profiles/gemm_pmc_traffic.json)
             o["roofline"] = r
         return o
+
+    # ---- the CPU baseline leg first (rank 0, N = 1): the GPU passes then run back to back.  The GPU idles during this leg -
+    # a utilisation average taken over the whole bench.py run (the driver's gpu_busy) includes these seconds; the line says so.
+    cpu_base = None
+    if world == 1 and not a.no_cpu_baseline and a.config != "mixed_ubn_sht":
+        # torch-CPU sgemm on the GPU box's host peaks at 16-32 threads (tools/cpu_threads_scan.py: 1.3 TFLOP/s
+        # at 16-32, 0.5 at 128 of 256 hardware threads), so the baseline uses min(32, available) threads
+        t_cpu = time.perf_counter()
+        cpu_base = cpu_baseline(a.config, min(32, len(os.sched_getaffinity(0))))
+        cpu_base["wall_s"] = round(time.perf_counter() - t_cpu, 1)
+        cpu_base["note"] = ("timed BEFORE the GPU passes with the GPU idle: a GPU-utilisation average over the whole bench.py run "
+                            "includes these wall_s seconds of host-only work")
 
     # ---- the headline pass -------------------------------------------------------------------------------------------
     head_res = timed_pass(a.config, a.dtype)
@@ -632,16 +674,19 @@ def main():
                                       f"fresh weights and Adagrad state for the timed pass",
                           "feed": feed_txt, "global_videos": 2 * bs_global, "parallelism": f"dp{world}",
                           "per_rank_pairs": bs_local, "per_rank_sequences": nseq, "allreduce_MB": head_res["allreduce_MB"],
-                          "rccl_ranks": rccl_ranks},
+                          "rccl_ranks": rccl_ranks,
+                          # N > 1: HIP events on the launch stream around backward and around reducer.finish() (max over ranks, mean
+                          # over the timed steps): how much of the gradient all-reduce the backward did not hide
+                          **(head_res["comm"] or {}),
+                          "grad_reduce_dtype": a.grad_reduce_dtype,
+                          "nccl_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_"))}},
                "loss_first_timed_step": head_res["loss_first"], "loss_last_timed_step": head_res["loss_last"],
                "hbm_peak_GB": round(head_res["hbm"] / 1e9, 2), "roofline": roof}
         out.update(extras)
         if pcie:
             out["pcie_inclusive"] = pcie
-        if world == 1 and not a.no_cpu_baseline and not mixed:
-            # torch-CPU sgemm on the GPU box's host peaks at 16-32 threads (tools/cpu_threads_scan.py: 1.3 TFLOP/s
-            # at 16-32, 0.5 at 128 of 256 hardware threads), so the baseline uses min(32, available) threads
-            out["cpu_baseline"] = cpu_baseline(last, min(32, len(os.sched_getaffinity(0))))
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or force_dist:
         dist.destroy_process_group()

@@ -306,6 +306,13 @@ int lstc_cls_concat_bwd(const float* dy, float* dx, int64_t N, int32_t S, int32_
  * `partial` is caller workspace of n_partial*cols floats.  Bias / LayerNorm / pos-enc gradients. */
 int lstc_colsum(const float* x, int64_t rows, int32_t cols, int32_t ld, float* partial, int32_t n_partial,
                 float* out, int32_t accumulate, void* stream);
+/* `batch` column sums in the same two launches: plane b is x + b * batch_stride ([rows, ld]), its result out[b * cols ...];
+ * `partial` holds batch * min(rows, n_partial) * cols floats.  Per plane the arithmetic (row -> partial row -> accumulator, order
+ * of every addition) is lstc_colsum's two-pass form, so out[b] is bit-identical to lstc_colsum of plane b.  The LayerNorm
+ * backward's three per-workgroup partial planes (dgamma, dbeta, dbias: autograd of nn.LayerNorm / nn.Linear.bias, models/FFN.py:
+ * 19-21, models/MultiHeadAttention.py:123-126) are reduced by ONE call instead of three. */
+int lstc_colsum_batched(const float* x, int32_t batch, int64_t rows, int32_t cols, int32_t ld, int64_t batch_stride,
+                        float* partial, int32_t n_partial, float* out, void* stream);
 
 /* y[i] = x[i] * keep(i)/(1-p) with the GEMM epilogue's mask (dropout backward / standalone dropout). */
 int lstc_dropout_apply(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);

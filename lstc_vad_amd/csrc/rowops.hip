@@ -455,10 +455,13 @@ __global__ void __launch_bounds__(NT) cls_concat_bwd_kernel(const float* __restr
 
 // ---------------------------------------------------------------------------------- colsum
 // pass 1: grid (ceil(cols/NT), n_partial): workgroup y sums rows y, y+n_partial, ... of NT columns.
+// (blockIdx.z = plane of a batched call, lstc_colsum_batched: planes are `xstride` / n_partial * cols floats apart)
 __global__ void __launch_bounds__(NT) colsum_pass1(const float* __restrict__ x, int64_t rows, int cols, int ld,
-                                                    float* __restrict__ partial) {
+                                                    float* __restrict__ partial, int64_t xstride = 0) {
     const int c = blockIdx.x * NT + threadIdx.x;
     if (c >= cols) return;
+    x += (size_t)blockIdx.z * xstride;
+    partial += (size_t)blockIdx.z * gridDim.y * cols;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     const int64_t step = gridDim.y;
     int64_t r = blockIdx.y;
@@ -476,6 +479,8 @@ __global__ void __launch_bounds__(NT) colsum_pass1(const float* __restrict__ x, 
 __global__ void __launch_bounds__(NT) colsum_pass2(const float* __restrict__ partial, int n_partial, int cols,
                                                     float* __restrict__ out, int accumulate) {
     __shared__ float red[NT];
+    partial += (size_t)blockIdx.y * n_partial * cols;          // blockIdx.y = plane of a batched call (0 otherwise)
+    out += (size_t)blockIdx.y * cols;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int lane_p = threadIdx.x >> 6;                 // 0..3
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -985,6 +990,17 @@ int lstc_colsum(const float* x, int64_t rows, int32_t cols, int32_t ld, float* p
     }
     hipLaunchKernelGGL(colsum_pass1, dim3((cols + NT - 1) / NT, np), NT, 0, st, x, rows, cols, ld, partial);
     hipLaunchKernelGGL(colsum_pass2, dim3((cols + 63) / 64), NT, 0, st, partial, np, cols, out, accumulate);
+    return lstc_launch_status();
+}
+
+int lstc_colsum_batched(const float* x, int32_t batch, int64_t rows, int32_t cols, int32_t ld, int64_t batch_stride,
+                        float* partial, int32_t n_partial, float* out, void* stream) {
+    if (!x || !partial || !out) return LSTC_E_NULL;
+    if (batch <= 0 || batch > 65535 || rows <= 0 || cols <= 0 || ld < cols || n_partial <= 0 || batch_stride < 0) return LSTC_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int np = (int)(rows < n_partial ? rows : n_partial);
+    hipLaunchKernelGGL(colsum_pass1, dim3((cols + NT - 1) / NT, np, batch), NT, 0, st, x, rows, cols, ld, partial, batch_stride);
+    hipLaunchKernelGGL(colsum_pass2, dim3((cols + 63) / 64, batch), NT, 0, st, partial, np, cols, out, 0);
     return lstc_launch_status();
 }
 

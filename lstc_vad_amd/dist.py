@@ -163,17 +163,39 @@ def direct_grad_parameters(encoder, head) -> List[torch.nn.Parameter]:
     return out
 
 
-def encoder_head_buckets(encoder, head) -> List[List[torch.nn.Parameter]]:
+def encoder_head_buckets(encoder, head, n_buckets=None) -> List[List[torch.nn.Parameter]]:
     """Backward-ordered buckets for an ``Encoder`` + head pair: head, then encoder layers last to first
-    (layer-level parameters that feed the first layer — cls_token / position_enc / input LayerNorm — go last)."""
+    (layer-level parameters that feed the first layer — cls_token / position_enc / input LayerNorm — go last).
+    ``n_buckets`` (None = one bucket per layer + head [+ rest], the default): the finest backward-ordered pieces - head, then per
+    layer its FFN parameters and its attention parameters, layers last to first, then the rest - merged into that many
+    consecutive groups of roughly equal bytes (1 = a single all-reduce after the backward; up to 2 x layers + 2).  xGMI is
+    point-to-point, so few large messages are the starting point; the knob exists so one run can be compared with another
+    (bench.py --buckets)."""
     used = {id(p) for p in encoder.used_parameters()}
-    buckets = [list(head.parameters())]
+    pieces = [list(head.parameters())]
+    per_layer = []
     in_layers = set()
     for layer in reversed(list(encoder.layer_stack)):
         ps = [p for p in layer.parameters() if id(p) in used]
         in_layers.update(id(p) for p in ps)
-        buckets.append(ps)
+        ffn_ids = {id(p) for p in layer.pos_ffn.parameters()} if hasattr(layer, "pos_ffn") else set()
+        ffn = [p for p in ps if id(p) in ffn_ids]
+        attn = [p for p in ps if id(p) not in ffn_ids]
+        per_layer.append(ps)
+        pieces += [g for g in (ffn, attn) if g]              # backward reaches a layer's FFN before its attention
     rest = [p for p in encoder.parameters() if id(p) in used and id(p) not in in_layers]
     if rest:
-        buckets.append(rest)
-    return buckets
+        pieces.append(rest)
+    if n_buckets is None:
+        return [list(head.parameters())] + per_layer + ([rest] if rest else [])
+    n_buckets = max(1, min(int(n_buckets), len(pieces)))
+    size = lambda g: sum(p.numel() for p in g)
+    total, out, cur, acc = sum(size(g) for g in pieces), [], [], 0
+    for i, g in enumerate(pieces):
+        cur += g
+        acc += size(g)
+        left_pieces, left_groups = len(pieces) - i - 1, n_buckets - len(out) - 1
+        if left_groups > 0 and (acc >= total * (len(out) + 1) / n_buckets or left_pieces == left_groups):
+            out.append(cur); cur = []
+    out.append(cur)
+    return [g for g in out if g]

@@ -21,7 +21,7 @@ from .optim import Adagrad, clip_grad_norm_
 class TrainStep:
     def __init__(self, args, mode: str, encoder, head, lr_encoder: float, lr_head: float, weight_decay: float,
                  group=None, cls_only: bool = True, loss_rank=None, loss_exchange=None, fuse_qkv="auto",
-                 grad_reduce_dtype: str = "fp32"):
+                 grad_reduce_dtype: str = "fp32", n_buckets=None):
         # cls_only=False evaluates the last encoder layer for every token like the reference does (its extra rows are
         # never read); kept for A/B measurements — results are identical (tests/test_hip_parity.py)
         self.cls_only = cls_only
@@ -44,7 +44,10 @@ class TrainStep:
                                   {"params": head.parameters(), "lr": lr_head}], weight_decay=weight_decay)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         force = os.environ.get("LSTC_FORCE_DIST", "0") == "1" and dist.is_available() and dist.is_initialized()
-        self.reducer = (GradAllReducer(encoder_head_buckets(encoder, head), group, force=force, reduce_dtype=grad_reduce_dtype,
+        # measurement hook (bench.py at N > 1): a list to receive (before backward, after backward, after reducer.finish()) HIP events
+        # of every step on the launch stream - backward time and the part of the gradient all-reduce that the backward did not hide
+        self.comm_events = None
+        self.reducer = (GradAllReducer(encoder_head_buckets(encoder, head, n_buckets), group, force=force, reduce_dtype=grad_reduce_dtype,
                                        direct=direct_grad_parameters(encoder, head))
                         if (self.world > 1 or force) else None)
 
@@ -94,9 +97,18 @@ class TrainStep:
             self.reducer.zero_grad()
         else:
             self.optimizer.zero_grad(set_to_none=True)
+        ev = self.comm_events
+        if ev is not None:
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            marks[0].record()
         loss.backward()
+        if ev is not None:
+            marks[1].record()
         if self.reducer is not None:
             self.reducer.finish()
+        if ev is not None:
+            marks[2].record()                  # the launch stream reaches this only when every bucket's reduction has landed
+            ev.append(marks)
         if getattr(self.args, "clip_grad", False):
             clip_grad_norm_(self.encoder.parameters(), 10)
             clip_grad_norm_(self.head.parameters(), 10)

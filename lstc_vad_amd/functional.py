@@ -535,6 +535,23 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate=False
     return out
 
 
+def colsum_planes(x3: torch.Tensor, n: Optional[int] = None) -> torch.Tensor:
+    """Column sums of the first ``n`` planes of a contiguous [planes, rows, cols] tensor -> [n, cols], in TWO launches whatever
+    ``n`` (lstc_colsum_batched); row ``b`` is bit-identical to ``colsum(x3[b])`` when that takes the two-pass form."""
+    planes, rows, cols = x3.shape
+    n = planes if n is None else n
+    out = torch.empty((n, cols), device=x3.device, dtype=torch.float32)
+    if rows <= 12 or not x3.is_contiguous():            # colsum's one-pass small-row form: keep its arithmetic
+        for b in range(n):
+            colsum(x3[b], out=out[b])
+        return out
+    npart = int(min(rows, 128))
+    partial = torch.empty((n, npart, cols), device=x3.device, dtype=torch.float32)
+    check(_lib.load().lstc_colsum_batched(dev_ptr(x3), n, rows, cols, cols, rows * cols, dev_ptr(partial), npart, dev_ptr(out),
+                                          stream_ptr()), "lstc_colsum_batched")
+    return out
+
+
 def dropout_apply(x: torch.Tensor, p: float, seed: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     x = x.contiguous()
     if out is None:
@@ -593,9 +610,8 @@ def layernorm_bwd(dy2, x2, gamma, mean, rstd):
     check(_lib.load().lstc_layernorm_bwd(dev_ptr(dy2), dev_ptr(x2), dev_ptr(gamma), dev_ptr(mean), dev_ptr(rstd),
                                          dev_ptr(dx), dev_ptr(partial), n_partial, rows, d, stream_ptr()),
           "lstc_layernorm_bwd")
-    dgamma = colsum(partial[0])
-    dbeta = colsum(partial[1])
-    return dx, dgamma, dbeta
+    sums = colsum_planes(partial)
+    return dx, sums[0], sums[1]
 
 
 def layernorm_bwd_branch(dz2, y, gamma, mean, rstd, p: float, seed: int, layer_norm: bool, want_bias: bool):
@@ -616,8 +632,8 @@ def layernorm_bwd_branch(dz2, y, gamma, mean, rstd, p: float, seed: int, layer_n
         check(lib.lstc_layernorm_bwd_drop_pack(dev_ptr(dz2), dev_ptr(y), dev_ptr(gamma), dev_ptr(mean), dev_ptr(rstd),
                                                dev_ptr(dy), dev_ptr(partial), n_partial, rows, d, float(p), int(seed),
                                                dev_ptr(buf), stream_ptr()), "lstc_layernorm_bwd_drop_pack")
-        return (dy, Packed(buf, rows, d, _lib.BF16P), colsum(partial[0]), colsum(partial[1]),
-                colsum(partial[2]) if want_bias else None)
+        sums = colsum_planes(partial, 3 if want_bias else 2)        # dgamma, dbeta(, dbias): one batched two-pass sum
+        return dy, Packed(buf, rows, d, _lib.BF16P), sums[0], sums[1], (sums[2] if want_bias else None)
     if layer_norm and p > 0 and _FUSE_PACKS and d in (512, 1024, 2048) and rows * d <= 0xffffffff:
         # f32 modes: the same kernel writes the dropped gradient as a second f32 result (no lstc_dropout_apply pass, and the
         # bias gradient's column sums come out of the same pass)
@@ -629,7 +645,8 @@ def layernorm_bwd_branch(dz2, y, gamma, mean, rstd, p: float, seed: int, layer_n
         check(lib.lstc_layernorm_bwd_drop(dev_ptr(dz2), dev_ptr(y), dev_ptr(gamma), dev_ptr(mean), dev_ptr(rstd), dev_ptr(dy),
                                           dev_ptr(df), dev_ptr(partial), n_partial, rows, d, float(p), int(seed), stream_ptr()),
               "lstc_layernorm_bwd_drop")
-        return dy, df, colsum(partial[0]), colsum(partial[1]), (colsum(partial[2]) if want_bias else None)
+        sums = colsum_planes(partial, 3 if want_bias else 2)
+        return dy, df, sums[0], sums[1], (sums[2] if want_bias else None)
     dgamma = dbeta = None
     if layer_norm:
         dy, dgamma, dbeta = layernorm_bwd(dz2, y, gamma, mean, rstd)

@@ -117,6 +117,17 @@ def test_bucket_order_and_unused_parameters():
     assert ids == {id(p) for p in enc.used_parameters()} | {id(p) for p in head.parameters()}
     assert id(enc.layer_norm.weight) not in ids and id(enc.layer_stack[0].slf_attn.layer_norm.weight) not in ids
     assert b[1][0] is next(iter(enc.layer_stack[2].parameters()))      # last layer first (backward order)
+    # bench.py --buckets N: the finest backward-ordered pieces (head, per layer FFN then attention, rest) merged into N
+    # consecutive groups - every used parameter exactly once, backward order kept, 1 <= groups <= pieces
+    flat_default = [id(p) for g in b for p in g]
+    for n in (1, 2, 3, 5, 7, 50):
+        g_n = encoder_head_buckets(enc, head, n)
+        ids_n = [id(p) for g in g_n for p in g]
+        assert len(g_n) == min(n, 7) and sorted(ids_n) == sorted(flat_default) and len(set(ids_n)) == len(ids_n)
+        assert ids_n[:6] == flat_default[:6]                           # head first
+    from lstc_vad_amd.dist import direct_grad_parameters
+    dp = direct_grad_parameters(enc, head)
+    assert len(dp) == 3 * 6 + 1 and all(p.dim() == 2 for p in dp) and {id(p) for p in dp} <= ids
 
 
 def _mixed_worker(rank, world, port, q):
