@@ -1265,6 +1265,77 @@ def test_full_width_training_step_matches_reference_golden(name, cls_only):
     _full_width_golden_check(name, cls_only)
 
 
+@pytest.mark.parametrize("name,dtype", [("ltn_full", "fp32"), ("stn_mil_ce_full", "fp32"), ("ltn_ubnormal_full", "fp32"), ("ltn_full", "f32x3")])
+def test_full_width_dropout_on_step_replays_through_oracle(name, dtype):
+    """Every dropout ON at PRODUCTION width (the reference's masks come from torch's generator and cannot be replayed, so the
+    full-width goldens run with rate 0): the HIP step's masks are exported (lstc_dropout_mask: the same key derivation and hash
+    the fused sites use) and injected into the oracle - which the rate-0 goldens pin to the reference at these widths - on the
+    host cores.  Covers what no golden can: the dropout + residual epilogue of the PIPE 5 GEMM on full tiles, the LayerNorm
+    backward's fused dropout replay and bias-gradient sums at d = 2048 / 1024, attention dropout at d_k = 256 (S = 49, 17, 81),
+    the CLS-only last layer's dropout sites, the padded n_hidden = 3027 block - at the reference's rates (0.2 / 0.2 / 0.1, head
+    0.6).  Bars: scores 1e-4, loss 2e-5; gradients un-aligned (a ReLU unit on the rounding edge may fall either way, as in the
+    golden tests' first pass) and compared on EVERY entry, not a 256-entry sample: 1e-2 of the tensor maximum (measured 8e-5 ...
+    5.1e-3: one flipped unit rewrites its whole row of dW1, and an all-entries maximum finds that row), norms 1e-3."""
+    from cases import FULL_CASES, fill_params
+    from lstc_vad_amd import functional as Fn
+    from lstc_vad_amd import synthetic as syn
+    mode, ekw, skw, seed = FULL_CASES[name]
+    d = ekw["d_model"]
+    pa, pf, pn_, ph = 0.2, 0.2, 0.1, 0.6
+    from lstc_vad_amd.models import Encoder, Regressor, Classifier
+    enc = Encoder(n_layers=3, MHA_attn_dropout=pa, MHA_fc_dropout=pf, FFN_dropout=pn_, position_dropout=0.0, weight_init=False, **ekw)
+    head = Classifier(d, ph, weight_init=False) if mode == "LTN" else Regressor(d, ph, weight_init=False)
+    fill_params(enc, seed); fill_params(head, seed + 1)
+    enc_P = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in enc.state_dict().items()}
+    head_P = {k: v.detach().clone().requires_grad_(True) for k, v in head.state_dict().items()}
+    enc, head = enc.to(DEV).train(), head.to(DEV).train()
+    args = _args(mode, skw)
+    nf, _, af, al = syn.training_batch(skw["batch_size"], skw["part_num"], skw["part_len"], skw["n_patch"], d, seed=seed,
+                                       with_pseudo=True, threshold=0.6)
+    nf, af, al = (torch.from_numpy(x) for x in (nf, af, al))
+    Fn.set_compute_dtype(dtype)
+    try:
+        torch.manual_seed(4321)
+        Fn.reset_rng()
+        with Fn.record_dropout() as sites:
+            enc_out, outputs, loss, sc = _step(enc, head, mode, args, nf.to(DEV), af.to(DEV), al.to(DEV), d, cls_only=True)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        Fn.set_compute_dtype("fp32")
+    S_full = 1 + (args.part_len * args.n_patch if mode == "LTN" else args.n_patch)
+    masks = {}
+    for site, pp, sd, shape in sites:
+        m = Fn.dropout_mask(shape, pp, sd, DEV).cpu()
+        if site.endswith("dropout#cls") and len(shape) == 2 or (site.startswith("layer_stack.2.pos_ffn") and len(shape) == 2):
+            full = torch.ones(shape[0], S_full, shape[1], dtype=torch.uint8)          # CLS-only last layer: the mask covers token 0
+            full[:, 0, :] = m
+            m = full
+        masks[site.replace("#cls", "")] = m
+    assert len(masks) == len(sites) >= 3 * 3 + 2
+    ecfg, st = oracle_cfgs(mode, dict(ekw), dict(skw), dropout=0.0)
+    ecfg.MHA_attn_dropout, ecfg.MHA_fc_dropout, ecfg.FFN_dropout = pa, pf, pn_
+    st.head_dropout = ph
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    out = orc.forward_loss(enc_P, head_P, ecfg, st, nf, af, al, training=True, masks=masks)
+    out["loss"].backward()
+    assert max_abs_diff(outputs.reshape(out["outputs"].shape), out["outputs"]) < 1e-4            # north_star tolerance
+    assert abs(float(sc[0]) - float(out["loss"].detach())) < 2e-5
+    worst = 0.0
+    for mod, P in ((enc, enc_P), (head, head_P)):
+        for k, pr in mod.named_parameters():
+            if pr.grad is None:
+                assert P[k].grad is None, k
+                continue
+            g = P[k].grad
+            gmax, gnorm = float(g.abs().max()), float(g.double().norm())
+            err = max_abs_diff(pr.grad, g)
+            assert err < 1e-2 * gmax + 1e-7, (k, err, gmax)
+            assert abs(float(pr.grad.double().norm()) - gnorm) < UNALIGNED_NORM_BAR * gnorm + 1e-9, k
+            worst = max(worst, err / gmax if gmax > 0 else 0.0)
+    print(f"\n[dropout on, full width] {name} {dtype}: worst gradient entry {worst:.2e} of its tensor max (every entry, not a sample)")
+
+
 @pytest.mark.parametrize("name", FULL_NAMES)
 def test_f32x3_full_width_training_step_matches_reference_golden(name):
     """The f32x3 GEMM mode (products of the large GEMMs on the f16 matrix cores, csrc/gemm_pk.hip) at its DEFAULT thresholds
