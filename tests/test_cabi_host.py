@@ -37,8 +37,9 @@ def test_descriptor_layouts_match_header(lib, tmp_path):
     """The ctypes mirrors against the C compiler's own layout of include/lstc_hip.h: sizeof and the offset of every field of
     the three descriptors (a C program built with gcc prints them)."""
     import subprocess
-    from lstc_vad_amd._lib import GemmDesc, AttnDesc, LossDesc, AdagradItem
-    structs = {"LstcGemmDesc": GemmDesc, "LstcAttnDesc": AttnDesc, "LstcLossDesc": LossDesc, "LstcAdagradItem": AdagradItem}
+    from lstc_vad_amd._lib import GemmDesc, AttnDesc, LossDesc, AdagradItem, VecItem, PackItem
+    structs = {"LstcGemmDesc": GemmDesc, "LstcAttnDesc": AttnDesc, "LstcLossDesc": LossDesc, "LstcAdagradItem": AdagradItem,
+               "LstcVecItem": VecItem, "LstcPackItem": PackItem}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "lstc_hip.h"', 'int main(void) {']
     for cname, ct in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -76,8 +77,16 @@ def test_production_library_refuses_tuning_variants(lib):
 
 
 def test_host_side_validation_error_codes(lib):
-    from lstc_vad_amd._lib import GemmDesc, AttnDesc, LossDesc
+    from lstc_vad_amd._lib import GemmDesc, AttnDesc, LossDesc, VecItem
     assert lib.lstc_gemm(None, None) == -1
+    # round-4 entry points: multi-tensor norm / clip and the batched column sums refuse bad arguments before any launch
+    items = (VecItem * 2)(VecItem(16, 10000), VecItem(32, 5))
+    assert lib.lstc_sqnorm_multi_scratch(items, 2) == 3 and lib.lstc_sqnorm_multi_scratch(None, 2) == 0      # ceil(10000 / 8192) + 1
+    assert lib.lstc_sqnorm_multi(None, 2, 16, 3, 16, None) == -1 and lib.lstc_sqnorm_multi(items, 0, 16, 3, 16, None) == -2
+    assert lib.lstc_sqnorm_multi(items, 2, 16, 2, 16, None) == -2                                             # scratch too small
+    assert lib.lstc_clip_scale_multi(items, 2, None, 10.0, None) == -1 and lib.lstc_clip_scale_multi(items, 2, 16, 0.0, None) == -2
+    assert lib.lstc_colsum_batched(None, 3, 8, 8, 8, 64, 16, 8, 16, None) == -1
+    assert lib.lstc_colsum_batched(16, 0, 8, 8, 8, 64, 16, 8, 16, None) == -2 and lib.lstc_colsum_batched(16, 3, 8, 8, 4, 64, 16, 8, 16, None) == -2
     d = GemmDesc()
     assert lib.lstc_gemm(C.byref(d), None) == -1                      # NULL operands
     d.A = d.B = d.C = 16
