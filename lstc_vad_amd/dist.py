@@ -51,6 +51,7 @@ class GradAllReducer:
         self._sizes: List[int] = []
         self._handles = []
         self._bucket_of = {}
+        self._view_ptr = {}
         self._accum_from: List[int] = []           # per bucket: first element of the autograd-accumulated (zero-filled) tail
         direct_ids = {id(p) for p in direct}
         for bi, params in enumerate(param_groups):
@@ -69,6 +70,7 @@ class GradAllReducer:
                 views.append((p, v))
                 off += p.numel()
                 self._bucket_of[p] = len(self.buckets)
+                self._view_ptr[p] = v.data_ptr()
                 if id(p) in direct_ids:
                     # the producing kernel writes into ``v`` and the Function calls back (functional.deliver): always installed -
                     # also on one rank without a process group - so the single-rank bucket path runs what N ranks run
@@ -101,9 +103,16 @@ class GradAllReducer:
 
     def _hook(self, p):
         bi = self._bucket_of[p]
+        if p.grad is None or p.grad.data_ptr() != self._view_ptr[p]:
+            return            # somebody else owns .grad now (the model is being used without this reducer): not our step
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
             self._handles.append(self._launch(bi, True))
+        elif self._pending[bi] < 0:
+            # a parameter reported twice in one backward (a weight used by two Functions): a direct gradient would have been
+            # OVERWRITTEN in its bucket slot, and the bucket's all-reduce has already been launched
+            raise RuntimeError("GradAllReducer: a parameter delivered its gradient twice in one backward pass (shared weights are "
+                               "not supported by the bucket path; call zero_grad() before every backward)")
 
     def finish(self):
         """Call after ``backward()`` and before the optimizer step."""
