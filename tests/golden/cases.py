@@ -59,6 +59,12 @@ FULL_CASES = {
     # BASELINE config 3's third stage (Train/spatio_transformer_MIL_CE.py:23-44,156-181) at the width it is quoted on: the STN
     # (F = 3027, Regressor head) under the co-teaching loss - MIL with the flat-slice l1 quirk + the weighted BCE of the
     # part-mean scores against the pseudo labels (lambda_normal / lambda_abnormal, 1e-8 inside the logs)
+    # --clip_grad (Train/temporal_transformer_shanghaitech.py:139-141) where it DOES something: at this width the encoder's
+    # gradient norm is ~14 > 10, so clip_grad_norm_ really scales (the reduced-width clip case has norm 0.7: the coefficient clamps
+    # to 1 there and only the norm computation is exercised)
+    "ltn_clip_full": ("LTN", dict(d_model=2048, n_head=8, d_k=256, d_v=256, d_inner=4096, MHA_layerNorm=True,
+                                  FFN_layerNorm=True, relative_pe=True, window_size=4, window_depth=3),
+                      dict(batch_size=4, part_num=16, part_len=3, n_patch=16, clip_grad=True), 38),   # 128 sequences, S = 49
     "stn_mil_ce_full": ("STN_MIL_CE", dict(d_model=2048, n_head=8, d_k=256, d_v=256, d_inner=3027, FFN_layerNorm=True),
                         dict(batch_size=2, part_num=16, part_len=4, n_patch=16), 37),   # 256 sequences, S = 17, 4352 tokens
 }

@@ -246,6 +246,14 @@ def run_full_case(name, mode, enc_kw, st_kw, seed, relu_edge=None):
         enc_out, outputs, score, loss, mil, err, l1, aux = ref_forward_loss(mode, args, enc, head, tnf, taf, tal)
         opt.zero_grad()
         loss.backward()
+        if args.clip_grad:                   # Train/temporal_transformer_shanghaitech.py:139-141
+            # the float64 norm of the same gradients next to the one torch's clip_grad_norm_ computes: on the CPU its float32
+            # norm of norms over 100.7 M elements comes out 3.1e-4 LOW here (10.40038 against 10.40359), and the clip
+            # coefficient - hence every clipped gradient the fixture holds - inherits that
+            out[f"clip_total_norm_f64_step{step}"] = np.array(
+                [float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None))) for m in (enc, head)])
+            out[f"clip_total_norm_step{step}"] = np.array([float(torch.nn.utils.clip_grad_norm_(enc.parameters(), 10)),
+                                                           float(torch.nn.utils.clip_grad_norm_(head.parameters(), 10))], np.float64)
         if step == 0:
             for h in hooks:
                 h.remove()

@@ -107,7 +107,7 @@ def test_param_shapes_match_reference_counts_and_keys():
     assert sorted(z["stn_state_keys"].tolist()) == sorted(orc.encoder_param_shapes(stn))
 
 
-@pytest.mark.parametrize("name", ["ltn_full", "stn_full", "ltn_ucf_full", "ltn_ubnormal_full", "stn_mil_ce_full"])
+@pytest.mark.parametrize("name", ["ltn_full", "stn_full", "ltn_ucf_full", "ltn_ubnormal_full", "stn_mil_ce_full", "ltn_clip_full"])
 def test_full_width_step_against_reference_samples(name):
     """The oracle at BASELINE widths (d=2048, 8x256 heads, F=4096 / 3027) against the reference's own full-width run:
     scores, scalars, sampled gradient entries, gradient norms (tests/golden/make_golden.py ``run_full_case``)."""
@@ -147,8 +147,15 @@ def test_full_width_step_against_reference_samples(name):
         assert {k for k, g in G.items() if g is not None} == want
         for k in want:
             g = G[k].detach().reshape(-1)
-            gmax, gnorm = float(z[f"{pre}_gmax.{k}"]), float(z[f"{pre}_gnorm.{k}"])
-            assert max_abs_diff(g[torch.from_numpy(sample_index(g.numel()))], z[f"{pre}_gs.{k}"]) < 2e-4 * gmax + 1e-9, (pre, k)
+            # --clip_grad case: torch-CPU's float32 total norm is 3.1e-4 low on 100.7 M elements; the oracle clips with the float64
+            # norm, so the reference's clipped gradients are rescaled by coef(f64 norm) / coef(torch's norm) (both in the fixture)
+            r = 1.0
+            if "clip_total_norm_f64_step0" in z.files:
+                coef = lambda n: min(1.0, 10.0 / (float(n) + 1e-6))
+                i = 0 if pre == "enc" else 1
+                r = coef(z["clip_total_norm_f64_step0"][i]) / coef(z["clip_total_norm_step0"][i])
+            gmax, gnorm = r * float(z[f"{pre}_gmax.{k}"]), r * float(z[f"{pre}_gnorm.{k}"])
+            assert max_abs_diff(g[torch.from_numpy(sample_index(g.numel()))], r * z[f"{pre}_gs.{k}"].astype(np.float64)) < 2e-4 * gmax + 1e-9, (pre, k)
             assert abs(float(g.double().norm()) - gnorm) < 1e-4 * gnorm + 1e-12, (pre, k)
     for pre, Pn in (("enc", enc_P1), ("head", head_P1)):       # after ONE step here; the fixture holds step 2: bound only
         for k in (enc_g if pre == "enc" else head_g):
