@@ -212,3 +212,43 @@ def test_two_rank_mixed_step_over_gloo_matches_both_reference_goldens():
         for k, v in res[name + ".weights"].items():
             diff = (torch.from_numpy(v) - ref_w[k]).abs()
             assert float((diff > 5e-5).float().mean()) <= 1e-3 and float(diff.max()) <= 4e-4 + 1e-6, (name, k, float(diff.max()))
+
+
+def _bench_line(extra_args, env_extra=None):
+    import json
+    import subprocess
+    env = dict(os.environ, PYTHONPATH=ROOT, HIP_VISIBLE_DEVICES="0")
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch_size", "2", "--part_num", "8",
+                        "--no-extras", "--no-h2d", "--no-cpu-baseline"] + extra_args, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2500:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                                   # ONE JSON line on stdout, nothing else (RCCL's banner goes to stderr)
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract_and_the_forced_rccl_bucket_path():
+    """bench.py at a small batch (2 pairs x 8 parts: seconds): the JSON contract of the driver - metric / value / unit / n_gpus /
+    steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload + roofline {bound,
+    achieved, peak, unit, frac, traffic} - and, with the RCCL bucket path forced onto the one GPU (LSTC_FORCE_DIST=1: a real
+    NCCL communicator of one rank, gradient sinks, async all-reduce per bucket), the fields a first N-GPU run explains itself
+    with: backward_ms_per_step, comm_exposed_ms_per_step, allreduce_buckets (--buckets honoured), bucket_MB, nccl_env with
+    --nccl_algo / --nccl_proto passed through.  Same loss with and without the bucket path (same seeds, same kernels)."""
+    o = _bench_line([])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in o, k
+    assert o["n_gpus"] == 1 and o["steps"] == 3 and o["warmup"] == 1 and o["higher_is_better"] is True and o["vs_baseline"] is None
+    assert o["unit"] == "snippets/s" and o["dtype"] == "f32" and o["data"] == "synthetic" and "workload" in o["config"]
+    assert abs(o["value"] - 2 * 2 * 8 * 3 / (o["ms_per_step"] * 1e-3)) < 0.02 * o["value"]                # snippets per step / step time
+    rf = o["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert "comm_exposed_ms_per_step" not in o["config"] and o["config"]["rccl_ranks"] == 1
+    port = _free_port()
+    f = _bench_line(["--buckets", "2", "--nccl_algo", "Ring", "--nccl_proto", "Simple"],
+                    {"LSTC_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    c = f["config"]
+    assert c["allreduce_buckets"] == [2] and len(c["bucket_MB"][0]) == 2 and abs(sum(c["bucket_MB"][0]) - c["allreduce_MB"]) < 0.5
+    assert c["backward_ms_per_step"] > 0 and 0 <= c["comm_exposed_ms_per_step"] < c["backward_ms_per_step"]
+    assert c["nccl_env"].get("NCCL_ALGO") == "Ring" and c["nccl_env"].get("NCCL_PROTO") == "Simple" and c["rccl_ranks"] == 1
+    assert abs(f["loss_first_timed_step"] - o["loss_first_timed_step"]) < 1e-6 and abs(f["loss_last_timed_step"] - o["loss_last_timed_step"]) < 1e-6
