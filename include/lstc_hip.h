@@ -331,7 +331,7 @@ int lstc_dropout_seed_device(const uint64_t* dev_word);
  * softmax(x W^T + b) (c=2, models/Classifier.py:10).  x [rows, 32]. */
 int lstc_head_out_fwd(const float* x, const float* W, const float* b, float* out, int64_t rows, int32_t c,
                       void* stream);
-/* dx [rows,32], dW [c,32], db [c] from d(out); dW/db are ADDED to (caller zeroes) by one workgroup in a fixed order. */
+/* dx [rows,32], dW [c,32], db [c] from d(out); dW/db are WRITTEN (round 4: no caller-side fill) by one workgroup that sums in a fixed order. */
 int lstc_head_out_bwd(const float* x, const float* W, const float* out, const float* dout,
                       float* dx, float* dW, float* db, int64_t rows, int32_t c, void* stream);
 

@@ -631,8 +631,8 @@ __global__ void __launch_bounds__(NT) head_out_bwd_kernel(const float* __restric
         float v = accw[0][threadIdx.x];
 #pragma unroll
         for (int q = 1; q < NT / 64; ++q) v += accw[q][threadIdx.x];
-        if (threadIdx.x < c * 32) dW[threadIdx.x] += v;
-        else if (threadIdx.x >= 64 && threadIdx.x - 64 < c) db[threadIdx.x - 64] += v;
+        if (threadIdx.x < c * 32) dW[threadIdx.x] = v;             // written, not added to: one workgroup holds the whole sum
+        else if (threadIdx.x >= 64 && threadIdx.x - 64 < c) db[threadIdx.x - 64] = v;
     }
 }
 

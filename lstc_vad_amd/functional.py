@@ -1403,8 +1403,8 @@ class HeadFunction(torch.autograd.Function):
         rows, c, p = x2.shape[0], cf["c"], cf["p"]
         dout = dout.contiguous()
         dh2 = torch.empty_like(h2)
-        dw5 = torch.zeros_like(w5)
-        db5 = torch.zeros((c,), device=x2.device, dtype=torch.float32)
+        dw5 = torch.empty_like(w5)                 # written by the kernel (one workgroup, fixed order): no fill
+        db5 = torch.empty((c,), device=x2.device, dtype=torch.float32)
         check(_lib.load().lstc_head_out_bwd(dev_ptr(h2), dev_ptr(w5), dev_ptr(out), dev_ptr(dout), dev_ptr(dh2),
                                             dev_ptr(dw5), dev_ptr(db5), rows, c, stream_ptr()), "lstc_head_out_bwd")
         da2 = dropout_apply(dh2, p, cf["s2"]) if p > 0 else dh2          # grad of Linear(512,32) output
@@ -1436,7 +1436,9 @@ class VadLossFunction(torch.autograd.Function):
         d.lambda_normal, d.lambda_abnormal = cfg.get("lambda_normal", 0.0), cfg.get("lambda_abnormal", 0.0)
         dout = torch.empty_like(out)
         scalars = torch.empty((5,), device=dev, dtype=torch.float32)
-        bag = torch.zeros((2 * cfg["bs_global"],), device=dev, dtype=torch.float32)
+        # the bag vector is an exchange buffer: only a rank-sharded batch needs it (zero-filled: the other ranks' slots are summed in)
+        sharded = cfg["bs_local"] != cfg["bs_global"]
+        bag = torch.zeros((2 * cfg["bs_global"],), device=dev, dtype=torch.float32) if sharded else None
         labs = abn_labels.contiguous().float() if abn_labels is not None else None
         tg = targets.contiguous().float() if targets is not None else None
         d.out, d.abn_labels, d.targets, d.bag = dev_ptr(out), dev_ptr(labs), dev_ptr(tg), dev_ptr(bag)
