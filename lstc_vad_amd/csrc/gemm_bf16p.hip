@@ -37,6 +37,12 @@ typedef float floatx4v __attribute__((ext_vector_type(4)));
 #ifndef P1_NT_S16
 #define P1_NT_S16 1                      // NT form on v_mfma_f32_16x16x32_bf16 (0: 32x32x16, A/B builds)
 #endif
+#ifndef P1_SPLIT_MAJOR
+#define P1_SPLIT_MAJOR 1                 // item order, see set_item (0 / 0: the round-3 order, A/B builds)
+#endif
+#ifndef P1_GROUP_M
+#define P1_GROUP_M 4
+#endif
 constexpr int NT8 = 512;                 // 8 waves
 constexpr int P1_TILE = 4096;            // bf16 elements of one packed tile (128 rows x 32 k = 8 KB)
 constexpr int P1_SLOT = 2048;            // 64 rows x 32 k (4 KB)
@@ -144,7 +150,7 @@ struct P1Params {
     int M, N, ldc, ldr, ld_relu, flags;
     float alpha;
     DropKey dk;
-    int tilesN, nsteps, steps_per_split;     // K steps of 64
+    int tilesM, tilesN, nsteps, steps_per_split;     // K steps of 64
     int splits, total_items;                 // K splits launched; work items = tiles x splits
     int KBa, KBb;                            // 32-k tiles per 128-row block of the A / B pack (even)
     long long split_stride;                  // elements between the outputs of consecutive K splits (0: atomics into one C)
@@ -183,9 +189,35 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
     const int first = (G & 7) ? (int)blockIdx.x : ((int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3));
     int item = first;
     int mb = 0, nb = 0, kt0 = 0, nkt = 0;
+    // item -> (K split, tile).  Consecutive items run side by side on one XCD (32 per round), so they should SHARE operands:
+    //   P1_SPLIT_MAJOR: the split index is the slow one (items of one split are consecutive: the tiles of a split share the token
+    //     slices of both packs; split-fastest put the four splits of ONE tile side by side, which share nothing - the weight-
+    //     gradient form then fetched the X pack once per XCD: 3.6 GB of L2 misses for 0.82 GB of packs);
+    //   P1_GROUP_M: inside the tile index, groups of P1_GROUP_M consecutive M panels are walked M fastest, so 32 consecutive tiles
+    //     cover P1_GROUP_M panels x 32 / P1_GROUP_M N tiles whatever tilesN is (row-major: 32 / tilesN panels x tilesN tiles -
+    //     1.3 x 24 for the fused Q|K|V projection, whose 12-MB weight then streamed through every XCD's L2 each round).
+    // Same-box A/B (tools/bf16p_order_ab.sh, round 4): weight gradients 2048 x 2048 x 100352 0.661 -> 0.625 ms, 6144 x 2048 1.789 ->
+    // 1.657, 2048 x 4096 1.186 -> 1.113 (FETCH_SIZE x 2 of the first: 3.63 -> 1.22 GB); forward N = 4096 1.517 -> 1.470, N = 6144
+    // 2.213 -> 2.123 (FETCH x 2 9.6 -> 4.5 GB); N = 2048 products unchanged (8 N tiles: both orders coincide).
     auto set_item = [&](int w) {
+#if P1_SPLIT_MAJOR
+        const int ntiles = p.tilesM * p.tilesN;
+        const int sp = w / ntiles, tile = w - sp * ntiles;
+#else
         const int tile = w / p.splits, sp = w - tile * p.splits;
+#endif
+#if P1_GROUP_M
+        {
+            const int per_group = P1_GROUP_M * p.tilesN;
+            const int gid = tile / per_group, first_m = gid * P1_GROUP_M;
+            const int gsz = min(p.tilesM - first_m, P1_GROUP_M);
+            const int loc = tile - gid * per_group;
+            mb = first_m + loc % gsz;
+            nb = loc / gsz;
+        }
+#else
         mb = tile / p.tilesN; nb = tile - mb * p.tilesN;
+#endif
         kt0 = sp * p.steps_per_split;
         nkt = min(p.nsteps, kt0 + p.steps_per_split) - kt0;
     };
@@ -873,6 +905,7 @@ __attribute__((visibility("hidden"))) int lstc_gemm_bf16p_impl(const LstcGemmDes
     p.steps_per_split = (p.nsteps + splits - 1) / splits;
     const int eff_splits = (p.nsteps + p.steps_per_split - 1) / p.steps_per_split;
     const int tilesM = (d->M + 255) / 256;
+    p.tilesM = tilesM;
     p.tilesN = (d->N + 255) / 256;
     p.splits = eff_splits;
     p.total_items = tilesM * p.tilesN * eff_splits;

@@ -27,6 +27,9 @@
 #include "lstc_common.h"
 #include <type_traits>
 
+#ifndef LSTC_F32_GROUP_M
+#define LSTC_F32_GROUP_M 8          /* grouped tile order inside an XCD's run, see the tile map (0: row-major, the order of rounds 1-3) */
+#endif
 namespace {
 
 constexpr int BK = 32;
@@ -238,7 +241,24 @@ __global__ void __launch_bounds__(WGM* WGN * 64) gemm_f32_kernel(const GemmParam
         const int q = nwg >> 3, r = nwg & 7;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+#if LSTC_F32_GROUP_M
+    // grouped order: inside the linear tile index, groups of GROUP_M consecutive M panels are walked M fastest, so the 64 tiles
+    // resident on an XCD cover 8 panels x 8 N tiles instead of 4 x 16 (N = 2048): per K step they touch 8 + 8 operand chunks
+    // instead of 4 + 16.  Same-box A/B (tools/f32_group_ab.sh, round 4), 100352 x 2048 x 2048: FETCH_SIZE 3.61e6 -> 2.41e6 KB (HBM-side
+    // traffic per launch 8.04 -> 5.64 GB), L2 hit rate 70.6 -> 79.4 %, 5.62 -> 5.60 ms (NT), 5.65 -> 5.61 (NN), N = 4096 11.27 -> 11.21
+    int mt, nt;
+    {
+        constexpr int GM = LSTC_F32_GROUP_M;
+        const int per_group = GM * p.tilesN;
+        const int gid = pid / per_group, first_m = gid * GM;
+        const int gsz = min(p.tilesM - first_m, GM);
+        const int loc = pid - gid * per_group;
+        mt = first_m + loc % gsz;
+        nt = loc / gsz;
+    }
+#else
     const int mt = pid / p.tilesN, nt = pid % p.tilesN;
+#endif
     const int m0 = mt * BM, n0 = nt * BN;
     const int kt0 = blockIdx.y * p.ktiles_per_split;
     const int kt1 = min(p.ktiles, kt0 + p.ktiles_per_split);
