@@ -170,6 +170,28 @@ struct PkParams {
     int epi_f4;          // 0: scalar epilogue; 1 / 2: float4 epilogue (lstc_common.h, epilogue_f4) without / with one per-element operand
 };
 
+#ifndef PK_GROUP_M
+#define PK_GROUP_M 8          /* grouped tile order inside an XCD's run (as csrc/gemm_f32.hip); 0 = row-major, the order of rounds 1-3.
+                                 Same-box A/B, round 4: 100352 x 4096 x 2048 4.44 -> 4.13 ms, x 2048 x 2048 2.16 -> 2.14, weight gradient
+                                 2.22 -> 2.15, f32x3 LTN step 117.1 / 117.2 -> 115.6 / 115.7 ms; bit-identical products */
+#endif
+// linear tile index (after the XCD remap) -> (M tile, N tile): row-major, or groups of PK_GROUP_M consecutive M tiles walked M
+// fastest - the 64 tiles resident on an XCD then cover 8 x 8 tiles instead of 4 x 16 and share twice as much per K step
+__device__ __forceinline__ void pk_tile_of(int pid, int tilesM, int tilesN, int& mb, int& nb) {
+#if PK_GROUP_M
+    const int per_group = PK_GROUP_M * tilesN;
+    const int gid = pid / per_group, first_m = gid * PK_GROUP_M;
+    const int gsz = min(tilesM - first_m, PK_GROUP_M);
+    const int loc = pid - gid * per_group;
+    mb = first_m + loc % gsz;
+    nb = loc / gsz;
+#else
+    mb = pid / tilesN;
+    nb = pid % tilesN;
+#endif
+}
+
+
 // plane pairs by decreasing magnitude: q = 0: hh, 1: hl, 2: lh
 __device__ __forceinline__ constexpr int pa(int q) { return q == 2 ? 1 : 0; }
 __device__ __forceinline__ constexpr int pb(int q) { return q == 1 ? 1 : 0; }
@@ -191,7 +213,8 @@ __global__ void __launch_bounds__(NT, 1) gemm_pk_kernel(const PkParams p) {
         const int nwg = gridDim.x, xcd = pid & 7, idx = pid >> 3, q = nwg >> 3, r = nwg & 7;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int mb = pid / p.tilesN, nb = pid % p.tilesN;
+    int mb, nb;
+    pk_tile_of(pid, (int)gridDim.x / p.tilesN, p.tilesN, mb, nb);
     const int kt0 = blockIdx.y * p.ktiles_per_split;
     const int nkt = min(p.KB, kt0 + p.ktiles_per_split) - kt0;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), wm = wave >> 1, wn = wave & 1;
@@ -394,7 +417,8 @@ __global__ void __launch_bounds__(NT, 2) gemm_pk2s_kernel(const PkParams p) {
         const int nwg = gridDim.x, xcd = pid & 7, idx = pid >> 3, q = nwg >> 3, r = nwg & 7;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int mb = pid / p.tilesN, nb = pid % p.tilesN;
+    int mb, nb;
+    pk_tile_of(pid, (int)gridDim.x / p.tilesN, p.tilesN, mb, nb);
     const int kt0 = blockIdx.y * p.ktiles_per_split;
     const int nkt = min(p.KB, kt0 + p.ktiles_per_split) - kt0;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), wm = wave >> 1, wn = wave & 1;
@@ -580,7 +604,8 @@ __global__ void __launch_bounds__(NT, 1) gemm_pkw_kernel(const PkParams p) {
         const int nwg = gridDim.x, xcd = pid & 7, idx = pid >> 3, q = nwg >> 3, r = nwg & 7;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int mb = pid / p.tilesN, nb = pid % p.tilesN;          // 256-row tile, 128-column tile
+    int mb, nb;
+    pk_tile_of(pid, (int)gridDim.x / p.tilesN, p.tilesN, mb, nb);
     const int kt0 = blockIdx.y * p.ktiles_per_split;
     const int nkt = min(p.KB, kt0 + p.ktiles_per_split) - kt0;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), wm = wave >> 1, wn = wave & 1;
