@@ -301,8 +301,9 @@ def main():
                     "the rank's token count leaves the three separate products with badly filled tile rounds, engine.TrainStep)")
     ap.add_argument("--grad_reduce_dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient all-reduce "
                     "(bf16: buckets rounded by lstc_cast_f32_bf16, half the xGMI bytes; default fp32 = the reference's numerics)")
-    ap.add_argument("--buckets", type=int, default=0, help="gradient all-reduce buckets per model (0 = default: head + one per encoder "
-                    "layer, backward order; 1 = one all-reduce after the backward; up to 8 = FFN / attention halves of every layer)")
+    ap.add_argument("--buckets", type=int, default=0, help="gradient all-reduce buckets per model (0 = default: head + the FFN half and "
+                    "the attention half of every encoder layer, backward order - 7 buckets of <= 67 MB for the LTN; N = the same pieces "
+                    "merged into N groups of about equal bytes; 1 = one all-reduce after the backward)")
     ap.add_argument("--nccl_algo", default="", help="sets NCCL_ALGO for RCCL (e.g. Ring, Tree) before the communicator is created; recorded in config")
     ap.add_argument("--nccl_proto", default="", help="sets NCCL_PROTO for RCCL (e.g. Simple, LL, LL128); recorded in config")
     ap.add_argument("--graph", action="store_true", help="run the step as ONE captured HIP graph (lstc_vad_amd.engine.GraphedStep; N=1 "

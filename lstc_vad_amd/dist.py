@@ -175,7 +175,9 @@ def direct_grad_parameters(encoder, head) -> List[torch.nn.Parameter]:
 def encoder_head_buckets(encoder, head, n_buckets=None) -> List[List[torch.nn.Parameter]]:
     """Backward-ordered buckets for an ``Encoder`` + head pair: head, then encoder layers last to first
     (layer-level parameters that feed the first layer — cls_token / position_enc / input LayerNorm — go last).
-    ``n_buckets`` (None = one bucket per layer + head [+ rest], the default): the finest backward-ordered pieces - head, then per
+    ``n_buckets`` (None = one bucket per layer + head [+ rest]; "finest" = every piece its own bucket - what engine.TrainStep uses:
+    the bucket that becomes ready LAST, layer 0's attention weights, is the one whose all-reduce no backward work can hide, so it
+    should be as small as a still-large message allows: 67 MB instead of 134 MB at the LTN widths): the finest backward-ordered pieces - head, then per
     layer its FFN parameters and its attention parameters, layers last to first, then the rest - merged into that many
     consecutive groups of roughly equal bytes (1 = a single all-reduce after the backward; up to 2 x layers + 2).  xGMI is
     point-to-point, so few large messages are the starting point; the knob exists so one run can be compared with another
@@ -197,6 +199,8 @@ def encoder_head_buckets(encoder, head, n_buckets=None) -> List[List[torch.nn.Pa
         pieces.append(rest)
     if n_buckets is None:
         return [list(head.parameters())] + per_layer + ([rest] if rest else [])
+    if n_buckets == "finest":
+        return [g for g in pieces if g]
     n_buckets = max(1, min(int(n_buckets), len(pieces)))
     size = lambda g: sum(p.numel() for p in g)
     total, out, cur, acc = sum(size(g) for g in pieces), [], [], 0

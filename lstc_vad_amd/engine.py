@@ -47,7 +47,12 @@ class TrainStep:
         # measurement hook (bench.py at N > 1): a list to receive (before backward, after backward, after reducer.finish()) HIP events
         # of every step on the launch stream - backward time and the part of the gradient all-reduce that the backward did not hide
         self.comm_events = None
-        self.reducer = (GradAllReducer(encoder_head_buckets(encoder, head, n_buckets), group, force=force, reduce_dtype=grad_reduce_dtype,
+        # default bucketing: head, then per layer (last to first) its FFN half and its attention half - 2 x layers + 1 buckets of
+        # <= 67 MB at the LTN widths.  Only the LAST bucket's reduction (layer 0's attention weights, ready when the backward ends)
+        # cannot hide under the backward; halving it halves what is exposed, and 67 MB is still far above the size at which
+        # RCCL's rings reach their bandwidth (bench.py --buckets N merges the pieces into N groups for comparison runs)
+        self.reducer = (GradAllReducer(encoder_head_buckets(encoder, head, "finest" if n_buckets is None else n_buckets), group,
+                                       force=force, reduce_dtype=grad_reduce_dtype,
                                        direct=direct_grad_parameters(encoder, head))
                         if (self.world > 1 or force) else None)
 
