@@ -15,6 +15,23 @@
 // sequences before one atomic flush.
 #include "attention_common.h"
 
+// Grid of the first / second generation kernels: one workgroup per (chunk of sequences, head).  ATTN_HEAD_FAST: the HEAD is the
+// fast grid index, so the workgroups dispatched together read the 8 heads' 1-KB column slices of the SAME token rows - whole 8-KB
+// rows of Q / K / V / dO per DRAM page - instead of one 1-KB slice out of every 8 KB of far-apart rows (A/B builds: 0 = chunk fast,
+// the order of rounds 1-3).  gridDim.y <= 65535 bounds the chunk count in that form.
+#ifndef ATTN_HEAD_FAST
+#define ATTN_HEAD_FAST 0
+#endif
+#if ATTN_HEAD_FAST
+#define ATTN_CHUNK ((int)blockIdx.y)
+#define ATTN_HEAD ((int)blockIdx.x)
+#define ATTN_GRID(chunks, H) dim3((unsigned)(H), (unsigned)(chunks))
+#else
+#define ATTN_CHUNK ((int)blockIdx.x)
+#define ATTN_HEAD ((int)blockIdx.y)
+#define ATTN_GRID(chunks, H) dim3((unsigned)(chunks), (unsigned)(H))
+#endif
+
 namespace {
 using namespace lstc_attn;
 
@@ -177,7 +194,7 @@ __global__ void __launch_bounds__(NT, T <= 2 ? 4 : 2) attn_fwd_kernel(const Attn
     constexpr bool BF = false;       // first generation: exact-f32 products only (bf16 products made these latency-bound loops slower)
     constexpr int SP = 32 * T, LD = SP + 1, NJ = (SP + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int n = blockIdx.x, h = blockIdx.y, S = p.S;
+    const int n = ATTN_CHUNK, h = ATTN_HEAD, S = p.S;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* Qb = p.Q + (size_t)n * S * p.ldq + (size_t)h * p.dk;
     const float* Kb = p.K + (size_t)n * S * p.ldk + (size_t)h * p.dk;
@@ -252,7 +269,7 @@ __global__ void __launch_bounds__(NT, T <= 3 ? 2 : 1) attn_bwd_kernel(const Attn
     float* Dm = sm;                 // dP~ then dA
     float* Pm = sm + SP * LD;       // dropped probabilities
     float* tacc = sm + 2 * SP * LD; // [NT/64][table_rows] bias-table gradient of this head, one copy per wave
-    const int h = blockIdx.y, S = p.S;
+    const int h = ATTN_HEAD, S = p.S;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool has_bias = p.index_ld > 0 && p.dtable != nullptr;
     if (has_bias)
@@ -260,7 +277,7 @@ __global__ void __launch_bounds__(NT, T <= 3 ? 2 : 1) attn_bwd_kernel(const Attn
     // a wave owns its copy: within one row i the S - 1 columns map to distinct table rows (relative offsets of distinct
     // positions differ), and a wave walks its rows in order, so plain read-modify-write is race-free and the sum order fixed
     float* const tw = tacc + wave * p.table_rows;
-    const int n_begin = blockIdx.x * p.n_per_wg;
+    const int n_begin = ATTN_CHUNK * p.n_per_wg;
     const int n_end = min(p.N, n_begin + p.n_per_wg);
 #pragma unroll 1
     for (int n = n_begin; n < n_end; ++n) {
@@ -324,7 +341,7 @@ __global__ void __launch_bounds__(NT, T <= 3 ? 2 : 1) attn_bwd_kernel(const Attn
             float v = tacc[i];
 #pragma unroll
             for (int w = 1; w < NT / 64; ++w) v += tacc[w * p.table_rows + i];
-            if (p.table_partials) p.dtable[((size_t)blockIdx.x * p.table_rows + i) * p.H + h] = v;
+            if (p.table_partials) p.dtable[((size_t)ATTN_CHUNK * p.table_rows + i) * p.H + h] = v;
             else atomicAdd(&p.dtable[(size_t)i * p.H + h], v);
         }
     }
@@ -418,14 +435,14 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) attn_bwd2_kernel(con
     float* stage = sm + ST0;
     float* DmT = stage;                          // dA^T (phase 2 / 3): the staging ring is idle after phase 1 (SP * LD <= 4 * CH)
     float* tacc = stage + 4 * CH;                // [NW][table_rows]
-    const int h = blockIdx.y, S = p.S;
+    const int h = ATTN_HEAD, S = p.S;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, h2 = lane >> 5;
     const bool has_bias = p.index_ld > 0 && p.dtable != nullptr;
     if (has_bias)
         for (int i = threadIdx.x; i < NW * p.table_rows; i += 64 * NW) tacc[i] = 0.f;
     float* const tw = tacc + wave * p.table_rows;
-    const int n_begin = blockIdx.x * p.n_per_wg;
+    const int n_begin = ATTN_CHUNK * p.n_per_wg;
     const int n_end = min(p.N, n_begin + p.n_per_wg);
     const uint32_t stage_b = (uint32_t)(ST0 * 4);       // dynamic LDS starts at byte 0 of the workgroup's allocation
     const int nchunks = p.dv >> 5;
@@ -594,7 +611,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) attn_bwd2_kernel(con
             float v = tacc[i];
 #pragma unroll
             for (int w = 1; w < NW; ++w) v += tacc[w * p.table_rows + i];
-            if (p.table_partials) p.dtable[((size_t)blockIdx.x * p.table_rows + i) * p.H + h] = v;
+            if (p.table_partials) p.dtable[((size_t)ATTN_CHUNK * p.table_rows + i) * p.H + h] = v;
             else atomicAdd(&p.dtable[(size_t)i * p.H + h], v);
         }
     }
@@ -614,7 +631,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) attn_fwd2_kernel(con
     constexpr int ST0 = (SP * LD + 3) & ~3;
     float* stage = sm + ST0;                     // staging ring [buf][operand][SP][32]; after phase 1: Pd^T ([k][i])
     float* PT = stage;
-    const int n = blockIdx.x, h = blockIdx.y, S = p.S;
+    const int n = ATTN_CHUNK, h = ATTN_HEAD, S = p.S;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, h2 = lane >> 5;
     const float* Qb = p.Q + (size_t)n * S * p.ldq + (size_t)h * p.dk;
@@ -878,7 +895,7 @@ int lstc_attn_fwd(const LstcAttnDesc* d, void* stream) {
         return attn3f_fwd_launch(p, T, (p.N + npw - 1) / npw, st);
     }
     const size_t lds = (size_t)(32 * T) * (32 * T + 1) * sizeof(float);
-    dim3 grid(p.N, p.H);
+    dim3 grid = ATTN_GRID(p.N, p.H);
     if ((T == 1 || T == 3 || (bf && T == 2)) && p.vec_qk && p.vec_v && (p.dk % 32) == 0 && (p.dv % 32) == 0 && (d->variant == 0 || d->variant == 2)) {
         // second-generation kernel (LDS-DMA staged Q K^T, register-resident V rows).  Interleaved A/B on one MI355X
         // (tools/attn_time.py): S = 17 0.283 vs 0.350 ms; S = 49 with exact-f32 products 1.10 vs 1.02 ms (the first generation's 4
@@ -947,8 +964,9 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
         npw = npw < 1 ? 1 : (npw > 16 ? 16 : npw);
     }
     p.n_per_wg = npw;
-    dim3 grid((p.N + npw - 1) / npw, p.H);
-    if (p.table_partials && (int)grid.x != d->dtable_chunks) return LSTC_E_SHAPE;
+    const int chunks_ = (p.N + npw - 1) / npw;
+    dim3 grid = ATTN_GRID(chunks_, p.H);
+    if (p.table_partials && chunks_ != d->dtable_chunks) return LSTC_E_SHAPE;
     // second-generation kernel (LDS-DMA staged dP, register-resident B rows): d_k, d_v multiples of 32, aligned operands
     // S = 49: 1.63 vs 2.75 ms, S = 17: 0.53 vs 1.19 ms per LTN / STN layer (interleaved A/B); S = 81 (T = 3): 138 KB of LDS =
     // one workgroup per CU; with 4 waves that was no faster than the first generation (193 spilled registers, 7.3 vs 7.1 ms),
@@ -973,7 +991,7 @@ int lstc_attn_bwd(const LstcAttnDesc* d, void* stream) {
     }
     if (d->in_pack_cols > 0) {      // third generation: packed bf16 inputs and outputs
         if (!p.dQp) return LSTC_E_UNSUPPORTED;
-        return attn3_bwd_launch(p, T, (int)grid.x, st);
+        return attn3_bwd_launch(p, T, chunks_, st);
     }
     if (v2) {
         const int SP = 32 * T, NW = T == 3 ? 8 : 4;      // 64 < S <= 96: 138 KB of LDS = one workgroup per CU, so that one runs 8 waves
