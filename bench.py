@@ -97,100 +97,13 @@ def cpu_baseline(cfg_name, threads):
 
 
 # ---------------------------------------------------------------------------------------------- N-rank launcher
-def _tail(path, n=25):
-    try:
-        with open(path, "r", errors="replace") as f:
-            return f.readlines()[-n:]
-    except OSError:
-        return []
-
-
 def launch_ranks(n, argv, script=None, rank_timeout_s=600.0):
-    """``python bench.py --gpus N`` without a launcher: start N fresh rank processes (this parent has not touched the GPU and
-    never will), relay rank 0's JSON line, fail if any rank fails.  Replaces the reference's single-process
-    ``nn.DataParallel`` wrap (Train/temporal_transformer_shanghaitech.py:76-78) with one process per GPU.
-
-    Watchdog: a rank stuck in RCCL initialisation (or anywhere else) would otherwise hang the parent until the caller's own
-    timeout with nothing to read.  After ``rank_timeout_s`` seconds the exact child PIDs started here are terminated (then
-    killed), every rank's last stderr lines are printed and the launcher returns 1.  Every rank's stderr goes to its own
-    temporary file (relayed to this process's stderr at the end), so the tails exist whichever rank is the stuck one."""
-    import socket
-    import subprocess
-    import tempfile
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    procs, errs = [], []
-    t_start = time.monotonic()
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this pool
-        ef = tempfile.NamedTemporaryFile("w+", prefix=f"lstc_bench_rank{r}_", suffix=".err", delete=False)
-        errs.append(ef)
-        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else ef, stderr=ef, text=True))
-    line = None
-    failed = None
-    timed_out = False
-    out0 = procs[0].stdout
-    import selectors
-    sel = selectors.DefaultSelector()
-    sel.register(out0, selectors.EVENT_READ)
-    open0 = True
-    while True:
-        if open0:
-            for _key, _ in sel.select(timeout=0.5):
-                ln = out0.readline()
-                if ln == "":
-                    open0 = False
-                    sel.unregister(out0)
-                elif ln.lstrip().startswith("{"):
-                    line = ln.strip()
-                else:
-                    sys.stderr.write(ln)
-        else:
-            time.sleep(0.2)
-        codes = [p.poll() for p in procs]
-        bad = [i for i, c in enumerate(codes) if c not in (None, 0)]
-        if bad and failed is None and not timed_out:
-            failed = (bad[0], codes[bad[0]])
-            for p in procs:                                      # exact PIDs we started, nothing by pattern
-                if p.poll() is None:
-                    p.terminate()
-        if not timed_out and failed is None and rank_timeout_s > 0 and time.monotonic() - t_start > rank_timeout_s and \
-                any(c is None for c in codes):
-            timed_out = True
-            stuck = [i for i, c in enumerate(codes) if c is None]
-            sys.stderr.write(f"[bench] watchdog: rank(s) {stuck} still running after {rank_timeout_s:.0f} s; stopping all ranks\n")
-            for p in procs:
-                if p.poll() is None:
-                    p.terminate()
-            t_kill = time.monotonic() + 10.0
-            while time.monotonic() < t_kill and any(p.poll() is None for p in procs):
-                time.sleep(0.1)
-            for p in procs:
-                if p.poll() is None:
-                    p.kill()
-        if all(c is not None for c in codes) and (not open0 or timed_out):
-            break
-    for r, ef in enumerate(errs):                                # relay the ranks' stderr: rank 0 whole, the others' tails
-        ef.flush(); ef.close()
-        lines = _tail(ef.name, 10 ** 6 if r == 0 and failed is None and not timed_out else 25)
-        if lines and (r == 0 or failed is not None or timed_out):
-            sys.stderr.write(f"---- rank {r} stderr{' (last lines)' if (failed is not None or timed_out) else ''} ----\n" + "".join(lines))
-        try:
-            os.unlink(ef.name)
-        except OSError:
-            pass
-    if timed_out:
-        return 1
-    if failed is not None:
-        sys.stderr.write(f"[bench] rank {failed[0]} exited with code {failed[1]}; all ranks stopped\n")
-        return 1
-    if line is None:
-        sys.stderr.write("[bench] rank 0 printed no JSON line\n")
-        return 1
-    print(line, flush=True)
-    return 0
+    """``python bench.py --gpus N`` without a launcher: lstc_vad_amd.launch.launch_ranks (N fresh rank processes started before this
+    process touches the GPU, rank 0's JSON line relayed, watchdog, stderr tails) - the same launcher ``Train/*.py --data_parallel
+    --gpu 0,1,...`` uses.  Replaces the reference's single-process ``nn.DataParallel`` wrap
+    (Train/temporal_transformer_shanghaitech.py:76-78) with one process per GPU."""
+    from lstc_vad_amd.launch import launch_ranks as _launch
+    return _launch(n, argv, script=script or os.path.abspath(__file__), rank_timeout_s=rank_timeout_s, relay="json", tag="bench")
 
 
 # ---------------------------------------------------------------------------------------------- synthetic resident feed
@@ -287,6 +200,10 @@ def main():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "f32x3"],
                     help="GEMM compute type of `value`: fp32 = exact-f32 MFMA (headline, parity mode); bf16 = bf16 MFMA, f32 "
                          "storage/accumulate (BASELINE configs 3/5); f32x3 = f32-accurate products on the f16 matrix cores")
+    ap.add_argument("--act_dtype", default="bf16", choices=["bf16", "fp32"],
+                    help="bf16 compute mode only: storage of the residual stream between encoder blocks - bf16 (default: every activation "
+                         "and residual-stream gradient between the CLS concat and the last full layer exists only as a packed bf16 "
+                         "operand, DESIGN 3.1d) or fp32 (rounds 1-4: f32 activations between the blocks)")
     ap.add_argument("--lr_scale", type=float, default=1e-3, help="multiplies the reference learning rates (1e-4 / 1e-2): with "
                     "i.i.d. synthetic features the classifier saturates within two Adagrad steps at the reference rates and the "
                     "backward then runs on near-zero operands; timing does not depend on it")
@@ -355,6 +272,7 @@ def main():
     from lstc_vad_amd import functional as Fn
     from lstc_vad_amd.engine import MixedStep, TrainStep
     from lstc_vad_amd.models import Classifier, Encoder, Regressor
+    Fn.set_act_dtype(a.act_dtype)
 
     def sync():
         if world > 1:
@@ -559,6 +477,8 @@ def main():
              "ms_per_step": round(1e3 * res["dt"] / res["steps"], 3), "ms_per_step_median": round(res["step_ms_median"], 3),
              "loss_first_timed_step": res["loss_first"],
              "loss_last_timed_step": res["loss_last"], "hbm_peak_GB": round(res["hbm"] / 1e9, 2)}
+        if dtype == "bf16":
+            o["act_dtype"] = a.act_dtype
         r = roofline_of(res, dtype, cfg)
         if r:
             t = pmc_traffic(cfg, dtype)
@@ -680,6 +600,7 @@ def main():
                           # over the timed steps): how much of the gradient all-reduce the backward did not hide
                           **(head_res["comm"] or {}),
                           "grad_reduce_dtype": a.grad_reduce_dtype,
+                          **({"act_dtype": a.act_dtype} if a.dtype == "bf16" else {}),
                           "nccl_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_"))}},
                "loss_first_timed_step": head_res["loss_first"], "loss_last_timed_step": head_res["loss_last"],
                "hbm_peak_GB": round(head_res["hbm"] / 1e9, 2), "roofline": roof}

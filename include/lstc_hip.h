@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LSTC_VERSION 100            /* 0.1.0 */
+#define LSTC_VERSION 110            /* 0.1.1: see INTEGRATION.md, "ABI history" */
 
 enum {
     LSTC_OK = 0,
@@ -76,8 +76,12 @@ enum {
      *   OUT_PACK:       C is an lstc_pack1 buffer (lstc_pack1_bytes(M, N)) that receives the result rounded to bf16 in the layout
      *                   of a packed [M, N] operand - the output of W1 (models/FFN.py:17) IS the A operand of W2 and of dW2, and
      *                   the gradient of that hidden IS the operand of dW1 / dX: no f32 copy, no lstc_pack1 pass (ldc ignored);
-     *   RELU_MASK_PACK: relu_src is such a pack (the hidden's sign is read from its bf16 form; ld_relu ignored). */
-    LSTC_EPI_OUT_PACK = 128, LSTC_EPI_RELU_MASK_PACK = 256
+     *   RELU_MASK_PACK: relu_src is such a pack (the hidden's sign is read from its bf16 form; ld_relu ignored);
+     *   RESIDUAL_PACK:  residual is such a pack of [M, N] (ldr ignored; with RESIDUAL and OUT_PACK, never with RELU_MASK): the
+     *                   bf16 activation stream - dropout(fc(o)) + x (models/MultiHeadAttention.py:123-124), dropout(W2 h + b2) + x
+     *                   (models/FFN.py:17-19) and the input gradients dX + dy read their residual as 2 bytes per element from
+     *                   the pack the previous block's LayerNorm wrote and leave 2 bytes per element for the next one. */
+    LSTC_EPI_OUT_PACK = 128, LSTC_EPI_RELU_MASK_PACK = 256, LSTC_EPI_RESIDUAL_PACK = 512
 };
 
 typedef struct LstcGemmDesc {
@@ -287,6 +291,24 @@ int lstc_layernorm_bwd_drop_pack(const float* dy, const float* x, const float* g
                                  float* dx, float* partial, int32_t n_partial, int64_t rows, int32_t d, float dropout_p,
                                  uint64_t dropout_seed, void* packed, void* stream);
 
+/* bf16 ACTIVATION STREAM (round 5; the bf16 compute mode's default where the shapes allow).  Between the CLS concat and the last
+ * full encoder layer no f32 activation exists: the residual sums dropout(f) + x (models/MultiHeadAttention.py:123-124,
+ * models/FFN.py:17-19) leave the GEMM epilogues as lstc_pack1 operands (LSTC_EPI_OUT_PACK + LSTC_EPI_RESIDUAL_PACK), these two
+ * kernels run nn.LayerNorm (models/MultiHeadAttention.py:125-126, models/FFN.py:20-21) and its backward ON the packs, and the
+ * gradient of the residual stream travels as packs too - 2 bytes per element per pass instead of 4 (+2 for the pack).
+ * Statistics, normalisation, dropout replay and the partial sums are f32 arithmetic; only what is stored is bf16 (RNE).
+ *   lstc_layernorm_fwd_act: exactly one of x (f32 [rows, d]) / x_pack (pack of [rows, d]) is the input; y (f32) and / or y_pack
+ *                           receive the result (the last full layer hands f32 to the CLS-only layer).
+ *   lstc_layernorm_bwd_act: x_pack = the forward's input pack; the incoming gradient is dy (f32) or dy_pack; dx_pack (may be
+ *                           NULL: nobody reads layer 0's) = gradient of the residual sum, df_pack = dropout-replay(dx) exactly
+ *                           as lstc_layernorm_bwd_drop_pack, partial [3, n_partial, d] = dgamma, dbeta, column sums of df.
+ * rows % 256 == 0 and d = 1024 or 2048 (LSTC_E_UNSUPPORTED otherwise); every pack lstc_pack1_bytes(rows, d) bytes, 16-B aligned. */
+int lstc_layernorm_fwd_act(const float* x, const void* x_pack, const float* gamma, const float* beta, float* y, void* y_pack,
+                           float* mean, float* rstd, int64_t rows, int32_t d, float eps, void* stream);
+int lstc_layernorm_bwd_act(const float* dy, const void* dy_pack, const void* x_pack, const float* gamma, const float* mean,
+                           const float* rstd, void* dx_pack, float* partial, int32_t n_partial, int64_t rows, int32_t d,
+                           float dropout_p, uint64_t dropout_seed, void* df_pack, void* stream);
+
 /* CLS = mean over tokens (or `cls_token` if not NULL), prepended; optional `pos` [S, d] added to every
  * sequence — models/Encoder.py:51-58.  x [N, S-1, d] -> y [N, S, d].  When `x_hi` is not NULL, sequences
  * [0, n_lo) are read from `x` and [n_lo, N) from `x_hi`: the reference's torch.cat([norm_feats, abnorm_feats])
@@ -294,7 +316,8 @@ int lstc_layernorm_bwd_drop_pack(const float* dy, const float* x, const float* g
 int lstc_cls_concat_fwd(const float* x, const float* x_hi, int64_t n_lo, const float* cls_token, const float* pos,
                         float* y, int64_t N, int32_t S, int32_t d, void* stream);
 /* The same with the packed bf16 form of y ([N*S, d], lstc_pack1 layout) written next to it: layer 0's A operand in bf16 mode
- * (N*S a multiple of 256, d a multiple of 64; else LSTC_E_UNSUPPORTED). */
+ * (N*S a multiple of 256, d a multiple of 64; else LSTC_E_UNSUPPORTED).  y may be NULL (round 5, the bf16 activation stream: the
+ * pack is then the only output; d % 4 == 0 and 16-B aligned operands required). */
 int lstc_cls_concat_fwd_pack(const float* x, const float* x_hi, int64_t n_lo, const float* cls_token, const float* pos,
                              float* y, int64_t N, int32_t S, int32_t d, void* packed, void* stream);
 

@@ -17,12 +17,12 @@ LIB_PATH = os.environ.get("LSTC_LIBRARY") or os.path.join(_HERE, "liblstc_hip.so
 
 F32, BF16, F32X3, BF16P = 0, 1, 2, 3
 EPI_BIAS, EPI_RELU, EPI_DROPOUT, EPI_RESIDUAL, EPI_RELU_MASK, EPI_ACCUM, EPI_OUT_F32 = 1, 2, 4, 8, 16, 32, 64
-EPI_OUT_PACK, EPI_RELU_MASK_PACK = 128, 256
+EPI_OUT_PACK, EPI_RELU_MASK_PACK, EPI_RESIDUAL_PACK = 128, 256, 512
 
 EXPORTS = (
     "lstc_gemm", "lstc_attn_fwd", "lstc_attn_bwd", "lstc_attn_cls_fwd", "lstc_attn_cls_bwd", "lstc_cls_dot", "lstc_cls_wsum",
     "lstc_cls_outer", "lstc_layernorm_fwd", "lstc_layernorm_bwd", "lstc_layernorm_fwd_pack",
-    "lstc_layernorm_bwd_drop_pack", "lstc_layernorm_bwd_drop",
+    "lstc_layernorm_bwd_drop_pack", "lstc_layernorm_bwd_drop", "lstc_layernorm_fwd_act", "lstc_layernorm_bwd_act",
     "lstc_cls_concat_fwd", "lstc_cls_concat_fwd_pack", "lstc_cls_concat_bwd", "lstc_colsum", "lstc_colsum_batched", "lstc_dropout_apply", "lstc_dropout_mask", "lstc_dropout_seed_device",
     "lstc_head_out_fwd", "lstc_head_out_bwd", "lstc_vad_loss", "lstc_adagrad_step", "lstc_adagrad_multi", "lstc_sqnorm_accum", "lstc_scale",
     "lstc_sqnorm_multi_scratch", "lstc_sqnorm_multi", "lstc_clip_scale_multi",
@@ -112,6 +112,8 @@ def load():
         "lstc_layernorm_fwd_pack": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp, vp],
         "lstc_layernorm_bwd_drop_pack": [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, f32, u64, vp, vp],
         "lstc_layernorm_bwd_drop": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, f32, u64, vp],
+        "lstc_layernorm_fwd_act": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
+        "lstc_layernorm_bwd_act": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, f32, u64, vp, vp],
         "lstc_cls_concat_fwd": [vp, vp, i64, vp, vp, vp, i64, i32, i32, vp],
         "lstc_cls_concat_fwd_pack": [vp, vp, i64, vp, vp, vp, i64, i32, i32, vp, vp],
         "lstc_cls_concat_bwd": [vp, vp, i64, i32, i32, i32, vp],

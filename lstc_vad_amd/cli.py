@@ -140,6 +140,97 @@ def complete_args(script: str, args=None, argv=None) -> Namespace:
     return full
 
 
+def namespace_to_argv(script: str, args: Namespace) -> list:
+    """The command line that parses back to ``args`` (flags of ``build_parser(script)`` only): what the rank processes of a
+    ``--data_parallel`` run are started with when ``train(args)`` was handed a Namespace instead of sys.argv."""
+    argv = []
+    for act in build_parser(script)._actions:
+        if not act.option_strings or act.dest == "help" or not hasattr(args, act.dest):
+            continue
+        v = getattr(args, act.dest)
+        if isinstance(act, argparse._StoreTrueAction):
+            if v:
+                argv.append(act.option_strings[0])
+        elif v is not None:
+            argv += [act.option_strings[0], repr(v) if isinstance(v, float) else str(v)]
+    return argv
+
+
+def _launch_data_parallel(script: str, args: Namespace):
+    """``--data_parallel --gpu 0,1,2,3`` IS the multi-GPU run upstream (``nn.DataParallel`` over every visible device,
+    Train/temporal_transformer_shanghaitech.py:76-78, ``--gpu`` -> CUDA_VISIBLE_DEVICES :328).  Here: one rank per listed GPU,
+    started by lstc_vad_amd.launch.launch_ranks BEFORE this process touches a GPU (the children set the devices; the parent only
+    relays rank 0's output and watches the ranks).  The ranks are started with the command line that parses back to ``args``, so
+    ``train(args)`` on a caller-built Namespace launches the same job as the script's own command line.  Returns None when this
+    process should do the work itself (one device listed, or already a rank of a launched / torchrun job), else ("done", what rank
+    0 handed back)."""
+    if not getattr(args, "data_parallel", False) or "WORLD_SIZE" in os.environ:
+        return None
+    from .launch import launch_ranks, parse_devices
+    devs = parse_devices(getattr(args, "gpu", "0"))
+    if len(devs) < 2:
+        return None
+    n_ranks = len(devs)
+    if os.environ.get("LSTC_SHARE_DEVICE") == "1":          # test boxes with ONE GPU: --gpu 0,0 = two ranks on device 0 (gloo collectives)
+        devs = sorted(set(devs), key=devs.index)
+    bs = getattr(args, "batch_size", None)
+    if script in SCRIPTS and bs is not None and bs % n_ranks:
+        raise SystemExit(f"--batch_size {bs} (pairs of the global batch) does not split over the {n_ranks} GPUs of --gpu {args.gpu}")
+    folder = "Test" if script.startswith("evaluation") else "Train"
+    child = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), folder, script + ".py")
+    rc = launch_ranks(n_ranks, namespace_to_argv(script, args), script=child,
+                      rank_timeout_s=float(os.environ.get("LSTC_RANK_TIMEOUT_S", "0")), relay="all", devices=devs, tag=script)
+    if rc:
+        raise SystemExit(rc)
+    res = launch_ranks.last_result
+    return ("done", float(res) if res not in (None, "None") else None)
+
+
+def _init_ranks(torch):
+    """(rank, world, device) of this process; joins the RCCL process group when it is one of several ranks."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("LSTC_SHARE_DEVICE") == "1":          # every rank on device 0 (one-GPU test boxes; RCCL refuses that, so gloo)
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("LSTC_DIST_BACKEND", "nccl")         # nccl = RCCL over xGMI
+        if not dist.is_initialized():
+            dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+    return rank, world, dev
+
+
+class _LateLog:
+    """Step scalars reach the log ONE STEP LATE on rank 0: step k's five scalars are copied to pinned host memory behind step k's
+    kernels and read when step k + 1 has been queued, so the host never waits for the step it has just launched (the reference
+    formats CUDA scalars right after the step, Train/temporal_transformer_shanghaitech.py:143 - a device sync per step; here rank
+    0 runs ahead like the other ranks).  ``flush()`` before anything that must see the log complete (evaluation, exit)."""
+
+    def __init__(self, torch, emit):
+        self.torch, self.emit = torch, emit
+        self.buf = torch.empty(5, dtype=torch.float32).pin_memory()
+        self.pending = None
+
+    def push(self, it, epoch, sc):
+        self.flush()
+        self.buf.copy_(sc.detach().reshape(-1)[:5], non_blocking=True)
+        ev = self.torch.cuda.Event()
+        ev.record()
+        self.pending = (it, epoch, ev)
+
+    def flush(self):
+        if self.pending is None:
+            return
+        it, epoch, ev = self.pending
+        self.pending = None
+        ev.synchronize()
+        self.emit(it, epoch, *(float(x) for x in self.buf.tolist()))
+
+
 def _apply_compute_dtype(args):
     from . import functional as Fn
     Fn.set_compute_dtype(getattr(args, "compute_dtype", "fp32"))
@@ -165,6 +256,9 @@ def _logger(args, script):
 def train(script: str, argv=None, args=None):
     mode, head_kind, pre = SCRIPTS[script]
     args = complete_args(script, args, argv)
+    launched = _launch_data_parallel(script, args)
+    if launched is not None:
+        return launched[1]
     if "LOCAL_RANK" not in os.environ:                      # single process: honour --gpu like the reference does
         os.environ.setdefault("HIP_VISIBLE_DEVICES", str(getattr(args, "gpu", 0)))
     import numpy as np
@@ -181,18 +275,10 @@ def train(script: str, argv=None, args=None):
     if not torch.cuda.is_available():
         raise SystemExit("no HIP device visible: the LSTC_VAD training path here is MI355X-only (no CPU fallback)")
     _apply_compute_dtype(args)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    rank, world, dev = _init_ranks(torch)
     logger, log_dir = _logger(args, script) if rank == 0 else (logging.getLogger("null"), "")
-    if getattr(args, "data_parallel", False) and world == 1 and rank == 0:
-        logger.info("--data_parallel: nn.DataParallel is replaced by one process per GPU; launch with "
-                    "`python -m torch.distributed.run --nproc-per-node N` to use N GPUs")
+    if getattr(args, "data_parallel", False) and rank == 0:
+        logger.info("--data_parallel: %d rank(s), one process per GPU (--gpu %s), RCCL gradient all-reduce" % (world, getattr(args, "gpu", "")))
 
     part_len = _get(args, "part_len", pre)
     d_model = args.d_model
@@ -261,27 +347,37 @@ def train(script: str, argv=None, args=None):
     inter = int(getattr(args, "inter_epoch", 10))
     sel = Selector(script, args)
     it = 0
+
+    def emit(it_, epoch_, loss, mil, err, l1, aux):
+        if mode == "LTN":
+            logger.info('[{}/{}]: loss {:.4f}, MIL_loss {:.4f}, CE_loss {:.4f} MIL_l1 {:.4f}'.format(it_, epoch_, loss, mil, aux, l1))
+        elif mode == "STN":
+            logger.info('[{}/{}]: loss {:.4f}, err {:.4f}, l1 {:.4f}'.format(it_, epoch_, loss, err, l1))
+        else:
+            logger.info('Round 0 [{}/{}]: spatio_loss {:.4f}, CE_loss {:.4f}, MIL_loss {:.4f}, err {:.4f}, l1 {:.4f}'.format(
+                it_, epoch_, loss, aux, mil, err, l1))
+    late = _LateLog(torch, emit) if rank == 0 else None
     for epoch in range(epochs):
         for norm_feats, norm_labs, abnorm_feats, abnorm_labs in data:
             sc = ts.step(norm_feats, abnorm_feats, abnorm_labs)
-            if rank == 0:
-                loss, mil, err, l1, aux = (float(x) for x in sc.cpu())          # one D2H copy per step
-                if mode == "LTN":
-                    logger.info('[{}/{}]: loss {:.4f}, MIL_loss {:.4f}, CE_loss {:.4f} MIL_l1 {:.4f}'.format(it, epoch, loss, mil, aux, l1))
-                elif mode == "STN":
-                    logger.info('[{}/{}]: loss {:.4f}, err {:.4f}, l1 {:.4f}'.format(it, epoch, loss, err, l1))
-                else:
-                    logger.info('Round 0 [{}/{}]: spatio_loss {:.4f}, CE_loss {:.4f}, MIL_loss {:.4f}, err {:.4f}, l1 {:.4f}'.format(
-                        it, epoch, loss, aux, mil, err, l1))
+            if late is not None:
+                late.push(it, epoch, sc)          # the PREVIOUS step's line is written now: no sync on the step just queued
             it += 1
             if args.steps and it >= args.steps:
                 break
+        if late is not None:
+            late.flush()
         data.shuffle_keys()
         last = script == "spatio_transformer_MIL_CE" and epoch == epochs - 1          # MIL_CE.py:218 also evaluates the last epoch
-        if rank == 0 and (epoch % inter == 0 or last):
+        if epoch % inter == 0 or last:
+            # EVERY rank evaluates: the videos of the test (and train) list are sharded over the ranks (pipeline._ScoreBoard) and
+            # every rank ends up with the same AUCs, so no rank sits in a collective while another scores the whole list; rank 0
+            # alone logs and writes the checkpoints
             auc_test, auc_train = eval_fn()
             enc.train(); head.train()
             save_auc, lines = sel.update(epoch, auc_test, auc_train)
+            if rank != 0:
+                save_auc, lines = None, []
             if save_auc is not None:
                 logger.info("saving model......")
                 enc_path, head_path = checkpoint_names(script, args, save_auc)
@@ -293,13 +389,14 @@ def train(script: str, argv=None, args=None):
                 logger.info("save complete.")
             for ln in lines:
                 logger.info(ln)
-            logger.info('======================================================================================')
+            if rank == 0:
+                logger.info('======================================================================================')
         if args.steps and it >= args.steps:
             break
     if rank == 0 and getattr(args, "save_final", ""):
         torch.save(enc.state_dict(), args.save_final + "encoder.ckpt")
         torch.save(head.state_dict(), args.save_final + "head.ckpt")
-    if rank == 0 and script == "spatio_transformer_MIL_CE" and real and getattr(args, "temporal_pseudo_path", ""):
+    if script == "spatio_transformer_MIL_CE" and real and getattr(args, "temporal_pseudo_path", ""):
         # end of the round (Train/spatio_transformer_MIL_CE.py:392-414): RE-LOAD --spatio_model_path / --regression_model_path
         # (the files, not the weights just trained - upstream expects the user's best checkpoint there) and write the next
         # temporal model's pseudo labels, score > --threshold else 0, to --temporal_pseudo_path (np.save appends .npy)
@@ -311,12 +408,16 @@ def train(script: str, argv=None, args=None):
         dataset = str(getattr(args, "dataset", "SHT"))
         gen(enc.eval(), head.eval(), "STN", dataset if dataset in ("UCF", "UBnormal") else "SHT", args.dataset_path, args.training_txt,
             args.threshold, part_len=1, n_patch=args.n_patch, d_model=d_model, segment_len=args.segment_len,
-            out_path=args.temporal_pseudo_path)
+            out_path=args.temporal_pseudo_path, rank=rank, world=world)      # sharded over the ranks; rank 0 writes the file
         enc.train(); head.train()
-        logger.info("temporal pseudo label generation finished.")
+        if rank == 0:
+            logger.info("temporal pseudo label generation finished.")
     if world > 1:
         dist.destroy_process_group()
-    return sel.best_test if sel.rule["on"] == "test" else sel.best_train
+    best = sel.best_test if sel.rule["on"] == "test" else sel.best_train
+    if rank == 0 and os.environ.get("LSTC_LAUNCHED") == "1":
+        print(f"LSTC_RESULT {best!r}", flush=True)          # handed back to the --data_parallel parent (launch.launch_ranks)
+    return best
 
 
 class _HostPairs:
@@ -392,10 +493,11 @@ def _real_data(script, args, mode, part_len, pseudo_path, dev, rank, world, enc,
         auc_test = auc_train = 0.0
         if getattr(args, "testing_txt", ""):
             auc_test = evaluate_auc(enc.eval(), head.eval(), kind, dataset, test_arc, args.testing_txt, masks, part_len,
-                                    args.n_patch, args.segment_len)
+                                    args.n_patch, args.segment_len, rank=rank, world=world)
         if train_arc and dataset != "UCF":
             auc_train = evaluate_train_auc(enc.eval(), head.eval(), kind, dataset, train_arc, args.training_txt,
-                                           getattr(args, "test_mask_dir", ""), part_len, args.n_patch, args.segment_len)
+                                           getattr(args, "test_mask_dir", ""), part_len, args.n_patch, args.segment_len,
+                                           rank=rank, world=world)
         return auc_test, auc_train
     return data, eval_fn
 
@@ -441,7 +543,12 @@ def generate_pseudo_labels(script: str, argv=None, args=None):
     (else 0), save ``{key: [n_clips, 1]}`` with ``np.save`` (the pickled-dict format utils/load_dataset.py:20 reads)."""
     mode = "LTN" if script.endswith("temporal") else "STN"
     args = complete_args(script, args, argv)
-    os.environ.setdefault("HIP_VISIBLE_DEVICES", str(getattr(args, "gpu", 0)))
+    # --data_parallel --gpu 0,1,...: the training videos are sharded over one rank per listed GPU (pipeline._ScoreBoard); rank 0
+    # writes the file (upstream wraps the models in nn.DataParallel here too, Train/pseudo_labels_generator_temporal.py:58-60)
+    if _launch_data_parallel(script, args) is not None:
+        return None
+    if "LOCAL_RANK" not in os.environ:
+        os.environ.setdefault("HIP_VISIBLE_DEVICES", str(getattr(args, "gpu", 0)))
     import numpy as np
     import torch
     from .data import SyntheticVideos
@@ -449,7 +556,7 @@ def generate_pseudo_labels(script: str, argv=None, args=None):
     if not torch.cuda.is_available():
         raise SystemExit("no HIP device visible: MI355X-only path")
     _apply_compute_dtype(args)
-    dev = torch.device("cuda", 0)
+    rank, world, dev = _init_ranks(torch)
     part_len = getattr(args, "part_len", 1)
     enc = Encoder(n_layers=args.n_layers, n_head=args.n_head, d_k=args.d_k, d_v=args.d_v, d_model=args.d_model,
                   d_inner=args.n_hidden, MHA_layerNorm=args.MHA_layerNorm, FFN_layerNorm=args.FFN_layerNorm,
@@ -473,8 +580,13 @@ def generate_pseudo_labels(script: str, argv=None, args=None):
         from .pipeline import generate_pseudo_labels as run
         out = run(enc, head, mode, args.dataset, args.dataset_path, args.training_txt, args.threshold, part_len=part_len,
                   n_patch=args.n_patch, d_model=args.d_model, segment_len=args.segment_len,
-                  classifier_head=(mode == "STN" and args.n_layers == 1), out_path=args.pseudo_labels_path)
-        print(f"{'temporal' if mode == 'LTN' else 'spatio'} pseudo label generation finished.")
+                  classifier_head=(mode == "STN" and args.n_layers == 1), out_path=args.pseudo_labels_path, rank=rank, world=world)
+        if rank == 0:
+            print(f"{'temporal' if mode == 'LTN' else 'spatio'} pseudo label generation finished.")
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
         return out
     # same seed -> same synthetic training videos (keys, lengths) as the Train/*.py loops on rank 0
     data = SyntheticVideos(args.synthetic_pairs or 8, 1, 1, part_len, args.n_patch, args.d_model, dev,

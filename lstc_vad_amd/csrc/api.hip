@@ -22,7 +22,7 @@ int lstc_gemm(const LstcGemmDesc* d, void* stream) {
     if (d->dtype == LSTC_F32) return lstc_gemm_f32_impl(d, st);
     if (d->dtype == LSTC_BF16 && lstc_gemm_bf16_impl) return lstc_gemm_bf16_impl(d, st);
     if (d->dtype == LSTC_F32X3) return lstc_gemm_f32x3_impl(d, st);
-    if ((d->flags & (LSTC_EPI_OUT_PACK | LSTC_EPI_RELU_MASK_PACK)) && d->dtype != LSTC_BF16P) return LSTC_E_UNSUPPORTED;
+    if ((d->flags & (LSTC_EPI_OUT_PACK | LSTC_EPI_RELU_MASK_PACK | LSTC_EPI_RESIDUAL_PACK)) && d->dtype != LSTC_BF16P) return LSTC_E_UNSUPPORTED;
     if (d->dtype == LSTC_BF16P) return lstc_gemm_bf16p_impl(d, st);
     return LSTC_E_UNSUPPORTED;
 }

@@ -43,6 +43,11 @@ typedef float floatx4v __attribute__((ext_vector_type(4)));
 #ifndef P1_GROUP_M
 #define P1_GROUP_M 4
 #endif
+#ifndef P1_RPK_ASM
+#define P1_RPK_ASM 1                     // packed residual loads of the pipelined epilogue: 1 = inline asm with hand-counted waits (default);
+                                         // 0 = ordinary loads - the compiler then sinks them below the hand-placed waits and spills around
+                                         // them (scratch traffic counts in vmcnt too): wrong results with a bias, kept only as a warning
+#endif
 constexpr int NT8 = 512;                 // 8 waves
 constexpr int P1_TILE = 4096;            // bf16 elements of one packed tile (128 rows x 32 k = 8 KB)
 constexpr int P1_SLOT = 2048;            // 64 rows x 32 k (4 KB)
@@ -158,6 +163,7 @@ struct P1Params {
     int vec_epi;                             // 16-B epilogue accesses allowed (N, ld's multiples of 4, pointers 16-B aligned)
     int out_kbp;                             // LSTC_EPI_OUT_PACK: C is an lstc_pack1 buffer of [M, N]; its 32-k tiles per row block (else 0)
     int mask_kbp;                            // LSTC_EPI_RELU_MASK_PACK: relu_src is an lstc_pack1 buffer of [M, N] (else 0)
+    int res_kbp;                             // LSTC_EPI_RESIDUAL_PACK: res is an lstc_pack1 buffer of [M, N] (else 0)
 };
 
 constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
@@ -172,13 +178,15 @@ constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >>
 // S16 (NT form only): the products run on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 - same FLOP per cycle, same fragment
 // bytes, but the chip holds a higher clock on this shape under load (MI355X_MICROARCH.md, DVFS give-back item 7).
 // EPK (S16 only): 0 = f32 output / f32 ReLU-mask operand; 1 = the output is written as a packed bf16 operand (LSTC_EPI_OUT_PACK);
-// 2 = packed output AND the ReLU mask read from a packed operand (LSTC_EPI_RELU_MASK_PACK); 3 = packed mask, f32 output.
+// 2 = packed output AND the ReLU mask read from a packed operand (LSTC_EPI_RELU_MASK_PACK); 3 = packed mask, f32 output;
+// 4 = packed output AND the residual read from a packed operand (LSTC_EPI_RESIDUAL_PACK: the bf16 activation stream of
+// round 5 - the residual sum dropout(f) + x and the input gradient dX + dy never exist in f32).
 template <bool TR, bool S16, int EPK = 0>
 __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
     const DropKey dkn = drop_key_now(p.dk);      // graph replays: seed + device offset (lstc_dropout_seed_device)
     static_assert(!(TR && S16), "the transposed-read form keeps the 32x32x16 shape");
     static_assert(EPK == 0 || S16, "packed outputs / masks exist on the pipelined epilogue of the S16 form only");
-    constexpr bool OPK = EPK == 1 || EPK == 2, MPK = EPK == 2 || EPK == 3;
+    constexpr bool OPK = EPK == 1 || EPK == 2 || EPK == 4, MPK = EPK == 2 || EPK == 3, RPK = EPK == 4;
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_p1[];
     bf16_t* const smem = smem_p1;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -579,6 +587,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                 typedef unsigned uint2v __attribute__((ext_vector_type(2)));
                 typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
                 uint2v axp[MPK ? 2 : 1][MPK ? 4 : 1];
+                uint2v axr[RPK ? 2 : 1][RPK ? 4 : 1];      // RPK: 4 bf16 of the packed residual per group, hand-counted like ax
                 const int hdma = has_next ? (nkt > 1 ? 16 : 8) : 0;                              // LDS-DMA of the next item in flight
 #define P1_FE_LOAD(b, set)                                                                                              \
                 do {                                                                                                    \
@@ -590,6 +599,11 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                                also covers the previous batch's stores - the price of never having these registers in flight     \
                                behind its back; the f32 operands below stay hand-counted) */                                      \
                             axp[MPK ? set : 0][MPK ? g_ : 0] = *reinterpret_cast<const uint2v*>(reinterpret_cast<const char*>(mb_) + ((g_ & 1) ? offP1 : offP0)); \
+                        } else if constexpr (RPK) {   /* the tile address is wave-uniform (SGPRs), the lane offset one of two VGPRs */ \
+                            const bf16_t* rb_ = reinterpret_cast<const bf16_t*>(p.res) +                                  \
+                                ((size_t)(2 * cmb + wr) * p.res_kbp + cnb * 8 + wc * 2 + ((b) >> 2)) * P1_TILE + (2 * ((b) & 3) + (g_ >> 1)) * 512; \
+                            if constexpr (P1_RPK_ASM) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(axr[RPK ? set : 0][RPK ? g_ : 0]) : "v"((g_ & 1) ? offP1 : offP0), "s"(rb_) : "memory"); \
+                            else axr[RPK ? set : 0][RPK ? g_ : 0] = *reinterpret_cast<const uint2v*>(reinterpret_cast<const char*>(rb_) + ((g_ & 1) ? offP1 : offP0)); \
                         } else {                                                                                        \
                             const float* ab_ = aux + (size_t)(urow0 + (2 * ((b) & 3) + (g_ >> 1)) * 16 + 4 * (g_ & 1)) * ldx + (ucol0 + 32 * ((b) >> 2)); \
                             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ax[set][g_]) : "v"(offX), "s"(ab_) : "memory"); \
@@ -607,7 +621,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                     r1 = __int_as_float(__builtin_amdgcn_mov_dpp(s1, 0xB1, 0xF, 0xF, true));
                     if (b0) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
                 };
-#define P1_FE_GROUP(v0, v1, v2, v3, rt, hf, cp, bv, av, mv)                                                                  \
+#define P1_FE_GROUP(v0, v1, v2, v3, rt, hf, cp, bv, av, mv, rv)                                                              \
                 do {                                                                                                    \
                     float4 v = make_float4((v0) * alpha + (bv)[0], (v1) * alpha + (bv)[1], (v2) * alpha + (bv)[2], (v3) * alpha + (bv)[3]); \
                     if (flags & LSTC_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); } \
@@ -618,7 +632,12 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                         v.z = drop_keep(idx + 2, dkn) ? v.z * dkn.scale : 0.f;                                         \
                         v.w = drop_keep(idx + 3, dkn) ? v.w * dkn.scale : 0.f;                                         \
                     }                                                                                                   \
-                    if (flags & LSTC_EPI_RESIDUAL) { v.x += (av)[0]; v.y += (av)[1]; v.z += (av)[2]; v.w += (av)[3]; }    \
+                    if (RPK || (flags & LSTC_EPI_RESIDUAL)) {                                                            \
+                        if constexpr (RPK) {   /* bf16 -> f32 is a 16-bit shift: exact */                               \
+                            v.x += __uint_as_float((rv)[0] << 16); v.y += __uint_as_float((rv)[0] & 0xffff0000u);        \
+                            v.z += __uint_as_float((rv)[1] << 16); v.w += __uint_as_float((rv)[1] & 0xffff0000u);        \
+                        } else { v.x += (av)[0]; v.y += (av)[1]; v.z += (av)[2]; v.w += (av)[3]; }                       \
+                    }                                                                                                   \
                     if (flags & LSTC_EPI_RELU_MASK) {                                                                    \
                         if constexpr (MPK) {   /* bf16 > 0 <=> the element's 16 bits, as the upper half of an int32, are > 0 */ \
                             v.x = (int)((mv)[0] << 16) > 0 ? v.x : 0.f; v.y = (int)((mv)[0] & 0xffff0000u) > 0 ? v.y : 0.f; \
@@ -639,10 +658,12 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                         asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(offC), "v"(sv_), "s"(cb_) : "memory"); \
                     }                                                                                                   \
                 } while (0)
-                if (aux) { P1_FE_LOAD(0, 0); }
+                // RPK: the launcher admits the variant only with LSTC_EPI_RESIDUAL set - no runtime branch around the loads (with one
+                // the register allocator spilled the first batch's in-flight destinations: tools/isa_guard.py)
+                if (RPK || aux) { P1_FE_LOAD(0, 0); }
 #pragma unroll
                 for (int b = 0; b < 8; ++b) {
-                    if (aux) {
+                    if (RPK || aux) {
                         if (b < 7) { P1_FE_LOAD(b + 1, (b + 1) & 1); }
                         if (b == 0 || b == 7) __builtin_amdgcn_s_waitcnt(vmcnt_imm(4)); else __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));
                     } else if (b == 0 && (flags & LSTC_EPI_BIAS)) {                               // the head DMA stays in flight
@@ -657,7 +678,8 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                     if (b == 0) { asm volatile("" : "+v"(fbias[0]), "+v"(fbias[1])); }
 #pragma unroll
                     for (int g_ = 0; g_ < 4; ++g_) {
-                        if constexpr (!MPK) asm volatile("" : "+v"(ax[b & 1][g_]));
+                        if constexpr (RPK && P1_RPK_ASM) asm volatile("" : "+v"(axr[RPK ? (b & 1) : 0][RPK ? g_ : 0]));
+                        else if constexpr (!MPK) asm volatile("" : "+v"(ax[b & 1][g_]));
                     }
                     const int cp2 = b >> 2;
 #pragma unroll
@@ -679,8 +701,10 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                         } while (0)
                         if (!P1_ABL_NOXPOSE) { P1_SWAP(x0, y0); P1_SWAP(x1, y1); P1_SWAP(x2, y2); P1_SWAP(x3, y3); }
 #undef P1_SWAP
-                        P1_FE_GROUP(x0, x1, x2, x3, rt, 0, cp2, fbias[cp2], ax[b & 1][2 * r2], axp[MPK ? (b & 1) : 0][MPK ? 2 * r2 : 0]);
-                        P1_FE_GROUP(y0, y1, y2, y3, rt, 1, cp2, fbias[cp2], ax[b & 1][2 * r2 + 1], axp[MPK ? (b & 1) : 0][MPK ? 2 * r2 + 1 : 0]);
+                        P1_FE_GROUP(x0, x1, x2, x3, rt, 0, cp2, fbias[cp2], ax[b & 1][2 * r2], axp[MPK ? (b & 1) : 0][MPK ? 2 * r2 : 0],
+                                    axr[RPK ? (b & 1) : 0][RPK ? 2 * r2 : 0]);
+                        P1_FE_GROUP(y0, y1, y2, y3, rt, 1, cp2, fbias[cp2], ax[b & 1][2 * r2 + 1], axp[MPK ? (b & 1) : 0][MPK ? 2 * r2 + 1 : 0],
+                                    axr[RPK ? (b & 1) : 0][RPK ? 2 * r2 + 1 : 0]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -860,7 +884,7 @@ __attribute__((visibility("hidden"))) int lstc_gemm_bf16p_impl(const LstcGemmDes
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (!(d->flags & LSTC_EPI_OUT_PACK) && d->ldc < d->N)) return LSTC_E_SHAPE;
     if (d->batch > 1) return LSTC_E_UNSUPPORTED;
     if ((d->flags & LSTC_EPI_BIAS) && !d->bias) return LSTC_E_NULL;
-    if ((d->flags & LSTC_EPI_RESIDUAL) && (!d->residual || d->ldr < d->N)) return LSTC_E_NULL;
+    if ((d->flags & LSTC_EPI_RESIDUAL) && (!d->residual || (!(d->flags & LSTC_EPI_RESIDUAL_PACK) && d->ldr < d->N))) return LSTC_E_NULL;
     if ((d->flags & LSTC_EPI_RELU_MASK) && (!d->relu_src || (!(d->flags & LSTC_EPI_RELU_MASK_PACK) && d->ld_relu < d->N))) return LSTC_E_NULL;
     if ((d->flags & LSTC_EPI_DROPOUT) && (uint64_t)d->M * (uint64_t)d->N > 0xffffffffull) return LSTC_E_RANGE;
     if (!aligned16(d->A) || !aligned16(d->B)) return LSTC_E_ALIGN;
@@ -875,9 +899,12 @@ __attribute__((visibility("hidden"))) int lstc_gemm_bf16p_impl(const LstcGemmDes
     p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = (float*)d->C;
     p.bias = d->bias; p.res = (const float*)d->residual; p.relu_src = (const float*)d->relu_src;
     p.M = d->M; p.N = d->N; p.ldc = d->ldc; p.ldr = d->ldr; p.ld_relu = d->ld_relu; p.alpha = d->alpha;
-    p.flags = d->flags & ~(LSTC_EPI_OUT_PACK | LSTC_EPI_RELU_MASK_PACK);
+    p.flags = d->flags & ~(LSTC_EPI_OUT_PACK | LSTC_EPI_RELU_MASK_PACK | LSTC_EPI_RESIDUAL_PACK);
     p.out_kbp = (d->flags & LSTC_EPI_OUT_PACK) ? (int)p1_kbp(d->N) : 0;
     p.mask_kbp = (d->flags & LSTC_EPI_RELU_MASK_PACK) ? (int)p1_kbp(d->N) : 0;
+    p.res_kbp = (d->flags & LSTC_EPI_RESIDUAL_PACK) ? (int)p1_kbp(d->N) : 0;
+    // a packed residual comes with a packed output only (the bf16 activation stream), never with a ReLU mask
+    if (p.res_kbp && (!(d->flags & LSTC_EPI_RESIDUAL) || !p.out_kbp || (d->flags & LSTC_EPI_RELU_MASK))) return LSTC_E_UNSUPPORTED;
     if (p.out_kbp || p.mask_kbp) {
         // packed outputs / mask operands exist on the pipelined epilogue only: NT form on whole 256 x 256 tiles, no K split
         if (tr || splits > 1 || !P1_NT_S16 || d->M % 256 || d->N % 256 || (d->flags & LSTC_EPI_ACCUM) || d->variant != 0 ||
@@ -893,7 +920,7 @@ __attribute__((visibility("hidden"))) int lstc_gemm_bf16p_impl(const LstcGemmDes
 #endif
     p.vec_epi = (d->N % 4 == 0) && (d->ldc % 4 == 0) && aligned16(d->C) && (p.split_stride % 4 == 0) &&
                 (!(d->flags & LSTC_EPI_BIAS) || aligned16(d->bias)) &&
-                (!(d->flags & LSTC_EPI_RESIDUAL) || (aligned16(d->residual) && d->ldr % 4 == 0)) &&
+                (!(d->flags & LSTC_EPI_RESIDUAL) || (aligned16(d->residual) && (p.res_kbp || d->ldr % 4 == 0))) &&
                 (!(d->flags & LSTC_EPI_RELU_MASK) || (aligned16(d->relu_src) && (p.mask_kbp || d->ld_relu % 4 == 0)));
     if ((p.out_kbp || p.mask_kbp) && !p.vec_epi) return LSTC_E_ALIGN;
 #ifdef LSTC_TUNING
@@ -927,16 +954,18 @@ __attribute__((visibility("hidden"))) int lstc_gemm_bf16p_impl(const LstcGemmDes
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         setup.end(dev_);
     }
     const int n_cu = n_cu_dev[cur & 63].load(std::memory_order_relaxed);
     const int grid = p.total_items < n_cu ? p.total_items : n_cu;       // persistent: one workgroup per CU (128 KB of LDS each)
     if (tr) hipLaunchKernelGGL((gemm_bf16p_kernel<true, false>), dim3(grid), dim3(NT8), lds, st, p);
     else if (P1_NT_S16) {
-        const int epk = p.out_kbp ? (p.mask_kbp ? 2 : 1) : (p.mask_kbp ? 3 : 0);
+        const int epk = p.res_kbp ? 4 : p.out_kbp ? (p.mask_kbp ? 2 : 1) : (p.mask_kbp ? 3 : 0);
         if (epk == 0) hipLaunchKernelGGL((gemm_bf16p_kernel<false, true, 0>), dim3(grid), dim3(NT8), lds, st, p);
         else if (epk == 1) hipLaunchKernelGGL((gemm_bf16p_kernel<false, true, 1>), dim3(grid), dim3(NT8), lds, st, p);
         else if (epk == 2) hipLaunchKernelGGL((gemm_bf16p_kernel<false, true, 2>), dim3(grid), dim3(NT8), lds, st, p);
+        else if (epk == 4) hipLaunchKernelGGL((gemm_bf16p_kernel<false, true, 4>), dim3(grid), dim3(NT8), lds, st, p);
         else hipLaunchKernelGGL((gemm_bf16p_kernel<false, true, 3>), dim3(grid), dim3(NT8), lds, st, p);
     }
     else hipLaunchKernelGGL((gemm_bf16p_kernel<false, false>), dim3(grid), dim3(NT8), lds, st, p);

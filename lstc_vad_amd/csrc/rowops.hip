@@ -309,6 +309,183 @@ __global__ void __launch_bounds__(NT) ln_bwd_pack2(const float* __restrict__ dy,
     }
 }
 
+// ---- bf16 activation stream (round 5; --dtype bf16 with bf16 activations).  Between the CLS concat and the last full layer's
+// LayerNorm no f32 activation exists: the residual sums leave the GEMM epilogues as lstc_pack1 operands (LSTC_EPI_OUT_PACK +
+// LSTC_EPI_RESIDUAL_PACK), the LayerNorm reads that pack and writes the pack the next block consumes (A operand AND residual),
+// and the gradient of the residual stream travels the same way.  A lane owns 16-B chunks (8 consecutive columns) of its row:
+// chunk c8 of row r is one 16-B access at p1_offset(r, 8 c8, KBp); 4 lanes cover a tile row's 64 contiguous bytes.
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+
+// One wave per row, NC = d / 512 chunks per lane.  XP: x is a pack (else f32 [rows, d]); YF / YP: write y as f32 / as a pack.
+template <int NC, bool XP, bool YF, bool YP>
+__global__ void __launch_bounds__(NT) ln_fwd_act(const float* __restrict__ x, const __bf16* __restrict__ xp,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  float* __restrict__ y, __bf16* __restrict__ yp, float* __restrict__ mean,
+                                                  float* __restrict__ rstd, int64_t rows, int d, float eps, int KBp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (NT / 64);
+    float g[NC][8], b[NC][8];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c0 = 8 * (lane + 64 * i);
+        const float4 g0 = *reinterpret_cast<const float4*>(gamma + c0), g1 = *reinterpret_cast<const float4*>(gamma + c0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(beta + c0), b1 = *reinterpret_cast<const float4*>(beta + c0 + 4);
+        g[i][0] = g0.x; g[i][1] = g0.y; g[i][2] = g0.z; g[i][3] = g0.w; g[i][4] = g1.x; g[i][5] = g1.y; g[i][6] = g1.z; g[i][7] = g1.w;
+        b[i][0] = b0.x; b[i][1] = b0.y; b[i][2] = b0.z; b[i][3] = b0.w; b[i][4] = b1.x; b[i][5] = b1.y; b[i][6] = b1.z; b[i][7] = b1.w;
+    }
+    for (int64_t r = wave0; r < rows; r += nwaves) {
+        float v[NC][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c0 = 8 * (lane + 64 * i);
+            if constexpr (XP) {
+                const bf16x8v h = *reinterpret_cast<const bf16x8v*>(xp + p1_offset(r, c0, KBp));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[i][j] = (float)h[j];
+            } else {
+                const float4 a0 = *reinterpret_cast<const float4*>(x + r * d + c0), a1 = *reinterpret_cast<const float4*>(x + r * d + c0 + 4);
+                v[i][0] = a0.x; v[i][1] = a0.y; v[i][2] = a0.z; v[i][3] = a0.w; v[i][4] = a1.x; v[i][5] = a1.y; v[i][6] = a1.z; v[i][7] = a1.w;
+            }
+            s += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
+        }
+        const float mu = wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float a = v[i][j] - mu; q += a * a; }
+        const float rs = 1.f / sqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c0 = 8 * (lane + 64 * i);
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * g[i][j] + b[i][j];
+            if constexpr (YF) {
+                *reinterpret_cast<float4*>(y + r * d + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4*>(y + r * d + c0 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            }
+            if constexpr (YP) {
+                bf16x8v h;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) h[j] = (__bf16)o[j];
+                *reinterpret_cast<bf16x8v*>(yp + p1_offset(r, c0, KBp)) = h;
+            }
+        }
+        if (lane == 0) {
+            mean[r] = mu;
+            rstd[r] = rs;
+        }
+    }
+}
+
+// Backward of z = LayerNorm(dropout(f) + x) on packs: two waves per row (NCH = d / 1024 chunks per lane each), the structure of
+// ln_bwd_pack2.  xp = pack of the pre-LayerNorm sum; the incoming gradient is a pack (DYP) or f32; DX: the gradient of the
+// residual sum leaves as a pack (the residual operand of the block's input-gradient GEMM) - not at all when nobody reads it
+// (layer 0).  dfp = pack of dropout-replay(dx); partial [3, gridDim.x, d] = dgamma, dbeta, column sums of df.
+template <int NCH, bool DYP, bool DX>
+__global__ void __launch_bounds__(NT) ln_bwd_act(const float* __restrict__ dy, const __bf16* __restrict__ dyp,
+                                                  const __bf16* __restrict__ xp, const float* __restrict__ gamma,
+                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                  __bf16* __restrict__ dxp, float* __restrict__ partial, int64_t rows, int d,
+                                                  __bf16* __restrict__ dfp, int KBp, DropKey key) {
+    key = drop_key_now(key);
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][d] combine buffer, then [2][4][64][2] per-lane row sums
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, slot = wv >> 1, half = wv & 1;
+    const int hc = d >> 4;                                        // 16-B chunks per half row
+    float* red = sm + 2 * d;
+    float g[NCH][8], ag[NCH][8], ab[NCH][8], ad[NCH][8];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c0 = 8 * (half * hc + lane + 64 * i);
+        const float4 g0 = *reinterpret_cast<const float4*>(gamma + c0), g1 = *reinterpret_cast<const float4*>(gamma + c0 + 4);
+        g[i][0] = g0.x; g[i][1] = g0.y; g[i][2] = g0.z; g[i][3] = g0.w; g[i][4] = g1.x; g[i][5] = g1.y; g[i][6] = g1.z; g[i][7] = g1.w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ag[i][j] = ab[i][j] = ad[i][j] = 0.f;
+    }
+    const int64_t stride = (int64_t)gridDim.x * 2;
+    const int64_t iters = (rows + stride - 1) / stride;
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t r = it * stride + (int64_t)blockIdx.x * 2 + slot;
+        const bool live = r < rows;
+        const int64_t rr = live ? r : 0;
+        const float mu = mean[rr], rs = rstd[rr];
+        float xh[NCH][8], gd[NCH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c0 = 8 * (half * hc + lane + 64 * i);
+            if (live) {
+                const bf16x8v xv = *reinterpret_cast<const bf16x8v*>(xp + p1_offset(rr, c0, KBp));
+                float dv[8];
+                if constexpr (DYP) {
+                    const bf16x8v dh = *reinterpret_cast<const bf16x8v*>(dyp + p1_offset(rr, c0, KBp));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dv[j] = (float)dh[j];
+                } else {
+                    const float4 a0 = *reinterpret_cast<const float4*>(dy + rr * d + c0), a1 = *reinterpret_cast<const float4*>(dy + rr * d + c0 + 4);
+                    dv[0] = a0.x; dv[1] = a0.y; dv[2] = a0.z; dv[3] = a0.w; dv[4] = a1.x; dv[5] = a1.y; dv[6] = a1.z; dv[7] = a1.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    xh[i][j] = ((float)xv[j] - mu) * rs;
+                    gd[i][j] = dv[j] * g[i][j];
+                    s1 += gd[i][j];
+                    s2 += gd[i][j] * xh[i][j];
+                    ag[i][j] += dv[j] * xh[i][j];
+                    ab[i][j] += dv[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xh[i][j] = gd[i][j] = 0.f;
+            }
+        }
+        float2* rb = reinterpret_cast<float2*>(red) + (it & 1) * 256;
+        rb[wv * 64 + lane] = make_float2(s1, s2);
+        __syncthreads();
+        const float2 pa = rb[(slot * 2) * 64 + lane], pb = rb[(slot * 2 + 1) * 64 + lane];
+        const float m1 = wave_sum(pa.x + pb.x) / (float)d, m2 = wave_sum(pa.y + pb.y) / (float)d;
+        if (!live) continue;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c0 = 8 * (half * hc + lane + 64 * i);
+            const uint32_t fi = (uint32_t)(r * d) + (uint32_t)c0;
+            bf16x8v ho, hf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float ov = rs * (gd[i][j] - m1 - xh[i][j] * m2);
+                const float f = drop_keep(fi + j, key) ? ov * key.scale : 0.f;
+                ad[i][j] += f;
+                ho[j] = (__bf16)ov;
+                hf[j] = (__bf16)f;
+            }
+            const size_t off = p1_offset(r, c0, KBp);
+            if constexpr (DX) *reinterpret_cast<bf16x8v*>(dxp + off) = ho;
+            *reinterpret_cast<bf16x8v*>(dfp + off) = hf;
+        }
+    }
+    // combine the two row slots through LDS, one partial row per workgroup and kind
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c0 = 8 * (half * hc + lane + 64 * i);
+            float* dst = sm + slot * d + c0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[j] = which == 0 ? ag[i][j] : which == 1 ? ab[i][j] : ad[i][j];
+        }
+        __syncthreads();
+        for (int cc = threadIdx.x; cc < (d >> 2); cc += NT) {
+            const float4 t = reinterpret_cast<const float4*>(sm)[cc], u = reinterpret_cast<const float4*>(sm)[(d >> 2) + cc];
+            reinterpret_cast<float4*>(partial + ((size_t)which * gridDim.x + blockIdx.x) * d)[cc] =
+                make_float4(t.x + u.x, t.y + u.y, t.z + u.z, t.w + u.w);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(NT) ln_bwd_generic(const float* __restrict__ dy, const float* __restrict__ x,
                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, float* __restrict__ dx,
@@ -414,7 +591,7 @@ __global__ void __launch_bounds__(NT) cls_concat_fwd_vec4_kernel(const float4* _
     const int c4 = blockIdx.y * NT + threadIdx.x;
     if (c4 >= d4) return;
     const float4* xr = (x_hi && n >= n_lo ? x_hi + (n - n_lo) * (int64_t)(S - 1) * d4 : x + n * (int64_t)(S - 1) * d4) + c4;
-    float4* yr = y + n * (int64_t)S * d4 + c4;
+    float4* yr = y ? y + n * (int64_t)S * d4 + c4 : nullptr;       // NULL: pack only (bf16 activation stream)
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     auto emit = [&](int64_t row, const float4& w) {
         bf16x4v h;
@@ -433,14 +610,14 @@ __global__ void __launch_bounds__(NT) cls_concat_fwd_vec4_kernel(const float4* _
             const float4 pv = pos[(int64_t)(t + 1) * d4 + c4];
             w.x += pv.x; w.y += pv.y; w.z += pv.z; w.w += pv.w;
         }
-        yr[(int64_t)(t + 1) * d4] = w;
+        if (yr) yr[(int64_t)(t + 1) * d4] = w;
         if (packed) emit(n * S + t + 1, w);
     }
     float4 cv;
     if (cls) cv = cls[c4];
     else { const float r = (float)(S - 1); cv = make_float4(s.x / r, s.y / r, s.z / r, s.w / r); }
     if (pos) { const float4 pv = pos[c4]; cv.x += pv.x; cv.y += pv.y; cv.z += pv.z; cv.w += pv.w; }
-    yr[0] = cv;
+    if (yr) yr[0] = cv;
     if (packed) emit(n * S, cv);
 }
 
@@ -943,6 +1120,60 @@ int lstc_layernorm_bwd_drop(const float* dy, const float* x, const float* gamma,
     return lstc_launch_status();
 }
 
+// bf16 activation stream: the model widths only (d = 1024 / 2048), rows filling the pack's tile grid
+static bool act_shape_ok(int64_t rows, int32_t d) { return rows % 256 == 0 && (d == 1024 || d == 2048); }
+
+int lstc_layernorm_fwd_act(const float* x, const void* x_pack, const float* gamma, const float* beta, float* y, void* y_pack,
+                           float* mean, float* rstd, int64_t rows, int32_t d, float eps, void* stream) {
+    if ((!x) == (!x_pack) || !gamma || !beta || (!y && !y_pack) || !mean || !rstd) return LSTC_E_NULL;
+    if (rows <= 0 || d <= 0) return LSTC_E_SHAPE;
+    if (!act_shape_ok(rows, d)) return LSTC_E_UNSUPPORTED;
+    if (!(aligned16(x) && aligned16(x_pack) && aligned16(y) && aligned16(y_pack) && aligned16(gamma) && aligned16(beta))) return LSTC_E_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(rows, NT / 64, 4096);
+    const int KBp = d / 32;
+    const __bf16* xp = (const __bf16*)x_pack;
+    __bf16* yp = (__bf16*)y_pack;
+#define LN_FWD_ACT(NC, XP, YF, YP) hipLaunchKernelGGL((ln_fwd_act<NC, XP, YF, YP>), grid, NT, 0, st, x, xp, gamma, beta, y, yp, mean, rstd, rows, d, eps, KBp)
+#define LN_FWD_ACT_D(XP, YF, YP) do { if (d == 1024) LN_FWD_ACT(2, XP, YF, YP); else LN_FWD_ACT(4, XP, YF, YP); } while (0)
+    if (x_pack) {
+        if (y && y_pack) LN_FWD_ACT_D(true, true, true);
+        else if (y) LN_FWD_ACT_D(true, true, false);
+        else LN_FWD_ACT_D(true, false, true);
+    } else {
+        if (y && y_pack) LN_FWD_ACT_D(false, true, true);
+        else if (y) LN_FWD_ACT_D(false, true, false);
+        else LN_FWD_ACT_D(false, false, true);
+    }
+#undef LN_FWD_ACT_D
+#undef LN_FWD_ACT
+    return lstc_launch_status();
+}
+
+int lstc_layernorm_bwd_act(const float* dy, const void* dy_pack, const void* x_pack, const float* gamma, const float* mean,
+                           const float* rstd, void* dx_pack, float* partial, int32_t n_partial, int64_t rows, int32_t d,
+                           float dropout_p, uint64_t dropout_seed, void* df_pack, void* stream) {
+    if ((!dy) == (!dy_pack) || !x_pack || !gamma || !mean || !rstd || !partial || !df_pack) return LSTC_E_NULL;
+    if (rows <= 0 || d <= 0 || n_partial <= 0 || !(dropout_p >= 0.f && dropout_p < 1.f)) return LSTC_E_SHAPE;
+    if (!act_shape_ok(rows, d)) return LSTC_E_UNSUPPORTED;
+    if ((uint64_t)rows * (uint64_t)d > 0xffffffffull) return LSTC_E_RANGE;      // 32-bit dropout counter
+    if (!(aligned16(dy) && aligned16(dy_pack) && aligned16(x_pack) && aligned16(dx_pack) && aligned16(gamma) && aligned16(partial) &&
+          aligned16(df_pack))) return LSTC_E_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const DropKey key = make_drop_key(dropout_p, dropout_seed);
+    const int KBp = d / 32;
+    const size_t lds2 = (size_t)(2 * d + 1024) * sizeof(float);
+    const __bf16 *dyp = (const __bf16*)dy_pack, *xp = (const __bf16*)x_pack;
+    __bf16 *dxp = (__bf16*)dx_pack, *dfp = (__bf16*)df_pack;
+#define LN_BWD_ACT(NCH, DYP, DX) hipLaunchKernelGGL((ln_bwd_act<NCH, DYP, DX>), n_partial, NT, lds2, st, dy, dyp, xp, gamma, mean, rstd, dxp, partial, rows, d, dfp, KBp, key)
+#define LN_BWD_ACT_D(DYP, DX) do { if (d == 1024) LN_BWD_ACT(1, DYP, DX); else LN_BWD_ACT(2, DYP, DX); } while (0)
+    if (dy_pack) { if (dx_pack) LN_BWD_ACT_D(true, true); else LN_BWD_ACT_D(true, false); }
+    else { if (dx_pack) LN_BWD_ACT_D(false, true); else LN_BWD_ACT_D(false, false); }
+#undef LN_BWD_ACT_D
+#undef LN_BWD_ACT
+    return lstc_launch_status();
+}
+
 static void launch_cls_concat_fwd(const float* x, const float* x_hi, int64_t n_lo, const float* cls_token, const float* pos, float* y,
                                   int64_t N, int32_t S, int32_t d, __bf16* packed, int KBp, hipStream_t st) {
     if (d % 4 == 0 && aligned16(x) && aligned16(y) && (!x_hi || aligned16(x_hi)) && (!cls_token || aligned16(cls_token)) &&
@@ -965,10 +1196,13 @@ int lstc_cls_concat_fwd(const float* x, const float* x_hi, int64_t n_lo, const f
 
 int lstc_cls_concat_fwd_pack(const float* x, const float* x_hi, int64_t n_lo, const float* cls_token, const float* pos,
                              float* y, int64_t N, int32_t S, int32_t d, void* packed, void* stream) {
-    if (!x || !y || !packed) return LSTC_E_NULL;
+    if (!x || !packed) return LSTC_E_NULL;
     if (N <= 0 || S < 2 || d <= 0 || (x_hi && (n_lo < 0 || n_lo > N))) return LSTC_E_SHAPE;
     if ((N * S) % 256 != 0 || d % 64 != 0) return LSTC_E_UNSUPPORTED;      // the rows fill the pack's even tile grid exactly
     if (!aligned16(packed)) return LSTC_E_ALIGN;
+    // y == NULL (pack only: the bf16 activation stream) exists on the 16-B kernel
+    if (!y && !(d % 4 == 0 && aligned16(x) && (!x_hi || aligned16(x_hi)) && (!cls_token || aligned16(cls_token)) && (!pos || aligned16(pos))))
+        return LSTC_E_ALIGN;
     launch_cls_concat_fwd(x, x_hi, n_lo, cls_token, pos, y, N, S, d, (__bf16*)packed, d / 32, (hipStream_t)stream);
     return lstc_launch_status();
 }

@@ -53,6 +53,8 @@ class GradAllReducer:
         self._bucket_of = {}
         self._view_ptr = {}
         self._accum_from: List[int] = []           # per bucket: first element of the autograd-accumulated (zero-filled) tail
+        self._direct: List[torch.nn.Parameter] = []       # parameters with a gradient sink, and which of them delivered this step
+        self._delivered = set()
         direct_ids = {id(p) for p in direct}
         for bi, params in enumerate(param_groups):
             params = [p for p in params if p.requires_grad]
@@ -65,6 +67,11 @@ class GradAllReducer:
             views = []
             self._accum_from.append(sum(p.numel() for p in params if id(p) in direct_ids))
             for p in params:
+                if id(p) in direct_ids and off % 4:
+                    # a sink is the C operand of a GEMM / the destination of a 16-B-vectorised ordered sum: the one-pass and the
+                    # two-pass column sums add in different orders, so "same values as the plain path" needs the aligned form
+                    raise RuntimeError("GradAllReducer: a direct gradient slot must start on a 16-byte boundary (every direct "
+                                       "weight in front of it needs numel % 4 == 0)")
                 v = flat[off:off + p.numel()].view_as(p)
                 p.grad = v                       # the optimizer reads the gradient here either way
                 views.append((p, v))
@@ -75,6 +82,7 @@ class GradAllReducer:
                     # the producing kernel writes into ``v`` and the Function calls back (functional.deliver): always installed -
                     # also on one rank without a process group - so the single-rank bucket path runs what N ranks run
                     p.__dict__["_lstc_grad_sink"] = (v, self._sink_done)
+                    self._direct.append(p)
                 elif self.active and overlap:
                     p.register_post_accumulate_grad_hook(self._hook)    # autograd accumulates in place into the bucket
             self.buckets.append(flat)
@@ -95,11 +103,29 @@ class GradAllReducer:
                 if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                     p.grad = v
         self._handles = []
+        self._delivered.clear()
 
     def _sink_done(self, p):
-        """A direct gradient has been issued into its slot (called from the Function's backward, on the launch stream)."""
+        """A direct gradient has been issued into its slot (called from the Function's backward, on the launch stream).  The
+        bookkeeping runs in EVERY mode (one rank without a process group, overlap off): a sink is WRITTEN, not accumulated into,
+        so a weight that delivers twice between two zero_grad() calls (shared by two Functions, or two backward passes) would
+        silently keep only its last gradient while its biases accumulate through autograd - refuse that loudly."""
+        if id(p) in self._delivered:
+            raise RuntimeError("GradAllReducer: a weight delivered its gradient twice since zero_grad() (its bucket slot is written, "
+                               "not accumulated: shared weights / several backward passes per step are not supported by the "
+                               "bucket path)")
+        self._delivered.add(id(p))
         if self.active and self.overlap:
             self._hook(p)
+
+    def _check_direct(self):
+        """Every direct weight whose sink is in force must have delivered exactly once this step: zero_grad() does not clear the
+        direct region, so a weight whose Function did not run would hand LAST step's gradient to the optimizer."""
+        missing = [p for p in self._direct if id(p) not in self._delivered and p.grad is not None
+                   and p.grad.data_ptr() == self._view_ptr[p]]
+        if missing:
+            raise RuntimeError(f"GradAllReducer: {len(missing)} direct weight gradient(s) were not produced this step "
+                               f"(shapes {[tuple(p.shape) for p in missing[:4]]}): their bucket slots hold stale values")
 
     def _hook(self, p):
         bi = self._bucket_of[p]
@@ -116,6 +142,7 @@ class GradAllReducer:
 
     def finish(self):
         """Call after ``backward()`` and before the optimizer step."""
+        self._check_direct()
         if not self.active:
             return
         if not self.overlap:

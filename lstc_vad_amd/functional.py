@@ -17,7 +17,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (EPI_ACCUM, EPI_BIAS, EPI_DROPOUT, EPI_OUT_PACK, EPI_RELU, EPI_RELU_MASK, EPI_RELU_MASK_PACK, EPI_RESIDUAL, F32, AttnDesc, GemmDesc,
+from ._lib import (EPI_ACCUM, EPI_BIAS, EPI_DROPOUT, EPI_OUT_PACK, EPI_RELU, EPI_RELU_MASK, EPI_RELU_MASK_PACK, EPI_RESIDUAL, EPI_RESIDUAL_PACK, F32, AttnDesc, GemmDesc,
                    LossDesc, check, dev_ptr, stream_ptr)
 
 # ------------------------------------------------------------------------------------------ RNG
@@ -87,6 +87,83 @@ def set_compute_dtype(name: str):
 
 def get_compute_dtype() -> str:
     return {_lib.BF16: "bf16", _lib.F32X3: "f32x3"}.get(_compute_dtype, "fp32")
+
+
+# ---- bf16 activation stream (round 5).  bf16 mode only: between the CLS concat and the last full encoder layer every activation
+# and every gradient of the residual stream lives ONLY as an lstc_pack1 operand (2 B per element): the GEMM epilogues read the
+# residual from a pack and write the pre-LayerNorm sum as a pack (LSTC_EPI_RESIDUAL_PACK + LSTC_EPI_OUT_PACK), the LayerNorm kernels
+# run on packs (lstc_layernorm_fwd_act / _bwd_act).  "fp32" keeps rounds 1-4's f32 activations between the blocks.
+_ACT16 = os.environ.get("LSTC_ACT_DTYPE", "bf16").lower() not in ("fp32", "f32", "float32")
+
+
+def set_act_dtype(name: str):
+    """"bf16" (default) | "fp32": storage of the residual stream between encoder blocks in the bf16 compute mode."""
+    global _ACT16
+    if name in ("bf16", "bfloat16"):
+        _ACT16 = True
+    elif name in ("fp32", "f32", "float32"):
+        _ACT16 = False
+    else:
+        raise ValueError(name)
+
+
+def get_act_dtype() -> str:
+    return "bf16" if (_ACT16 and _compute_dtype == _lib.BF16) else "fp32"
+
+
+class PackedAct:
+    """An activation [N, S, d] of the bf16 stream as the model classes pass it between blocks: ``t`` is the autograd-tracked
+    torch.bfloat16 view of the lstc_pack1 buffer of the [N*S, d] matrix (its gradient is a buffer of the same layout), ``shape``
+    the logical shape."""
+    __slots__ = ("t", "shape")
+
+    def __init__(self, t, shape):
+        self.t, self.shape = t, tuple(shape)
+
+    def pack(self) -> "Packed":
+        return _act_pack(self.t, self.shape[0] * self.shape[1], self.shape[2])
+
+
+def _act_pack(t: torch.Tensor, rows: int, d: int) -> "Packed":
+    """The ``Packed`` operand behind a bf16 stream tensor."""
+    if t.dtype != torch.bfloat16 or t.dim() != 1 or not t.is_contiguous() or \
+            t.numel() * 2 != int(_lib.load().lstc_pack1_bytes(rows, d)):
+        raise RuntimeError(f"bf16 activation stream: expected the bf16 view of an lstc_pack1 buffer of [{rows}, {d}], got "
+                           f"{tuple(t.shape)} {t.dtype}")
+    return Packed(t.view(torch.uint8), rows, d, _lib.BF16P)
+
+
+def _act_tensor(pk: "Packed") -> torch.Tensor:
+    return pk.buf.view(torch.bfloat16)
+
+
+def act_rows_ok(rows: int, d: int) -> bool:
+    """[rows, d] activations the bf16 stream can carry (include/lstc_hip.h, lstc_layernorm_fwd_act)."""
+    return _ACT16 and d in (1024, 2048) and _fused_pack_shape(rows, d) and rows * d <= 0xffffffff
+
+
+def act_chain_ok(N: int, S: int, dm: int, layers) -> bool:
+    """Can the full encoder layers ``layers`` run on the bf16 activation stream for N sequences of S tokens?  Everything the act
+    paths of MHAFunction / FFNFunction assume: LayerNorm after both blocks, fused Q|K|V weights, the packed-operand attention
+    kernels, every product of the block on whole 256-tiles of the packed kernel."""
+    M = N * S
+    if not layers or not act_rows_ok(M, dm):
+        return False
+    for layer in layers:
+        a, f = layer.slf_attn, layer.pos_ffn
+        if not (layer.FFN_need and a.layerNorm_flag and f.layerNorm_flag and a.d_model == dm):
+            return False
+        H, dk, dv = a.n_head, a.d_k, a.d_v
+        wqkv = _fused_qkv_weight(a.w_qs.weight, a.w_ks.weight, a.w_vs.weight)
+        if wqkv is None or wqkv.shape[0] != H * (2 * dk + dv):
+            return False
+        if not (attn_packed_inputs(N, S, H, dk, dv) and packed_out_shape(M, wqkv.shape[0]) and packed_out_shape(M, H * dv) and
+                packed_out_shape(M, dm) and a.fc.weight.shape[0] >= max(_x3_min[0], 1)):
+            return False
+        Fp = _padded_hidden(f.w_1.weight.shape[0])
+        if not (packed_out_shape(M, Fp) and f.w_2.weight.shape[0] >= max(_x3_min[0], 1)):
+            return False
+    return True
 
 
 # ---- packed operands of the f32x3 GEMM (csrc/gemm_pk.hip) ------------------------------------------------------------
@@ -328,7 +405,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
     if dropout is not None and dropout[0] > 0.0:
         flags |= EPI_DROPOUT
         d.dropout_p, d.dropout_seed = float(dropout[0]), int(dropout[1])
-    if residual is not None:
+    if isinstance(residual, Packed):
+        if (residual.rows, residual.K, residual.kind) != (M, N, _lib.BF16P) or not out_pack:
+            raise RuntimeError(f"gemm: packed residual is {residual.rows}x{residual.K} (kind {residual.kind}), the product is {M}x{N}"
+                               f" (out_pack={out_pack})")
+        flags |= EPI_RESIDUAL | EPI_RESIDUAL_PACK
+        d.residual, d.ldr = dev_ptr(residual.buf), N
+    elif residual is not None:
         flags |= EPI_RESIDUAL
         pr, rr, rc_, ldr = _mat(residual)
         if (rr, rc_) != (M, N):
@@ -656,6 +739,51 @@ def layernorm_bwd_branch(dz2, y, gamma, mean, rstd, p: float, seed: int, layer_n
     return dy, df, dgamma, dbeta, (colsum(df) if want_bias else None)
 
 
+def layernorm_fwd_act(x, gamma, beta, eps=1e-6, want_f32=False, want_pack=True):
+    """LayerNorm of the bf16 stream (lstc_layernorm_fwd_act): ``x`` a ``Packed`` [rows, d] (or an f32 [rows, d] tensor); returns
+    (y f32 | None, y Packed | None, mean, rstd)."""
+    if isinstance(x, Packed):
+        rows, d, dev, px, pxp = x.rows, x.K, x.buf.device, None, dev_ptr(x.buf)
+    else:
+        rows, d = x.shape
+        dev, px, pxp = x.device, dev_ptr(x.contiguous()), None
+    lib = _lib.load()
+    y = torch.empty((rows, d), device=dev, dtype=torch.float32) if want_f32 else None
+    ybuf = torch.empty((int(lib.lstc_pack1_bytes(rows, d)),), device=dev, dtype=torch.uint8) if want_pack else None
+    mean = torch.empty((rows,), device=dev, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    check(lib.lstc_layernorm_fwd_act(px, pxp, dev_ptr(gamma), dev_ptr(beta), dev_ptr(y), dev_ptr(ybuf), dev_ptr(mean), dev_ptr(rstd),
+                                     rows, d, float(eps), stream_ptr()), "lstc_layernorm_fwd_act")
+    return y, (Packed(ybuf, rows, d, _lib.BF16P) if want_pack else None), mean, rstd
+
+
+def layernorm_bwd_act(dz, y: Packed, gamma, mean, rstd, p: float, seed: int, want_dx: bool, want_bias: bool):
+    """Backward of ``z = LayerNorm(dropout(f) + x)`` on the bf16 stream (lstc_layernorm_bwd_act).  ``dz``: ``Packed`` or f32
+    [rows, d]; ``y``: the pack of the pre-LayerNorm sum.  Returns (dy Packed | None, df Packed, dgamma, dbeta, dbias | None)."""
+    rows, d, dev = y.rows, y.K, y.buf.device
+    lib = _lib.load()
+    if isinstance(dz, Packed):
+        if (dz.rows, dz.K) != (rows, d):
+            raise RuntimeError(f"layernorm_bwd_act: gradient pack is [{dz.rows}, {dz.K}], the activation [{rows}, {d}]")
+        pdz, pdzp = None, dev_ptr(dz.buf)
+    else:
+        dz = dz.contiguous()
+        if tuple(dz.shape) != (rows, d) or dz.dtype != torch.float32:
+            raise RuntimeError(f"layernorm_bwd_act: gradient is {tuple(dz.shape)} {dz.dtype}, the activation [{rows}, {d}]")
+        pdz, pdzp = dev_ptr(dz), None
+    nbytes = int(lib.lstc_pack1_bytes(rows, d))
+    dxbuf = torch.empty((nbytes,), device=dev, dtype=torch.uint8) if want_dx else None
+    dfbuf = torch.empty((nbytes,), device=dev, dtype=torch.uint8)
+    n_partial = int(min(max(rows // 4, 1), 768))
+    partial = torch.empty((3, n_partial, d), device=dev, dtype=torch.float32)
+    check(lib.lstc_layernorm_bwd_act(pdz, pdzp, dev_ptr(y.buf), dev_ptr(gamma), dev_ptr(mean), dev_ptr(rstd), dev_ptr(dxbuf),
+                                     dev_ptr(partial), n_partial, rows, d, float(p), int(seed), dev_ptr(dfbuf), stream_ptr()),
+          "lstc_layernorm_bwd_act")
+    sums = colsum_planes(partial, 3 if want_bias else 2)
+    return ((Packed(dxbuf, rows, d, _lib.BF16P) if want_dx else None), Packed(dfbuf, rows, d, _lib.BF16P), sums[0], sums[1],
+            (sums[2] if want_bias else None))
+
+
 def _attn_dtype():
     """LstcAttnDesc.dtype of the current compute mode: bf16 mode contracts bf16-rounded operands on the bf16 MFMA."""
     return _lib.BF16 if (_compute_dtype == _lib.BF16 and not _ATTN_F32) else F32
@@ -882,7 +1010,63 @@ class MHAFunction(torch.autograd.Function):
     backward: hand-derived; every contraction is an lstc_gemm / lstc_attn_bwd launch."""
 
     @staticmethod
+    def _forward_act(ctx, x, wq, wk, wv, wfc, ln_w, ln_b, table, index, cfg):
+        """The block on the bf16 activation stream: ``x`` is the bf16 view of the pack of [N*S, d] (PackedAct.t).  Every product runs
+        pack -> pack; the only f32 arrays are the probabilities and the LayerNorm statistics."""
+        N, S, dm = cfg["act_shape"]
+        M = N * S
+        H, dk, dv = cfg["n_head"], cfg["d_k"], cfg["d_v"]
+        training = cfg["training"]
+        p_attn = cfg["attn_dropout"] if training else 0.0
+        p_fc = cfg["fc_dropout"] if training else 0.0
+        out16 = bool(cfg.get("act16_out", False))
+        xp = _act_pack(x, M, dm)
+        wqkv = _fused_qkv_weight(wq, wk, wv)
+        if not cfg["layer_norm"] or wqkv is None or not (attn_packed_inputs(N, S, H, dk, dv) and packed_out_shape(M, wqkv.shape[0]) and
+                                                         packed_out_shape(M, H * dv) and packed_out_shape(M, dm)):
+            raise RuntimeError("MHAFunction: this layer / shape cannot run on the bf16 activation stream (functional.act_chain_ok)")
+        qkv_p = gemm(xp, wqkv, trans_b=True, out_pack=True)
+        seed_a = next_seed() if p_attn > 0 else 0
+        seed_f = next_seed() if p_fc > 0 else 0
+        if p_attn > 0:
+            _note(cfg["site"] + "attn_dropout", p_attn, seed_a, (N, H, S, S))
+        if p_fc > 0:
+            _note(cfg["site"] + "dropout", p_fc, seed_f, (N, S, dm))
+        op, probs = attn_fwd(qkv_p, None, None, N, S, H, dk, dv, table, index, p_attn, seed_a)
+        yp = gemm(op, wfc, trans_b=True, dropout=(p_fc, seed_f), residual=xp, out_pack=True)
+        zf, zp, mean, rstd = layernorm_fwd_act(yp, ln_w, ln_b, 1e-6, want_f32=not out16, want_pack=out16)
+        ctx.act = dict(xp=xp, qkv_p=qkv_p, op=op, yp=yp, out16=out16)
+        ctx.cfg = dict(cfg, N=N, S=S, p_attn=p_attn, p_fc=p_fc, seed_a=seed_a, seed_f=seed_f)
+        ctx.save_for_backward(wq, wk, wv, wfc, ln_w, table, index, probs, mean, rstd)
+        ctx.mark_non_differentiable(probs)
+        return (_act_tensor(zp) if out16 else zf.view(N, S, dm)), probs
+
+    @staticmethod
+    def _backward_act(ctx, dz):
+        wq, wk, wv, wfc, ln_w, table, index, probs, mean, rstd = ctx.saved_tensors
+        c, a = ctx.cfg, ctx.act
+        N, S, H, dk, dv = c["N"], c["S"], c["n_head"], c["d_k"], c["d_v"]
+        M = N * S
+        xp, qkv_p, op, yp = a["xp"], a["qkv_p"], a["op"], a["yp"]
+        dm = xp.K
+        want_dx = ctx.needs_input_grad[0]
+        dzin = _act_pack(dz.contiguous(), M, dm) if a["out16"] else dz.contiguous().view(M, dm)
+        dy, df, dln_w, dln_b, _ = layernorm_bwd_act(dzin, yp, ln_w, mean, rstd, c["p_fc"], c["seed_f"], want_dx, False)
+        dwfc = deliver(wfc, wgrad(df, None, op, out=grad_sink(wfc)))
+        do = gemm(df, wfc, out_pack=True)
+        wqkv = _fused_qkv_weight(wq, wk, wv)
+        rq, rk = wq.shape[0], wk.shape[0]
+        dqkv, _, _, dtable = attn_bwd(do, qkv_p, None, None, probs, N, S, H, dk, dv, table, index, c["p_attn"], c["seed_a"])
+        dwqkv = wgrad(dqkv, None, xp, out=fused_grad_sink(wq, wk, wv))
+        dwq, dwk, dwv = deliver(wq, dwqkv[:rq]), deliver(wk, dwqkv[rq: rq + rk]), deliver(wv, dwqkv[rq + rk:])
+        dx = _act_tensor(gemm(dqkv, wqkv, residual=dy, out_pack=True)) if want_dx else None
+        return dx, dwq, dwk, dwv, dwfc, dln_w, dln_b, dtable, None, None
+
+    @staticmethod
     def forward(ctx, x, wq, wk, wv, wfc, ln_w, ln_b, table, index, cfg):
+        ctx.is_act = x.dtype == torch.bfloat16
+        if ctx.is_act:
+            return MHAFunction._forward_act(ctx, x, wq, wk, wv, wfc, ln_w, ln_b, table, index, cfg)
         N, S, dm = x.shape
         H, dk, dv = cfg["n_head"], cfg["d_k"], cfg["d_v"]
         training = cfg["training"]
@@ -937,6 +1121,8 @@ class MHAFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz, _dprobs):
+        if ctx.is_act:
+            return MHAFunction._backward_act(ctx, dz)
         x2, wq, wk, wv, wfc, ln_w, table, index, q, k, v, o, probs, y, mean, rstd = ctx.saved_tensors
         c = ctx.cfg
         N, S, H, dk, dv = c["N"], c["S"], c["n_head"], c["d_k"], c["d_v"]
@@ -1211,11 +1397,83 @@ def _padded_hidden(F: int) -> int:
     return (F + 3) // 4 * 4
 
 
+def _ffn_padded_weights(w1, b1, w2, Fp, device):
+    """W1, b1, W2 at the padded hidden width ``Fp`` (zero rows / bias entries / columns appended; copies cached on the W1 parameter
+    until the weights change: evaluation loops call the block per video)."""
+    F, dm = w1.shape
+    stamp = (_wstamp(w1), _wstamp(w2), _wstamp(b1), Fp, w1._version, b1._version, w2._version, w1.data_ptr(), b1.data_ptr(), w2.data_ptr())
+    hit = w1.__dict__.get("_lstc_padded")
+    if hit is None or hit[0] != stamp:
+        w1p = torch.zeros((Fp, dm), device=device, dtype=torch.float32)
+        w1p[:F].copy_(w1.detach())
+        b1p = torch.zeros((Fp,), device=device, dtype=torch.float32)
+        b1p[:F].copy_(b1.detach())
+        w2p = torch.zeros((w2.shape[0], Fp), device=device, dtype=torch.float32)
+        w2p[:, :F].copy_(w2.detach())
+        hit = (stamp, (w1p, b1p, w2p))
+        w1.__dict__["_lstc_padded"] = hit
+    return hit[1]
+
+
 class FFNFunction(torch.autograd.Function):
     """models/FFN.py:14-22: LN?( dropout(W2 relu(W1 x + b1) + b2) + x )."""
 
     @staticmethod
+    def _forward_act(ctx, x, w1, b1, w2, b2, ln_w, ln_b, cfg):
+        """The block on the bf16 activation stream (see MHAFunction._forward_act)."""
+        N, S, dm = cfg["act_shape"]
+        M = N * S
+        p = cfg["dropout"] if cfg["training"] else 0.0
+        seed = next_seed() if p > 0 else 0
+        if p > 0:
+            _note(cfg["site"] + "dropout", p, seed, (N, S, dm))
+        out16 = bool(cfg.get("act16_out", False))
+        F = w1.shape[0]
+        Fp = _padded_hidden(F)
+        ctx.F = F
+        ctx.w_params = (w1, w2)
+        if Fp != F:
+            w1, b1, w2 = _ffn_padded_weights(w1, b1, w2, Fp, x.device)
+        if not cfg["layer_norm"] or not (packed_out_shape(M, Fp) and packed_out_shape(M, dm)):
+            raise RuntimeError("FFNFunction: this layer / shape cannot run on the bf16 activation stream (functional.act_chain_ok)")
+        xp = _act_pack(x, M, dm)
+        hp = gemm(xp, w1, trans_b=True, bias=b1, relu=True, out_pack=True)
+        yp = gemm(hp, w2, trans_b=True, bias=b2, dropout=(p, seed), residual=xp, out_pack=True)
+        zf, zp, mean, rstd = layernorm_fwd_act(yp, ln_w, ln_b, 1e-6, want_f32=not out16, want_pack=out16)
+        ctx.act = dict(xp=xp, hp=hp, yp=yp, out16=out16)
+        ctx.cfg = dict(cfg, p=p, seed=seed, shape=(N, S, dm))
+        ctx.save_for_backward(w1, w2, ln_w, mean, rstd)
+        return _act_tensor(zp) if out16 else zf.view(N, S, dm)
+
+    @staticmethod
+    def _backward_act(ctx, dz):
+        w1, w2, ln_w, mean, rstd = ctx.saved_tensors
+        c, a = ctx.cfg, ctx.act
+        N, S, dm = c["shape"]
+        M = N * S
+        xp, hp, yp = a["xp"], a["hp"], a["yp"]
+        want_dx = ctx.needs_input_grad[0]
+        dzin = _act_pack(dz.contiguous(), M, dm) if a["out16"] else dz.contiguous().view(M, dm)
+        dy, df, dln_w, dln_b, db2 = layernorm_bwd_act(dzin, yp, ln_w, mean, rstd, c["p"], c["seed"], want_dx, True)
+        w1o, w2o = ctx.w_params
+        padded = w1.shape[0] != ctx.F
+        s1, s2 = (None, None) if padded else (grad_sink(w1o), grad_sink(w2o))
+        dw2 = wgrad(df, None, hp, out=s2)
+        dh1 = gemm(df, w2, relu_mask=hp, out_pack=True)
+        db1 = colsum_pack(dh1)
+        dw1 = wgrad(dh1, None, xp, out=s1)
+        dx = _act_tensor(gemm(dh1, w1, residual=dy, out_pack=True)) if want_dx else None
+        if padded:
+            dw1, db1, dw2 = dw1[:ctx.F], db1[:ctx.F].contiguous(), dw2[:, :ctx.F]
+            if grad_sink(w2o) is None:
+                dw2 = dw2.contiguous()
+        return dx, deliver(w1o, dw1), db1, deliver(w2o, dw2), db2, dln_w, dln_b, None
+
+    @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, ln_w, ln_b, cfg):
+        ctx.is_act = x.dtype == torch.bfloat16
+        if ctx.is_act:
+            return FFNFunction._forward_act(ctx, x, w1, b1, w2, b2, ln_w, ln_b, cfg)
         shape = x.shape
         dm = shape[-1]
         x2 = x.contiguous().view(-1, dm)
@@ -1232,19 +1490,7 @@ class FFNFunction(torch.autograd.Function):
             # zero rows / columns / bias entries appended to W1, b1, W2 - the extra hidden units are relu(0) = 0 and meet zero
             # weights, so y, dx and the real rows of every gradient are unchanged, and all five products with the hidden in
             # them take the aligned (vector-load, full-tile, packable) paths
-            # (copies cached on the W1 parameter until the weights change: evaluation loops call the block per video)
-            stamp = (_wstamp(w1), _wstamp(w2), Fp, w1._version, b1._version, w2._version, w1.data_ptr(), b1.data_ptr(), w2.data_ptr())
-            hit = w1.__dict__.get("_lstc_padded")
-            if hit is None or hit[0] != stamp:
-                w1p = torch.zeros((Fp, dm), device=x2.device, dtype=torch.float32)
-                w1p[:F].copy_(w1.detach())
-                b1p = torch.zeros((Fp,), device=x2.device, dtype=torch.float32)
-                b1p[:F].copy_(b1.detach())
-                w2p = torch.zeros((w2.shape[0], Fp), device=x2.device, dtype=torch.float32)
-                w2p[:, :F].copy_(w2.detach())
-                hit = (stamp, (w1p, b1p, w2p))
-                w1.__dict__["_lstc_padded"] = hit
-            w1, b1, w2 = hit[1]
+            w1, b1, w2 = _ffn_padded_weights(w1, b1, w2, Fp, x2.device)
         xp = maybe_pack(x2)
         if xp is not None and packed_out_shape(x2.shape[0], w1.shape[0]) and w2.shape[0] >= max(_x3_min[0], 1):
             # bf16 mode: the hidden exists only as the packed bf16 operand W2 (and dW2, and the ReLU mask of the backward) reads
@@ -1266,6 +1512,8 @@ class FFNFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz):
+        if ctx.is_act:
+            return FFNFunction._backward_act(ctx, dz)
         x2, w1, w2, ln_w, h1, y, mean, rstd = ctx.saved_tensors
         c = ctx.cfg
         dz2 = dz.contiguous().view(-1, dz.shape[-1])
@@ -1314,13 +1562,25 @@ class ClsConcatFunction(torch.autograd.Function):
     """models/Encoder.py:51-58: CLS (token mean or learned) prepended, optional learned position table added."""
 
     @staticmethod
-    def forward(ctx, x, cls_token, pos, x_hi=None):
+    def forward(ctx, x, cls_token, pos, x_hi=None, pack_only=False):
         # x_hi: optional second half of the batch (abnormal sequences); the cat is fused into the kernel
+        # pack_only: the bf16 activation stream - the result exists only as layer 0's packed operand (returned as its bf16 view)
         N_lo, Sm1, dm = x.shape
         N = N_lo + (x_hi.shape[0] if x_hi is not None else 0)
         S = Sm1 + 1
         x = x.contiguous()
         x_hi = x_hi.contiguous() if x_hi is not None else None
+        ctx.pack_only = bool(pack_only)
+        if pack_only:
+            if cls_token is not None or pos is not None or ctx.needs_input_grad[0] or not act_rows_ok(N * S, dm):
+                raise RuntimeError("ClsConcatFunction(pack_only): nothing upstream may need a gradient and [N*S, d] must fit the bf16 stream")
+            lib = _lib.load()
+            buf = torch.empty((int(lib.lstc_pack1_bytes(N * S, dm)),), device=x.device, dtype=torch.uint8)
+            check(lib.lstc_cls_concat_fwd_pack(dev_ptr(x), dev_ptr(x_hi), N_lo, None, None, None, N, S, dm, dev_ptr(buf),
+                                               stream_ptr()), "lstc_cls_concat_fwd_pack")
+            ctx.two = x_hi is not None
+            ctx.meta = (N, S, dm, False, None)
+            return buf.view(torch.bfloat16)
         y = torch.empty((N, S, dm), device=x.device, dtype=torch.float32)
         pos_s = pos[0, :S].contiguous() if pos is not None else None
         cls_v = cls_token.reshape(-1) if cls_token is not None else None
@@ -1341,6 +1601,8 @@ class ClsConcatFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         N, S, dm, learned, pos_shape = ctx.meta
+        if ctx.pack_only:
+            return None, None, None, None, None
         dy = dy.contiguous()
         dx = dcls = dpos = None
         if ctx.needs_input_grad[0]:
@@ -1356,7 +1618,7 @@ class ClsConcatFunction(torch.autograd.Function):
             if pos_shape is not None:
                 dpos = torch.zeros(pos_shape, device=dy.device, dtype=torch.float32)
                 dpos[0, :S] = tok.view(S, dm)
-        return dx, dcls, dpos, None
+        return dx, dcls, dpos, None, None
 
 
 class DropoutFunction(torch.autograd.Function):

@@ -2,7 +2,7 @@
 import torch
 from torch import nn
 
-from ..functional import ClsConcatFunction, DropoutFunction, LayerNormFunction, drop_producer_packs
+from ..functional import ClsConcatFunction, DropoutFunction, LayerNormFunction, PackedAct, act_chain_ok, drop_producer_packs
 from .EncoderLayer import EncoderLayer
 
 
@@ -58,7 +58,21 @@ class Encoder(nn.Module):
                 skip.update(id(p) for p in layer.pos_ffn.layer_norm.parameters())
         return [p for p in self.parameters() if id(p) not in skip]
 
-    def _embed(self, enc_output, enc_output_hi=None):
+    def _act_chain(self, enc_output, enc_output_hi, layers) -> bool:
+        """bf16 mode: do ``layers`` (the full encoder layers of this call) run on the bf16 activation stream?  Only when nothing in
+        front of them needs a gradient or an f32 copy (no input LayerNorm, learned CLS token or position table) and every block
+        qualifies (functional.act_chain_ok)."""
+        if self.input_layerNorm or self.CLS_learned or self.position_encoding or enc_output.requires_grad or \
+                enc_output.dtype != torch.float32 or not enc_output.is_cuda or enc_output.dim() != 3:
+            return False
+        N = enc_output.shape[0] + (enc_output_hi.shape[0] if enc_output_hi is not None else 0)
+        return act_chain_ok(N, enc_output.shape[1] + 1, enc_output.shape[2], layers)
+
+    def _embed(self, enc_output, enc_output_hi=None, pack_only=False):
+        if pack_only:
+            N = enc_output.shape[0] + (enc_output_hi.shape[0] if enc_output_hi is not None else 0)
+            t = ClsConcatFunction.apply(enc_output, None, None, enc_output_hi, True)
+            return PackedAct(t, (N, enc_output.shape[1] + 1, enc_output.shape[2]))
         if self.input_layerNorm:
             if enc_output_hi is not None:
                 enc_output, enc_output_hi = torch.cat([enc_output, enc_output_hi], 0), None
@@ -75,10 +89,13 @@ class Encoder(nn.Module):
         Train/spatio_transformer_shanghaitech.py:97), so the last layer evaluates its query, output projection and
         FFN for that token alone (K/V still use every token).  Saves ~25 % of the step's FLOPs at 3 layers."""
         # enc_output_hi: optional second half of the batch (the abnormal sequences) so the caller need not cat
-        enc_output = self._embed(enc_output, enc_output_hi)
         n = len(self.layer_stack)
+        act = self._act_chain(enc_output, enc_output_hi, list(self.layer_stack[:-1]))
+        enc_output = self._embed(enc_output, enc_output_hi, pack_only=act)
         for i, layer in enumerate(self.layer_stack[:-1]):
             layer.pos_ffn._emit_pack = i + 1 < n - 1          # the CLS-only last layer reads no packed operand
+            # bf16 activation stream: every block hands a pack on, except the one in front of the CLS-only layer (f32 rows)
+            layer.slf_attn._act16_out, layer.pos_ffn._act16_out = act, act and i + 1 < n - 1
             enc_output = layer(enc_output)[0]
         out = self.layer_stack[-1].forward_cls(enc_output)
         drop_producer_packs()
@@ -86,14 +103,11 @@ class Encoder(nn.Module):
 
     def forward(self, enc_output, src_mask=None, return_attn=False, return_attn_v=False):
         attn_list, v_list = [], []
-        if self.input_layerNorm:
-            enc_output = LayerNormFunction.apply(enc_output, self.layer_norm.weight, self.layer_norm.bias)
-        enc_output = ClsConcatFunction.apply(enc_output, self.cls_token if self.CLS_learned else None,
-                                             self.position_enc if self.position_encoding else None)
-        if self.position_encoding and self.training and self.position_dropout.p > 0:
-            enc_output = DropoutFunction.apply(enc_output, self.position_dropout.p, "position_dropout")
+        act = not return_attn_v and src_mask is None and self._act_chain(enc_output, None, list(self.layer_stack))
+        enc_output = self._embed(enc_output, None, pack_only=act)
         for i, layer in enumerate(self.layer_stack):
             layer.pos_ffn._emit_pack = i + 1 < len(self.layer_stack)      # the last layer's output goes to the caller
+            layer.slf_attn._act16_out, layer.pos_ffn._act16_out = act, act and i + 1 < len(self.layer_stack)
             res = layer(enc_output, slf_attn_mask=src_mask, return_attn=return_attn, return_attn_v=return_attn_v)
             enc_output = res[0]
             if return_attn or return_attn_v:

@@ -7,7 +7,7 @@ arithmetic runs in ``MHAFunction`` (GEMM -> fused attention core -> GEMM epilogu
 import torch
 from torch import nn
 
-from ..functional import MHAClsAssocFunction, MHAClsFunction, MHAFunction
+from ..functional import MHAClsAssocFunction, MHAClsFunction, MHAFunction, PackedAct
 
 
 def relative_position_index_3d(window_depth: int, window_size: int) -> torch.Tensor:
@@ -58,6 +58,7 @@ class MultiHeadAttention(nn.Module):
             self.register_buffer("relative_position_index", relative_position_index_2d(window_size))
             nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
         self._site = ""
+        self._act16_out = False        # bf16 activation stream: hand the result on as a PackedAct (set per call by Encoder)
         self.cls_assoc = True          # last-layer CLS attention without materialising K / V (see functional)
 
     def fuse_qkv_(self):
@@ -100,12 +101,20 @@ class MultiHeadAttention(nn.Module):
         cfg = dict(n_head=self.n_head, d_k=self.d_k, d_v=self.d_v, layer_norm=self.layerNorm_flag,
                    attn_dropout=self.attn_dropout.p, fc_dropout=self.dropout.p, training=self.training,
                    site=self._site)
+        act = isinstance(q, PackedAct)
+        if act:        # bf16 activation stream (functional.PackedAct): the pack's bf16 view goes through autograd, the shape rides in cfg
+            if return_attn_v:
+                raise NotImplementedError("return_attn_v needs the f32 activations (Encoder keeps them when it is asked for)")
+            cfg.update(act_shape=q.shape, act16_out=self._act16_out)
+            shape, q = q.shape, q.t
         out, probs = MHAFunction.apply(
             q, self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.fc.weight,
             self.layer_norm.weight if self.layerNorm_flag else None,
             self.layer_norm.bias if self.layerNorm_flag else None,
             self.relative_position_bias_table if has_bias else None,
             self.relative_position_index if has_bias else None, cfg)
+        if act and self._act16_out:
+            out = PackedAct(out, shape)
         if return_attn_v:
             N, S = q.shape[0], q.shape[1]
             from ..functional import gemm

@@ -88,16 +88,28 @@ def ucf_bins(feats, n_frames, segment_len=16, max_clips=32):
     return torch.stack(rows), r
 
 
-def ltn_ucf_bin_sequences(feats, n_frames, part_len, segment_len=16, normalize=True, rewindow=True, max_clips=32):
-    """-> (sequences, [(beg, end)] in bin units, r).  ``rewindow`` moves a short tail part back so that it spans
-    ``part_len`` bins (Test/evaluation_UCF.py:66-67 - there ``beg`` itself moves, so the frames it labels move too)."""
-    bins, r = ucf_bins(feats, n_frames, segment_len, max_clips)
-    d = bins.shape[-1]
+def ucf_bin_ranges(part_len, rewindow=True, max_clips=32):
+    """[(beg, end)] in bin units of the parts a UCF video is scored in - a function of the flags alone (every video has 32
+    bins), so a rank that does not own a video still knows how many scores it contributes (pipeline, sharded passes)."""
     ranges = []
     for beg, end in part_ranges(max_clips, part_len):
         if rewindow and end - beg < part_len:
             beg = end - part_len
         ranges.append((beg, end))
+    return ranges
+
+
+def ucf_bin_edges(n_frames, segment_len=16, max_clips=32):
+    """r [33]: bin i covers clips r[i]:r[i+1] (Test/evaluation_UCF.py:54)."""
+    return np.linspace(0, n_frames // segment_len, max_clips + 1, dtype=np.int32)
+
+
+def ltn_ucf_bin_sequences(feats, n_frames, part_len, segment_len=16, normalize=True, rewindow=True, max_clips=32):
+    """-> (sequences, [(beg, end)] in bin units, r).  ``rewindow`` moves a short tail part back so that it spans
+    ``part_len`` bins (Test/evaluation_UCF.py:66-67 - there ``beg`` itself moves, so the frames it labels move too)."""
+    bins, r = ucf_bins(feats, n_frames, segment_len, max_clips)
+    d = bins.shape[-1]
+    ranges = ucf_bin_ranges(part_len, rewindow, max_clips)
     seqs = [bins[b:e].reshape(-1, d) for b, e in ranges]
     if normalize:
         seqs = [torch.nn.functional.normalize(s, p=2, dim=-1) for s in seqs]

@@ -200,3 +200,70 @@ def test_host_shape_rules_of_the_packed_and_padded_paths():
     finally:
         Fn.set_compute_dtype("fp32")
     assert Fn._attn_dtype() == Fn._lib.F32 and not Fn._fused_pack_shape(100352, 2048)
+
+
+def test_namespace_round_trips_through_the_rank_command_line():
+    """``train(args)`` on a caller-built Namespace starts its ranks with the command line that parses back to that Namespace
+    (cli.namespace_to_argv): every flag of every script survives the round trip, floats exactly."""
+    from lstc_vad_amd import cli
+    for script in list(cli.SCRIPTS) + ["pseudo_labels_generator_temporal", "pseudo_labels_generator_spatio"]:
+        has = lambda f: any(x[0] == f for x in cli._FLAGS[script])
+        a = cli.complete_args(script, argv=["--gpu", "0,1"] + (["--data_parallel"] if has("--data_parallel") else []) +
+                              (["--lr_encoder", "0.000123456789"] if has("--lr_encoder") else []))
+        back = cli.complete_args(script, argv=cli.namespace_to_argv(script, a))
+        assert vars(back) == vars(a), script
+
+
+def test_data_parallel_flag_starts_one_rank_per_listed_gpu(monkeypatch, tmp_path):
+    """``python Train/<script>.py --data_parallel --gpu 0,1,2,3`` IS the multi-GPU run (Train/temporal_transformer_shanghaitech.py:
+    76-78, :328): cli.train hands over to lstc_vad_amd.launch.launch_ranks - one rank per listed GPU, the Train script itself as the
+    rank program, the devices exported to the ranks - BEFORE importing torch's GPU side, and returns what rank 0 handed back.  One
+    listed GPU, or a process that already is a rank, runs the training itself.  The launcher is exercised with stub rank programs
+    (no GPU needed): stdout of rank 0 passes through, the LSTC_RESULT line comes back, a failing rank fails the run."""
+    from lstc_vad_amd import cli, launch
+    calls = []
+
+    def fake(n, argv, script=None, rank_timeout_s=0.0, relay="json", devices=None, tag="", extra_env=None):
+        calls.append(dict(n=n, argv=list(argv), script=script, relay=relay, devices=devices))
+        fake.last_result = "0.75"
+        return 0
+    fake.last_result = None
+    monkeypatch.setattr(launch, "launch_ranks", fake)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    got = cli.train("temporal_transformer_shanghaitech", argv=["--data_parallel", "--gpu", "0,1,2,3", "--batch_size", "8", "--epochs", "3"])
+    assert got == 0.75 and len(calls) == 1
+    c = calls[0]
+    assert c["n"] == 4 and c["devices"] == ["0", "1", "2", "3"] and c["relay"] == "all"
+    assert c["script"].endswith(os.path.join("Train", "temporal_transformer_shanghaitech.py")) and os.path.exists(c["script"])
+    back = cli.complete_args("temporal_transformer_shanghaitech", argv=c["argv"])
+    assert back.data_parallel and back.gpu == "0,1,2,3" and back.batch_size == 8 and back.epochs == 3
+    with pytest.raises(SystemExit):                          # the pair count must split over the ranks (SURVEY 8e)
+        cli.train("temporal_transformer_shanghaitech", argv=["--data_parallel", "--gpu", "0,1,2", "--batch_size", "8"])
+    # already a rank (torchrun / a launched child), or one device: no launch - the call goes on to the training itself,
+    # which needs a GPU: here it stops at "no HIP device visible"
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    assert cli._launch_data_parallel("temporal_transformer_shanghaitech", back) is None
+    monkeypatch.delenv("WORLD_SIZE")
+    one = cli.complete_args("temporal_transformer_shanghaitech", argv=["--data_parallel", "--gpu", "2"])
+    assert cli._launch_data_parallel("temporal_transformer_shanghaitech", one) is None
+    assert len(calls) == 1
+    # the generators take the same flags upstream
+    gen = cli.complete_args("pseudo_labels_generator_temporal", argv=["--data_parallel", "--gpu", "0,1"])
+    assert cli._launch_data_parallel("pseudo_labels_generator_temporal", gen) == ("done", 0.75) and calls[-1]["n"] == 2
+    monkeypatch.undo()
+    # the real launcher with stub rank programs
+    ok = tmp_path / "rank_ok.py"
+    ok.write_text("import os, sys\n"
+                  "r = int(os.environ['RANK'])\n"
+                  "assert os.environ['HIP_VISIBLE_DEVICES'] == '2,5' and os.environ['LSTC_LAUNCHED'] == '1' and os.environ['LOCAL_RANK'] == str(r)\n"
+                  "print('line from rank', r, flush=True)\n"
+                  "if r == 0: print('LSTC_RESULT 0.5', flush=True)\n")
+    import contextlib
+    import io
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rc = launch.launch_ranks(2, ["--x", "1"], script=str(ok), relay="all", devices=["2", "5"], tag="t", rank_timeout_s=60)
+    assert rc == 0 and launch.launch_ranks.last_result == "0.5" and buf.getvalue().strip() == "line from rank 0"
+    bad = tmp_path / "rank_bad.py"
+    bad.write_text("import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(3)\ntime.sleep(30)\n")
+    assert launch.launch_ranks(2, [], script=str(bad), relay="all", tag="t", rank_timeout_s=60) == 1

@@ -297,3 +297,60 @@ def test_direct_gradient_sinks_write_into_the_bucket_without_fill_or_accumulate(
         p.join(60)
         assert p.exitcode == 0
     assert worst < 1e-5 and launched_early
+
+
+def test_direct_gradient_sinks_refuse_double_and_missing_deliveries_in_every_mode():
+    """a sink is written, not accumulated into.  On ONE rank without a process group (the inactive bucket path) and with
+    overlap off, the reducer used to skip its per-parameter bookkeeping: a weight used twice in one backward, or two backward
+    passes before finish(), silently kept only the last weight gradient while the biases accumulated - and a weight whose Function
+    did not run kept last step's gradient (zero_grad() does not clear the direct region).  Both now raise."""
+    sys.path.insert(0, ROOT)
+    from lstc_vad_amd import functional as Fn
+    from lstc_vad_amd.dist import GradAllReducer
+
+    class Lin(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, b):
+            ctx.save_for_backward(x, w)
+            return x @ w.t() + b
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w = ctx.saved_tensors
+            out = Fn.grad_sink(w)
+            dw = torch.mm(dy.t(), x, out=out) if out is not None else dy.t() @ x
+            return dy @ w, Fn.deliver(w, dw), dy.sum(0)
+
+    g = torch.Generator().manual_seed(3)
+    w = torch.nn.Parameter(torch.randn(4, 4, generator=g))
+    w2 = torch.nn.Parameter(torch.randn(4, 4, generator=g))
+    b = torch.nn.Parameter(torch.randn(4, generator=g))
+    x = torch.randn(3, 4, generator=g)
+    for overlap in (True, False):
+        red = GradAllReducer([[b, w, w2]], overlap=overlap, direct=[w, w2])
+        assert not red.active
+        # every direct weight delivers once: fine
+        red.zero_grad()
+        Lin.apply(Lin.apply(x, w, b), w2, b).sum().backward()
+        red.finish()
+        want = w.grad.clone()
+        # a second backward before zero_grad(): refused
+        with pytest.raises(RuntimeError, match="twice"):
+            Lin.apply(Lin.apply(x, w, b), w2, b).sum().backward()
+        # one weight shared by two Functions in one backward: refused
+        red.zero_grad()
+        with pytest.raises(RuntimeError, match="twice"):
+            Lin.apply(Lin.apply(x, w, b), w, b).sum().backward()
+        # a direct weight whose Function did not run this step: its slot would hold last step's values
+        red.zero_grad()
+        Lin.apply(x, w, b).sum().backward()
+        with pytest.raises(RuntimeError, match="not produced"):
+            red.finish()
+        assert want is not None
+        for p in (w, w2, b):
+            p.grad = None
+            p.__dict__.pop("_lstc_grad_sink", None)
+    # the layout keeps direct slots 16-byte aligned
+    odd = torch.nn.Parameter(torch.randn(3, generator=g))
+    with pytest.raises(RuntimeError, match="16-byte"):
+        GradAllReducer([[odd, w]], direct=[odd, w])

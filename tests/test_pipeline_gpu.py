@@ -370,3 +370,73 @@ def test_coteaching_chain_in_bf16_tracks_the_fp32_chain(world, chain_fp32, tmp_p
         assert same >= 0.98 * total, (f, same, total)
     assert abs(B["ltn_test_auc"] - A["ltn_test_auc"]) < 1e-2, (B["ltn_test_auc"], A["ltn_test_auc"])
     assert differs > 1e-5, "bf16 chain equals the fp32 chain to the last digit: the mode did not run"
+
+
+def test_data_parallel_command_line_starts_ranks_and_shards_evaluation_and_labels(world, tmp_path):
+    """``python Train/<script>.py --data_parallel --gpu 0,0`` on the one-GPU test box (LSTC_SHARE_DEVICE=1: both ranks on device
+    0; RCCL refuses that, so LSTC_DIST_BACKEND=gloo carries the collectives - everything else is the multi-GPU job): the script
+    starts its two ranks ITSELF (lstc_vad_amd.launch), every rank evaluates its share of the test and training videos
+    (pipeline._ScoreBoard) and rank 0 logs / saves.  With both learning rates 0 the weights never move, so the AUC lines, the save
+    decision and the checkpoint names must equal the single-process run CHARACTER FOR CHARACTER; the sharded pseudo-label
+    generator must write a label file equal to the single-rank one bit for bit."""
+    def cmd(save, log, extra):
+        return ["--dataset_path", world["sht_feats"], "--training_txt", world["sht_train"], "--testing_txt", world["sht_test"],
+                "--test_mask_dir", world["sht_masks"], "--model_save_dir", save, "--batch_size", "2", "--part_num", "3",
+                "--n_patch", "16", "--n_head", "2", "--d_model", "32", "--d_k", "16", "--d_v", "16", "--FFN_layerNorm",
+                "--load_model", "--lr_encoder", "0", "--epochs", "2", "--inter_epoch", "1", "--seed", "3", "--save_threshold", "0.05",
+                "--log_dir", log, "--part_len", "3", "--n_hidden", "64", "--MHA_layerNorm", "--relative_position_encoding",
+                "--load_temporal_model_path", world["ltn_sht_enc.ckpt"], "--load_classifier_model_path", world["ltn_sht_cls.ckpt"],
+                "--lr_classifier", "0", "--saved_prefix", "pre_"] + extra
+    env2 = dict(os.environ, PYTHONPATH=ROOT, LSTC_SHARE_DEVICE="1", LSTC_DIST_BACKEND="gloo", LSTC_RANK_TIMEOUT_S="500")
+    env2.pop("HIP_VISIBLE_DEVICES", None)
+    save1, save2 = str(tmp_path / "ck1") + os.sep, str(tmp_path / "ck2") + os.sep
+    r1 = _run("Train", "temporal_transformer_shanghaitech.py", cmd(save1, str(tmp_path / "log1"), []))
+    assert r1.returncode == 0, r1.stderr[-2500:]
+    r2 = subprocess.run([sys.executable, "temporal_transformer_shanghaitech.py"] + cmd(save2, str(tmp_path / "log2"), ["--data_parallel", "--gpu", "0,0"]),
+                        cwd=os.path.join(ROOT, "Train"), env=env2, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-2500:]
+    assert "--data_parallel: 2 rank(s)" in r2.stderr
+
+    def auc_lines(err):
+        return [l.split(": ", 1)[1] for l in err.splitlines() if "_AUC" in l and ": " in l]
+    assert auc_lines(r1.stderr) and auc_lines(r1.stderr) == auc_lines(r2.stderr), (auc_lines(r1.stderr), auc_lines(r2.stderr))
+    assert sorted(os.listdir(save1)) == sorted(os.listdir(save2)) and len(os.listdir(save1)) >= 2
+    assert r2.stderr.count("saving model......") == r1.stderr.count("saving model......")       # rank 0 alone saves
+    # the generator: two ranks score the training videos, rank 0 writes the file
+    gen = ["--d_model", "32", "--n_head", "2", "--d_k", "16", "--d_v", "16", "--n_hidden", "64", "--MHA_layerNorm", "--FFN_layerNorm",
+           "--relative_position_encoding", "--part_len", "3", "--dataset", "SHT", "--dataset_path", world["sht_feats"],
+           "--training_txt", world["sht_train"], "--temporal_model_path", world["ltn_sht_enc.ckpt"], "--classifier_model_path",
+           world["ltn_sht_cls.ckpt"], "--threshold", "0.45"]
+    p1, p2 = str(tmp_path / "pl1.npy"), str(tmp_path / "pl2.npy")
+    g1 = _run("Train", "pseudo_labels_generator_temporal.py", gen + ["--pseudo_labels_path", p1])
+    assert g1.returncode == 0, g1.stderr[-2000:]
+    g2 = subprocess.run([sys.executable, "pseudo_labels_generator_temporal.py"] + gen + ["--pseudo_labels_path", p2, "--data_parallel", "--gpu", "0,0"],
+                        cwd=os.path.join(ROOT, "Train"), env=env2, capture_output=True, text=True, timeout=900)
+    assert g2.returncode == 0, g2.stderr[-2500:]
+    a, b = np.load(p1, allow_pickle=True).tolist(), np.load(p2, allow_pickle=True).tolist()
+    assert list(a) == list(b) and all(np.array_equal(a[k], b[k]) for k in a)
+    _check_pseudo(b, "pl/t_sht/", 0.45)
+
+
+def test_sharded_evaluation_is_bitwise_the_single_rank_evaluation(world):
+    """pipeline.evaluate_auc / evaluate_train_auc / generate_pseudo_labels with two emulated ranks on the HIP model (fp32): every
+    frame score, label, AUC and label row equals the single-rank pass BIT FOR BIT - a sequence's score does not depend on what
+    shares its batch, and the exchange is a zero-padded sum."""
+    enc, head = _load(world, "ltn_sht_enc.ckpt", pw.LTN_SHT, "ltn_sht_cls.ckpt", Classifier)
+
+    def two(run):
+        kept = {}
+        run(1, 2, lambda flat: kept.__setitem__(1, flat.clone()))
+        return run(0, 2, lambda flat: flat.add_(kept[1]))
+    ev = lambda r=None, w=None, ex=None: pipeline.evaluate_auc(enc, head, "LTN", "SHT", world["sht_feats"], world["sht_test"], world["sht_masks"],
+                                                               3, 16, return_frames=True, rank=r, world=w, exchange=ex, pool_sequences=5)
+    a1, a2 = ev(), two(ev)
+    assert a1[0] == a2[0] and np.array_equal(a1[1], a2[1]) and np.array_equal(a1[2], a2[2])
+    tr = lambda r=None, w=None, ex=None: pipeline.evaluate_train_auc(enc, head, "LTN", "SHT", world["sht_feats"], world["sht_train"],
+                                                                     world["sht_masks"], 3, 16, return_frames=True, rank=r, world=w, exchange=ex)
+    b1, b2 = tr(), two(tr)
+    assert b1[0] == b2[0] and np.array_equal(b1[1], b2[1]) and np.array_equal(b1[2], b2[2])
+    pl = lambda r=None, w=None, ex=None: pipeline.generate_pseudo_labels(enc, head, "LTN", "SHT", world["sht_feats"], world["sht_train"], 0.45,
+                                                                         part_len=3, rank=r, world=w, exchange=ex)
+    c1, c2 = pl(), two(pl)
+    assert list(c1) == list(c2) and all(np.array_equal(c1[k], c2[k]) for k in c1)

@@ -332,3 +332,58 @@ def test_loader_worker_rng_streams_like_the_reference_dataloader(world, name):
     with ds_mod.WorkerStreams(0, seed).batch(3):
         pass
     assert np.array_equal(np.random.get_state()[1], a0)
+
+
+# ---- the same stages sharded over ranks (round 5) ----------------------------------------------------------------------
+
+def _emulate_two_ranks(run):
+    """``run(rank, world, exchange)`` for both ranks of a two-rank pass in ONE process: rank 1's zero-padded score vector is kept
+    and added into rank 0's, which is what the SUM all-reduce of pipeline._ScoreBoard leaves on every rank."""
+    kept = {}
+    run(1, 2, lambda flat: kept.__setitem__(1, flat.clone()))
+    return run(0, 2, lambda flat: flat.add_(kept[1]))
+
+
+def test_sharded_passes_equal_the_single_rank_passes(world, tmp_path):
+    """pipeline.generate_pseudo_labels / evaluate_auc / evaluate_train_auc with the videos of the list dealt to two ranks
+    (i % 2), every rank walking the whole list on the host and scoring only its own videos: keys, shapes, labels and zero
+    patterns identical to the single-rank pass, scores equal (the oracle's CPU BLAS is the model here, so to 2e-6; the HIP model
+    is batch-invariant and tests/test_pipeline_gpu.py requires bit equality).  Rank 0 alone writes the label file."""
+    enc = _OracleEncoder(world["ltn_sht_enc.ckpt"], pw.LTN_SHT); head = _OracleHead(world["ltn_sht_cls.ckpt"], "classifier")
+    one = pipeline.generate_pseudo_labels(enc, head, "LTN", "SHT", world["sht_feats"], world["sht_train"], 0.45, part_len=3)
+    p0, p1 = str(tmp_path / "r0.npy"), str(tmp_path / "r1.npy")
+    two = _emulate_two_ranks(lambda r, w, ex: pipeline.generate_pseudo_labels(
+        enc, head, "LTN", "SHT", world["sht_feats"], world["sht_train"], 0.45, part_len=3, out_path=(p0 if r == 0 else p1),
+        rank=r, world=w, exchange=ex, pool_sequences=7))
+    assert os.path.exists(p0) and not os.path.exists(p1)
+    assert list(one) == list(two)
+    for k in one:
+        assert one[k].shape == two[k].shape and two[k].dtype == np.float32
+        near = np.abs(np.where(one[k] > 0, one[k], two[k]) - 0.45) < 1e-5
+        assert np.all(np.abs(one[k] - two[k])[~near] < 2e-6), k
+    _check_pseudo(two, "pl/t_sht/", 0.45)
+    for tag, dataset, txt, masks, feats in (("sht", "SHT", "sht_test", "sht_masks", "sht_feats"),
+                                             ("ubn", "UBnormal", "ubn_test", "ubn_masks", "ubn_feats")):
+        auc, s, l = _emulate_two_ranks(lambda r, w, ex: pipeline.evaluate_auc(
+            enc, head, "LTN", dataset, world[feats], world[txt], world[masks], 3, 16, return_frames=True, rank=r, world=w, exchange=ex))
+        assert np.max(np.abs(s - G[f"ev/{tag}/scores"])) < 2e-6 and np.array_equal(l, G[f"ev/{tag}/labels"])
+        assert abs(auc - float(G[f"ev/{tag}/auc"][0])) < 1e-6
+    a1 = pipeline.evaluate_train_auc(enc, head, "LTN", "SHT", world["sht_feats"], world["sht_train"], world["sht_masks"], 3, 16,
+                                     return_frames=True)
+    a2 = _emulate_two_ranks(lambda r, w, ex: pipeline.evaluate_train_auc(
+        enc, head, "LTN", "SHT", world["sht_feats"], world["sht_train"], world["sht_masks"], 3, 16, return_frames=True, rank=r, world=w,
+        exchange=ex))
+    assert np.array_equal(a1[2], a2[2]) and np.max(np.abs(a1[1] - a2[1])) < 2e-6 and abs(a1[0] - a2[0]) < 1e-6
+    # UCF: a non-owner reads only the list line and the ground truth of a video
+    enc = _OracleEncoder(world["ltn_ucf_enc.ckpt"], pw.LTN_UCF); head = _OracleHead(world["ltn_ucf_cls.ckpt"], "classifier")
+    auc, s, l = _emulate_two_ranks(lambda r, w, ex: pipeline.evaluate_auc(
+        enc, head, "LTN", "UCF", world["ucf_feats"], world["ucf_test"], world["ucf_gt"], 2, 9, return_frames=True, rank=r, world=w,
+        exchange=ex))
+    assert np.max(np.abs(s - G["ev/ucf/scores"])) < 2e-6 and np.array_equal(l, G["ev/ucf/labels"])
+    two = _emulate_two_ranks(lambda r, w, ex: pipeline.generate_pseudo_labels(
+        enc, head, "LTN", "UCF", world["ucf_feats"], world["ucf_train"], 0.25, part_len=2, n_patch=9, rank=r, world=w, exchange=ex))
+    _check_pseudo(two, "pl/t_ucf/", 0.25)
+    enc = _OracleEncoder(world["stn_sht_enc.ckpt"], pw.STN_SHT); head = _OracleHead(world["stn_sht_reg.ckpt"], "regressor")
+    two = _emulate_two_ranks(lambda r, w, ex: pipeline.generate_pseudo_labels(
+        enc, head, "STN", "SHT", world["sht_feats"], world["sht_train"], 0.34, rank=r, world=w, exchange=ex))
+    _check_pseudo(two, "pl/s_sht/", 0.34)
