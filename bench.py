@@ -139,6 +139,7 @@ class SyntheticResidentPairs:
         self.rng_state = np.random.RandomState(seed + 1).get_state()          # sampler stream (np.random global, saved/restored)
         self.n_vid, self.pos = n_vid, 0
         self.order = None
+        self.lazy = os.environ.get("LSTC_EAGER_GATHER", "0") != "1"      # clip indices to the step (gather fused into the CLS concat)
         self._shuffle()
 
     def _with_rng(self, fn):
@@ -178,7 +179,7 @@ class SyntheticResidentPairs:
                             labs[j - lo] = self.pseudo[vid][w]
         self._with_rng(draw)
         self.pos += self.bs
-        out, labs_d = self.feed.gather(idx, labs)
+        out, labs_d = self.feed.gather(idx, labs, lazy=self.lazy)
         return out[0], out[1], labs_d
 
 
@@ -228,7 +229,9 @@ def main():
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the N=1 sub-objects (static_batch, stn_headline, bf16, f32x3)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the N=1 sub-objects (static_batch, stn_headline, bf16, f32x3, coteach_loop)")
+    ap.add_argument("--no-coteach", action="store_true", help="skip the coteach_loop sub-object (BASELINE config 3: one timed round of the "
+                    "co-teaching loop through the Train/ and Test/ entry points, tools/coteach_round.py)")
     a = ap.parse_args()
     if a.nccl_algo:
         os.environ["NCCL_ALGO"] = a.nccl_algo            # inherited by the rank processes launch_ranks starts
@@ -326,6 +329,8 @@ def main():
             tss = [p[0] for p in parts]
         else:
             ts, nxt, src = make(cfg, bs_local, bs_global, 0, feed)
+            if a.graph and src is not None:
+                src.lazy = False                   # a captured step reads its batch from static buffers
             if a.graph:
                 if world > 1:
                     raise SystemExit("--graph captures the single-rank step only")
@@ -523,6 +528,21 @@ def main():
             extras["f32x3"] = dict(sub_object(timed_pass(a.config, "f32x3"), a.config, "f32x3"),
                                    dtype="f32 storage and accumulation; products of the large GEMMs on the f16 matrix cores (two scaled "
                                          "f16 planes per operand, hh + hl + lh); narrower than IEEE f32 products, reported as an extra")
+    if solo and a.config == "ltn_sht" and a.dtype == "fp32" and not a.no_coteach:
+        # BASELINE config 3 ("Full STN -> pseudo-label -> LTN co-teaching loop, ShanghaiTech config, bf16, 1xMI355X"): one round through
+        # the command-line entry points, timed stage by stage (tools/coteach_round.py; README.md:21-36 of the reference is the loop)
+        import shutil
+        import tempfile
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        tmp = tempfile.mkdtemp(prefix="lstc_coteach_")
+        try:
+            from coteach_round import run_round
+            extras["coteach_loop"] = run_round(tmp, "bf16", steps=6, pairs=48)
+        except Exception as e:                      # the headline must survive a failure of an extra
+            extras["coteach_loop"] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+            Fn.set_compute_dtype("fp32")
     pcie = None
     if (a.h2d or not a.no_h2d) and world == 1 and not force_dist and a.config != "mixed_ubn_sht":
         from lstc_vad_amd.feed import PinnedFeeder

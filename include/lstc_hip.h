@@ -321,6 +321,14 @@ int lstc_cls_concat_fwd(const float* x, const float* x_hi, int64_t n_lo, const f
 int lstc_cls_concat_fwd_pack(const float* x, const float* x_hi, int64_t n_lo, const float* cls_token, const float* pos,
                              float* y, int64_t N, int32_t S, int32_t d, void* packed, void* stream);
 
+/* The same pass fed STRAIGHT from an HBM-resident feature bank [bank_clips, P, d] (round 5): token t of sequence n is patch t % P of
+ * clip clip_idx[n * (S-1)/P + t / P], i.e. lstc_gather_rows (the batch formation `feat[chosen[...], :]`, utils/load_dataset.py:88 +
+ * default collate) + the torch.cat + the CLS concat in ONE pass over the features - the gathered batch [B, T, P, d] is never
+ * written.  y (f32 [N, S, d]) and / or packed (lstc_pack1 of [N*S, d]: N*S a multiple of 256, d of 64) receive the result.
+ * (S-1) % P == 0, d % 4 == 0, 16-B aligned bases; idx entries must lie in [0, bank_clips). */
+int lstc_cls_concat_gather_fwd(const float* bank, int64_t bank_clips, const int64_t* clip_idx, int32_t P, const float* cls_token,
+                               const float* pos, float* y, int64_t N, int32_t S, int32_t d, void* packed, void* stream);
+
 /* Gradient w.r.t. the Encoder input, needed only when something upstream is trainable (input_layerNorm,
  * models/Encoder.py:48-49): dx[n,t,:] = dy[n,t+1,:] + (mean_cls ? dy[n,0,:]/(S-1) : 0). */
 int lstc_cls_concat_bwd(const float* dy, float* dx, int64_t N, int32_t S, int32_t d, int32_t mean_cls, void* stream);

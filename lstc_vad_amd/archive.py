@@ -43,6 +43,13 @@ class FeatureArchive:
             return np.load(f, mmap_mode="r")
         return self._h5[key][:]
 
+    def shape(self, key: str) -> tuple:
+        """Shape of a member without reading its data where the container allows (HDF5 object header, .npy header of a directory
+        archive; an .npz member is decompressed): what a rank needs of a video it does not own (pipeline, sharded passes)."""
+        if self.kind == "h5":
+            return tuple(self._h5[key].shape)
+        return tuple(self[key].shape)
+
     def __contains__(self, key: str) -> bool:
         if self.kind == "npz":
             return key in self._npz.files

@@ -25,6 +25,9 @@ import sys
 from argparse import Namespace
 
 _FLAGS = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "cli_flags.json")))
+# timing record of the last train / generate_pseudo_labels / evaluate_cli call of this process (bench.py's coteach_loop reads it):
+# steps and seconds between device synchronisations, so the figures are kernel time of the stage, not process start-up
+LAST_RUN = {}
 _TYPES = {"int": int, "float": float, "str": str}
 
 SCRIPTS = {
@@ -357,12 +360,16 @@ def train(script: str, argv=None, args=None):
             logger.info('Round 0 [{}/{}]: spatio_loss {:.4f}, CE_loss {:.4f}, MIL_loss {:.4f}, err {:.4f}, l1 {:.4f}'.format(
                 it_, epoch_, loss, aux, mil, err, l1))
     late = _LateLog(torch, emit) if rank == 0 else None
+    import time as _time
+    t_first, t_eval = None, 0.0
     for epoch in range(epochs):
         for norm_feats, norm_labs, abnorm_feats, abnorm_labs in data:
             sc = ts.step(norm_feats, abnorm_feats, abnorm_labs)
             if late is not None:
                 late.push(it, epoch, sc)          # the PREVIOUS step's line is written now: no sync on the step just queued
             it += 1
+            if it == 1:                           # LAST_RUN: steady-state step rate from the end of the first step on
+                torch.cuda.synchronize(); t_first = _time.perf_counter()
             if args.steps and it >= args.steps:
                 break
         if late is not None:
@@ -373,7 +380,9 @@ def train(script: str, argv=None, args=None):
             # EVERY rank evaluates: the videos of the test (and train) list are sharded over the ranks (pipeline._ScoreBoard) and
             # every rank ends up with the same AUCs, so no rank sits in a collective while another scores the whole list; rank 0
             # alone logs and writes the checkpoints
+            torch.cuda.synchronize(); t_e = _time.perf_counter()
             auc_test, auc_train = eval_fn()
+            torch.cuda.synchronize(); t_eval += _time.perf_counter() - t_e
             enc.train(); head.train()
             save_auc, lines = sel.update(epoch, auc_test, auc_train)
             if rank != 0:
@@ -393,6 +402,11 @@ def train(script: str, argv=None, args=None):
                 logger.info('======================================================================================')
         if args.steps and it >= args.steps:
             break
+    torch.cuda.synchronize()
+    LAST_RUN.clear()
+    LAST_RUN.update(script=script, steps=it, steady_steps=max(it - 1, 0),
+                    steady_s=(_time.perf_counter() - t_first - t_eval) if t_first is not None else 0.0, eval_s=t_eval,
+                    snippets_per_step=2 * args.batch_size * args.part_num * part_len, world=world)
     if rank == 0 and getattr(args, "save_final", ""):
         torch.save(enc.state_dict(), args.save_final + "encoder.ckpt")
         torch.save(head.state_dict(), args.save_final + "head.ckpt")
@@ -478,7 +492,14 @@ def _real_data(script, args, mode, part_len, pseudo_path, dev, rank, world, enc,
     k = {"temporal_transformer_shanghaitech": 4, "temporal_transformer_UBnormal": 4, "temporal_transformer_UCF": 1}.get(
         script, int(getattr(args, "num_workers", 0) or 0))
     streams = lds.WorkerStreams(k, int(getattr(args, "seed", 0)))
-    data = (_HostPairs if ds.lazy else lds.ResidentPairs)(ds, args.batch_size, dev, rank, world, streams)
+    # HBM-resident feed whenever the set fits (eager AND lazy single-crop datasets: upstream's per-item archive reads exist because
+    # host memory cannot hold UCF-Crime; 288 GB of HBM can); ten-crop datasets and sets beyond 60 % of the free HBM stay host-staged
+    import torch
+    resident = lds.ResidentPairs.serves(ds) and os.environ.get("LSTC_HOST_FEED", "0") != "1" and \
+        lds.ResidentPairs.bank_bytes(ds) < 0.6 * torch.cuda.mem_get_info(dev)[0]
+    data = (lds.ResidentPairs if resident else _HostPairs)(ds, args.batch_size, dev, rank, world, streams)
+    if resident:
+        data.lazy_rows = True          # TrainStep gathers inside the CLS concat (lstc_cls_concat_gather_fwd)
     masks = getattr(args, "test_mask_path", "") if dataset == "UCF" else getattr(args, "test_mask_dir", "")
     test_arc = getattr(args, "test_dataset_path", "") or args.dataset_path
     kind = "LTN" if mode == "LTN" else "STN"
@@ -578,9 +599,15 @@ def generate_pseudo_labels(script: str, argv=None, args=None):
     enc, head = enc.to(dev).eval(), head.to(dev).eval()
     if not args.synthetic and args.dataset_path:
         from .pipeline import generate_pseudo_labels as run
+        import time as _time
+        torch.cuda.synchronize(); t0 = _time.perf_counter()
         out = run(enc, head, mode, args.dataset, args.dataset_path, args.training_txt, args.threshold, part_len=part_len,
                   n_patch=args.n_patch, d_model=args.d_model, segment_len=args.segment_len,
                   classifier_head=(mode == "STN" and args.n_layers == 1), out_path=args.pseudo_labels_path, rank=rank, world=world)
+        torch.cuda.synchronize()
+        LAST_RUN.clear()
+        LAST_RUN.update(script=script, clips=int(sum(v.shape[0] for v in out.values())) if args.dataset != "UCF" else None,
+                        videos=len(out), score_s=_time.perf_counter() - t0, world=world)
         if rank == 0:
             print(f"{'temporal' if mode == 'LTN' else 'spatio'} pseudo label generation finished.")
         if world > 1:
@@ -638,8 +665,13 @@ def evaluate_cli(script: str, argv=None, args=None):
     if not args.synthetic and args.dataset_path:
         from .pipeline import evaluate_auc
         masks = args.test_mask_path if ucf else args.test_mask_dir
-        auc = evaluate_auc(enc, head, "LTN", "UCF" if ucf else args.dataset, args.dataset_path, args.testing_txt, masks,
-                           part_len, args.n_patch, seg)
+        import time as _time
+        torch.cuda.synchronize(); t0 = _time.perf_counter()
+        auc, fs, _ = evaluate_auc(enc, head, "LTN", "UCF" if ucf else args.dataset, args.dataset_path, args.testing_txt, masks,
+                                  part_len, args.n_patch, seg, return_frames=True)
+        torch.cuda.synchronize()
+        LAST_RUN.clear()
+        LAST_RUN.update(script=script, clips=int(fs.shape[0]) // seg, score_s=_time.perf_counter() - t0, world=1)
         print("auc = ", auc)
         return auc
     data = SyntheticVideos(2, 1, 1, part_len, args.n_patch, args.d_model, dev, seed=0)

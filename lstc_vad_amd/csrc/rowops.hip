@@ -317,6 +317,9 @@ __global__ void __launch_bounds__(NT) ln_bwd_pack2(const float* __restrict__ dy,
 typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
 
 // One wave per row, NC = d / 512 chunks per lane.  XP: x is a pack (else f32 [rows, d]); YF / YP: write y as f32 / as a pack.
+// (Measured and not kept: the next row's chunks prefetched before the current row is reduced - with gamma / beta in registers
+// that is 174 VGPRs = 2 waves per SIMD; with gamma / beta in LDS 124 VGPRs = 4 waves, and 221 us instead of 173 us per 100352 x
+// 2048 launch: the reduction waits on the LDS reads.  The plain form below is the fastest of the three.)
 template <int NC, bool XP, bool YF, bool YP>
 __global__ void __launch_bounds__(NT) ln_fwd_act(const float* __restrict__ x, const __bf16* __restrict__ xp,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -407,30 +410,48 @@ __global__ void __launch_bounds__(NT) ln_bwd_act(const float* __restrict__ dy, c
     }
     const int64_t stride = (int64_t)gridDim.x * 2;
     const int64_t iters = (rows + stride - 1) / stride;
+    // operands of iteration it + 1 are requested before iteration it is reduced (raw bf16: 8 - 16 registers per tensor): twice the
+    // bytes in flight per wave.  Rows beyond the end are clamped to row 0 (never used: ``live``).
+    bf16x8v xc[NCH], xn[NCH], dc[DYP ? NCH : 1], dn[DYP ? NCH : 1];
+    float4 fc[DYP ? 1 : 2 * NCH], fn[DYP ? 1 : 2 * NCH];
+    auto fetch = [&](int64_t it, bf16x8v* xo, bf16x8v* dpo, float4* dfo) {
+        const int64_t r = it * stride + (int64_t)blockIdx.x * 2 + slot;
+        const int64_t rr = r < rows ? r : 0;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c0 = 8 * (half * hc + lane + 64 * i);
+            const size_t off = p1_offset(rr, c0, KBp);
+            xo[i] = *reinterpret_cast<const bf16x8v*>(xp + off);
+            if constexpr (DYP) dpo[i] = *reinterpret_cast<const bf16x8v*>(dyp + off);
+            else {
+                dfo[2 * i] = *reinterpret_cast<const float4*>(dy + rr * d + c0);
+                dfo[2 * i + 1] = *reinterpret_cast<const float4*>(dy + rr * d + c0 + 4);
+            }
+        }
+    };
+    if (iters > 0) fetch(0, xc, dc, fc);
     for (int64_t it = 0; it < iters; ++it) {
         const int64_t r = it * stride + (int64_t)blockIdx.x * 2 + slot;
         const bool live = r < rows;
         const int64_t rr = live ? r : 0;
+        if (it + 1 < iters) fetch(it + 1, xn, dn, fn);
         const float mu = mean[rr], rs = rstd[rr];
         float xh[NCH][8], gd[NCH][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c0 = 8 * (half * hc + lane + 64 * i);
             if (live) {
-                const bf16x8v xv = *reinterpret_cast<const bf16x8v*>(xp + p1_offset(rr, c0, KBp));
                 float dv[8];
                 if constexpr (DYP) {
-                    const bf16x8v dh = *reinterpret_cast<const bf16x8v*>(dyp + p1_offset(rr, c0, KBp));
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) dv[j] = (float)dh[j];
+                    for (int j = 0; j < 8; ++j) dv[j] = (float)dc[i][j];
                 } else {
-                    const float4 a0 = *reinterpret_cast<const float4*>(dy + rr * d + c0), a1 = *reinterpret_cast<const float4*>(dy + rr * d + c0 + 4);
+                    const float4 a0 = fc[2 * i], a1 = fc[2 * i + 1];
                     dv[0] = a0.x; dv[1] = a0.y; dv[2] = a0.z; dv[3] = a0.w; dv[4] = a1.x; dv[5] = a1.y; dv[6] = a1.z; dv[7] = a1.w;
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    xh[i][j] = ((float)xv[j] - mu) * rs;
+                    xh[i][j] = ((float)xc[i][j] - mu) * rs;
                     gd[i][j] = dv[j] * g[i][j];
                     s1 += gd[i][j];
                     s2 += gd[i][j] * xh[i][j];
@@ -447,23 +468,30 @@ __global__ void __launch_bounds__(NT) ln_bwd_act(const float* __restrict__ dy, c
         __syncthreads();
         const float2 pa = rb[(slot * 2) * 64 + lane], pb = rb[(slot * 2 + 1) * 64 + lane];
         const float m1 = wave_sum(pa.x + pb.x) / (float)d, m2 = wave_sum(pa.y + pb.y) / (float)d;
-        if (!live) continue;
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c0 = 8 * (half * hc + lane + 64 * i);
+                const uint32_t fi = (uint32_t)(r * d) + (uint32_t)c0;
+                bf16x8v ho, hf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float ov = rs * (gd[i][j] - m1 - xh[i][j] * m2);
+                    const float f = drop_keep(fi + j, key) ? ov * key.scale : 0.f;
+                    ad[i][j] += f;
+                    ho[j] = (__bf16)ov;
+                    hf[j] = (__bf16)f;
+                }
+                const size_t off = p1_offset(r, c0, KBp);
+                if constexpr (DX) *reinterpret_cast<bf16x8v*>(dxp + off) = ho;
+                *reinterpret_cast<bf16x8v*>(dfp + off) = hf;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c0 = 8 * (half * hc + lane + 64 * i);
-            const uint32_t fi = (uint32_t)(r * d) + (uint32_t)c0;
-            bf16x8v ho, hf;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float ov = rs * (gd[i][j] - m1 - xh[i][j] * m2);
-                const float f = drop_keep(fi + j, key) ? ov * key.scale : 0.f;
-                ad[i][j] += f;
-                ho[j] = (__bf16)ov;
-                hf[j] = (__bf16)f;
-            }
-            const size_t off = p1_offset(r, c0, KBp);
-            if constexpr (DX) *reinterpret_cast<bf16x8v*>(dxp + off) = ho;
-            *reinterpret_cast<bf16x8v*>(dfp + off) = hf;
+            xc[i] = xn[i];
+            if constexpr (DYP) dc[i] = dn[i];
+            else { fc[2 * i] = fn[2 * i]; fc[2 * i + 1] = fn[2 * i + 1]; }
         }
     }
     // combine the two row slots through LDS, one partial row per workgroup and kind
@@ -583,14 +611,20 @@ __global__ void __launch_bounds__(NT) cls_concat_fwd_kernel(const float* __restr
 // token loop unrolled so that several rows are in flight per lane.  Same per-column arithmetic in the same order (the mean CLS
 // token is a sequential sum over the tokens), so the results are bitwise those of the scalar kernel, which took 569 us for the
 // headline batch in bf16 mode (2.0 GB moved: 3.6 TB/s) with its 4-B loads and 2-B pack stores.
+// GATHER (round 5): ``clip_idx`` != NULL makes x a feature BANK [clips, P, d] and token t of sequence n the patch t % P of clip
+// clip_idx[n * (S - 1) / P + t / P] - the batch formation (lstc_gather_rows: 805 MB written and read again at the headline shape) is
+// fused into this pass.  The index of a token is wave-uniform (one sequence per workgroup): a scalar load.
+template <bool GATHER>
 __global__ void __launch_bounds__(NT) cls_concat_fwd_vec4_kernel(const float4* __restrict__ x, const float4* __restrict__ x_hi,
                                                                   int64_t n_lo, const float4* __restrict__ cls,
                                                                   const float4* __restrict__ pos, float4* __restrict__ y, int S,
-                                                                  int d4, __bf16* __restrict__ packed, int KBp) {
+                                                                  int d4, __bf16* __restrict__ packed, int KBp,
+                                                                  const int64_t* __restrict__ clip_idx, int P) {
     const int64_t n = blockIdx.x;
     const int c4 = blockIdx.y * NT + threadIdx.x;
     if (c4 >= d4) return;
     const float4* xr = (x_hi && n >= n_lo ? x_hi + (n - n_lo) * (int64_t)(S - 1) * d4 : x + n * (int64_t)(S - 1) * d4) + c4;
+    const int64_t* ci = GATHER ? clip_idx + n * (int64_t)((S - 1) / P) : nullptr;
     float4* yr = y ? y + n * (int64_t)S * d4 + c4 : nullptr;       // NULL: pack only (bf16 activation stream)
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     auto emit = [&](int64_t row, const float4& w) {
@@ -603,7 +637,9 @@ __global__ void __launch_bounds__(NT) cls_concat_fwd_vec4_kernel(const float4* _
 #endif
 #pragma unroll CLS_CONCAT_UNROLL
     for (int t = 0; t < S - 1; ++t) {
-        const float4 v = xr[(int64_t)t * d4];
+        float4 v;
+        if constexpr (GATHER) v = x[(ci[t / P] * P + t % P) * (int64_t)d4 + c4];
+        else v = xr[(int64_t)t * d4];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         float4 w = v;
         if (pos) {
@@ -1178,8 +1214,9 @@ static void launch_cls_concat_fwd(const float* x, const float* x_hi, int64_t n_l
                                   int64_t N, int32_t S, int32_t d, __bf16* packed, int KBp, hipStream_t st) {
     if (d % 4 == 0 && aligned16(x) && aligned16(y) && (!x_hi || aligned16(x_hi)) && (!cls_token || aligned16(cls_token)) &&
         (!pos || aligned16(pos))) {
-        hipLaunchKernelGGL(cls_concat_fwd_vec4_kernel, dim3((unsigned)N, (d / 4 + NT - 1) / NT), NT, 0, st, (const float4*)x,
-                           (const float4*)x_hi, n_lo, (const float4*)cls_token, (const float4*)pos, (float4*)y, S, d / 4, packed, KBp);
+        hipLaunchKernelGGL(cls_concat_fwd_vec4_kernel<false>, dim3((unsigned)N, (d / 4 + NT - 1) / NT), NT, 0, st, (const float4*)x,
+                           (const float4*)x_hi, n_lo, (const float4*)cls_token, (const float4*)pos, (float4*)y, S, d / 4, packed, KBp,
+                           (const int64_t*)nullptr, 1);
         return;
     }
     hipLaunchKernelGGL(cls_concat_fwd_kernel, dim3((unsigned)N, (d + NT - 1) / NT), NT, 0, st, x, x_hi, n_lo, cls_token, pos, y, S, d,
@@ -1204,6 +1241,19 @@ int lstc_cls_concat_fwd_pack(const float* x, const float* x_hi, int64_t n_lo, co
     if (!y && !(d % 4 == 0 && aligned16(x) && (!x_hi || aligned16(x_hi)) && (!cls_token || aligned16(cls_token)) && (!pos || aligned16(pos))))
         return LSTC_E_ALIGN;
     launch_cls_concat_fwd(x, x_hi, n_lo, cls_token, pos, y, N, S, d, (__bf16*)packed, d / 32, (hipStream_t)stream);
+    return lstc_launch_status();
+}
+
+int lstc_cls_concat_gather_fwd(const float* bank, int64_t bank_clips, const int64_t* clip_idx, int32_t P, const float* cls_token,
+                               const float* pos, float* y, int64_t N, int32_t S, int32_t d, void* packed, void* stream) {
+    if (!bank || !clip_idx || (!y && !packed)) return LSTC_E_NULL;
+    if (N <= 0 || S < 2 || d <= 0 || P <= 0 || bank_clips <= 0 || (S - 1) % P != 0) return LSTC_E_SHAPE;
+    if (packed && ((N * S) % 256 != 0 || d % 64 != 0)) return LSTC_E_UNSUPPORTED;      // the rows fill the pack's even tile grid exactly
+    if (d % 4 != 0 || !aligned16(bank) || !aligned16(y) || !aligned16(packed) || (cls_token && !aligned16(cls_token)) || (pos && !aligned16(pos)))
+        return LSTC_E_ALIGN;
+    hipLaunchKernelGGL(cls_concat_fwd_vec4_kernel<true>, dim3((unsigned)N, (d / 4 + NT - 1) / NT), NT, 0, (hipStream_t)stream,
+                       (const float4*)bank, (const float4*)nullptr, (int64_t)0, (const float4*)cls_token, (const float4*)pos, (float4*)y, S,
+                       d / 4, (__bf16*)packed, d / 32, clip_idx, P);
     return lstc_launch_status();
 }
 

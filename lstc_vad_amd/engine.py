@@ -84,6 +84,21 @@ class TrainStep:
     def forward_loss(self, norm_feats, abnorm_feats, abnorm_labs):
         a, d = self.args, norm_feats.shape[-1]
         tokens = a.part_len * a.n_patch if self.mode == "LTN" else a.n_patch
+        from .feed import LazyRows
+        if isinstance(norm_feats, LazyRows) or isinstance(abnorm_feats, LazyRows):
+            # an HBM-resident feed handed over clip INDICES (feed.LazyRows): batch formation, cat and CLS concat are one pass over the
+            # bank (lstc_cls_concat_gather_fwd) - where the encoder takes its input that way; otherwise gather now
+            if (self.cls_only and isinstance(norm_feats, LazyRows) and norm_feats.pairs_with(abnorm_feats) and
+                    not self.encoder.input_layerNorm and norm_feats.bank.dim() == 3 and norm_feats.bank.shape[1] == a.n_patch):
+                Lc = a.part_len if self.mode == "LTN" else 1
+                n_seq = 2 * norm_feats.bs * norm_feats.rows // Lc
+                cls = self.encoder.forward_cls((norm_feats.bank, norm_feats.idx_flat, n_seq, Lc))
+                outputs = self.head(cls)
+                loss, scalars = training_loss(self.args, self.mode, outputs, abnorm_labs, group=self.group,
+                                              distributed=self.loss_rank, exchange=self.loss_exchange)
+                return loss, scalars, outputs
+            norm_feats = norm_feats.materialize() if isinstance(norm_feats, LazyRows) else norm_feats
+            abnorm_feats = abnorm_feats.materialize() if isinstance(abnorm_feats, LazyRows) else abnorm_feats
         # normal sequences first, abnormal second (A1); the cat itself is fused into the CLS-concat kernel
         if self.cls_only:
             cls = self.encoder.forward_cls(norm_feats.float().reshape(-1, tokens, d), abnorm_feats.float().reshape(-1, tokens, d))

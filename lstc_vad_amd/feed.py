@@ -64,6 +64,31 @@ class PinnedFeeder:
             self._consumed[cur] = ev
 
 
+class LazyRows:
+    """``bank[idx]`` that has NOT been formed: one half (``kind`` 0 = normal, 1 = abnormal videos) of a training batch
+    ``[2, bs, rows]`` of clip indices into an HBM-resident bank ``[clips, P, d]``.  ``engine.TrainStep`` hands the index vector to
+    the fused gather + CLS-concat kernel (lstc_cls_concat_gather_fwd: the gathered batch is never written); everything else calls
+    ``materialize()`` (lstc_gather_rows) and sees the ordinary ``[bs, rows, P, d]`` tensor."""
+
+    def __init__(self, bank, idx_flat, kind, bs, rows):
+        self.bank, self.idx_flat, self.kind, self.bs, self.rows = bank, idx_flat, kind, bs, rows
+        self.shape = (bs, rows) + tuple(bank.shape[1:])
+        self.device = bank.device
+
+    def idx(self):
+        n = self.bs * self.rows
+        return self.idx_flat[self.kind * n:(self.kind + 1) * n]
+
+    def materialize(self):
+        from . import functional as F
+        return F.gather_rows(self.bank, self.idx()).reshape(self.shape)
+
+    def pairs_with(self, other) -> bool:
+        """Is ``other`` the abnormal half of the batch this is the normal half of (one flat index vector, normal first)?"""
+        return (isinstance(other, LazyRows) and other.idx_flat is self.idx_flat and self.kind == 0 and other.kind == 1 and
+                (other.bs, other.rows) == (self.bs, self.rows))
+
+
 class ResidentBank:
     """Features resident in HBM as ONE ``[total_clips, ...row]`` tensor; a training batch is formed on the device by
     ``lstc_gather_rows`` from clip indices the host sampler produced (MI355X-first data feed: a whole training set fits in
@@ -98,9 +123,15 @@ class ResidentBank:
         self._done[s] = ev
         return outs
 
-    def gather(self, idx, *extras):
+    def gather(self, idx, *extras, lazy=False):
         """``idx``: int64 numpy array of clip rows (any shape); returns ``bank[idx]`` with shape ``idx.shape + row`` plus the
-        ``extras`` (small numpy arrays, e.g. labels) as device tensors."""
+        ``extras`` (small numpy arrays, e.g. labels) as device tensors.  ``lazy`` (``idx`` of shape [2, bs, rows]): the two
+        halves come back as ``LazyRows`` - the indices are on the device, the rows are gathered by whoever consumes them."""
         dev = self._stage([idx.reshape(-1)] + list(extras))
+        if lazy:
+            if idx.ndim != 3 or idx.shape[0] != 2:
+                raise ValueError("gather(lazy=True) takes the [2, bs, rows] index array of a normal / abnormal pair batch")
+            return ((LazyRows(self.bank, dev[0], 0, idx.shape[1], idx.shape[2]), LazyRows(self.bank, dev[0], 1, idx.shape[1], idx.shape[2])),
+                    *dev[1:])
         out = self.F.gather_rows(self.bank, dev[0]).reshape(tuple(idx.shape) + tuple(self.bank.shape[1:]))
         return (out, *dev[1:])

@@ -1562,9 +1562,13 @@ class ClsConcatFunction(torch.autograd.Function):
     """models/Encoder.py:51-58: CLS (token mean or learned) prepended, optional learned position table added."""
 
     @staticmethod
-    def forward(ctx, x, cls_token, pos, x_hi=None, pack_only=False):
+    def forward(ctx, x, cls_token, pos, x_hi=None, pack_only=False, gather=None):
         # x_hi: optional second half of the batch (abnormal sequences); the cat is fused into the kernel
         # pack_only: the bf16 activation stream - the result exists only as layer 0's packed operand (returned as its bf16 view)
+        # gather = (clip_idx int64 [N * Lc] on the device, N, Lc): x is a feature BANK [clips, P, d] and sequence n the clips
+        #   clip_idx[n*Lc : (n+1)*Lc] - batch formation, cat and CLS concat in one pass (lstc_cls_concat_gather_fwd)
+        if gather is not None:
+            return ClsConcatFunction._forward_gather(ctx, x, cls_token, pos, pack_only, gather)
         N_lo, Sm1, dm = x.shape
         N = N_lo + (x_hi.shape[0] if x_hi is not None else 0)
         S = Sm1 + 1
@@ -1598,11 +1602,13 @@ class ClsConcatFunction(torch.autograd.Function):
         ctx.meta = (N, S, dm, cls_token is not None, pos.shape if pos is not None else None)
         return y
 
+    _forward_gather = None          # bound below: functional._cls_concat_gather
+
     @staticmethod
     def backward(ctx, dy):
         N, S, dm, learned, pos_shape = ctx.meta
         if ctx.pack_only:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         dy = dy.contiguous()
         dx = dcls = dpos = None
         if ctx.needs_input_grad[0]:
@@ -1618,7 +1624,36 @@ class ClsConcatFunction(torch.autograd.Function):
             if pos_shape is not None:
                 dpos = torch.zeros(pos_shape, device=dy.device, dtype=torch.float32)
                 dpos[0, :S] = tok.view(S, dm)
-        return dx, dcls, dpos, None, None
+        return dx, dcls, dpos, None, None, None
+
+
+def _cls_concat_gather(ctx, bank, cls_token, pos, pack_only, gather):
+    idx, N, Lc = gather
+    clips, P, dm = bank.shape
+    S = Lc * P + 1
+    if bank.dtype != torch.float32 or not bank.is_contiguous() or idx.dtype != torch.int64 or idx.numel() != N * Lc or bank.requires_grad:
+        raise RuntimeError("ClsConcatFunction(gather): bank must be a contiguous float32 [clips, P, d] tensor without gradient and idx int64 [N * Lc]")
+    lib = _lib.load()
+    want_pack = pack_only or _fused_pack_shape(N * S, dm)
+    if pack_only and (cls_token is not None or pos is not None or not act_rows_ok(N * S, dm)):
+        raise RuntimeError("ClsConcatFunction(pack_only): nothing upstream may need a gradient and [N*S, d] must fit the bf16 stream")
+    y = None if pack_only else torch.empty((N, S, dm), device=bank.device, dtype=torch.float32)
+    buf = torch.empty((int(lib.lstc_pack1_bytes(N * S, dm)),), device=bank.device, dtype=torch.uint8) if want_pack else None
+    pos_s = pos[0, :S].contiguous() if pos is not None else None
+    cls_v = cls_token.reshape(-1) if cls_token is not None else None
+    check(lib.lstc_cls_concat_gather_fwd(dev_ptr(bank), clips, dev_ptr(idx.contiguous()), P, dev_ptr(cls_v), dev_ptr(pos_s), dev_ptr(y),
+                                         N, S, dm, dev_ptr(buf), stream_ptr()), "lstc_cls_concat_gather_fwd")
+    ctx.pack_only = bool(pack_only)
+    ctx.two = False
+    ctx.meta = (N, S, dm, cls_token is not None, pos.shape if pos is not None else None)
+    if pack_only:
+        return buf.view(torch.bfloat16)
+    if want_pack:
+        _register_pack(y.view(N * S, dm), Packed(buf, N * S, dm, _lib.BF16P))
+    return y
+
+
+ClsConcatFunction._forward_gather = staticmethod(_cls_concat_gather)
 
 
 class DropoutFunction(torch.autograd.Function):

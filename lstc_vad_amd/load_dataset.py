@@ -326,7 +326,8 @@ class _WorkerScope:
 def shard_plan(ds, offsets, n_norm, b, bs, rank=0, world=1):
     """Window indices + labels of global batch ``b`` (``bs`` pairs) for rank ``rank`` of ``world``: pairs
     ``[rank*bs/world, (rank+1)*bs/world)``.  The sampler runs for EVERY pair (same ``np.random`` consumption on every rank
-    as in the single-process run), so the ranks' shards are disjoint and their union is the single-process batch."""
+    as in the single-process run), so the ranks' shards are disjoint and their union is the single-process batch.  A video's
+    clip count is the length of its slice of the bank (``offsets``): lazy datasets hold only keys in ``norm_feats``."""
     rows = ds.part_num * ds.part_len
     bl = bs // world
     lo = rank * bl
@@ -336,10 +337,11 @@ def shard_plan(ds, offsets, n_norm, b, bs, rank=0, world=1):
         item = b * bs + j
         ni, ai = ds.norm_iters[item], ds.abnorm_iters[item]
         for kind, vid in ((0, ni), (1, ai)):
-            feats = (ds.norm_feats if kind == 0 else ds.abnorm_feats)[vid]
+            slot = vid + (n_norm if kind else 0)
+            n_clips = int(offsets[slot + 1] - offsets[slot])
             keys = ds.norm_keys if kind == 0 else ds.abnorm_keys
-            l = ds._labels_for(feats.shape[0], ds._pseudo(keys[vid]), "Normal" if kind == 0 else "Abnormal")
-            w = window_indices(feats.shape[0], ds.part_num, ds.part_len, ds.sample)     # consumes np.random on every rank
+            l = ds._labels_for(n_clips, ds._pseudo(keys[vid]), "Normal" if kind == 0 else "Abnormal")
+            w = window_indices(n_clips, ds.part_num, ds.part_len, ds.sample)     # consumes np.random on every rank
             if lo <= j < lo + bl:
                 idx[kind, j - lo] = w + offsets[vid + (n_norm if kind else 0)]
                 labs[kind, j - lo] = np.asarray(l, np.float32).reshape(-1, 1)[w] if np.ndim(l) == 1 else l[w]
@@ -353,7 +355,15 @@ class ResidentPairs:
     a batch is formed by ``lstc_gather_rows`` from the window indices that the dataset's own sampler produces on the host
     (same ``np.random`` consumption as iterating the dataset with ``DataLoader(batch_size, drop_last=True,
     num_workers=0, shuffle=False)``), so the batches are bit-identical to the host path while no feature bytes cross
-    PCIe per step.  Labels are tiny and travel with the indices."""
+    PCIe per step.  Labels are tiny and travel with the indices.
+
+    Round 5: the LAZY single-crop datasets too (``SH_Train_Origin_Dataset_MutualTraining`` - the co-teaching stage of BASELINE
+    config 3 - and ``UCF_Train_Origin_Dataset`` without ``crop_return``).  Upstream re-reads a video from the archive for every
+    item because the host cannot hold the set; 288 GB of HBM can (UCF-Crime: ~90 GB of fp32 features), and what an item holds
+    does not depend on when its video was read: each video goes through the dataset's own ``_fetch`` ONCE at construction (UCF:
+    videos of at most ``part_len`` clips are repeated, utils/load_dataset.py:437-438) and lands in the bank.  The host-staged path
+    (``cli._HostPairs``) moved 1.2 GB per step over PCIe for the reference's MIL_CE batch: 717 ms per step against 58 ms for the
+    same model on the resident feed (tools/coteach_round.py)."""
 
     def __init__(self, dataset: _PairSource, batch_size: int, device, rank: int = 0, world: int = 1, streams: "WorkerStreams" = None):
         """``batch_size`` = pairs of the GLOBAL batch (the reference's ``--batch_size``); under data parallelism rank ``r``
@@ -361,22 +371,53 @@ class ResidentPairs:
         sampler for the whole global batch - same ``np.random`` consumption as the single-process run - so the ranks'
         shards are disjoint and their union IS the single-process batch."""
         from .feed import ResidentBank
-        if dataset.lazy or dataset.ten_crop:
-            raise ValueError("ResidentPairs serves the eager single-crop datasets (SH / UBnormal)")
+        if not self.serves(dataset):
+            raise ValueError("ResidentPairs serves the single-crop datasets (SH / UBnormal / UCF without crop_return)")
         if batch_size % world:
             raise ValueError(f"--batch_size {batch_size} pairs do not split over {world} ranks")
         self.ds, self.bs, self.device, self.rank, self.world = dataset, batch_size, device, rank, world
         self.streams = streams or WorkerStreams(0, 0)
         P = dataset.n_patch
-        vids = dataset.norm_feats + dataset.abnorm_feats
+        entries = dataset.norm_feats + dataset.abnorm_feats           # arrays (eager) or archive keys (lazy)
         cut = (lambda f: f) if P == 1 else (lambda f: f[:, :P, :])
-        self.offsets = np.concatenate([[0], np.cumsum([v.shape[0] for v in vids])]).astype(np.int64)
         self.n_norm = len(dataset.norm_feats)
-        self.row_shape = tuple(cut(vids[0]).shape[1:])
+        if dataset.lazy:
+            # two passes over the archive: clip counts first (one allocation of the bank), then one upload per video; nothing but
+            # the video in flight is held on the host
+            keep_np, keep_py = np.random.get_state(), random.getstate()      # _fetch of a single-crop dataset draws nothing; be sure
+            lens = [int(dataset._fetch(e).shape[0]) for e in entries]
+        else:
+            lens = [int(v.shape[0]) for v in entries]
+        self.offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        first = dataset._fetch(entries[0]) if dataset.lazy else entries[0]
+        self.row_shape = tuple(cut(first).shape[1:])
         self.bank = torch.empty((int(self.offsets[-1]),) + self.row_shape, dtype=torch.float32, device=device)
-        for o, v in zip(self.offsets[:-1], vids):            # one staged copy per video, then everything is resident
+        for o, e in zip(self.offsets[:-1], entries):         # one staged copy per video, then everything is resident
+            v = dataset._fetch(e) if dataset.lazy else e
             self.bank[o:o + v.shape[0]].copy_(torch.from_numpy(np.ascontiguousarray(cut(v), dtype=np.float32)))
+        if dataset.lazy:
+            np.random.set_state(keep_np); random.setstate(keep_py)
         self.feed = ResidentBank(self.bank)
+
+    @staticmethod
+    def serves(dataset) -> bool:
+        """Single-crop datasets only: a ten-crop item picks its crop with ``random`` per item (it stays on the host path)."""
+        return not dataset.ten_crop and not getattr(dataset, "crop_return", False)
+
+    @staticmethod
+    def bank_bytes(dataset) -> int:
+        """Bytes the bank of ``dataset`` would take (fp32), from the archive's shapes alone."""
+        from .archive import FeatureArchive
+        P = dataset.n_patch
+        if not dataset.lazy:
+            return int(sum(4 * v.shape[0] * int(np.prod(v.shape[1:])) * (min(P, v.shape[1]) / v.shape[1] if v.ndim == 3 else 1.0)
+                           for v in dataset.norm_feats + dataset.abnorm_feats))
+        tot = 0
+        with FeatureArchive(dataset.h5_path) as arc:
+            for k in dataset.norm_feats + dataset.abnorm_feats:
+                shp = arc.shape(k)
+                tot += 4 * int(np.prod(shp)) * (2 if shp[0] <= dataset.part_len and hasattr(dataset, "frames_per_clip") else 1)
+        return int(tot)
 
     def __len__(self):
         return len(self.ds) // self.bs
@@ -391,7 +432,9 @@ class ResidentPairs:
         for b in range(len(self)):
             with self.streams.batch(b):
                 idx, labs = self.plan(b)
-            out, labs_d = self.feed.gather(idx, labs)
+            # lazy_rows (set by the training CLI): the halves are feed.LazyRows - engine.TrainStep fuses the gather into the CLS
+            # concat; default: the gathered tensors (what DataLoader would have collated)
+            out, labs_d = self.feed.gather(idx, labs, lazy=getattr(self, "lazy_rows", False))
             yield out[0], labs_d[0], out[1], labs_d[1]
 
     def shuffle_keys(self):

@@ -58,17 +58,40 @@ class Encoder(nn.Module):
                 skip.update(id(p) for p in layer.pos_ffn.layer_norm.parameters())
         return [p for p in self.parameters() if id(p) not in skip]
 
+    @staticmethod
+    def _gather_spec(x):
+        """``x`` = (bank [clips, P, d], clip_idx int64 [N * Lc] on the device, N, Lc): sequences still to be gathered out of an
+        HBM-resident feature bank (engine.TrainStep on a feed.LazyRows batch) -> (N, S - 1, d)."""
+        bank, idx, N, Lc = x
+        return N, Lc * bank.shape[1], bank.shape[2]
+
     def _act_chain(self, enc_output, enc_output_hi, layers) -> bool:
         """bf16 mode: do ``layers`` (the full encoder layers of this call) run on the bf16 activation stream?  Only when nothing in
         front of them needs a gradient or an f32 copy (no input LayerNorm, learned CLS token or position table) and every block
         qualifies (functional.act_chain_ok)."""
-        if self.input_layerNorm or self.CLS_learned or self.position_encoding or enc_output.requires_grad or \
-                enc_output.dtype != torch.float32 or not enc_output.is_cuda or enc_output.dim() != 3:
+        if self.input_layerNorm or self.CLS_learned or self.position_encoding:
+            return False
+        if isinstance(enc_output, tuple):
+            N, Sm1, d = self._gather_spec(enc_output)
+            return act_chain_ok(N, Sm1 + 1, d, layers)
+        if enc_output.requires_grad or enc_output.dtype != torch.float32 or not enc_output.is_cuda or enc_output.dim() != 3:
             return False
         N = enc_output.shape[0] + (enc_output_hi.shape[0] if enc_output_hi is not None else 0)
         return act_chain_ok(N, enc_output.shape[1] + 1, enc_output.shape[2], layers)
 
     def _embed(self, enc_output, enc_output_hi=None, pack_only=False):
+        if isinstance(enc_output, tuple):
+            # batch formation fused into the CLS concat (lstc_cls_concat_gather_fwd): the gathered batch is never written
+            bank, idx, N, Lc = enc_output
+            if self.input_layerNorm:
+                raise RuntimeError("Encoder: a gather spec cannot feed the input LayerNorm (materialise the batch first)")
+            out = ClsConcatFunction.apply(bank, self.cls_token if self.CLS_learned else None,
+                                          self.position_enc if self.position_encoding else None, None, pack_only, (idx, N, Lc))
+            if pack_only:
+                return PackedAct(out, (N, Lc * bank.shape[1] + 1, bank.shape[2]))
+            if self.position_encoding and self.training and self.position_dropout.p > 0:
+                out = DropoutFunction.apply(out, self.position_dropout.p, "position_dropout")
+            return out
         if pack_only:
             N = enc_output.shape[0] + (enc_output_hi.shape[0] if enc_output_hi is not None else 0)
             t = ClsConcatFunction.apply(enc_output, None, None, enc_output_hi, True)

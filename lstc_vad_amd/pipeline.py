@@ -147,8 +147,8 @@ def generate_pseudo_labels(enc, head, mode, dataset, dataset_path, training_txt,
         for i, (line, key) in enumerate(_train_keys(dataset, training_txt)):
             keys.append(key + ".npy")
             if mode == "STN":
-                a = arc[key + ".npy"]
-                board.add_clips(i, a.shape[0], lambda a=a: scoring.stn_clip_scores(enc, head, _dev(a, device), classifier_head),
+                board.add_clips(i, arc.shape(key + ".npy")[0],
+                                lambda key=key: scoring.stn_clip_scores(enc, head, _dev(arc[key + ".npy"], device), classifier_head),
                                 lambda v: _threshold(v, threshold))
                 continue
             if dataset == "UCF":
@@ -159,11 +159,10 @@ def generate_pseudo_labels(enc, head, mode, dataset, dataset_path, training_txt,
                     f = _dev(feats, device).view(-1, n_patch, d_model)
                     return scoring.ltn_ucf_bin_sequences(f, n_frames, part_len, segment_len, normalize=False, rewindow=False)[0]
             else:
-                a = arc[key + ".npy"]
-                ranges = scoring.part_ranges(a.shape[0], part_len)
+                ranges = scoring.part_ranges(arc.shape(key + ".npy")[0], part_len)
 
-                def make(a=a):
-                    return scoring.ltn_part_sequences(_dev(a, device), part_len, tail="short")[0]
+                def make(key=key):
+                    return scoring.ltn_part_sequences(_dev(arc[key + ".npy"], device), part_len, tail="short")[0]
             board.add_ltn(i, len(ranges), make,
                           lambda v, ranges=ranges: _threshold(np.concatenate([np.repeat(x, e - b) for x, (b, e) in zip(v, ranges)]),
                                                               threshold))
@@ -211,8 +210,8 @@ def evaluate_auc(enc, head, mode, dataset, dataset_path, testing_txt, masks, par
             if mode != "LTN":
                 if feats is None:
                     with FeatureArchive(dataset_path) as arc:
-                        a = arc[_ucf_line(line)[0] + ".npy"]
-                        n_clips = int(np.prod(a.shape)) // (n_patch * a.shape[-1])
+                        shp = arc.shape(_ucf_line(line)[0] + ".npy")
+                        n_clips = int(np.prod(shp)) // (n_patch * shp[-1])
                 else:
                     n_clips = int(np.prod(feats.shape)) // (n_patch * feats.shape[-1])
 
@@ -277,13 +276,12 @@ def evaluate_train_auc(enc, head, mode, dataset, train_archive, training_txt, ma
                 # the published UBnormal list holds a FRAME COUNT there (train_video_names_frames.txt; upstream then looks for
                 # a mask of every video and stops) - the class of such a line comes from the file name
                 abnormal = not key.startswith("normal")
-            a = arc[key + ".npy"]
-            n = a.shape[0]
+            n = arc.shape(key + ".npy")[0]
             if mode != "LTN":
                 def fin(v, abnormal=abnormal, key=key):
                     s = np.repeat(v, segment_len)
                     return s, frame_labels(abnormal, key, s.shape[0])
-                board.add_clips(i, n, lambda a=a: scoring.stn_clip_scores(enc, head, _dev(a, device, n_patch)), fin)
+                board.add_clips(i, n, lambda key=key: scoring.stn_clip_scores(enc, head, _dev(arc[key + ".npy"], device, n_patch)), fin)
                 continue
             ranges = scoring.part_ranges(n, part_len)
 
@@ -291,6 +289,7 @@ def evaluate_train_auc(enc, head, mode, dataset, train_archive, training_txt, ma
                 sfr = np.concatenate([np.full((e - b) * segment_len, float(x), np.float32) for x, (b, e) in zip(v, ranges)])
                 return sfr, frame_labels(abnormal, key, sfr.shape[0])
             board.add_ltn(i, len(ranges),
-                          lambda a=a: scoring.ltn_part_sequences(_dev(a, device, n_patch), part_len, tail="rewindow")[0], expand)
+                          lambda key=key: scoring.ltn_part_sequences(_dev(arc[key + ".npy"], device, n_patch), part_len, tail="rewindow")[0],
+                          expand)
         rows = board.results()
     return _auc_of(rows, return_frames)

@@ -207,3 +207,62 @@ def test_bf16_activation_stream_step_is_bit_reproducible_with_dropout_on():
             assert torch.equal(ga[k], gb[k]), k
     for k in wa:
         assert torch.equal(wa[k], wb[k]), k
+
+
+@pytest.mark.parametrize("compute,d,heads", [("fp32", 128, (4, 32)), ("bf16", 2048, (8, 256))])
+def test_fused_gather_cls_concat_step_is_bitwise_the_gathered_batch_step(compute, d, heads):
+    """feed.LazyRows: an HBM-resident feed hands the step clip INDICES and lstc_cls_concat_gather_fwd forms batch, cat and CLS concat in
+    one pass over the bank - the gathered batch [B, T, P, d] is never written.  Same arithmetic in the same order as lstc_gather_rows
+    + lstc_cls_concat_fwd: two optimisation steps from both kinds of batch give bit-identical scalars and weights, in the exact-f32
+    mode (f32 rows + learned CLS token and position table, the y path) and in bf16 mode at width (pack only: the bf16 stream)."""
+    from argparse import Namespace
+    from lstc_vad_amd import functional as Fn
+    from lstc_vad_amd.engine import TrainStep
+    from lstc_vad_amd.feed import LazyRows, ResidentBank
+    from lstc_vad_amd.models import Classifier, Encoder
+    bs, pn, L, P = 4, 32, 3, 16
+    g = torch.Generator(device=DEV).manual_seed(3)
+    bank = 0.5 * torch.relu(torch.randn(700, P, d, device=DEV, generator=g))
+    rs = np.random.RandomState(4)
+    idxs = [rs.randint(0, 700, size=(2, bs, pn * L)).astype(np.int64) for _ in range(2)]
+    labs = [rs.rand(bs, pn * L, 1).astype(np.float32) for _ in range(2)]
+
+    def run(lazy):
+        torch.manual_seed(1)
+        wide = compute == "bf16"
+        enc = Encoder(n_layers=3, n_head=heads[0], d_k=heads[1], d_v=heads[1], d_model=d, d_inner=2 * d, MHA_attn_dropout=0.1, MHA_fc_dropout=0.1,
+                      FFN_dropout=0.1, MHA_layerNorm=True, FFN_layerNorm=True, relative_pe=True, window_size=4, window_depth=L,
+                      CLS_learned=not wide, position_encoding=not wide, position_dropout=0.0).to(DEV).train()
+        head = Classifier(d, 0.3).to(DEV).train()
+        args = Namespace(batch_size=bs, part_num=pn, part_len=L, n_patch=P, lambda_1=0.01, lambda_MIL=1.0, lambda_CE=0.8, temporal_only=False,
+                         clip_grad=False)
+        Fn.reset_rng()
+        ts = TrainStep(args, "LTN", enc, head, 1e-5, 1e-4, 1e-3, fuse_qkv="on" if wide else "off")
+        feed = ResidentBank(bank)
+        kinds, out = [], []
+        real = Fn.ClsConcatFunction._forward_gather
+
+        def spy(*a, **k):
+            kinds.append("gather")
+            return real(*a, **k)
+        Fn.ClsConcatFunction._forward_gather = staticmethod(spy)
+        try:
+            for idx, lab in zip(idxs, labs):
+                (nf, af), al = feed.gather(idx, lab, lazy=lazy)
+                assert isinstance(nf, LazyRows) == lazy
+                out.append(ts.step(nf, af, al).clone())
+            torch.cuda.synchronize()
+        finally:
+            Fn.ClsConcatFunction._forward_gather = staticmethod(real)
+        return out, {k: v.detach().clone() for k, v in enc.state_dict().items()}, kinds
+    Fn.set_compute_dtype(compute)
+    try:
+        a, wa, ka = run(True)
+        b, wb, kb = run(False)
+    finally:
+        Fn.set_compute_dtype("fp32")
+    assert ka == ["gather", "gather"] and kb == []
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), (x, y)
+    for k in wa:
+        assert torch.equal(wa[k], wb[k]), k

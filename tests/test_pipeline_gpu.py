@@ -96,10 +96,12 @@ def test_gather_rows_is_an_exact_row_copy():
         F.gather_rows(torch.zeros(4, 3, device=DEV), torch.zeros(2, dtype=torch.int64, device=DEV))     # 3 floats: not x4
 
 
-@pytest.mark.parametrize("name", ["sh_uniform", "sh_random_pseudo", "ubn_uniform", "ubn_random"])
+@pytest.mark.parametrize("name", ["sh_uniform", "sh_random_pseudo", "ubn_uniform", "ubn_random", "sh_mutual_uniform_pseudo", "sh_mutual_random",
+                                  "ucf_uniform", "ucf_random_pseudo"])
 def test_resident_pairs_serve_the_host_batches(world, name):
     """Batches gathered out of HBM == default-collated dataset items with the same seeds (which the CPU suite pins to the
-    reference's classes)."""
+    reference's classes) - round 5: also for the LAZY single-crop datasets (the co-teaching stage's MutualTraining class and UCF,
+    whose items upstream re-reads from the archive one by one)."""
     spec = DATASET_CASES[name]
     np.random.seed(spec["seed"]); random.seed(spec["seed"])
     host = build_dataset(ds_mod, spec, world)
