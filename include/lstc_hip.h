@@ -347,6 +347,11 @@ int lstc_colsum_batched(const float* x, int32_t batch, int64_t rows, int32_t col
 
 /* y[i] = x[i] * keep(i)/(1-p) with the GEMM epilogue's mask (dropout backward / standalone dropout). */
 int lstc_dropout_apply(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* The same on an lstc_pack1 operand [rows, d] (rows % 256 == 0, d % 64 == 0): y_pack = dropout-replay(x_pack) with the mask of
+ * the flat index row * d + col, bf16 in, bf16 out (one more RNE rounding).  The bf16 activation stream's backward of a block
+ * WITHOUT LayerNorm (models/MultiHeadAttention.py:123-124 with layerNorm = False: the STN configs): the incoming gradient pack
+ * is the gradient of dropout(f) + x, its dropped form the operand of fc's weight and input gradients. */
+int lstc_dropout_apply_pack(const void* x_pack, void* y_pack, int64_t rows, int32_t d, float p, uint64_t seed, void* stream);
 /* mask[i] = keep(i) ? 1 : 0 — exported so tests can replay a HIP dropout run through the oracle. */
 int lstc_dropout_mask(uint8_t* mask, int64_t n, float p, uint64_t seed, void* stream);
 /* Dropout seeds for a captured step (hipGraph).  Every entry that draws a dropout mask takes its 64-bit seed BY VALUE, so a

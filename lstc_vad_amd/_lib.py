@@ -23,7 +23,7 @@ EXPORTS = (
     "lstc_gemm", "lstc_attn_fwd", "lstc_attn_bwd", "lstc_attn_cls_fwd", "lstc_attn_cls_bwd", "lstc_cls_dot", "lstc_cls_wsum",
     "lstc_cls_outer", "lstc_layernorm_fwd", "lstc_layernorm_bwd", "lstc_layernorm_fwd_pack",
     "lstc_layernorm_bwd_drop_pack", "lstc_layernorm_bwd_drop", "lstc_layernorm_fwd_act", "lstc_layernorm_bwd_act",
-    "lstc_cls_concat_fwd", "lstc_cls_concat_fwd_pack", "lstc_cls_concat_gather_fwd", "lstc_cls_concat_bwd", "lstc_colsum", "lstc_colsum_batched", "lstc_dropout_apply", "lstc_dropout_mask", "lstc_dropout_seed_device",
+    "lstc_cls_concat_fwd", "lstc_cls_concat_fwd_pack", "lstc_cls_concat_gather_fwd", "lstc_cls_concat_bwd", "lstc_colsum", "lstc_colsum_batched", "lstc_dropout_apply", "lstc_dropout_apply_pack", "lstc_dropout_mask", "lstc_dropout_seed_device",
     "lstc_head_out_fwd", "lstc_head_out_bwd", "lstc_vad_loss", "lstc_adagrad_step", "lstc_adagrad_multi", "lstc_sqnorm_accum", "lstc_scale",
     "lstc_sqnorm_multi_scratch", "lstc_sqnorm_multi", "lstc_clip_scale_multi",
     "lstc_gather_rows", "lstc_cast_f32_bf16", "lstc_cast_bf16_f32", "lstc_pack3", "lstc_pack3_bytes", "lstc_pack1", "lstc_pack1_multi", "lstc_pack1_bytes", "lstc_colsum_pack1", "lstc_gemm_splits",
@@ -121,6 +121,7 @@ def load():
         "lstc_colsum": [vp, i64, i32, i32, vp, i32, vp, i32, vp],
         "lstc_colsum_batched": [vp, i32, i64, i32, i32, i64, vp, i32, vp, vp],
         "lstc_dropout_apply": [vp, vp, i64, f32, u64, vp],
+        "lstc_dropout_apply_pack": [vp, vp, i64, i32, f32, u64, vp],
         "lstc_dropout_mask": [vp, i64, f32, u64, vp],
         "lstc_dropout_seed_device": [vp],
         "lstc_head_out_fwd": [vp, vp, vp, vp, i64, i32, vp],

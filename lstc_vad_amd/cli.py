@@ -361,7 +361,7 @@ def train(script: str, argv=None, args=None):
                 it_, epoch_, loss, aux, mil, err, l1))
     late = _LateLog(torch, emit) if rank == 0 else None
     import time as _time
-    t_first, t_eval = None, 0.0
+    t_first, t_eval, t_save = None, 0.0, 0.0
     for epoch in range(epochs):
         for norm_feats, norm_labs, abnorm_feats, abnorm_labs in data:
             sc = ts.step(norm_feats, abnorm_feats, abnorm_labs)
@@ -388,6 +388,7 @@ def train(script: str, argv=None, args=None):
             if rank != 0:
                 save_auc, lines = None, []
             if save_auc is not None:
+                t_s = _time.perf_counter()
                 logger.info("saving model......")
                 enc_path, head_path = checkpoint_names(script, args, save_auc)
                 if not (getattr(args, "model_save_dir", "") or ""):                   # no directory given: next to the log
@@ -396,6 +397,7 @@ def train(script: str, argv=None, args=None):
                 torch.save(enc.state_dict(), enc_path)
                 torch.save(head.state_dict(), head_path)
                 logger.info("save complete.")
+                t_save += _time.perf_counter() - t_s
             for ln in lines:
                 logger.info(ln)
             if rank == 0:
@@ -405,7 +407,8 @@ def train(script: str, argv=None, args=None):
     torch.cuda.synchronize()
     LAST_RUN.clear()
     LAST_RUN.update(script=script, steps=it, steady_steps=max(it - 1, 0),
-                    steady_s=(_time.perf_counter() - t_first - t_eval) if t_first is not None else 0.0, eval_s=t_eval,
+                    steady_s=(_time.perf_counter() - t_first - t_eval - t_save) if t_first is not None else 0.0, eval_s=t_eval,
+                    save_s=t_save,
                     snippets_per_step=2 * args.batch_size * args.part_num * part_len, world=world)
     if rank == 0 and getattr(args, "save_final", ""):
         torch.save(enc.state_dict(), args.save_final + "encoder.ckpt")

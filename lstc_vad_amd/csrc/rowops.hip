@@ -754,6 +754,26 @@ __global__ void __launch_bounds__(NT) dropout_apply_kernel(const float* __restri
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride)
         y[i] = drop_keep((uint32_t)i, k) ? x[i] * k.scale : 0.f;
 }
+// The same on an lstc_pack1 operand [rows, d] (bf16 activation stream: the backward of a block WITHOUT LayerNorm, whose incoming
+// gradient pack is the gradient of dropout(f) + x as it stands).  A thread owns one 16-B chunk in STORAGE order (fully coalesced);
+// the element's flat index row * d + col - the mask's counter - follows from the chunk's place in its 128-row x 32-k tile.
+__global__ void __launch_bounds__(NT) dropout_apply_pack_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y, int64_t chunks,
+                                                                 int KBp, int d, DropKey k) {
+    k = drop_key_now(k);
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    for (int64_t q = (int64_t)blockIdx.x * NT + threadIdx.x; q < chunks; q += stride) {
+        const int64_t tile = q >> 9;
+        const int rr = (int)(q & 511) >> 2, pc = (int)(q & 3), ch = pc ^ ((rr >> 2) & 3);
+        const int64_t row = (tile / KBp) * 128 + rr;
+        const int col0 = (int)(tile % KBp) * 32 + ch * 8;
+        const uint32_t fi = (uint32_t)(row * d) + (uint32_t)col0;
+        const bf16x8v v = reinterpret_cast<const bf16x8v*>(x)[q];
+        bf16x8v o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = drop_keep(fi + j, k) ? (__bf16)((float)v[j] * k.scale) : (__bf16)0.f;
+        reinterpret_cast<bf16x8v*>(y)[q] = o;
+    }
+}
 __global__ void __launch_bounds__(NT) dropout_mask_kernel(uint8_t* __restrict__ m, int64_t n, DropKey k) {
     k = drop_key_now(k);
     const int64_t stride = (int64_t)gridDim.x * NT;
@@ -1310,6 +1330,18 @@ int lstc_dropout_apply(const float* x, float* y, int64_t n, float p, uint64_t se
     if (n <= 0) return LSTC_E_SHAPE;
     if ((uint64_t)n > 0xffffffffull) return LSTC_E_RANGE;
     hipLaunchKernelGGL(dropout_apply_kernel, grid_for(n, NT * 4), NT, 0, (hipStream_t)stream, x, y, n, make_drop_key(p, seed));
+    return lstc_launch_status();
+}
+
+int lstc_dropout_apply_pack(const void* x_pack, void* y_pack, int64_t rows, int32_t d, float p, uint64_t seed, void* stream) {
+    if (!x_pack || !y_pack) return LSTC_E_NULL;
+    if (rows <= 0 || d <= 0 || !(p >= 0.f && p < 1.f)) return LSTC_E_SHAPE;
+    if (rows % 256 != 0 || d % 64 != 0) return LSTC_E_UNSUPPORTED;            // the matrix fills the pack's even tile grid exactly
+    if ((uint64_t)rows * (uint64_t)d > 0xffffffffull) return LSTC_E_RANGE;    // 32-bit dropout counter
+    if (!aligned16(x_pack) || !aligned16(y_pack)) return LSTC_E_ALIGN;
+    const int64_t chunks = rows * (int64_t)d / 8;
+    hipLaunchKernelGGL(dropout_apply_pack_kernel, grid_for(chunks, NT * 2), NT, 0, (hipStream_t)stream, (const __bf16*)x_pack,
+                       (__bf16*)y_pack, chunks, d / 32, d, make_drop_key(p, seed));
     return lstc_launch_status();
 }
 

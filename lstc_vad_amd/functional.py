@@ -151,7 +151,9 @@ def act_chain_ok(N: int, S: int, dm: int, layers) -> bool:
         return False
     for layer in layers:
         a, f = layer.slf_attn, layer.pos_ffn
-        if not (layer.FFN_need and a.layerNorm_flag and f.layerNorm_flag and a.d_model == dm):
+        # the FFN needs its LayerNorm (the stream's f32 exit - the block in front of the CLS-only layer - is an LN kernel); the
+        # attention block runs with or without one (STN configs: MHA_layerNorm = False, its sum dropout(fc(o)) + x IS the output)
+        if not (layer.FFN_need and f.layerNorm_flag and a.d_model == dm):
             return False
         H, dk, dv = a.n_head, a.d_k, a.d_v
         wqkv = _fused_qkv_weight(a.w_qs.weight, a.w_ks.weight, a.w_vs.weight)
@@ -644,6 +646,14 @@ def dropout_apply(x: torch.Tensor, p: float, seed: int, out: Optional[torch.Tens
     return out
 
 
+def dropout_apply_pack(x: "Packed", p: float, seed: int) -> "Packed":
+    """Dropout replay on a packed bf16 operand (lstc_dropout_apply_pack): the mask of the flat index row * K + col."""
+    buf = torch.empty_like(x.buf)
+    check(_lib.load().lstc_dropout_apply_pack(dev_ptr(x.buf), dev_ptr(buf), x.rows, x.K, float(p), int(seed), stream_ptr()),
+          "lstc_dropout_apply_pack")
+    return Packed(buf, x.rows, x.K, x.kind)
+
+
 def gather_rows(bank: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[r] = bank[idx[r]] over the leading dimension (``lstc_gather_rows``): forms a training batch from an
     HBM-resident feature bank.  ``idx`` int64 on the same device; trailing dims of ``bank`` must hold a multiple of 4 floats."""
@@ -1022,8 +1032,8 @@ class MHAFunction(torch.autograd.Function):
         out16 = bool(cfg.get("act16_out", False))
         xp = _act_pack(x, M, dm)
         wqkv = _fused_qkv_weight(wq, wk, wv)
-        if not cfg["layer_norm"] or wqkv is None or not (attn_packed_inputs(N, S, H, dk, dv) and packed_out_shape(M, wqkv.shape[0]) and
-                                                         packed_out_shape(M, H * dv) and packed_out_shape(M, dm)):
+        if wqkv is None or not (attn_packed_inputs(N, S, H, dk, dv) and packed_out_shape(M, wqkv.shape[0]) and
+                                packed_out_shape(M, H * dv) and packed_out_shape(M, dm)) or (not cfg["layer_norm"] and not out16):
             raise RuntimeError("MHAFunction: this layer / shape cannot run on the bf16 activation stream (functional.act_chain_ok)")
         qkv_p = gemm(xp, wqkv, trans_b=True, out_pack=True)
         seed_a = next_seed() if p_attn > 0 else 0
@@ -1034,8 +1044,11 @@ class MHAFunction(torch.autograd.Function):
             _note(cfg["site"] + "dropout", p_fc, seed_f, (N, S, dm))
         op, probs = attn_fwd(qkv_p, None, None, N, S, H, dk, dv, table, index, p_attn, seed_a)
         yp = gemm(op, wfc, trans_b=True, dropout=(p_fc, seed_f), residual=xp, out_pack=True)
-        zf, zp, mean, rstd = layernorm_fwd_act(yp, ln_w, ln_b, 1e-6, want_f32=not out16, want_pack=out16)
-        ctx.act = dict(xp=xp, qkv_p=qkv_p, op=op, yp=yp, out16=out16)
+        if cfg["layer_norm"]:
+            zf, zp, mean, rstd = layernorm_fwd_act(yp, ln_w, ln_b, 1e-6, want_f32=not out16, want_pack=out16)
+        else:                    # no LayerNorm (models/MultiHeadAttention.py:125-126 skipped): the packed sum is the block's output
+            zf, zp, mean, rstd = None, yp, None, None
+        ctx.act = dict(xp=xp, qkv_p=qkv_p, op=op, yp=yp if cfg["layer_norm"] else None, out16=out16)
         ctx.cfg = dict(cfg, N=N, S=S, p_attn=p_attn, p_fc=p_fc, seed_a=seed_a, seed_f=seed_f)
         ctx.save_for_backward(wq, wk, wv, wfc, ln_w, table, index, probs, mean, rstd)
         ctx.mark_non_differentiable(probs)
@@ -1051,7 +1064,11 @@ class MHAFunction(torch.autograd.Function):
         dm = xp.K
         want_dx = ctx.needs_input_grad[0]
         dzin = _act_pack(dz.contiguous(), M, dm) if a["out16"] else dz.contiguous().view(M, dm)
-        dy, df, dln_w, dln_b, _ = layernorm_bwd_act(dzin, yp, ln_w, mean, rstd, c["p_fc"], c["seed_f"], want_dx, False)
+        if c["layer_norm"]:
+            dy, df, dln_w, dln_b, _ = layernorm_bwd_act(dzin, yp, ln_w, mean, rstd, c["p_fc"], c["seed_f"], want_dx, False)
+        else:                    # z = dropout(f) + x: the incoming pack is the residual stream's gradient, its dropped form fc's
+            dy, dln_w, dln_b = dzin, None, None
+            df = dropout_apply_pack(dzin, c["p_fc"], c["seed_f"]) if c["p_fc"] > 0 else dzin
         dwfc = deliver(wfc, wgrad(df, None, op, out=grad_sink(wfc)))
         do = gemm(df, wfc, out_pack=True)
         wqkv = _fused_qkv_weight(wq, wk, wv)

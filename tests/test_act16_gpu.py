@@ -166,17 +166,19 @@ def _run_step(name, act, dropout=0.0, steps=1):
     return z, out, calls, {k: v.detach().clone() for k, v in enc.state_dict().items()}, peak
 
 
-@pytest.mark.parametrize("name", ["ltn_full_256", "ltn_ubnormal_full_256"])
-def test_bf16_activation_stream_step_tracks_the_f32_activation_step_and_the_reference(name):
+@pytest.mark.parametrize("name,n_ln", [("ltn_full_256", 4), ("ltn_ubnormal_full_256", 4), ("stn_full", 2), ("stn_mil_ce_full", 2)])
+def test_bf16_activation_stream_step_tracks_the_f32_activation_step_and_the_reference(name, n_ln):
     """BASELINE configs 2 / 5 at production width (256 sequences of S = 49 at d = 2048; S = 81 at d_model = 1024): the bf16-mode
     training step with the residual stream stored as bf16 packs against (i) the same step with f32 activations between the blocks
     (rounds 1-4) - scores and loss 2e-2 (measured 4e-3 / 1.04e-2 on the two cases), every large gradient's direction > 0.985 and norm
     within 3 % - and (ii) the
     reference's fp32 run (fixture): scores and loss within 2e-2 (the bar of test_full_width_bf16_step_tracks_reference).  The
-    stream really runs: four LayerNorms forward and backward on packs, none on the f32 path."""
+    stream really runs: four LayerNorms forward and backward on packs (two in the STN cases - BASELINE config 3's first and third
+    stage, 256 sequences of S = 17 with n_hidden = 3027 padded to 3072: their attention blocks have NO LayerNorm, the packed sum
+    dropout(fc(o)) + x is the block's output and lstc_dropout_apply_pack replays the mask on the gradient pack), none on the f32 path."""
     z, a16, calls16, _, peak16 = _run_step(name, "bf16")
     _, a32, calls32, _, peak32 = _run_step(name, "fp32")
-    assert calls16 == {"fwd": 4, "bwd": 4} and calls32 == {"fwd": 0, "bwd": 0}, (calls16, calls32)
+    assert calls16 == {"fwd": n_ln, "bwd": n_ln} and calls32 == {"fwd": 0, "bwd": 0}, (calls16, calls32)
     (o16, s16, g16), (o32, s32, g32) = a16[0], a32[0]
     assert max_abs_diff(o16, o32) < 2e-2 and abs(float(s16[0]) - float(s32[0])) < 2e-2
     assert max_abs_diff(o16.reshape(z["outputs"].shape), z["outputs"]) < 2e-2 and abs(float(s16[0]) - float(z["scalars"][0])) < 2e-2
@@ -195,12 +197,15 @@ def test_bf16_activation_stream_step_tracks_the_f32_activation_step_and_the_refe
     assert peak16 < peak32
 
 
-def test_bf16_activation_stream_step_is_bit_reproducible_with_dropout_on():
-    """Two runs of two optimisation steps with the reference's dropout rates on the stream: scalars, every gradient and the
-    weights bit for bit equal (no float atomics on the path: ordered partial sums everywhere)."""
-    _, a, ca, wa, _ = _run_step("ltn_full_256", "bf16", dropout=0.2, steps=2)
-    _, b, cb, wb, _ = _run_step("ltn_full_256", "bf16", dropout=0.2, steps=2)
-    assert ca == cb == {"fwd": 8, "bwd": 8}
+@pytest.mark.parametrize("name,n_ln", [("ltn_full_256", 8), ("stn_full", 4)])
+def test_bf16_activation_stream_step_is_bit_reproducible_with_dropout_on(name, n_ln):
+    """Two runs of two optimisation steps with dropout on (rate 0.2 everywhere) on the stream: scalars, every gradient and the
+    weights bit for bit equal (no float atomics on the path: ordered partial sums everywhere); the STN case runs the dropout
+    replay on a gradient pack (lstc_dropout_apply_pack) and must show the mask's zeros in the weights' motion - the dropped run
+    differs from the dropout-free run."""
+    _, a, ca, wa, _ = _run_step(name, "bf16", dropout=0.2, steps=2)
+    _, b, cb, wb, _ = _run_step(name, "bf16", dropout=0.2, steps=2)
+    assert ca == cb == {"fwd": n_ln, "bwd": n_ln}
     for (oa, sa, ga), (ob, sb, gb) in zip(a, b):
         assert torch.equal(oa, ob) and torch.equal(sa, sb)
         for k in ga:
@@ -266,3 +271,23 @@ def test_fused_gather_cls_concat_step_is_bitwise_the_gathered_batch_step(compute
         assert torch.equal(x, y), (x, y)
     for k in wa:
         assert torch.equal(wa[k], wb[k]), k
+
+
+def test_dropout_replay_on_a_pack_keeps_exactly_the_masks_elements():
+    """lstc_dropout_apply_pack against lstc_dropout_mask: the pack's element (row, col) is kept iff the mask of the flat index
+    row * d + col keeps it, scaled by 1 / (1 - p) and rounded once more to bf16."""
+    hp = _hp()
+    from lstc_vad_amd import functional as Fn
+    rows, d, p, seed = 512, 2048, 0.3, 0x1234567890ABCDEF
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x = _bf16(torch.randn(rows, d, device=DEV, generator=g))
+    Fn.set_compute_dtype("bf16"); Fn.set_x3_threshold(0, 0, 0)
+    try:
+        xp = Fn.pack3(x, False)
+        got = hp._unpack1(Fn.dropout_apply_pack(xp, p, seed).buf, rows, d)
+        keep = Fn.dropout_mask((rows, d), p, seed, DEV).bool()
+        torch.cuda.synchronize()
+    finally:
+        Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
+    want = torch.where(keep, _bf16(x * (1.0 / (1.0 - p))), torch.zeros_like(x))
+    assert torch.equal((got == 0), (want == 0)) and max_abs_diff(got, want) <= 2 ** -8 * float(want.abs().max())

@@ -151,6 +151,16 @@ static void timeit(int M, int N, int K, int tA, int tB, int variant, int split, 
         d.A = pA; d.B = pB;
         if (variant >= 7 && variant <= 9) { d.transA = 1; d.transB = 0; d.variant = p1 ? 0 : variant == 8 ? 2 : variant == 9 ? 3 : 1; } else { d.transA = 0; d.transB = 1; if (p1) d.variant = variant & ~15; }
     }
+    void *pC = nullptr, *pR = nullptr;
+    if (p1 && (flags & LSTC_EPI_OUT_PACK)) {                // timing of the packed-output / packed-residual epilogues (bf16 activation stream)
+        CK(hipMalloc(&pC, lstc_pack1_bytes(M, N)));
+        d.C = pC;
+        if (flags & LSTC_EPI_RESIDUAL_PACK) {
+            CK(hipMalloc(&pR, lstc_pack1_bytes(M, N)));
+            lstc_pack1(dC, M, N, N, 0, pR, nullptr);
+            d.residual = pR;
+        }
+    }
     for (int i = 0; i < 6; ++i) { int rc = lstc_gemm(&d, nullptr); if (rc) { printf("rc=%d\n", rc); return; } }   // clock ramp
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, nullptr));
@@ -159,10 +169,12 @@ static void timeit(int M, int N, int K, int tA, int tB, int variant, int split, 
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
     const double tf = 2.0 * M * N * (double)K / (ms * 1e-3) / 1e12;
     const double peak = (dtype == LSTC_BF16 || dtype == LSTC_BF16P) ? 2500.0 : 157.3;
-    printf("TIME %s M=%6d N=%5d K=%6d tA=%d tB=%d var=%d split=%d flags=%2d pad=%d,%d : %8.3f ms  %7.2f TFLOP/s (%.1f%% of %.1f)\n", dtype == LSTC_F32X3 ? "f32x3" : dtype == LSTC_BF16P ? "bf16p" : dtype ? "bf16c" : "f32", M, N, K, tA, tB,
+    printf("TIME %s M=%6d N=%5d K=%6d tA=%d tB=%d var=%d split=%d flags=%3d pad=%d,%d : %8.3f ms  %7.2f TFLOP/s (%.1f%% of %.1f)\n", dtype == LSTC_F32X3 ? "f32x3" : dtype == LSTC_BF16P ? "bf16p" : dtype ? "bf16c" : "f32", M, N, K, tA, tB,
            variant, split, flags, pad_a, pad_b, ms, tf, 100.0 * tf / peak, peak);
     if (pA) hipFree(pA);
     if (pB) hipFree(pB);
+    if (pC) hipFree(pC);
+    if (pR) hipFree(pR);
     fflush(stdout);
     hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dbias);
 }
