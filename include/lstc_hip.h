@@ -439,7 +439,8 @@ int lstc_sqnorm_accum(const float* x, int64_t n, float* out, void* stream);
  *                          partial per 8192-element slice into `scratch` (>= lstc_sqnorm_multi_scratch(items, count) floats),
  *                          then one workgroup adds the partials in index order - bit-reproducible, no float atomics;
  *   lstc_clip_scale_multi  x *= max_norm / (sqrt(sqnorm[0]) + 1e-6) for every tensor when that coefficient is < 1 (torch's
- *                          clamp to 1), the coefficient formed ON THE DEVICE from the value lstc_sqnorm_multi left there.
+ *                          clamp to 1; a NaN norm multiplies every tensor by NaN, as torch does), the coefficient formed ON THE
+ *                          DEVICE from the value lstc_sqnorm_multi left there.
  * `items` is a HOST array (it rides in the kernel arguments). */
 typedef struct LstcVecItem {
     float* x;

@@ -1008,9 +1008,11 @@ __global__ void __launch_bounds__(NT) sum_partials_kernel(const float* __restric
 }
 // x *= min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) for every tensor of the list, the coefficient formed on the device
 // (torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1); coefficient 1 leaves the data untouched.
+// A NaN total norm gives a NaN coefficient, and torch.clamp keeps NaN: every gradient is multiplied by it there - so here too
+// (round 5; rounds 1-4 returned early and kept a diverged step's NaN local).
 __global__ void __launch_bounds__(NT) clip_scale_multi_kernel(const VecBatch b, const float* __restrict__ sqnorm, float max_norm) {
     const float coef = max_norm / (sqrtf(sqnorm[0]) + 1e-6f);
-    if (!(coef < 1.0f)) return;
+    if (coef >= 1.0f) return;                 // NaN falls through: the gradients become NaN, as in torch
     int t = 0;
     while (t + 1 < b.count && (int)blockIdx.x >= b.first_wg[t + 1]) ++t;
     float* __restrict__ x = b.x[t];

@@ -63,7 +63,7 @@ def clip_grad_norm_(parameters, max_norm: float, norm_type: float = 2.0) -> torc
     the total norm as a 0-dim device tensor (torch returns a device tensor too)."""
     if norm_type != 2.0:
         raise NotImplementedError("clip_grad_norm_: only the L2 norm the LSTC_VAD scripts use")
-    params = [p for p in parameters if p.grad is not None]
+    params = [p for p in parameters if p.grad is not None and p.grad.numel() > 0]       # torch accepts empty tensors: nothing to scale
     if not params:
         return torch.zeros(())
     for p in params:

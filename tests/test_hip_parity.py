@@ -712,6 +712,14 @@ def test_clip_grad_norm_matches_torch_in_two_launches_without_host_sync():
             p2 = torch.nn.Parameter(torch.zeros_like(b0)); p2.grad = b0.clone(); ps2.append(p2)
         got2 = clip_grad_norm_(ps2, max_norm)
         assert torch.equal(got, got2) and all(torch.equal(a.grad, b.grad) for a, b in zip(ps_gpu, ps2))
+    # a diverged step: a NaN anywhere makes the total norm NaN and torch multiplies EVERY gradient by the NaN
+    # coefficient (clamp keeps NaN) - so does the HIP path; empty tensors are skipped like torch skips them
+    pn = [torch.nn.Parameter(torch.zeros(5, device=DEV)), torch.nn.Parameter(torch.zeros(7, device=DEV)), torch.nn.Parameter(torch.zeros(0, device=DEV))]
+    pn[0].grad = torch.tensor([1.0, float("nan"), 2.0, 3.0, 4.0], device=DEV)
+    pn[1].grad = torch.ones(7, device=DEV)
+    pn[2].grad = torch.zeros(0, device=DEV)
+    tot = clip_grad_norm_(pn, 10.0)
+    assert torch.isnan(tot) and torch.isnan(pn[0].grad).all() and torch.isnan(pn[1].grad).all()
 
 
 def test_fused_qkv_buffer_matches_separate_projections():
