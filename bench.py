@@ -523,8 +523,9 @@ def main():
                                           step_algorithmic_tflop=round(alg_tflop("stn_sht"), 3))
         if a.dtype == "fp32":
             extras["bf16"] = dict(sub_object(timed_pass(a.config, "bf16"), a.config, "bf16"),
-                                  dtype="bf16 MFMA (operands rounded to bf16 RNE), f32 accumulate, f32 master weights / activations "
-                                        "/ attention / LayerNorm / loss / Adagrad (BASELINE configs 3 and 5)")
+                                  dtype="bf16 MFMA (operands rounded to bf16 RNE), f32 accumulate, f32 master weights / softmax / "
+                                        "LayerNorm arithmetic / loss / Adagrad; activations between the full layers stored as bf16 packs "
+                                        "when act_dtype is bf16 (BASELINE configs 3 and 5)")
             extras["f32x3"] = dict(sub_object(timed_pass(a.config, "f32x3"), a.config, "f32x3"),
                                    dtype="f32 storage and accumulation; products of the large GEMMs on the f16 matrix cores (two scaled "
                                          "f16 planes per operand, hh + hl + lh); narrower than IEEE f32 products, reported as an extra")
@@ -603,7 +604,7 @@ def main():
                          "(SURVEY 8d's t_step)",
                "higher_is_better": True, "scaling": a.scaling,
                "vs_baseline": None, "dtype": {"fp32": "f32", "f32x3": "f32 (operands split into 2 scaled f16 planes, 3 f16-MFMA products, f32 accumulate)",
-                                              "bf16": "bf16 (f32 storage/accumulate)"}[a.dtype], "data": "synthetic",
+                                              "bf16": "bf16 (f32 accumulate, f32 master weights; activations as bf16 packs under act_dtype bf16)"}[a.dtype], "data": "synthetic",
                "config": {"workload": ("mixed batch (BASELINE config 5): UBnormal videos (d=1024, L=5, S=81) + SHT videos (d=2048, L=3, "
                                        "S=49) in equal numbers, two model pairs, one iteration; second model: " if mixed else "") +
                                       f"{last}: {mode} full training step (batch formation+fwd+loss+bwd+"
