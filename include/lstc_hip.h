@@ -259,6 +259,17 @@ int lstc_cls_wsum(const float* W, const float* X, float* Y, int64_t N, int32_t S
 int lstc_cls_outer(const float* W1, const float* U1, const float* W2, const float* U2, float* dX, int64_t N, int32_t S,
                    int32_t H, int32_t d, void* stream);
 
+/* The three passes above over a PACKED X (round 5: the bf16 activation stream hands the last full layer's output to the CLS-only
+ * layer as an lstc_pack1 operand of the [N*S, d] matrix and takes the gradient back as one; same reference lines).  Arithmetic is
+ * f32 on the widened bf16 values; lstc_cls_outer_pack rounds dX once (RNE) after adding `add0` [N, d] (may be NULL) to row 0 of
+ * every sequence - the CLS row's own terms dQ Wq + the residual gradient.  U, Y, W*, out, probs as above.
+ * Requirements: (N*S) % 256 == 0, d = 512 / 1024 / 2048, H <= 8 (LSTC_E_UNSUPPORTED otherwise), S <= 128, 16-B aligned pointers. */
+int lstc_cls_dot_pack(const float* U, const void* X_pack, float* out, float* probs, int64_t N, int32_t S, int32_t H, int32_t d,
+                      int32_t mode, float dropout_p, uint64_t seed, void* stream);
+int lstc_cls_wsum_pack(const float* W, const void* X_pack, float* Y, int64_t N, int32_t S, int32_t H, int32_t d, void* stream);
+int lstc_cls_outer_pack(const float* W1, const float* U1, const float* W2, const float* U2, const float* add0, void* dX_pack,
+                        int64_t N, int32_t S, int32_t H, int32_t d, void* stream);
+
 /* ------------------------------------------------------------------- row-wise kernels */
 /* y = LayerNorm(x) * gamma + beta over the last dim (eps inside the sqrt, biased variance) —
  * nn.LayerNorm(d_model, eps=1e-6): models/MultiHeadAttention.py:47,125-126; models/FFN.py:10,20-21;
@@ -352,6 +363,11 @@ int lstc_dropout_apply(const float* x, float* y, int64_t n, float p, uint64_t se
  * WITHOUT LayerNorm (models/MultiHeadAttention.py:123-124 with layerNorm = False: the STN configs): the incoming gradient pack
  * is the gradient of dropout(f) + x, its dropped form the operand of fc's weight and input gradients. */
 int lstc_dropout_apply_pack(const void* x_pack, void* y_pack, int64_t rows, int32_t d, float p, uint64_t seed, void* stream);
+/* out[i, 0:K] = the bf16 values of row row0 + i * row_step of an lstc_pack1 operand [rows, K], widened to f32 (i < n; K % 8 == 0,
+ * ldo % 4 == 0).  The CLS-only last layer reads its query rows (token 0 of every sequence: row0 = 0, row_step = S) out of the
+ * activation stream's pack (models/MultiHeadAttention.py:97 restricted to row 0); tests read whole packs back with it. */
+int lstc_unpack1_rows(const void* x_pack, int64_t rows, int32_t K, int64_t row0, int64_t row_step, int64_t n, float* out, int64_t ldo,
+                      void* stream);
 /* mask[i] = keep(i) ? 1 : 0 — exported so tests can replay a HIP dropout run through the oracle. */
 int lstc_dropout_mask(uint8_t* mask, int64_t n, float p, uint64_t seed, void* stream);
 /* Dropout seeds for a captured step (hipGraph).  Every entry that draws a dropout mask takes its 64-bit seed BY VALUE, so a

@@ -1235,6 +1235,67 @@ namespace {
 
 constexpr int ASSOC_MAXS = 128;
 
+// The per-(sequence, head) rows of dot products `sc` [H][S] (LDS) -> out / probs; modes of cls_dot_kernel.  One wave per head.
+__device__ inline void cls_dot_tail(float* sc, float* __restrict__ out, float* __restrict__ probs, int n, int S, int H, int mode,
+                                    const DropKey& dkey, int has_drop, int wave, int lane) {
+    for (int h = wave; h < H; h += NT / 64) {
+        float* row = sc + h * S;
+        float* orow = out + ((size_t)n * H + h) * S;
+        if (mode == 0) {
+            for (int j = lane; j < S; j += 64) orow[j] = row[j];
+            continue;
+        }
+        float* prow = probs + ((size_t)n * H + h) * S;
+        const uint32_t flat0 = ((uint32_t)n * H + h) * (uint32_t)(S * S);     // row 0 of the full [N,H,S,S] tensor
+        if (mode == 1) {
+            float v[2], m = -INFINITY;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = lane + 64 * jj;
+                v[jj] = j < S ? row[j] : -INFINITY;
+                m = fmaxf(m, v[jj]);
+            }
+            m = wave_max(m);
+            float s = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                v[jj] = (lane + 64 * jj < S) ? expf(v[jj] - m) : 0.f;
+                s += v[jj];
+            }
+            s = wave_sum(s);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = lane + 64 * jj;
+                if (j < S) {
+                    float pv = v[jj] / s;
+                    prow[j] = pv;
+                    if (has_drop) pv = drop_keep(flat0 + (uint32_t)j, dkey) ? pv * dkey.scale : 0.f;
+                    orow[j] = pv;
+                }
+            }
+        } else {
+            float pv[2], dp[2], rs = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = lane + 64 * jj;
+                pv[jj] = dp[jj] = 0.f;
+                if (j < S) {
+                    pv[jj] = prow[j];
+                    const float keep = has_drop ? (drop_keep(flat0 + (uint32_t)j, dkey) ? dkey.scale : 0.f) : 1.f;
+                    dp[jj] = row[j] * keep;
+                    rs += dp[jj] * pv[jj];
+                }
+            }
+            rs = wave_sum(rs);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = lane + 64 * jj;
+                if (j < S) orow[j] = pv[jj] * (dp[jj] - rs);
+            }
+        }
+    }
+}
+
 // mode 0: raw dot products; 1: softmax over j, probs -> `probs`, dropout(probs) -> `out`;
 // mode 2: `out` = P * (dP - sum_j dP P), dP = dot * keep  (softmax + dropout backward; `probs` is an input)
 template <int HT>
@@ -1295,62 +1356,7 @@ __global__ void __launch_bounds__(NT) cls_dot_kernel(const float* __restrict__ U
             }
     }
     __syncthreads();
-    for (int h = wave; h < H; h += NT / 64) {
-        float* row = sc + h * S;
-        float* orow = out + ((size_t)n * H + h) * S;
-        if (mode == 0) {
-            for (int j = lane; j < S; j += 64) orow[j] = row[j];
-            continue;
-        }
-        float* prow = probs + ((size_t)n * H + h) * S;
-        const uint32_t flat0 = ((uint32_t)n * H + h) * (uint32_t)(S * S);     // row 0 of the full [N,H,S,S] tensor
-        if (mode == 1) {
-            float v[2], m = -INFINITY;
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int j = lane + 64 * jj;
-                v[jj] = j < S ? row[j] : -INFINITY;
-                m = fmaxf(m, v[jj]);
-            }
-            m = wave_max(m);
-            float s = 0.f;
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                v[jj] = (lane + 64 * jj < S) ? expf(v[jj] - m) : 0.f;
-                s += v[jj];
-            }
-            s = wave_sum(s);
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int j = lane + 64 * jj;
-                if (j < S) {
-                    float pv = v[jj] / s;
-                    prow[j] = pv;
-                    if (has_drop) pv = drop_keep(flat0 + (uint32_t)j, dkey) ? pv * dkey.scale : 0.f;
-                    orow[j] = pv;
-                }
-            }
-        } else {
-            float pv[2], dp[2], rs = 0.f;
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int j = lane + 64 * jj;
-                pv[jj] = dp[jj] = 0.f;
-                if (j < S) {
-                    pv[jj] = prow[j];
-                    const float keep = has_drop ? (drop_keep(flat0 + (uint32_t)j, dkey) ? dkey.scale : 0.f) : 1.f;
-                    dp[jj] = row[j] * keep;
-                    rs += dp[jj] * pv[jj];
-                }
-            }
-            rs = wave_sum(rs);
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int j = lane + 64 * jj;
-                if (j < S) orow[j] = pv[jj] * (dp[jj] - rs);
-            }
-        }
-    }
+    cls_dot_tail(sc, out, probs, n, S, H, mode, dkey, has_drop, wave, lane);
 }
 
 template <int HT>
@@ -1418,6 +1424,262 @@ __global__ void __launch_bounds__(NT) cls_outer_kernel(const float* __restrict__
     }
 }
 
+// ---- the same three passes over a PACKED X (lstc_pack1 of the [N*S, d] matrix): the bf16 activation stream hands the last full
+// layer's output to the CLS-only layer as a pack, and takes the gradient back as one.  One workgroup per sequence.
+//   dot, outer: the f32 kernels above are VALU-bound (eight heads x every column on the vector unit: 310 / 218 us per 100352 x 2048
+//     launch where the bytes need 90 - 170), so these two run on v_mfma_f32_16x16x32_bf16: X's 16-B chunks ARE the A fragments (lane
+//     = token l & 15, chunk l >> 4 of the row's 64 B: sixteen tokens of a k tile are one contiguous KB), and every f32 operand
+//     enters as a bf16 pair hi + lo (hi = RNE(v), lo = RNE(v - hi): 16 mantissa bits; products of bf16 values are exact in the
+//     f32 accumulator) - X itself is bf16 already, so the dot products carry one f32-grade operand and one exact one, and dX is
+//     rounded to bf16 at the end anyway.
+//   wsum: stays on the vector unit (the token contraction would need transposed fragments): a thread owns ONE 8-column group (a 16-B
+//     chunk) of the rows of a sequence, G = d / 8 groups (64 per wave), NT / G row phases; the per-head sums live in registers.
+typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4c __attribute__((ext_vector_type(4)));
+typedef float floatx4c __attribute__((ext_vector_type(4)));
+constexpr int PK_RB = 8;         // rows requested per thread before the first one is used (wsum)
+
+__device__ inline void widen8(const bf16x8c& h, float (&f)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = (float)h[k];
+}
+
+// v[0..8) -> bf16 hi and lo parts (v = hi + lo up to 2^-17 |v|)
+__device__ inline void split8(const float (&v)[8], bf16x8c& hi, bf16x8c& lo) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        hi[k] = (__bf16)v[k];
+        lo[k] = (__bf16)(v[k] - (float)hi[k]);
+    }
+}
+
+// out[n, h, j] = sum_c U[n, h, c] X[n, j, c]: D[token, head] = X[token, k] U^T[k, head]; RBT blocks of 16 tokens, wave w takes the
+// k tiles w, w + 4, ...; the four waves' partial sums are added in wave order.
+template <int RBT>
+__global__ void __launch_bounds__(NT) cls_dot_pk_kernel(const float* __restrict__ U, const __bf16* __restrict__ Xp,
+                                                         float* __restrict__ out, float* __restrict__ probs, int S, int H, int d,
+                                                         int KBp, int mode, DropKey dkey, int has_drop) {
+    dkey = drop_key_now(dkey);
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sc = sm;                       // [H][S]
+    float* scw = sm + H * S;              // [NT / 64][H][S]
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hl = lane & 15, kg = lane >> 4;
+    const float* Un = U + ((size_t)n * H + min(hl, H - 1)) * d + kg * 8;
+    const bool live = hl < H;
+    const int64_t row0 = (int64_t)n * S;
+    floatx4c acc[RBT];
+#pragma unroll
+    for (int rb = 0; rb < RBT; ++rb) acc[rb] = floatx4c{0.f, 0.f, 0.f, 0.f};
+    const int nkt = d >> 5;
+    for (int kt = wave; kt < nkt; kt += NT / 64) {
+        bf16x8c a[RBT];
+#pragma unroll
+        for (int rb = 0; rb < RBT; ++rb)
+            a[rb] = *reinterpret_cast<const bf16x8c*>(Xp + p1_offset(row0 + min(rb * 16 + hl, S - 1), kt * 32 + kg * 8, KBp));
+        const float4 u0 = *reinterpret_cast<const float4*>(Un + kt * 32), u1 = *reinterpret_cast<const float4*>(Un + kt * 32 + 4);
+        float uf[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+        if (!live) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) uf[k] = 0.f;
+        }
+        bf16x8c bh, bl;
+        split8(uf, bh, bl);
+#pragma unroll
+        for (int rb = 0; rb < RBT; ++rb) {
+            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb], bh, acc[rb], 0, 0, 0);
+            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rb], bl, acc[rb], 0, 0, 0);
+        }
+    }
+    if (live) {                           // D: column (head) l & 15, rows (tokens) 4 (l >> 4) + r of the block
+#pragma unroll
+        for (int rb = 0; rb < RBT; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = rb * 16 + kg * 4 + r;
+                if (j < S) scw[(wave * H + hl) * S + j] = acc[rb][r];
+            }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < H * S; i += NT) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) s += scw[w * H * S + i];
+        sc[i] = s;
+    }
+    __syncthreads();
+    cls_dot_tail(sc, out, probs, n, S, H, mode, dkey, has_drop, wave, lane);
+}
+
+template <int HT>
+__global__ void __launch_bounds__(NT) cls_wsum_pk_kernel(const float* __restrict__ W, const __bf16* __restrict__ Xp,
+                                                          float* __restrict__ Y, int S, int H, int d, int KBp) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Wl = sm;                                         // [S][HT]: a row's weights are one or two 16-B broadcast reads
+    float* comb = sm + ((S * HT + 3) & ~3);                 // [RP - 1][HT * 8][G]: the other row phases' sums
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int WPR = d >> 9, RP = (NT / 64) / WPR, G = d >> 3;
+    const int cg = (wave % WPR) * 64 + lane, rp = wave / WPR;
+    for (int i = threadIdx.x; i < S * HT; i += NT) {
+        const int j = i / HT, h = i - j * HT;
+        Wl[i] = h < H ? W[((size_t)n * H + h) * S + j] : 0.f;
+    }
+    __syncthreads();
+    float acc[HT][8];
+#pragma unroll
+    for (int h = 0; h < HT; ++h)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[h][k] = 0.f;
+    const int64_t row0 = (int64_t)n * S;
+    for (int j0 = rp; j0 < S; j0 += RP * PK_RB) {
+        bf16x8c x[PK_RB];
+#pragma unroll
+        for (int b = 0; b < PK_RB; ++b)
+            x[b] = *reinterpret_cast<const bf16x8c*>(Xp + p1_offset(row0 + min(j0 + b * RP, S - 1), 8 * cg, KBp));
+#pragma unroll
+        for (int b = 0; b < PK_RB; ++b) {
+            const int j = j0 + b * RP;
+            if (j < S) {
+                float xf[8];
+                widen8(x[b], xf);
+#pragma unroll
+                for (int h = 0; h < HT; ++h) {
+                    const float w = Wl[j * HT + h];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[h][k] = fmaf(w, xf[k], acc[h][k]);     // the kernel's time is these FMAs
+                }
+            }
+        }
+    }
+    if (RP > 1) {                                           // block-uniform
+        if (rp > 0) {
+#pragma unroll
+            for (int h = 0; h < HT; ++h)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) comb[((size_t)(rp - 1) * HT * 8 + h * 8 + k) * G + cg] = acc[h][k];
+        }
+        __syncthreads();
+        if (rp == 0)
+            for (int r = 1; r < RP; ++r)
+#pragma unroll
+                for (int h = 0; h < HT; ++h)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[h][k] += comb[((size_t)(r - 1) * HT * 8 + h * 8 + k) * G + cg];
+    }
+    if (rp == 0) {
+#pragma unroll
+        for (int h = 0; h < HT; ++h)
+            if (h < H) {
+                float4* q = reinterpret_cast<float4*>(Y + ((size_t)n * H + h) * d + 8 * cg);
+                q[0] = make_float4(acc[h][0], acc[h][1], acc[h][2], acc[h][3]);
+                q[1] = make_float4(acc[h][4], acc[h][5], acc[h][6], acc[h][7]);
+            }
+    }
+}
+
+// dX[n, j, c] = sum_h W1[n,h,j] U1[n,h,c] + W2[n,h,j] U2[n,h,c] (+ add0[n, c] on row 0: the CLS row's own terms dQ Wq and the
+// residual gradient, joined before the one rounding), written as a pack.  Transposed product D'[c, j] = sum_k Ucat[k, c] Wcat[j, k]
+// over the 16 (head, operand) pairs, K = 32 per MFMA:
+//     MFMA 1   k 0-7: U1hi x W1hi   8-15: U2hi x W2hi   16-23: U1lo x W1hi   24-31: U2lo x W2hi
+//     MFMA 2   k 0-7: U1hi x W1lo   8-15: U2hi x W2lo   16-31: x 0                  (the lo x lo terms, 2^-16 of a product, are dropped)
+// so the A fragment (lane = column l & 15 of a 16-column half tile, k group l >> 4) is the same in both, and a lane ends with four
+// consecutive columns of one token per half; the halves' columns are interleaved so that the two quartets are one 16-B chunk, and a
+// store instruction completes sixteen tokens' 64-B lines of the k tile: one contiguous KB.
+template <int RBT>
+__global__ void __launch_bounds__(NT) cls_outer_pk_kernel(const float* __restrict__ W1, const float* __restrict__ U1,
+                                                           const float* __restrict__ W2, const float* __restrict__ U2,
+                                                           const float* __restrict__ add0, __bf16* __restrict__ dXp, int S, int H,
+                                                           int d, int KBp) {
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hl = lane & 15, kg = lane >> 4;
+    // B fragments (tokens): W1 for even k groups, W2 for odd ones; heads h < H, zero beyond
+    const float* Wsel = ((kg & 1) ? W2 : W1) + (size_t)n * H * S;
+    bf16x8c b1[RBT], b2[RBT];
+#pragma unroll
+    for (int rb = 0; rb < RBT; ++rb) {
+        const int j = min(rb * 16 + hl, S - 1);
+        float wf[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) wf[h] = h < H ? Wsel[h * S + j] : 0.f;
+        bf16x8c hi, lo;
+        split8(wf, hi, lo);
+        b1[rb] = hi;
+        if (kg >= 2) {
+#pragma unroll
+            for (int h = 0; h < 8; ++h) lo[h] = (__bf16)0.f;
+        }
+        b2[rb] = lo;
+    }
+    const float* Usel = ((kg & 1) ? U2 : U1) + (size_t)n * H * d;
+    const int64_t row0 = (int64_t)n * S;
+    // a wave's unit = one k tile (32 columns) as two MFMA halves; row i of half t stands for column 8 (i >> 2) + 4 t + (i & 3) of
+    // the tile, so the lane's four D rows of half 0 and of half 1 are the EIGHT consecutive columns 8 (l >> 4) ... + 7: one 16-B chunk
+    const int ccol = (hl >> 2) * 8 + (hl & 3);
+    for (int kt = wave; kt < (d >> 5); kt += NT / 64) {
+        const int c0 = kt * 32;
+        bf16x8c a[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float uf[8];
+#pragma unroll
+            for (int h = 0; h < 8; ++h) uf[h] = h < H ? Usel[(size_t)h * d + c0 + ccol + 4 * half] : 0.f;
+            bf16x8c hi, lo;
+            split8(uf, hi, lo);
+            a[half] = kg >= 2 ? lo : hi;
+        }
+        float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;
+        if (add0 && hl == 0) {
+            const float4* q = reinterpret_cast<const float4*>(add0 + (size_t)n * d + c0 + kg * 8);
+            e0 = q[0]; e1 = q[1];
+        }
+#pragma unroll
+        for (int rb = 0; rb < RBT; ++rb) {
+            floatx4c o0 = floatx4c{0.f, 0.f, 0.f, 0.f}, o1 = o0;
+            o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b1[rb], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b1[rb], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b2[rb], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b2[rb], o1, 0, 0, 0);
+            if (rb == 0) {                                    // token 0 = lanes hl == 0
+                o0[0] += e0.x; o0[1] += e0.y; o0[2] += e0.z; o0[3] += e0.w;
+                o1[0] += e1.x; o1[1] += e1.y; o1[2] += e1.z; o1[3] += e1.w;
+            }
+            const int j = rb * 16 + hl;
+            if (j < S) {
+                bf16x8c hv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { hv[r] = (__bf16)o0[r]; hv[4 + r] = (__bf16)o1[r]; }
+                *reinterpret_cast<bf16x8c*>(dXp + p1_offset(row0 + j, c0 + kg * 8, KBp)) = hv;
+            }
+        }
+    }
+}
+
+int assoc_pk_check(const void* a, const void* xp, const void* c, int64_t N, int S, int H, int d) {
+    if (!a || !xp || !c) return LSTC_E_NULL;
+    if (N <= 0 || S < 1 || H <= 0 || d <= 0) return LSTC_E_SHAPE;
+    if (S > ASSOC_MAXS) return LSTC_E_RANGE;
+    // whole 256-row tiles (the pack's grid is exact, as the stream's other kernels need it), a wave per 512 columns, the per-head
+    // vectors of 8 heads in registers
+    if (H > 8 || (d != 512 && d != 1024 && d != 2048) || (N * S) % 256 != 0) return LSTC_E_UNSUPPORTED;
+    if (!aligned16(a) || !aligned16(xp) || !aligned16(c)) return LSTC_E_ALIGN;
+    return 0;
+}
+
+#define LSTC_RB_DISPATCH(KERN, S, ...)                                           \
+    do {                                                                         \
+        if ((S) <= 32) hipLaunchKernelGGL(KERN<2>, __VA_ARGS__);                 \
+        else if ((S) <= 64) hipLaunchKernelGGL(KERN<4>, __VA_ARGS__);            \
+        else if ((S) <= 96) hipLaunchKernelGGL(KERN<6>, __VA_ARGS__);            \
+        else hipLaunchKernelGGL(KERN<8>, __VA_ARGS__);                           \
+    } while (0)
+
+#define LSTC_H8_DISPATCH(KERN, H, ...)                                           \
+    do {                                                                         \
+        if ((H) <= 2) hipLaunchKernelGGL(KERN<2>, __VA_ARGS__);                  \
+        else if ((H) <= 4) hipLaunchKernelGGL(KERN<4>, __VA_ARGS__);             \
+        else hipLaunchKernelGGL(KERN<8>, __VA_ARGS__);                           \
+    } while (0)
+
 int assoc_check(const void* a, const void* b, const void* c, int64_t N, int S, int H, int d) {
     if (!a || !b || !c) return LSTC_E_NULL;
     if (N <= 0 || S < 1 || H <= 0 || d <= 0) return LSTC_E_SHAPE;
@@ -1478,6 +1740,43 @@ int lstc_cls_outer(const float* W1, const float* U1, const float* W2, const floa
     if (!W1 || !W2) return LSTC_E_NULL;
     const size_t lds = (size_t)2 * H * S * sizeof(float);
     LSTC_H_DISPATCH(cls_outer_kernel, H, dim3((unsigned)N), dim3(NT), lds, (hipStream_t)stream, W1, U1, W2, U2, dX, S, H, d);
+    return lstc_launch_status();
+}
+
+int lstc_cls_dot_pack(const float* U, const void* X_pack, float* out, float* probs, int64_t N, int32_t S, int32_t H, int32_t d,
+                      int32_t mode, float dropout_p, uint64_t seed, void* stream) {
+    int rc = assoc_pk_check(U, X_pack, out, N, S, H, d);
+    if (rc) return rc;
+    if (mode < 0 || mode > 2) return LSTC_E_UNSUPPORTED;
+    if (mode != 0 && !probs) return LSTC_E_NULL;
+    if ((uint64_t)N * H * S * S > 0xffffffffull) return LSTC_E_RANGE;
+    const size_t lds = ((size_t)H * S + (size_t)(NT / 64) * H * S) * sizeof(float);
+    const DropKey dk = make_drop_key(dropout_p, seed);
+    const int has_drop = dropout_p > 0.f;
+    LSTC_RB_DISPATCH(cls_dot_pk_kernel, S, dim3((unsigned)N), dim3(NT), lds, (hipStream_t)stream, U, (const __bf16*)X_pack, out, probs,
+                     S, H, d, d / 32, mode, dk, has_drop);
+    return lstc_launch_status();
+}
+
+int lstc_cls_wsum_pack(const float* W, const void* X_pack, float* Y, int64_t N, int32_t S, int32_t H, int32_t d, void* stream) {
+    int rc = assoc_pk_check(W, X_pack, Y, N, S, H, d);
+    if (rc) return rc;
+    const int HT = H <= 2 ? 2 : H <= 4 ? 4 : 8;
+    const int RP = (NT / 64) / (d >> 9);
+    const size_t lds = ((size_t)((S * HT + 3) & ~3) + (size_t)(RP - 1) * HT * 8 * (d >> 3)) * sizeof(float);
+    LSTC_H8_DISPATCH(cls_wsum_pk_kernel, H, dim3((unsigned)N), dim3(NT), lds, (hipStream_t)stream, W, (const __bf16*)X_pack, Y, S, H, d,
+                     d / 32);
+    return lstc_launch_status();
+}
+
+int lstc_cls_outer_pack(const float* W1, const float* U1, const float* W2, const float* U2, const float* add0, void* dX_pack,
+                        int64_t N, int32_t S, int32_t H, int32_t d, void* stream) {
+    int rc = assoc_pk_check(U1, dX_pack, U2, N, S, H, d);
+    if (rc) return rc;
+    if (!W1 || !W2) return LSTC_E_NULL;
+    if (add0 && !aligned16(add0)) return LSTC_E_ALIGN;
+    LSTC_RB_DISPATCH(cls_outer_pk_kernel, S, dim3((unsigned)N), dim3(NT), 0, (hipStream_t)stream, W1, U1, W2, U2, add0,
+                     (__bf16*)dX_pack, S, H, d, d / 32);
     return lstc_launch_status();
 }
 

@@ -746,6 +746,21 @@ __global__ void __launch_bounds__(NT) colsum_few(const float* __restrict__ x, in
     *o = s;
 }
 
+// out[i, :] = widen(pack row row0 + i * step): n rows of an lstc_pack1 operand back as f32 (one thread per 16-B chunk)
+__global__ void __launch_bounds__(NT) unpack1_rows_kernel(const __bf16* __restrict__ pk, int KBp, int64_t row0, int64_t step, int64_t n,
+                                                           int K, float* __restrict__ out, int64_t ldo) {
+    const int cpr = K >> 3;
+    const int64_t total = n * cpr;
+    for (int64_t q = (int64_t)blockIdx.x * NT + threadIdx.x; q < total; q += (int64_t)gridDim.x * NT) {
+        const int64_t i = q / cpr;
+        const int c = (int)(q - i * cpr);
+        const bf16x8v h = *reinterpret_cast<const bf16x8v*>(pk + p1_offset(row0 + i * step, 8 * c, KBp));
+        float4* o = reinterpret_cast<float4*>(out + i * ldo + 8 * c);
+        o[0] = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        o[1] = make_float4((float)h[4], (float)h[5], (float)h[6], (float)h[7]);
+    }
+}
+
 // --------------------------------------------------------------------------------- dropout
 __global__ void __launch_bounds__(NT) dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                             int64_t n, DropKey k) {
@@ -1344,6 +1359,17 @@ int lstc_dropout_apply_pack(const void* x_pack, void* y_pack, int64_t rows, int3
     const int64_t chunks = rows * (int64_t)d / 8;
     hipLaunchKernelGGL(dropout_apply_pack_kernel, grid_for(chunks, NT * 2), NT, 0, (hipStream_t)stream, (const __bf16*)x_pack,
                        (__bf16*)y_pack, chunks, d / 32, d, make_drop_key(p, seed));
+    return lstc_launch_status();
+}
+
+int lstc_unpack1_rows(const void* x_pack, int64_t rows, int32_t K, int64_t row0, int64_t row_step, int64_t n, float* out, int64_t ldo,
+                      void* stream) {
+    if (!x_pack || !out) return LSTC_E_NULL;
+    if (rows <= 0 || K <= 0 || n <= 0 || row0 < 0 || row_step <= 0 || row0 + (n - 1) * row_step >= rows || ldo < K) return LSTC_E_SHAPE;
+    if (K % 8 != 0 || ldo % 4 != 0 || !aligned16(x_pack) || !aligned16(out)) return LSTC_E_ALIGN;
+    const int kb = (K + 31) / 32, KBp = kb + (kb & 1);               // 32-k tiles per row block (even: csrc/gemm_bf16p.hip p1_kbp)
+    hipLaunchKernelGGL(unpack1_rows_kernel, grid_for(n * (K / 8), NT), NT, 0, (hipStream_t)stream, (const __bf16*)x_pack, KBp, row0,
+                       row_step, n, K, out, ldo);
     return lstc_launch_status();
 }
 

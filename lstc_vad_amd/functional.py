@@ -191,6 +191,7 @@ _pack_prof = None          # list of (bytes_in, start_event, end_event) while be
 _wepoch = 0
 _memo_stack = []           # activation packs made inside one autograd-node body are shared by the GEMMs of that body
 _x3_min = (256, 256, 1 << 30)   # min(M, N), K, M*N*K from which a product goes to the packed kernel
+_CLS_PACK = os.environ.get("LSTC_CLS_PACK", "1") != "0"             # A/B hook: 0 = the CLS-only layer reads f32 rows (round 5's first form)
 _ATTN_F32 = os.environ.get("LSTC_ATTN_F32", "0") == "1"          # bf16 mode: keep the attention products on the exact-f32 MFMA
 _ATTN_VARIANT = int(os.environ.get("LSTC_ATTN_VARIANT", "0"))     # 1: first-generation attention kernels (A/B measurements)
 _BWD_NPW = int(os.environ.get("LSTC_ATTN_BWD_NPW", "0"))       # measurement hook: sequences per workgroup of the attention backward
@@ -1228,6 +1229,47 @@ def cls_outer(w1, u1, w2, u2, N, S, dm):
     return dx
 
 
+def unpack1_rows(pk: "Packed", row0: int = 0, step: int = 1, n: Optional[int] = None) -> torch.Tensor:
+    """Rows ``row0 + i * step`` (i < n) of a packed bf16 operand as f32 [n, K] (lstc_unpack1_rows)."""
+    if pk.kind != _lib.BF16P:
+        raise TypeError("unpack1_rows reads lstc_pack1 operands")
+    n = (pk.rows - row0 + step - 1) // step if n is None else n
+    out = torch.empty((n, pk.K), device=pk.buf.device, dtype=torch.float32)
+    check(_lib.load().lstc_unpack1_rows(dev_ptr(pk.buf), pk.rows, pk.K, row0, step, n, dev_ptr(out), pk.K, stream_ptr()),
+          "lstc_unpack1_rows")
+    return out
+
+
+def cls_pack_ok(N: int, S: int, H: int, dm: int) -> bool:
+    """Can the CLS-only layer read its [N, S, dm] input as a pack (include/lstc_hip.h, lstc_cls_dot_pack)?"""
+    return _ACT16 and _CLS_PACK and H <= 8 and S <= 128 and act_rows_ok(N * S, dm)
+
+
+def cls_dot_pack(u, xp: "Packed", N, S, mode, probs=None, p_drop=0.0, seed=0):
+    H = u.shape[1]
+    out = torch.empty((N, H, S), device=u.device, dtype=torch.float32)
+    if mode == 1:
+        probs = torch.empty((N, H, S), device=u.device, dtype=torch.float32)
+    check(_lib.load().lstc_cls_dot_pack(dev_ptr(u), dev_ptr(xp.buf), dev_ptr(out), dev_ptr(probs), N, S, H, xp.K, mode, float(p_drop),
+                                        int(seed), stream_ptr()), "lstc_cls_dot_pack")
+    return out, probs
+
+
+def cls_wsum_pack(w, xp: "Packed", N, S):
+    H = w.shape[1]
+    y = torch.empty((N, H, xp.K), device=w.device, dtype=torch.float32)
+    check(_lib.load().lstc_cls_wsum_pack(dev_ptr(w), dev_ptr(xp.buf), dev_ptr(y), N, S, H, xp.K, stream_ptr()), "lstc_cls_wsum_pack")
+    return y
+
+
+def cls_outer_pack(w1, u1, w2, u2, add0, N, S, dm) -> "Packed":
+    H = w1.shape[1]
+    buf = torch.empty((int(_lib.load().lstc_pack1_bytes(N * S, dm)),), device=w1.device, dtype=torch.uint8)
+    check(_lib.load().lstc_cls_outer_pack(dev_ptr(w1), dev_ptr(u1), dev_ptr(w2), dev_ptr(u2), dev_ptr(add0), dev_ptr(buf), N, S, H, dm,
+                                          stream_ptr()), "lstc_cls_outer_pack")
+    return Packed(buf, N * S, dm, _lib.BF16P)
+
+
 class MHAClsAssocFunction(torch.autograd.Function):
     """Last-layer CLS attention with the key / value projections re-associated away (csrc/attention.hip, "assoc"):
         u[n,h]  = (q[n,h] / sqrt(dk)) Wk_h          score[n,h,j] = u[n,h] . x[n,j]        (no K = X Wk^T GEMM)
@@ -1238,14 +1280,24 @@ class MHAClsAssocFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, wq, wk, wv, wfc, ln_w, ln_b, table, cfg):
-        N, S, dm = x.shape
+        # bf16 activation stream: x is the bf16 view of the pack of the last full layer's output (cfg["act_shape"]); the three
+        # passes over X read the pack (half the bytes), the CLS rows come out of it widened
+        xp = None
+        if x.dtype == torch.bfloat16:
+            N, S, dm = cfg["act_shape"]
+            xp = _act_pack(x, N * S, dm)
+        else:
+            N, S, dm = x.shape
         H, dk, dv = cfg["n_head"], cfg["d_k"], cfg["d_v"]
         training = cfg["training"]
         p_attn = cfg["attn_dropout"] if training else 0.0
         p_fc = cfg["fc_dropout"] if training else 0.0
         ctx.table_shape = None if table is None else tuple(table.shape)
-        x = x.contiguous()
-        xc = x[:, 0, :]
+        if xp is None:
+            x = x.contiguous()
+            xc = x[:, 0, :]
+        else:
+            xc = unpack1_rows(xp, 0, S, N)
         scale = 1.0 / (dk ** 0.5)
         qc = gemm(xc, wq, trans_b=True)                                                   # [N, H*dk]
         u = torch.empty((N, H, dm), device=x.device, dtype=torch.float32)
@@ -1256,8 +1308,12 @@ class MHAClsAssocFunction(torch.autograd.Function):
             _note(cfg["site"] + "attn_dropout#cls", p_attn, seed_a, (N, H, S, S))
         if p_fc > 0:
             _note(cfg["site"] + "dropout#cls", p_fc, seed_f, (N, dm))
-        pd, probs = cls_dot(u, x, 1, None, p_attn, seed_a)                                # dropped probs, probs
-        xb = cls_wsum(pd, x)                                                              # [N, H, d]
+        if xp is None:
+            pd, probs = cls_dot(u, x, 1, None, p_attn, seed_a)                            # dropped probs, probs
+            xb = cls_wsum(pd, x)                                                          # [N, H, d]
+        else:
+            pd, probs = cls_dot_pack(u, xp, N, S, 1, None, p_attn, seed_a)
+            xb = cls_wsum_pack(pd, xp, N, S)
         oc = torch.empty((N, H * dv), device=x.device, dtype=torch.float32)
         gemm_batched(xb, wv, oc, N, dv, dm, H * dm, dm, H * dv, False, True, H, dm, dv * dm, dv)
         y = gemm(oc, wfc, trans_b=True, dropout=(p_fc, seed_f), residual=xc)
@@ -1265,17 +1321,19 @@ class MHAClsAssocFunction(torch.autograd.Function):
             z, mean, rstd = layernorm_fwd(y, ln_w, ln_b, 1e-6)
         else:
             z, mean, rstd = y, None, None
-        ctx.cfg = dict(cfg, N=N, S=S, p_attn=p_attn, p_fc=p_fc, seed_a=seed_a, seed_f=seed_f, scale=scale)
-        ctx.save_for_backward(x, wq, wk, wv, wfc, ln_w, qc, u, pd, probs, xb, oc, y if cfg["layer_norm"] else None, mean, rstd)
+        ctx.cfg = dict(cfg, N=N, S=S, dm=dm, is_act=xp is not None, p_attn=p_attn, p_fc=p_fc, seed_a=seed_a, seed_f=seed_f, scale=scale)
+        ctx.save_for_backward(x, wq, wk, wv, wfc, ln_w, qc, u, pd, probs, xb, oc, y if cfg["layer_norm"] else None, mean, rstd,
+                              xc if xp is not None else None)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        x, wq, wk, wv, wfc, ln_w, qc, u, pd, probs, xb, oc, y, mean, rstd = ctx.saved_tensors
+        x, wq, wk, wv, wfc, ln_w, qc, u, pd, probs, xb, oc, y, mean, rstd, xc_saved = ctx.saved_tensors
         c = ctx.cfg
         N, S, H, dk, dv, scale = c["N"], c["S"], c["n_head"], c["d_k"], c["d_v"], c["scale"]
-        dm = x.shape[-1]
-        xc = x[:, 0, :]
+        dm = c["dm"]
+        xp = _act_pack(x, N * S, dm) if c["is_act"] else None
+        xc = xc_saved if xp is not None else x[:, 0, :]
         dz = dz.contiguous()
         dln_w = dln_b = None
         if c["layer_norm"]:
@@ -1290,8 +1348,12 @@ class MHAClsAssocFunction(torch.autograd.Function):
         dwv = grad_sink(wv)
         dwv = torch.empty_like(wv) if dwv is None else dwv
         gemm_batched(doc, xb, dwv, dv, dm, N, H * dv, H * dm, dm, True, False, H, dv, dm, dv * dm)
-        ds, _ = cls_dot(dxb, x, 2, probs, c["p_attn"], c["seed_a"])                       # d(logit) [N,H,S]
-        du = cls_wsum(ds, x)                                                              # [N, H, d]
+        if xp is None:
+            ds, _ = cls_dot(dxb, x, 2, probs, c["p_attn"], c["seed_a"])                   # d(logit) [N,H,S]
+            du = cls_wsum(ds, x)                                                          # [N, H, d]
+        else:
+            ds, _ = cls_dot_pack(dxb, xp, N, S, 2, probs, c["p_attn"], c["seed_a"])
+            du = cls_wsum_pack(ds, xp, N, S)
         dqc = torch.empty_like(qc)
         gemm_batched(du, wk, dqc, N, dk, dm, H * dm, dm, H * dk, False, True, H, dm, dk * dm, dk, alpha=scale)
         dwk = grad_sink(wk)
@@ -1300,8 +1362,11 @@ class MHAClsAssocFunction(torch.autograd.Function):
         dwq = wgrad(dqc, xc, out=grad_sink(wq))
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = cls_outer(pd, dxb, ds, u, N, S, dm)                                      # K/V paths, every token
-            gemm(dqc, wq, out=dx[:, 0, :], accumulate=True, residual=dy)                  # CLS rows: + dQ Wq + residual
+            if xp is None:
+                dx = cls_outer(pd, dxb, ds, u, N, S, dm)                                  # K/V paths, every token
+                gemm(dqc, wq, out=dx[:, 0, :], accumulate=True, residual=dy)              # CLS rows: + dQ Wq + residual
+            else:       # the gradient goes back as a pack; the CLS rows' own terms join row 0 before the one rounding
+                dx = _act_tensor(cls_outer_pack(pd, dxb, ds, u, gemm(dqc, wq, residual=dy), N, S, dm))
         dtable = None if ctx.table_shape is None else torch.zeros(ctx.table_shape, device=x.device, dtype=torch.float32)
         return dx, deliver(wq, dwq), deliver(wk, dwk), deliver(wv, dwv), dwfc, dln_w, dln_b, dtable, None
 

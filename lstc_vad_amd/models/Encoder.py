@@ -115,10 +115,13 @@ class Encoder(nn.Module):
         n = len(self.layer_stack)
         act = self._act_chain(enc_output, enc_output_hi, list(self.layer_stack[:-1]))
         enc_output = self._embed(enc_output, enc_output_hi, pack_only=act)
+        # the CLS-only layer reads the stream's pack too when its re-associated form applies (lstc_cls_dot_pack ...), else f32 rows
+        cls_pack = act and isinstance(enc_output, PackedAct) and \
+            self.layer_stack[-1].slf_attn.cls_takes_pack(enc_output.shape[0], enc_output.shape[1])
         for i, layer in enumerate(self.layer_stack[:-1]):
-            layer.pos_ffn._emit_pack = i + 1 < n - 1          # the CLS-only last layer reads no packed operand
-            # bf16 activation stream: every block hands a pack on, except the one in front of the CLS-only layer (f32 rows)
-            layer.slf_attn._act16_out, layer.pos_ffn._act16_out = act, act and i + 1 < n - 1
+            layer.pos_ffn._emit_pack = i + 1 < n - 1          # f32 activations: the CLS-only last layer reads no packed operand
+            # bf16 activation stream: every block hands a pack on
+            layer.slf_attn._act16_out, layer.pos_ffn._act16_out = act, act and (i + 1 < n - 1 or cls_pack)
             enc_output = layer(enc_output)[0]
         out = self.layer_stack[-1].forward_cls(enc_output)
         drop_producer_packs()

@@ -76,14 +76,25 @@ class MultiHeadAttention(nn.Module):
                 off += w.shape[0]
         return self
 
+    def _cls_assoc_ok(self, S):
+        return self.d_model % 4 == 0 and self.n_head <= 16 and S <= 128 and self.n_head * self.d_model <= 16384 and self.cls_assoc
+
+    def cls_takes_pack(self, N, S):
+        """Can ``forward_cls`` read its input as a PackedAct (functional.cls_pack_ok: lstc_cls_dot_pack and friends)?"""
+        from ..functional import cls_pack_ok
+        return self._cls_assoc_ok(S) and cls_pack_ok(N, S, self.n_head, self.d_model)
+
     def forward_cls(self, x):
         """CLS-query attention for the last encoder layer: x [N, S, d] -> [N, d] (== ``forward(x, x, x)[0][:, 0]``)."""
         cfg = dict(n_head=self.n_head, d_k=self.d_k, d_v=self.d_v, layer_norm=self.layerNorm_flag,
                    attn_dropout=self.attn_dropout.p, fc_dropout=self.dropout.p, training=self.training,
                    site=self._site)
-        # re-associated form (no K/V projection GEMMs) whenever its alignment rules hold, else the K/V-projecting form
-        fn = MHAClsAssocFunction if (self.d_model % 4 == 0 and self.n_head <= 16 and x.shape[1] <= 128
-                                     and self.n_head * self.d_model <= 16384 and self.cls_assoc) else MHAClsFunction
+        if isinstance(x, PackedAct):       # bf16 activation stream: Encoder checked cls_takes_pack(); the pack's bf16 view goes through autograd
+            cfg.update(act_shape=x.shape)
+            fn, x = MHAClsAssocFunction, x.t
+        else:
+            # re-associated form (no K/V projection GEMMs) whenever its alignment rules hold, else the K/V-projecting form
+            fn = MHAClsAssocFunction if self._cls_assoc_ok(x.shape[1]) else MHAClsFunction
         return fn.apply(x, self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.fc.weight,
                                     self.layer_norm.weight if self.layerNorm_flag else None,
                                     self.layer_norm.bias if self.layerNorm_flag else None,

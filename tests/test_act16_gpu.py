@@ -124,6 +124,70 @@ def test_layernorm_on_packs_matches_f64_on_the_packed_values(rows, d, p):
                                       dev_ptr(rstd), rows, d, 1e-6, stream_ptr()) == -1
 
 
+@pytest.mark.parametrize("N,S,H,d", [(256, 49, 8, 2048), (256, 81, 8, 1024), (512, 17, 8, 2048), (1024, 5, 4, 512), (256, 128, 2, 1024)])
+def test_cls_passes_over_a_packed_input_match_the_f32_kernels_on_the_packed_values(N, S, H, d):
+    """lstc_cls_dot_pack / lstc_cls_wsum_pack / lstc_cls_outer_pack (the CLS-only last layer on the bf16 activation stream) against
+    lstc_cls_dot / lstc_cls_wsum / lstc_cls_outer run on the f32 values the pack holds (lstc_unpack1_rows: exactly the bf16-rounded
+    input) and against f64 arithmetic on them: dot products (on the bf16 matrix cores, the f32 operand as a bf16 hi + lo pair) to
+    2e-6 of the row's magnitude bound, probabilities and the softmax backward to 1e-5, the weighted sums to 2e-6 of theirs, and the
+    packed dX within one bf16 rounding of the f64 result - with and without the CLS rows' extra term.  Also: the refusals of
+    include/lstc_hip.h."""
+    from lstc_vad_amd import _lib, functional as Fn
+    g = torch.Generator(device=DEV).manual_seed(21)
+    x = torch.randn(N, S, d, device=DEV, generator=g)
+    u = torch.randn(N, H, d, device=DEV, generator=g) * 0.05
+    u2 = torch.randn(N, H, d, device=DEV, generator=g)
+    w = torch.randn(N, H, S, device=DEV, generator=g)
+    w2 = torch.randn(N, H, S, device=DEV, generator=g)
+    add0 = torch.randn(N, d, device=DEV, generator=g)
+    Fn.set_compute_dtype("bf16")
+    try:
+        xp = Fn.pack3(x.view(N * S, d), False)
+        xw = Fn.unpack1_rows(xp).view(N, S, d)
+        assert torch.equal(xw, _bf16(x))                                          # the pack holds RNE(x); unpack widens exactly
+        assert torch.equal(Fn.unpack1_rows(xp, 0, S, N), xw[:, 0, :])             # the CLS rows
+        for mode, p in ((0, 0.0), (1, 0.0), (1, 0.3)):
+            ref, refp = Fn.cls_dot(u, xw, mode, None, p, 77)
+            got, gotp = Fn.cls_dot_pack(u, xp, N, S, mode, None, p, 77)
+            if mode == 0:
+                bound = float((u.abs().unsqueeze(2) * xw.abs().unsqueeze(1)).sum(-1).max())
+                assert max_abs_diff(got, ref) < 2e-6 * bound, (mode, max_abs_diff(got, ref), bound)
+            else:
+                assert max_abs_diff(gotp, refp) < 1e-5
+                assert torch.equal(got == 0, ref == 0) and max_abs_diff(got, ref) < 2e-5          # the same dropout mask
+        probs = torch.softmax(torch.randn(N, H, S, device=DEV, generator=g), -1)
+        ref, _ = Fn.cls_dot(u, xw, 2, probs, 0.3, 77)
+        got, _ = Fn.cls_dot_pack(u, xp, N, S, 2, probs, 0.3, 77)
+        assert max_abs_diff(got, ref) < 1e-5 * max(1.0, float(ref.abs().max()))
+        ref64 = torch.einsum("nhj,njc->nhc", w.double(), xw.double())
+        bound = float(torch.einsum("nhj,njc->nhc", w.abs(), xw.abs()).max())
+        got = Fn.cls_wsum_pack(w, xp, N, S)
+        assert max_abs_diff(got, ref64) < 2e-6 * bound and max_abs_diff(Fn.cls_wsum(w, xw), ref64) < 2e-6 * bound
+        # dX: f64 arithmetic on the same operands, then ONE bf16 rounding (half an ulp = 2^-9 relative; 2^-8 allows a value that sits on
+        # a rounding boundary to fall the other way) + the hi / lo operand split's 2^-16 of the products' magnitude
+        ref64 = torch.einsum("nhj,nhc->njc", w.double(), u.double()) + torch.einsum("nhj,nhc->njc", w2.double(), u2.double())
+        bound = float((torch.einsum("nhj,nhc->njc", w.abs(), u.abs()) + torch.einsum("nhj,nhc->njc", w2.abs(), u2.abs())).max())
+        for extra in (None, add0):
+            if extra is not None:
+                ref64[:, 0, :] += extra.double()
+            got = Fn.unpack1_rows(Fn.cls_outer_pack(w, u, w2, u2, extra, N, S, d)).view(N, S, d).double()
+            err = (got - ref64).abs() - ref64.abs() * 2.0 ** -8
+            assert float(err.max()) < 3e-5 * bound, (float(err.max()), bound)
+            half_ulp = torch.exp2(torch.floor(torch.log2(ref64.abs().clamp_min(1e-30))) - 8)          # bf16: 8 significant bits
+            assert float(((got - ref64).abs() > half_ulp + 3e-5 * bound).double().mean()) < 1e-4        # beyond the nearest bf16: rare
+        torch.cuda.synchronize()
+        lib = _lib.load()
+        from lstc_vad_amd.functional import dev_ptr, stream_ptr
+        y = torch.empty(N, H, d, device=DEV)
+        assert lib.lstc_cls_wsum_pack(dev_ptr(w), dev_ptr(xp.buf), dev_ptr(y), N, S, 16, d, stream_ptr()) == -4      # H > 8
+        assert lib.lstc_cls_wsum_pack(dev_ptr(w), dev_ptr(xp.buf), dev_ptr(y), N, S, H, 768, stream_ptr()) == -4     # d
+        assert lib.lstc_cls_wsum_pack(dev_ptr(w), dev_ptr(xp.buf), dev_ptr(y), N - 1, S, H, d, stream_ptr()) == -4   # rows % 256
+        assert lib.lstc_cls_wsum_pack(dev_ptr(w), None, dev_ptr(y), N, S, H, d, stream_ptr()) == -1
+        assert lib.lstc_unpack1_rows(dev_ptr(xp.buf), N * S, d, 0, S, N + 1, dev_ptr(y), d, stream_ptr()) == -2      # rows past the end
+    finally:
+        Fn.set_compute_dtype("fp32")
+
+
 def _run_step(name, act, dropout=0.0, steps=1):
     """One or more optimisation steps of a production-width case in bf16 mode with the given activation dtype."""
     hp = _hp()
@@ -136,18 +200,22 @@ def _run_step(name, act, dropout=0.0, steps=1):
                 m.p = dropout
     enc, head = enc.to(DEV).train(), head.to(DEV).train()
     args = hp._args(mode, skw)
+    _run_step.part_num = args.part_num
     nf, af, al = (torch.from_numpy(x).to(DEV) for x in (nf, af, al))
-    calls = {"fwd": 0, "bwd": 0}
-    real_f, real_b = Fn.layernorm_fwd_act, Fn.layernorm_bwd_act
+    calls = {"fwd": 0, "bwd": 0, "cls": 0}
+    real_f, real_b, real_c = Fn.layernorm_fwd_act, Fn.layernorm_bwd_act, Fn.cls_dot_pack
     def spy_f(*a, **k):
         calls["fwd"] += 1
         return real_f(*a, **k)
     def spy_b(*a, **k):
         calls["bwd"] += 1
         return real_b(*a, **k)
+    def spy_c(*a, **k):
+        calls["cls"] += 1
+        return real_c(*a, **k)
     Fn.set_compute_dtype("bf16"); Fn.set_act_dtype(act); Fn.reset_rng()
     torch.cuda.reset_peak_memory_stats()
-    Fn.layernorm_fwd_act, Fn.layernorm_bwd_act = spy_f, spy_b
+    Fn.layernorm_fwd_act, Fn.layernorm_bwd_act, Fn.cls_dot_pack = spy_f, spy_b, spy_c
     try:
         ts = TrainStep(args, mode, enc, head, 1e-6, 1e-6, 1e-3, fuse_qkv="on")
         out = []
@@ -161,7 +229,7 @@ def _run_step(name, act, dropout=0.0, steps=1):
         torch.cuda.synchronize()
         peak = torch.cuda.max_memory_allocated()
     finally:
-        Fn.layernorm_fwd_act, Fn.layernorm_bwd_act = real_f, real_b
+        Fn.layernorm_fwd_act, Fn.layernorm_bwd_act, Fn.cls_dot_pack = real_f, real_b, real_c
         Fn.set_compute_dtype("fp32"); Fn.set_act_dtype("bf16")
     return z, out, calls, {k: v.detach().clone() for k, v in enc.state_dict().items()}, peak
 
@@ -178,10 +246,16 @@ def test_bf16_activation_stream_step_tracks_the_f32_activation_step_and_the_refe
     dropout(fc(o)) + x is the block's output and lstc_dropout_apply_pack replays the mask on the gradient pack), none on the f32 path."""
     z, a16, calls16, _, peak16 = _run_step(name, "bf16")
     _, a32, calls32, _, peak32 = _run_step(name, "fp32")
-    assert calls16 == {"fwd": n_ln, "bwd": n_ln} and calls32 == {"fwd": 0, "bwd": 0}, (calls16, calls32)
+    # ... and the CLS-only last layer reads the stream's pack: lstc_cls_dot_pack once forward, once backward
+    assert calls16 == {"fwd": n_ln, "bwd": n_ln, "cls": 2} and calls32 == {"fwd": 0, "bwd": 0, "cls": 0}, (calls16, calls32)
     (o16, s16, g16), (o32, s32, g32) = a16[0], a32[0]
     assert max_abs_diff(o16, o32) < 2e-2 and abs(float(s16[0]) - float(s32[0])) < 2e-2
     assert max_abs_diff(o16.reshape(z["outputs"].shape), z["outputs"]) < 2e-2 and abs(float(s16[0]) - float(z["scalars"][0])) < 2e-2
+    # a video whose MIL maximum moved to another part between the two runs (test_hip_parity._mil_max_moves: its top two parts are
+    # closer than the score difference - ltn_ubnormal_full_256 has a pair 3.7e-4 apart) takes 1 / 16 of the ranking gradient with it:
+    # the direction bars then are 0.90 (measured 0.937)
+    flips = _hp()._mil_max_moves(o16, o32, _run_step.part_num)
+    assert flips <= 1
     worst = (1.0, "")
     for k in g32:
         if g32[k].numel() < 4096 or float(g32[k].norm()) == 0.0:
@@ -189,11 +263,12 @@ def test_bf16_activation_stream_step_tracks_the_f32_activation_step_and_the_refe
         a, b = g16[k].double().reshape(-1), g32[k].double().reshape(-1)
         cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
         worst = min(worst, (cos, k))
-        assert cos > (0.96 if k.endswith(("pos_ffn.w_1.weight", "pos_ffn.w_1.bias")) else 0.985), (k, cos)
+        bar = 0.90 if flips else (0.96 if k.endswith(("pos_ffn.w_1.weight", "pos_ffn.w_1.bias")) else 0.985)
+        assert cos > bar, (k, cos, flips)
         assert abs(float(a.norm() / b.norm()) - 1.0) < 0.03, k
     print(f"\n[act16 {name}] scores vs f32-activation step {max_abs_diff(o16, o32):.2e}, vs reference "
           f"{max_abs_diff(o16.reshape(z['outputs'].shape), z['outputs']):.2e}; worst gradient cosine {worst[0]:.4f} ({worst[1]}); "
-          f"peak memory {peak16 / 2**30:.2f} vs {peak32 / 2**30:.2f} GiB")
+          f"videos whose MIL maximum moved to another part: {flips}; peak memory {peak16 / 2**30:.2f} vs {peak32 / 2**30:.2f} GiB")
     assert peak16 < peak32
 
 
@@ -205,7 +280,7 @@ def test_bf16_activation_stream_step_is_bit_reproducible_with_dropout_on(name, n
     differs from the dropout-free run."""
     _, a, ca, wa, _ = _run_step(name, "bf16", dropout=0.2, steps=2)
     _, b, cb, wb, _ = _run_step(name, "bf16", dropout=0.2, steps=2)
-    assert ca == cb == {"fwd": n_ln, "bwd": n_ln}
+    assert ca == cb == {"fwd": n_ln, "bwd": n_ln, "cls": 4}
     for (oa, sa, ga), (ob, sb, gb) in zip(a, b):
         assert torch.equal(oa, ob) and torch.equal(sa, sb)
         for k in ga:

@@ -1625,6 +1625,26 @@ def test_f32x3_wgrad_with_uneven_k_splits(T):
     assert max_abs_diff(dw, ref) < 2e-4 * (T ** 0.5) * 0.05
 
 
+def _mil_max_moves(outputs, ref_outputs, part_num):
+    """LTN: the MIL ranking term reads ONE part per video - the maximum of column 1 over its parts (losses.get_MIL_loss,
+    Train/temporal_transformer_shanghaitech.py:25-36) - so two runs whose scores agree to the bf16 mode's 1e-2 can still hand a
+    video's ranking gradient to different parts when its top two parts are closer than that.  Such a move is a property of the
+    loss, not of the arithmetic.  Returns the number of videos whose maximum sits on another part than in ``ref_outputs``; every
+    one of them must be explained by the score difference (gap of the reference's top two parts < 2 x the largest score
+    difference).  0 for STN outputs (one column)."""
+    o, r = torch.as_tensor(outputs).detach().float().cpu(), torch.as_tensor(ref_outputs).detach().float().cpu()
+    if r.dim() != 2 or r.shape[1] != 2:
+        return 0
+    o = o.reshape(r.shape)
+    diff = float((o - r).abs().max())
+    b, br = o[:, 1].reshape(-1, part_num), r[:, 1].reshape(-1, part_num)
+    moved = (b.argmax(1) != br.argmax(1)).nonzero().reshape(-1).tolist()
+    for v in moved:
+        top = br[v].topk(2).values
+        assert float(top[0] - top[1]) < 2 * diff, (v, float(top[0] - top[1]), diff)
+    return len(moved)
+
+
 @pytest.mark.parametrize("name,fused", [(n, False) for n in FULL_NAMES] + [("stn_full", True), ("stn_mil_ce_full", True), ("ltn_ucf_full", True),
                                         ("ltn_full_256", True), ("ltn_ubnormal_full_256", True)])
 def test_full_width_bf16_step_tracks_reference(name, fused):
@@ -1663,6 +1683,12 @@ def test_full_width_bf16_step_tracks_reference(name, fused):
     assert seen and all(seen) == fused, seen
     assert max_abs_diff(outputs.reshape(z["outputs"].shape), z["outputs"]) < 2e-2
     assert abs(float(sc[0]) - float(z["scalars"][0])) < 2e-2
+    # a video whose MIL maximum sits on another part than in the reference's run (its top two parts closer than the score
+    # tolerance: ltn_ubnormal_full_256 has a pair 3.7e-4 apart) moves 1 / 16 of the ranking gradient: direction bar 0.90 then
+    moves = _mil_max_moves(outputs, z["outputs"], args.part_num)
+    assert moves <= 1
+    if moves:
+        print(f"\n[bf16 {name}] {moves} video's MIL maximum sits on another part than in the reference's run")
     for k, p in enc.named_parameters():
         if p.grad is None or p.numel() < 4096 or float(z[f"enc_gnorm.{k}"]) == 0.0:
             continue
@@ -1673,7 +1699,7 @@ def test_full_width_bf16_step_tracks_reference(name, fused):
         # ReLU decisions of the ~0.5 % of hidden units whose pre-activation lies within bf16 product rounding of zero (a
         # flipped unit rewrites its whole row of dW1; ltn_ucf_full layer 1: 0.968 on the sample at a norm ratio of 1.0006)
         # (the same holds for that layer's bias gradient db1 = column sums of the hidden's gradient: 0.976 on ltn_clip_full layer 1)
-        assert cos > (0.95 if k.endswith(("pos_ffn.w_1.weight", "pos_ffn.w_1.bias")) else 0.98), (k, cos)
+        assert cos > (0.90 if moves else 0.95 if k.endswith(("pos_ffn.w_1.weight", "pos_ffn.w_1.bias")) else 0.98), (k, cos, moves)
         assert abs(float(p.grad.double().norm()) / float(z[f"enc_gnorm.{k}"]) - 1.0) < 0.05, k
 
 
