@@ -188,7 +188,7 @@ def test_cls_passes_over_a_packed_input_match_the_f32_kernels_on_the_packed_valu
         Fn.set_compute_dtype("fp32")
 
 
-def _run_step(name, act, dropout=0.0, steps=1):
+def _run_step(name, act, dropout=0.0, steps=1, lrs=(1e-6, 1e-6, 1e-3)):
     """One or more optimisation steps of a production-width case in bf16 mode with the given activation dtype."""
     hp = _hp()
     from lstc_vad_amd import functional as Fn
@@ -217,7 +217,7 @@ def _run_step(name, act, dropout=0.0, steps=1):
     torch.cuda.reset_peak_memory_stats()
     Fn.layernorm_fwd_act, Fn.layernorm_bwd_act, Fn.cls_dot_pack = spy_f, spy_b, spy_c
     try:
-        ts = TrainStep(args, mode, enc, head, 1e-6, 1e-6, 1e-3, fuse_qkv="on")
+        ts = TrainStep(args, mode, enc, head, *lrs, fuse_qkv="on")
         out = []
         for _ in range(steps):
             loss, sc, outputs = ts.forward_loss(nf, af, al)
@@ -366,3 +366,35 @@ def test_dropout_replay_on_a_pack_keeps_exactly_the_masks_elements():
         Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
     want = torch.where(keep, _bf16(x * (1.0 / (1.0 - p))), torch.zeros_like(x))
     assert torch.equal((got == 0), (want == 0)) and max_abs_diff(got, want) <= 2 ** -8 * float(want.abs().max())
+
+@pytest.mark.parametrize("name", ["ltn_full_256", "stn_full"])
+def test_bf16_stream_two_steps_at_the_reference_learning_rates(name):
+    """The reference's Adagrad rates (1e-4 encoder, 1e-2 head, weight decay 1e-3; Train/temporal_transformer_shanghaitech.py:83-85)
+    at production width in bf16 mode: two optimisation steps on the stream against the reference's own two steps (the fixtures are
+    produced with exactly these rates; the fp32 tests hold the second step's scalars to 1e-4 and the weights to an Adagrad step).
+    Adagrad's first update moves every weight by lr * sign(g), so what bf16 products can change is the sign of entries whose
+    gradient sits at rounding level: the second step's scalars - evaluated on weights that differ from the reference's in those
+    entries - stay within 1e-2 of the reference's (measured 3e-8 on the LTN case, whose head the first 1e-2 update saturates in
+    the reference run too, and 2.5e-4 on the STN case), and of the sampled encoder weights no tensor has more than 10 % of its
+    entries further than half an Adagrad step from the reference's (measured worst 2.7 % / 6.6 %: layer 1's w_qs / the first FFN
+    bias), 4 % on average over the tensors (measured 1.2 % / 2.5 %); none is further than the two steps' worth."""
+    hp = _hp()
+    from cases import sample_index
+    z, out, calls, w, _ = _run_step(name, "bf16", steps=2, lrs=(1e-4, 1e-2, 1e-3))
+    s2 = out[1][1].cpu().double().numpy()
+    d_loss = float(np.abs(s2 - z["scalars_step2"]).max())
+    worst = {}
+    for k, v in w.items():
+        key = f"enc_w2s.{k}"
+        if key not in z.files or z[key].size == 0 or not v.is_floating_point():
+            continue
+        flat = v.reshape(-1)
+        got = flat[torch.from_numpy(sample_index(flat.numel())).to(flat.device)].cpu()
+        diff = (got - torch.from_numpy(z[key])).abs()
+        assert float(diff.max()) <= 2 * 2 * 1e-4 + 1e-6, (k, float(diff.max()))          # never more than the two steps' worth
+        worst[k] = float((diff > 0.5e-4).float().mean())
+    k_worst = max(worst, key=worst.get)
+    print(f"\n[act16 {name}, reference learning rates] second-step scalars differ by {d_loss:.2e}; weights further than half an Adagrad "
+          f"step from the reference's: worst tensor {worst[k_worst]:.3%} ({k_worst}), mean {np.mean(list(worst.values())):.3%}")
+    assert d_loss < 1e-2
+    assert worst[k_worst] < 0.10 and np.mean(list(worst.values())) < 0.04
