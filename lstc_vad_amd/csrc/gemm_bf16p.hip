@@ -958,7 +958,11 @@ __attribute__((visibility("hidden"))) int lstc_gemm_bf16p_impl(const LstcGemmDes
         setup.end(dev_);
     }
     const int n_cu = n_cu_dev[cur & 63].load(std::memory_order_relaxed);
-    const int grid = p.total_items < n_cu ? p.total_items : n_cu;       // persistent: one workgroup per CU (128 KB of LDS each)
+    // persistent: one workgroup per CU (128 KB of LDS each).  (Tried, round 5: whole rounds on fewer workgroups - 3136 items of the
+    // N = 2048 products are 12.25 rounds of 256 but exactly 14 of 224.  A round takes the same 55 - 56 us either way, so 14 of them
+    // lose: 0.732 -> 0.774 ms at K = 2048, 1.303 -> 1.350 at K = 4096, step 38.3 -> 39.2 ms.  The chip is not power-limited at this
+    // granularity: idle CUs buy the busy ones nothing.)
+    const int grid = p.total_items < n_cu ? p.total_items : n_cu;
     if (tr) hipLaunchKernelGGL((gemm_bf16p_kernel<true, false>), dim3(grid), dim3(NT8), lds, st, p);
     else if (P1_NT_S16) {
         const int epk = p.res_kbp ? 4 : p.out_kbp ? (p.mask_kbp ? 2 : 1) : (p.mask_kbp ? 3 : 0);
