@@ -590,8 +590,10 @@ def main():
             # work; on the algorithmic count the same step would read frac_on_algorithmic_flops (can exceed 1).
             roof["step_algorithmic_tflop"] = round(alg_tflop(a.config) / world, 3)          # per rank
             roof["frac_on_algorithmic_flops"] = round(alg_tflop(a.config) / world / (head_res["dt"] / a.steps) / roof["peak"], 4)
+        fused = os.environ.get("LSTC_EAGER_GATHER", "0") != "1" and not a.graph
         feed_txt = ("batch formed every step inside the timed region: host window sampler (utils/load_dataset.py:69-88 rule) + "
-                    "lstc_gather_rows from an HBM-resident bank of %s GB" % head_res["bank_GB"]) if a.feed == "resident" else \
+                    + ("the rows gathered inside the CLS concat (lstc_cls_concat_gather_fwd)" if fused else "lstc_gather_rows")
+                    + " from an HBM-resident bank of %s GB" % head_res["bank_GB"]) if a.feed == "resident" else \
             "one fixed HBM-resident batch (no batch formation in the timed region)"
         out = {"metric": "snippets/sec training step (B=64,T=32,P=16,d=2048)", "value": round(value, 1),
                "unit": "snippets/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
