@@ -363,6 +363,16 @@ int lstc_dropout_apply(const float* x, float* y, int64_t n, float p, uint64_t se
  * WITHOUT LayerNorm (models/MultiHeadAttention.py:123-124 with layerNorm = False: the STN configs): the incoming gradient pack
  * is the gradient of dropout(f) + x, its dropped form the operand of fc's weight and input gradients. */
 int lstc_dropout_apply_pack(const void* x_pack, void* y_pack, int64_t rows, int32_t d, float p, uint64_t seed, void* stream);
+/* Second half of a K-split small product (round 5): C = epi(parts[0] + ... + parts[splits - 1]), parts[i] = the [M, N] partial result
+ * of K chunk i at parts + i * part_stride (row-major, ld = N), added in chunk order; `flags` and the operands as LstcGemmDesc's
+ * epilogue (bias, ReLU, dropout of the flat index row * N + col, residual, ReLU mask, accumulate - in that order; no pack flags).
+ * The CLS-only last layer and the heads run [sequences, d] x [d, d] products whose few output tiles leave most of the chip idle
+ * while one workgroup walks the whole K range (models/MultiHeadAttention.py:97-126 on row 0, models/FFN.py:17-19,
+ * models/Classifier.py:8-14 for a rank's 256 sequences): the host side launches their K chunks as ONE batched lstc_gemm into
+ * `parts` and finishes here.  N, part_stride, ldc (ldr, ld_relu) multiples of 4; 16-B aligned pointers; M * N < 2^32. */
+int lstc_splitk_finish(const float* parts, int32_t splits, int64_t part_stride, int64_t M, int64_t N, const float* bias,
+                       const float* residual, int64_t ldr, const float* relu_src, int64_t ld_relu, float* C, int64_t ldc, int32_t flags,
+                       float dropout_p, uint64_t dropout_seed, void* stream);
 /* out[i, 0:K] = the bf16 values of row row0 + i * row_step of an lstc_pack1 operand [rows, K], widened to f32 (i < n; K % 8 == 0,
  * ldo % 4 == 0).  The CLS-only last layer reads its query rows (token 0 of every sequence: row0 = 0, row_step = S) out of the
  * activation stream's pack (models/MultiHeadAttention.py:97 restricted to row 0); tests read whole packs back with it. */

@@ -21,7 +21,7 @@ EPI_OUT_PACK, EPI_RELU_MASK_PACK, EPI_RESIDUAL_PACK = 128, 256, 512
 
 EXPORTS = (
     "lstc_gemm", "lstc_attn_fwd", "lstc_attn_bwd", "lstc_attn_cls_fwd", "lstc_attn_cls_bwd", "lstc_cls_dot", "lstc_cls_wsum",
-    "lstc_cls_outer", "lstc_cls_dot_pack", "lstc_cls_wsum_pack", "lstc_cls_outer_pack", "lstc_unpack1_rows", "lstc_layernorm_fwd", "lstc_layernorm_bwd", "lstc_layernorm_fwd_pack",
+    "lstc_cls_outer", "lstc_cls_dot_pack", "lstc_cls_wsum_pack", "lstc_cls_outer_pack", "lstc_unpack1_rows", "lstc_splitk_finish", "lstc_layernorm_fwd", "lstc_layernorm_bwd", "lstc_layernorm_fwd_pack",
     "lstc_layernorm_bwd_drop_pack", "lstc_layernorm_bwd_drop", "lstc_layernorm_fwd_act", "lstc_layernorm_bwd_act",
     "lstc_cls_concat_fwd", "lstc_cls_concat_fwd_pack", "lstc_cls_concat_gather_fwd", "lstc_cls_concat_bwd", "lstc_colsum", "lstc_colsum_batched", "lstc_dropout_apply", "lstc_dropout_apply_pack", "lstc_dropout_mask", "lstc_dropout_seed_device",
     "lstc_head_out_fwd", "lstc_head_out_bwd", "lstc_vad_loss", "lstc_adagrad_step", "lstc_adagrad_multi", "lstc_sqnorm_accum", "lstc_scale",
@@ -111,6 +111,7 @@ def load():
         "lstc_cls_wsum_pack": [vp, vp, vp, i64, i32, i32, i32, vp],
         "lstc_cls_outer_pack": [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp],
         "lstc_unpack1_rows": [vp, i64, i32, i64, i64, i64, vp, i64, vp],
+        "lstc_splitk_finish": [vp, i32, i64, i64, i64, vp, vp, i64, vp, i64, vp, i64, i32, f32, u64, vp],
         "lstc_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
         "lstc_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp],
         "lstc_layernorm_fwd_pack": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp, vp],

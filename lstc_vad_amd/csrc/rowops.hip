@@ -746,6 +746,50 @@ __global__ void __launch_bounds__(NT) colsum_few(const float* __restrict__ x, in
     *o = s;
 }
 
+// C = epi(parts[0] + parts[1] + ... + parts[s - 1]) with the epilogue of lstc_gemm (csrc/gemm_f32.hip: bias, ReLU, dropout of the flat
+// index row * N + col, residual, ReLU mask, accumulate - in that order); the K chunks of a small product arrive as separate partial
+// results and are added in chunk order (no atomics).  One thread per four columns.
+__global__ void __launch_bounds__(NT) splitk_finish_kernel(const float* __restrict__ parts, int s, int64_t part_stride, int M, int N,
+                                                            const float* __restrict__ bias, const float* __restrict__ res, int64_t ldr,
+                                                            const float* __restrict__ relu_src, int64_t ld_relu, float* __restrict__ C,
+                                                            int64_t ldc, int flags, DropKey dk) {
+    dk = drop_key_now(dk);
+    const int n4 = N >> 2;
+    const int64_t total = (int64_t)M * n4;
+    for (int64_t q = (int64_t)blockIdx.x * NT + threadIdx.x; q < total; q += (int64_t)gridDim.x * NT) {
+        const int row = (int)(q / n4), col = 4 * (int)(q - (int64_t)row * n4);
+        const float* pp = parts + (int64_t)row * N + col;
+        float4 v = *reinterpret_cast<const float4*>(pp);
+        for (int i = 1; i < s; ++i) {
+            const float4 x = *reinterpret_cast<const float4*>(pp + i * part_stride);
+            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+        }
+        if (flags & LSTC_EPI_BIAS) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + col);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (flags & LSTC_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (flags & LSTC_EPI_DROPOUT) {
+            const uint32_t idx = (uint32_t)row * (uint32_t)N + (uint32_t)col;
+            v.x = drop_keep(idx, dk) ? v.x * dk.scale : 0.f;
+            v.y = drop_keep(idx + 1, dk) ? v.y * dk.scale : 0.f;
+            v.z = drop_keep(idx + 2, dk) ? v.z * dk.scale : 0.f;
+            v.w = drop_keep(idx + 3, dk) ? v.w * dk.scale : 0.f;
+        }
+        if (flags & LSTC_EPI_RESIDUAL) {
+            const float4 x = *reinterpret_cast<const float4*>(res + (int64_t)row * ldr + col);
+            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+        }
+        if (flags & LSTC_EPI_RELU_MASK) {
+            const float4 x = *reinterpret_cast<const float4*>(relu_src + (int64_t)row * ld_relu + col);
+            v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f; v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
+        }
+        float4* cp = reinterpret_cast<float4*>(C + (int64_t)row * ldc + col);
+        if (flags & LSTC_EPI_ACCUM) { const float4 x = *cp; v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w; }
+        *cp = v;
+    }
+}
+
 // out[i, :] = widen(pack row row0 + i * step): n rows of an lstc_pack1 operand back as f32 (one thread per 16-B chunk)
 __global__ void __launch_bounds__(NT) unpack1_rows_kernel(const __bf16* __restrict__ pk, int KBp, int64_t row0, int64_t step, int64_t n,
                                                            int K, float* __restrict__ out, int64_t ldo) {
@@ -1359,6 +1403,25 @@ int lstc_dropout_apply_pack(const void* x_pack, void* y_pack, int64_t rows, int3
     const int64_t chunks = rows * (int64_t)d / 8;
     hipLaunchKernelGGL(dropout_apply_pack_kernel, grid_for(chunks, NT * 2), NT, 0, (hipStream_t)stream, (const __bf16*)x_pack,
                        (__bf16*)y_pack, chunks, d / 32, d, make_drop_key(p, seed));
+    return lstc_launch_status();
+}
+
+int lstc_splitk_finish(const float* parts, int32_t splits, int64_t part_stride, int64_t M, int64_t N, const float* bias,
+                       const float* residual, int64_t ldr, const float* relu_src, int64_t ld_relu, float* C, int64_t ldc, int32_t flags,
+                       float dropout_p, uint64_t dropout_seed, void* stream) {
+    if (!parts || !C) return LSTC_E_NULL;
+    if (((flags & LSTC_EPI_BIAS) && !bias) || ((flags & LSTC_EPI_RESIDUAL) && !residual) || ((flags & LSTC_EPI_RELU_MASK) && !relu_src))
+        return LSTC_E_NULL;
+    if (splits <= 0 || M <= 0 || N <= 0 || part_stride < M * N || ldc < N || ((flags & LSTC_EPI_RESIDUAL) && ldr < N) ||
+        ((flags & LSTC_EPI_RELU_MASK) && ld_relu < N) || !(dropout_p >= 0.f && dropout_p < 1.f)) return LSTC_E_SHAPE;
+    if (flags & ~(LSTC_EPI_BIAS | LSTC_EPI_RELU | LSTC_EPI_DROPOUT | LSTC_EPI_RESIDUAL | LSTC_EPI_RELU_MASK | LSTC_EPI_ACCUM))
+        return LSTC_E_UNSUPPORTED;
+    if (M > 0x7fffffffLL || N > 0x7fffffffLL || (uint64_t)M * (uint64_t)N > 0xffffffffull) return LSTC_E_RANGE;
+    if (N % 4 || part_stride % 4 || ldc % 4 || ((flags & LSTC_EPI_RESIDUAL) && ldr % 4) || ((flags & LSTC_EPI_RELU_MASK) && ld_relu % 4) ||
+        !aligned16(parts) || !aligned16(C) || !aligned16(bias) || !aligned16(residual) || !aligned16(relu_src)) return LSTC_E_ALIGN;
+    const DropKey dk = make_drop_key((flags & LSTC_EPI_DROPOUT) ? dropout_p : 0.f, dropout_seed);
+    hipLaunchKernelGGL(splitk_finish_kernel, grid_for(M * (N / 4), NT), NT, 0, (hipStream_t)stream, parts, (int)splits, part_stride, (int)M,
+                       (int)N, bias, residual, ldr, relu_src, ld_relu, C, ldc, (int)flags, dk);
     return lstc_launch_status();
 }
 

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import functools
 import os
 import weakref
 from contextlib import contextmanager
@@ -342,6 +343,106 @@ def _mat(t: torch.Tensor):
     return dev_ptr(t), t.shape[0], t.shape[1], (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))
 
 
+_SMALL_M_SPLIT = os.environ.get("LSTC_SMALL_M_SPLIT", "1") != "0"      # A/B hook: 0 = small products as ONE launch over the whole K range
+_small_m_depth = 0
+
+
+class small_m_products:
+    """Inside this context ``gemm`` may run a product with few output tiles (the CLS-only last layer and the heads: [sequences, d] x
+    [d, d], a rank's 256 sequences = 32 tiles of 128 x 128 on 256 CUs) as K chunks - ONE batched launch into partial results + the
+    fixed-order sum and epilogue of ``lstc_splitk_finish`` - instead of one workgroup per tile walking the whole K range (latency
+    bound: 123 us for 256 x 2048 x 2048 in fp32, 17 TFLOP/s).  Entered by the TRAINING-mode bodies of those Functions only: how a
+    product is chunked depends on its row count, so evaluation keeps the property that a row's scores do not depend on what else
+    is in the batch (tests: sharded / pooled evaluation bit-identical to per-video evaluation)."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _small_m_depth
+        _small_m_depth += 1 if self.on else 0
+        return self
+
+    def __exit__(self, *exc):
+        global _small_m_depth
+        _small_m_depth -= 1 if self.on else 0
+        return False
+
+
+def _small_m_split(M: int, N: int, K: int) -> int:
+    """K chunks for a product of few output tiles: the largest power of two <= 16 that keeps the items within one round of the
+    512 workgroup slots and every chunk >= 256 deep (whole 64-k steps); 1 = leave it alone (more than a quarter of a round already)."""
+    tiles = -(-M // 128) * -(-N // 128)
+    if tiles > 128 or K < 512 or N % 4 or M * N >= 1 << 32:
+        return 1
+    s = 1
+    while s < 16 and tiles * s * 2 <= 512 and K % (s * 2 * 64) == 0 and K // (s * 2) >= 256:
+        s *= 2
+    return s
+
+
+def _gemm_small_m(a, b, trans_a, trans_b, M, N, K, lda, ldb, s, out, bias, relu, dropout, residual, relu_mask, accumulate, alpha):
+    """``gemm`` as ``s`` K chunks (one batched launch) + lstc_splitk_finish; same epilogue semantics."""
+    dev = a.device
+    Kc = K // s
+    parts = torch.empty((s, M * N), device=dev, dtype=torch.float32)
+    gemm_batched(a, b, parts, M, N, Kc, lda, ldb, N, trans_a, trans_b, s, Kc * lda if trans_a else Kc, Kc if trans_b else Kc * ldb, M * N,
+                 alpha=alpha)
+    if out is None:
+        out = torch.empty((M, N), device=dev, dtype=torch.float32)
+    pc, cr, cc, ldc = _mat(out)
+    if (cr, cc) != (M, N):
+        raise RuntimeError(f"gemm: out is {cr}x{cc}, the product is {M}x{N}")
+    flags, p_drop, seed = 0, 0.0, 0
+    pbias = pres = pmask = None
+    ldr = ldm = 0
+    if bias is not None:
+        flags |= EPI_BIAS
+        pbias = dev_ptr(bias)
+    if relu:
+        flags |= EPI_RELU
+    if dropout is not None and dropout[0] > 0.0:
+        flags |= EPI_DROPOUT
+        p_drop, seed = float(dropout[0]), int(dropout[1])
+    if residual is not None:
+        flags |= EPI_RESIDUAL
+        pres, rr, rc_, ldr = _mat(residual)
+        if (rr, rc_) != (M, N):
+            raise RuntimeError(f"gemm: residual is {rr}x{rc_}, the product is {M}x{N}")
+    if relu_mask is not None:
+        flags |= EPI_RELU_MASK
+        pmask, mr, mc, ldm = _mat(relu_mask)
+        if (mr, mc) != (M, N):
+            raise RuntimeError(f"gemm: relu_mask is {mr}x{mc}, the product is {M}x{N}")
+    if accumulate:
+        flags |= EPI_ACCUM
+    check(_lib.load().lstc_splitk_finish(dev_ptr(parts), s, M * N, M, N, pbias, pres, ldr, pmask, ldm, pc, ldc, flags, p_drop, seed,
+                                         stream_ptr()), "lstc_splitk_finish")
+    return out
+
+
+def _small_m_fwd(fn):
+    """forward(ctx, x, ..., cfg) of a Function whose products may have few rows - the CLS-only last layer (x = [sequences, d] for its
+    FFN and the heads; the attention Functions of that layer by construction): small_m_products while the module is in training
+    mode.  A full layer's [N, S, d] input never enters the context (its products are large, and at reduced test sizes the fused /
+    unfused pack paths must keep routing alike)."""
+    @functools.wraps(fn)
+    def wrapper(ctx, *args):
+        on = bool(args[-1].get("training", False)) and (fn.__qualname__.startswith(("MHACls", "HeadFunction")) or args[0].dim() == 2)
+        ctx._small_m = on
+        with small_m_products(on):
+            return fn(ctx, *args)
+    return wrapper
+
+
+def _small_m_bwd(fn):
+    @functools.wraps(fn)
+    def wrapper(ctx, *args):
+        with small_m_products(bool(getattr(ctx, "_small_m", False))):
+            return fn(ctx, *args)
+    return wrapper
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out: Optional[torch.Tensor] = None,
          bias=None, relu=False, dropout=None, residual=None, relu_mask=None, accumulate=False, alpha=1.0,
          split_k=1, variant=0, out_pack=False) -> torch.Tensor:
@@ -360,6 +461,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
         Kb, N = (bc, br) if trans_b else (br, bc)
     if K != Kb:
         raise RuntimeError(f"gemm inner dims differ: {K} vs {Kb}")
+    if _small_m_depth > 0 and _SMALL_M_SPLIT and pa is not None and pb is not None and split_k == 1 and variant == 0 and not out_pack \
+            and not isinstance(residual, Packed) and not isinstance(relu_mask, Packed) and lda % 4 == 0 and ldb % 4 == 0:
+        s_small = _small_m_split(M, N, K)
+        if s_small > 1:
+            return _gemm_small_m(a, b, trans_a, trans_b, M, N, K, lda, ldb, s_small, out, bias, relu, dropout, residual, relu_mask,
+                                 accumulate, alpha)
     dtype = _compute_dtype
     pkind = _packed_kind()
     packed = False
@@ -451,6 +558,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
 
 def packed_out_shape(M: int, N: int) -> bool:
     """[M, N] results that the bf16 packed kernel can emit as a packed operand (include/lstc_hip.h, LSTC_EPI_OUT_PACK)."""
+    if _small_m_depth > 0 and _SMALL_M_SPLIT and -(-M // 128) * -(-N // 128) <= 128:
+        return False            # a small product of the CLS-only layer / the heads: its consumers run as K chunks on f32 operands
     return (_FUSE_PACKS and _packed_kind() == _lib.BF16P and M % 256 == 0 and N % 256 == 0 and
             M >= max(_x3_min[0], 1) and N >= max(_x3_min[1], 256) and M * N * max(_x3_min[0], 256) >= _x3_min[2])
 
@@ -1279,6 +1388,7 @@ class MHAClsAssocFunction(torch.autograd.Function):
     [N, dk] x [dk, d] products (one batched launch each) plus three passes over X."""
 
     @staticmethod
+    @_small_m_fwd
     def forward(ctx, x, wq, wk, wv, wfc, ln_w, ln_b, table, cfg):
         # bf16 activation stream: x is the bf16 view of the pack of the last full layer's output (cfg["act_shape"]); the three
         # passes over X read the pack (half the bytes), the CLS rows come out of it widened
@@ -1327,6 +1437,7 @@ class MHAClsAssocFunction(torch.autograd.Function):
         return z
 
     @staticmethod
+    @_small_m_bwd
     def backward(ctx, dz):
         x, wq, wk, wv, wfc, ln_w, qc, u, pd, probs, xb, oc, y, mean, rstd, xc_saved = ctx.saved_tensors
         c = ctx.cfg
@@ -1404,6 +1515,7 @@ class MHAClsFunction(torch.autograd.Function):
     x [N, S, d] -> [N, d].  Same math as MHAFunction row 0 (models/MultiHeadAttention.py:93-126)."""
 
     @staticmethod
+    @_small_m_fwd
     def forward(ctx, x, wq, wk, wv, wfc, ln_w, ln_b, table, cfg):
         # `table`: the layer's relative-position bias table.  Row 0 never sees the bias, so its gradient is exactly
         # zero — but the reference still hands Adagrad that zero tensor, and Adagrad applies weight decay to it
@@ -1437,6 +1549,7 @@ class MHAClsFunction(torch.autograd.Function):
         return z
 
     @staticmethod
+    @_small_m_bwd
     def backward(ctx, dz):
         x, wq, wk, wv, wfc, ln_w, qc, k, v, oc, probs, y, mean, rstd = ctx.saved_tensors
         c = ctx.cfg
@@ -1552,6 +1665,7 @@ class FFNFunction(torch.autograd.Function):
         return dx, deliver(w1o, dw1), db1, deliver(w2o, dw2), db2, dln_w, dln_b, None
 
     @staticmethod
+    @_small_m_fwd
     def forward(ctx, x, w1, b1, w2, b2, ln_w, ln_b, cfg):
         ctx.is_act = x.dtype == torch.bfloat16
         if ctx.is_act:
@@ -1593,6 +1707,7 @@ class FFNFunction(torch.autograd.Function):
         return z.view(shape)
 
     @staticmethod
+    @_small_m_bwd
     def backward(ctx, dz):
         if ctx.is_act:
             return FFNFunction._backward_act(ctx, dz)
@@ -1756,6 +1871,7 @@ class HeadFunction(torch.autograd.Function):
     view(-1,d) -> Linear(d,512)+ReLU+Drop -> Linear(512,32)+Drop -> Linear(32,c) -> Sigmoid | Softmax."""
 
     @staticmethod
+    @_small_m_fwd
     def forward(ctx, x, w0, b0, w3, b3, w5, b5, cfg):
         x2 = x.contiguous().view(-1, x.shape[-1])
         p = cfg["dropout"] if cfg["training"] else 0.0
@@ -1776,6 +1892,7 @@ class HeadFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_small_m_bwd
     def backward(ctx, dout):
         x2, w0, w3, w5, h1, h2, out = ctx.saved_tensors
         cf = ctx.cfg

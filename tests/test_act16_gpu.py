@@ -214,7 +214,9 @@ def _run_step(name, act, dropout=0.0, steps=1, lrs=(1e-6, 1e-6, 1e-3)):
         calls["cls"] += 1
         return real_c(*a, **k)
     Fn.set_compute_dtype("bf16"); Fn.set_act_dtype(act); Fn.reset_rng()
+    torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()           # what earlier runs' results still hold: the peak is reported above this
     Fn.layernorm_fwd_act, Fn.layernorm_bwd_act, Fn.cls_dot_pack = spy_f, spy_b, spy_c
     try:
         ts = TrainStep(args, mode, enc, head, *lrs, fuse_qkv="on")
@@ -227,7 +229,7 @@ def _run_step(name, act, dropout=0.0, steps=1, lrs=(1e-6, 1e-6, 1e-3)):
                         {k: p.grad.detach().clone() for k, p in enc.named_parameters() if p.grad is not None}))
             ts.optimizer.step()
         torch.cuda.synchronize()
-        peak = torch.cuda.max_memory_allocated()
+        peak = torch.cuda.max_memory_allocated() - base
     finally:
         Fn.layernorm_fwd_act, Fn.layernorm_bwd_act, Fn.cls_dot_pack = real_f, real_b, real_c
         Fn.set_compute_dtype("fp32"); Fn.set_act_dtype("bf16")

@@ -1,5 +1,5 @@
 """Per-launch table of the GEMMs of one LTN-SHT training step (HIP events around every lstc_gemm): shape class, ms, TFLOP/s.
-python tools/gemm_launch_table.py [fp32|bf16|f32x3] [config]"""
+python tools/gemm_launch_table.py [fp32|bf16|f32x3] [config] [pairs per step, default 32]"""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,7 +12,7 @@ dtype = sys.argv[1] if len(sys.argv) > 1 else "fp32"
 cfg = sys.argv[2] if len(sys.argv) > 2 else "ltn_sht"
 mode, ekw, skw, drops, _ = bench.CONFIGS[cfg]
 dev = torch.device("cuda", 0)
-bs, pn, L, P, d = 32, 32, skw["part_len"], skw["n_patch"], ekw["d_model"]
+bs, pn, L, P, d = (int(sys.argv[3]) if len(sys.argv) > 3 else 32), 32, skw["part_len"], skw["n_patch"], ekw["d_model"]
 args = Namespace(batch_size=bs, part_num=pn, part_len=L, n_patch=P, lambda_1=0.01, lambda_MIL=1.0, lambda_CE=0.8, lambda_BCE=1.0,
                  lambda_normal=0.2, lambda_abnormal=2.0, temporal_only=False, clip_grad=False)
 torch.manual_seed(0)
