@@ -373,7 +373,7 @@ def _small_m_split(M: int, N: int, K: int) -> int:
     """K chunks for a product of few output tiles: the largest power of two <= 16 that keeps the items within one round of the
     512 workgroup slots and every chunk >= 256 deep (whole 64-k steps); 1 = leave it alone (more than a quarter of a round already)."""
     tiles = -(-M // 128) * -(-N // 128)
-    if tiles > 128 or K < 512 or N % 4 or M * N >= 1 << 32:
+    if tiles > 128 or K < 512 or N % 4 or M * N >= 1 << 32:       # (2048-row products - 256 tiles - gain nothing in either mode: measured)
         return 1
     s = 1
     while s < 16 and tiles * s * 2 <= 512 and K % (s * 2 * 64) == 0 and K // (s * 2) >= 256:
