@@ -369,10 +369,14 @@ int lstc_dropout_apply_pack(const void* x_pack, void* y_pack, int64_t rows, int3
  * The CLS-only last layer and the heads run [sequences, d] x [d, d] products whose few output tiles leave most of the chip idle
  * while one workgroup walks the whole K range (models/MultiHeadAttention.py:97-126 on row 0, models/FFN.py:17-19,
  * models/Classifier.py:8-14 for a rank's 256 sequences): the host side launches their K chunks as ONE batched lstc_gemm into
- * `parts` and finishes here.  N, part_stride, ldc (ldr, ld_relu) multiples of 4; 16-B aligned pointers; M * N < 2^32. */
+ * `parts` and finishes here.  `groups` > 1: that many independent [M, N] results in one call (the per-head products q_h W_k,h /
+ * xbar_h W_v,h^T of the re-associated CLS attention) - group g's partials at parts + g * group_stride_parts, its result at
+ * C + g * group_stride_c; only the plain sum (optionally LSTC_EPI_ACCUM).  groups = 1: the strides are ignored.
+ * N, part_stride, ldc (ldr, ld_relu, group strides) multiples of 4; 16-B aligned pointers; groups * M * N < 2^32. */
 int lstc_splitk_finish(const float* parts, int32_t splits, int64_t part_stride, int64_t M, int64_t N, const float* bias,
                        const float* residual, int64_t ldr, const float* relu_src, int64_t ld_relu, float* C, int64_t ldc, int32_t flags,
-                       float dropout_p, uint64_t dropout_seed, void* stream);
+                       float dropout_p, uint64_t dropout_seed, int32_t groups, int64_t group_stride_parts, int64_t group_stride_c,
+                       void* stream);
 /* out[i, 0:K] = the bf16 values of row row0 + i * row_step of an lstc_pack1 operand [rows, K], widened to f32 (i < n; K % 8 == 0,
  * ldo % 4 == 0).  The CLS-only last layer reads its query rows (token 0 of every sequence: row0 = 0, row_step = S) out of the
  * activation stream's pack (models/MultiHeadAttention.py:97 restricted to row 0); tests read whole packs back with it. */

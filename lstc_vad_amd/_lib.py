@@ -111,7 +111,7 @@ def load():
         "lstc_cls_wsum_pack": [vp, vp, vp, i64, i32, i32, i32, vp],
         "lstc_cls_outer_pack": [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp],
         "lstc_unpack1_rows": [vp, i64, i32, i64, i64, i64, vp, i64, vp],
-        "lstc_splitk_finish": [vp, i32, i64, i64, i64, vp, vp, i64, vp, i64, vp, i64, i32, f32, u64, vp],
+        "lstc_splitk_finish": [vp, i32, i64, i64, i64, vp, vp, i64, vp, i64, vp, i64, i32, f32, u64, i32, i64, i64, vp],
         "lstc_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
         "lstc_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp],
         "lstc_layernorm_fwd_pack": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp, vp],

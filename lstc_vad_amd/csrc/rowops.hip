@@ -749,16 +749,20 @@ __global__ void __launch_bounds__(NT) colsum_few(const float* __restrict__ x, in
 // C = epi(parts[0] + parts[1] + ... + parts[s - 1]) with the epilogue of lstc_gemm (csrc/gemm_f32.hip: bias, ReLU, dropout of the flat
 // index row * N + col, residual, ReLU mask, accumulate - in that order); the K chunks of a small product arrive as separate partial
 // results and are added in chunk order (no atomics).  One thread per four columns.
+// `groups` > 1 (per-head products): group g's partials start at parts + g * group_stride_parts, its [M, N] result at C + g * group_stride_c.
 __global__ void __launch_bounds__(NT) splitk_finish_kernel(const float* __restrict__ parts, int s, int64_t part_stride, int M, int N,
                                                             const float* __restrict__ bias, const float* __restrict__ res, int64_t ldr,
                                                             const float* __restrict__ relu_src, int64_t ld_relu, float* __restrict__ C,
-                                                            int64_t ldc, int flags, DropKey dk) {
+                                                            int64_t ldc, int flags, DropKey dk, int groups, int64_t group_stride_parts,
+                                                            int64_t group_stride_c) {
     dk = drop_key_now(dk);
     const int n4 = N >> 2;
-    const int64_t total = (int64_t)M * n4;
-    for (int64_t q = (int64_t)blockIdx.x * NT + threadIdx.x; q < total; q += (int64_t)gridDim.x * NT) {
+    const int64_t per_group = (int64_t)M * n4, total = per_group * groups;
+    for (int64_t q0 = (int64_t)blockIdx.x * NT + threadIdx.x; q0 < total; q0 += (int64_t)gridDim.x * NT) {
+        const int grp = (int)(q0 / per_group);
+        const int64_t q = q0 - (int64_t)grp * per_group;
         const int row = (int)(q / n4), col = 4 * (int)(q - (int64_t)row * n4);
-        const float* pp = parts + (int64_t)row * N + col;
+        const float* pp = parts + (int64_t)grp * group_stride_parts + (int64_t)row * N + col;
         float4 v = *reinterpret_cast<const float4*>(pp);
         for (int i = 1; i < s; ++i) {
             const float4 x = *reinterpret_cast<const float4*>(pp + i * part_stride);
@@ -784,7 +788,7 @@ __global__ void __launch_bounds__(NT) splitk_finish_kernel(const float* __restri
             const float4 x = *reinterpret_cast<const float4*>(relu_src + (int64_t)row * ld_relu + col);
             v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f; v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
         }
-        float4* cp = reinterpret_cast<float4*>(C + (int64_t)row * ldc + col);
+        float4* cp = reinterpret_cast<float4*>(C + (int64_t)grp * group_stride_c + (int64_t)row * ldc + col);
         if (flags & LSTC_EPI_ACCUM) { const float4 x = *cp; v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w; }
         *cp = v;
     }
@@ -1408,7 +1412,8 @@ int lstc_dropout_apply_pack(const void* x_pack, void* y_pack, int64_t rows, int3
 
 int lstc_splitk_finish(const float* parts, int32_t splits, int64_t part_stride, int64_t M, int64_t N, const float* bias,
                        const float* residual, int64_t ldr, const float* relu_src, int64_t ld_relu, float* C, int64_t ldc, int32_t flags,
-                       float dropout_p, uint64_t dropout_seed, void* stream) {
+                       float dropout_p, uint64_t dropout_seed, int32_t groups, int64_t group_stride_parts, int64_t group_stride_c,
+                       void* stream) {
     if (!parts || !C) return LSTC_E_NULL;
     if (((flags & LSTC_EPI_BIAS) && !bias) || ((flags & LSTC_EPI_RESIDUAL) && !residual) || ((flags & LSTC_EPI_RELU_MASK) && !relu_src))
         return LSTC_E_NULL;
@@ -1416,12 +1421,16 @@ int lstc_splitk_finish(const float* parts, int32_t splits, int64_t part_stride, 
         ((flags & LSTC_EPI_RELU_MASK) && ld_relu < N) || !(dropout_p >= 0.f && dropout_p < 1.f)) return LSTC_E_SHAPE;
     if (flags & ~(LSTC_EPI_BIAS | LSTC_EPI_RELU | LSTC_EPI_DROPOUT | LSTC_EPI_RESIDUAL | LSTC_EPI_RELU_MASK | LSTC_EPI_ACCUM))
         return LSTC_E_UNSUPPORTED;
-    if (M > 0x7fffffffLL || N > 0x7fffffffLL || (uint64_t)M * (uint64_t)N > 0xffffffffull) return LSTC_E_RANGE;
+    if (groups < 1 || (groups > 1 && (group_stride_parts < (int64_t)splits * part_stride || group_stride_c <= 0))) return LSTC_E_SHAPE;
+    if (groups > 1 && (flags & ~LSTC_EPI_ACCUM)) return LSTC_E_UNSUPPORTED;          // per-head groups: plain sums only
+    if (M > 0x7fffffffLL || N > 0x7fffffffLL || (uint64_t)M * (uint64_t)N * (uint64_t)groups > 0xffffffffull) return LSTC_E_RANGE;
+    if (group_stride_parts % 4 || group_stride_c % 4) return LSTC_E_ALIGN;
     if (N % 4 || part_stride % 4 || ldc % 4 || ((flags & LSTC_EPI_RESIDUAL) && ldr % 4) || ((flags & LSTC_EPI_RELU_MASK) && ld_relu % 4) ||
         !aligned16(parts) || !aligned16(C) || !aligned16(bias) || !aligned16(residual) || !aligned16(relu_src)) return LSTC_E_ALIGN;
     const DropKey dk = make_drop_key((flags & LSTC_EPI_DROPOUT) ? dropout_p : 0.f, dropout_seed);
-    hipLaunchKernelGGL(splitk_finish_kernel, grid_for(M * (N / 4), NT), NT, 0, (hipStream_t)stream, parts, (int)splits, part_stride, (int)M,
-                       (int)N, bias, residual, ldr, relu_src, ld_relu, C, ldc, (int)flags, dk);
+    hipLaunchKernelGGL(splitk_finish_kernel, grid_for(M * (N / 4) * groups, NT), NT, 0, (hipStream_t)stream, parts, (int)splits, part_stride,
+                       (int)M, (int)N, bias, residual, ldr, relu_src, ld_relu, C, ldc, (int)flags, dk, (int)groups, group_stride_parts,
+                       group_stride_c);
     return lstc_launch_status();
 }
 

@@ -417,7 +417,40 @@ def _gemm_small_m(a, b, trans_a, trans_b, M, N, K, lda, ldb, s, out, bias, relu,
     if accumulate:
         flags |= EPI_ACCUM
     check(_lib.load().lstc_splitk_finish(dev_ptr(parts), s, M * N, M, N, pbias, pres, ldr, pmask, ldm, pc, ldc, flags, p_drop, seed,
-                                         stream_ptr()), "lstc_splitk_finish")
+                                         1, 0, 0, stream_ptr()), "lstc_splitk_finish")
+    return out
+
+
+def _head_k_chunks(w: torch.Tensor, H: int, dh: int, dm: int, s: int) -> torch.Tensor:
+    """``w`` [H * dh, dm] as [H, s, dh, dm / s] (every head's K chunks back to back, so chunk z = h * s + kc of a batched launch is
+    at z * dh * (dm / s)); kept until the weight changes (never across a graph capture: the copy must be part of the graph)."""
+    key = (s, _wstamp(w))
+    c = w.__dict__.get("_lstc_kchunks")
+    if c is None or c[0] != key or torch.cuda.is_current_stream_capturing():
+        c = (key, w.detach().view(H, dh, s, dm // s).permute(0, 2, 1, 3).contiguous())
+        w.__dict__["_lstc_kchunks"] = c
+    return c[1]
+
+
+def per_head_rows_wT(a3: torch.Tensor, w: torch.Tensor, out: torch.Tensor, N: int, dh: int, dm: int, H: int, alpha: float = 1.0):
+    """out[n, h * dh + j] = alpha * sum_c a3[n, h, c] * w[h * dh + j, c]: the per-head products x-bar_h W_v,h^T and du_h W_k,h^T of the
+    re-associated CLS attention (one batched launch over the heads).  With few sequences (small_m_products) the 4 H tiles of a
+    rank's 256 sequences walk K = d_model alone: then every head's K range is chunked as well - batch z = h * s + kc over A as
+    it lies, a [H, s, dh, K/s] arrangement of the weight and partials [H, s, N, dh] - and lstc_splitk_finish sums the groups."""
+    s = 1
+    if _small_m_depth > 0 and _SMALL_M_SPLIT and dh % 4 == 0:
+        tiles = H * -(-N // 128) * -(-dh // 128)
+        if tiles <= 128 and dm >= 512:
+            while s < 16 and tiles * s * 2 <= 512 and dm % (s * 2 * 64) == 0 and dm // (s * 2) >= 256:
+                s *= 2
+    if s == 1:
+        return gemm_batched(a3, w, out, N, dh, dm, H * dm, dm, H * dh, False, True, H, dm, dh * dm, dh, alpha=alpha)
+    Kc = dm // s
+    wc = _head_k_chunks(w, H, dh, dm, s)
+    parts = torch.empty((H * s, N * dh), device=a3.device, dtype=torch.float32)
+    gemm_batched(a3, wc, parts, N, dh, Kc, H * dm, Kc, dh, False, True, H * s, Kc, dh * Kc, N * dh, alpha=alpha)
+    check(_lib.load().lstc_splitk_finish(dev_ptr(parts), s, N * dh, N, dh, None, None, 0, None, 0, dev_ptr(out), H * dh, 0, 0.0, 0,
+                                         H, s * N * dh, dh, stream_ptr()), "lstc_splitk_finish")
     return out
 
 
@@ -461,8 +494,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
         Kb, N = (bc, br) if trans_b else (br, bc)
     if K != Kb:
         raise RuntimeError(f"gemm inner dims differ: {K} vs {Kb}")
+    # (not the products that feed a ReLU: which side of zero a pre-activation of magnitude 1e-7 lands on follows the summation order,
+    # and one flipped unit of the CLS-only layer's FFN rewrites a row of dW1 - they keep the k order of the one-launch form, which is
+    # also the evaluation's)
     if _small_m_depth > 0 and _SMALL_M_SPLIT and pa is not None and pb is not None and split_k == 1 and variant == 0 and not out_pack \
-            and not isinstance(residual, Packed) and not isinstance(relu_mask, Packed) and lda % 4 == 0 and ldb % 4 == 0:
+            and not relu and not isinstance(residual, Packed) and not isinstance(relu_mask, Packed) and lda % 4 == 0 and ldb % 4 == 0:
         s_small = _small_m_split(M, N, K)
         if s_small > 1:
             return _gemm_small_m(a, b, trans_a, trans_b, M, N, K, lda, ldb, s_small, out, bias, relu, dropout, residual, relu_mask,
@@ -1425,7 +1461,7 @@ class MHAClsAssocFunction(torch.autograd.Function):
             pd, probs = cls_dot_pack(u, xp, N, S, 1, None, p_attn, seed_a)
             xb = cls_wsum_pack(pd, xp, N, S)
         oc = torch.empty((N, H * dv), device=x.device, dtype=torch.float32)
-        gemm_batched(xb, wv, oc, N, dv, dm, H * dm, dm, H * dv, False, True, H, dm, dv * dm, dv)
+        per_head_rows_wT(xb, wv, oc, N, dv, dm, H)
         y = gemm(oc, wfc, trans_b=True, dropout=(p_fc, seed_f), residual=xc)
         if cfg["layer_norm"]:
             z, mean, rstd = layernorm_fwd(y, ln_w, ln_b, 1e-6)
@@ -1466,7 +1502,7 @@ class MHAClsAssocFunction(torch.autograd.Function):
             ds, _ = cls_dot_pack(dxb, xp, N, S, 2, probs, c["p_attn"], c["seed_a"])
             du = cls_wsum_pack(ds, xp, N, S)
         dqc = torch.empty_like(qc)
-        gemm_batched(du, wk, dqc, N, dk, dm, H * dm, dm, H * dk, False, True, H, dm, dk * dm, dk, alpha=scale)
+        per_head_rows_wT(du, wk, dqc, N, dk, dm, H, alpha=scale)
         dwk = grad_sink(wk)
         dwk = torch.empty_like(wk) if dwk is None else dwk
         gemm_batched(qc, du, dwk, dk, dm, N, H * dk, H * dm, dm, True, False, H, dk, dm, dk * dm, alpha=scale)
