@@ -424,7 +424,7 @@ def _gemm_small_m(a, b, trans_a, trans_b, M, N, K, lda, ldb, s, out, bias, relu,
 def _head_k_chunks(w: torch.Tensor, H: int, dh: int, dm: int, s: int) -> torch.Tensor:
     """``w`` [H * dh, dm] as [H, s, dh, dm / s] (every head's K chunks back to back, so chunk z = h * s + kc of a batched launch is
     at z * dh * (dm / s)); kept until the weight changes (never across a graph capture: the copy must be part of the graph)."""
-    key = (s, _wstamp(w))
+    key = (s, _wstamp(w), w._version, w.data_ptr())       # raw-pointer updates bump the stamp, torch's in-place ops the version
     c = w.__dict__.get("_lstc_kchunks")
     if c is None or c[0] != key or torch.cuda.is_current_stream_capturing():
         c = (key, w.detach().view(H, dh, s, dm // s).permute(0, 2, 1, 3).contiguous())
