@@ -254,6 +254,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the LSTC_VAD hot path here is HIP-only (no CPU fallback)")
+    share = os.environ.get("LSTC_SHARE_DEVICE") == "1"              # one-GPU test boxes: every rank on device 0 (a functional check
+    if share:                                                       # of the N-rank path, never a measurement; RCCL refuses it: gloo)
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: --gpus {world} but only {torch.cuda.device_count()} device(s) visible")
     torch.cuda.set_device(local_rank)
@@ -262,7 +265,10 @@ def main():
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if share:
+            dist.init_process_group(os.environ.get("LSTC_DIST_BACKEND", "gloo"), rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
     if a.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     strong = a.scaling == "strong"

@@ -252,3 +252,20 @@ def test_bench_line_contract_and_the_forced_rccl_bucket_path():
     assert c["backward_ms_per_step"] > 0 and 0 <= c["comm_exposed_ms_per_step"] < c["backward_ms_per_step"]
     assert c["nccl_env"].get("NCCL_ALGO") == "Ring" and c["nccl_env"].get("NCCL_PROTO") == "Simple" and c["rccl_ranks"] == 1
     assert abs(f["loss_first_timed_step"] - o["loss_first_timed_step"]) < 1e-6 and abs(f["loss_last_timed_step"] - o["loss_last_timed_step"]) < 1e-6
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_bench_two_ranks_start_themselves_and_report_one_line(dtype):
+    """``python bench.py --gpus 2`` as the driver would run it on a 2-GPU node, here with both ranks on the box's one GPU over gloo
+    (LSTC_SHARE_DEVICE=1: a functional check of the N-rank path of bench.py - its own launcher, the feed's per-rank shard of the
+    global batch with the gather fused into the CLS concat, the bag exchange, gradient sinks + bucketed all-reduce, the barrier /
+    max-over-ranks timing - never a measurement): ONE JSON line from rank 0 with n_gpus 2, dp2, the whole model's gradient bytes
+    in the buckets, value = the GLOBAL batch's snippets over the step time, finite falling loss."""
+    o = _bench_line(["--gpus", "2", "--dtype", dtype, "--batch_size", "4"],
+                    {"LSTC_SHARE_DEVICE": "1", "LSTC_DIST_BACKEND": "gloo", "MASTER_PORT": str(_free_port())})
+    c = o["config"]
+    assert o["n_gpus"] == 2 and c["parallelism"] == "dp2" and c["rccl_ranks"] == 2 and o["scaling"] == "strong"
+    assert c["per_rank_pairs"] == 2 and c["allreduce_MB"] > 400 and len(c["allreduce_buckets"]) == 1
+    assert abs(o["value"] - 2 * 4 * 8 * 3 / (o["ms_per_step"] * 1e-3)) < 0.02 * o["value"]          # global snippets per step / step time
+    assert 0 < o["loss_last_timed_step"] < 3 and 0 < o["loss_first_timed_step"] < 3
