@@ -309,7 +309,7 @@ int lstc_layernorm_bwd_drop_pack(const float* dy, const float* x, const float* g
  * gradient of the residual stream travels as packs too - 2 bytes per element per pass instead of 4 (+2 for the pack).
  * Statistics, normalisation, dropout replay and the partial sums are f32 arithmetic; only what is stored is bf16 (RNE).
  *   lstc_layernorm_fwd_act: exactly one of x (f32 [rows, d]) / x_pack (pack of [rows, d]) is the input; y (f32) and / or y_pack
- *                           receive the result (the last full layer hands f32 to the CLS-only layer).
+ *                           receive the result (f32: the stream's exit where the CLS-only layer cannot read a pack).
  *   lstc_layernorm_bwd_act: x_pack = the forward's input pack; the incoming gradient is dy (f32) or dy_pack; dx_pack (may be
  *                           NULL: nobody reads layer 0's) = gradient of the residual sum, df_pack = dropout-replay(dx) exactly
  *                           as lstc_layernorm_bwd_drop_pack, partial [3, n_partial, d] = dgamma, dbeta, column sums of df.

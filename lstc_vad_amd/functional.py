@@ -152,7 +152,7 @@ def act_chain_ok(N: int, S: int, dm: int, layers) -> bool:
         return False
     for layer in layers:
         a, f = layer.slf_attn, layer.pos_ffn
-        # the FFN needs its LayerNorm (the stream's f32 exit - the block in front of the CLS-only layer - is an LN kernel); the
+        # the FFN needs its LayerNorm (the stream's f32 exit - where the CLS-only layer or the caller wants rows - is an LN kernel); the
         # attention block runs with or without one (STN configs: MHA_layerNorm = False, its sum dropout(fc(o)) + x IS the output)
         if not (layer.FFN_need and f.layerNorm_flag and a.d_model == dm):
             return False
