@@ -173,7 +173,9 @@ struct PkParams {
 #ifndef PK_GROUP_M
 #define PK_GROUP_M 8          /* grouped tile order inside an XCD's run (as csrc/gemm_f32.hip); 0 = row-major, the order of rounds 1-3.
                                  Same-box A/B, round 4: 100352 x 4096 x 2048 4.44 -> 4.13 ms, x 2048 x 2048 2.16 -> 2.14, weight gradient
-                                 2.22 -> 2.15, f32x3 LTN step 117.1 / 117.2 -> 115.6 / 115.7 ms; bit-identical products */
+                                 2.22 -> 2.15, f32x3 LTN step 117.1 / 117.2 -> 115.6 / 115.7 ms; bit-identical products.  Round 5: 2 / 4 / 16 against 8 on the
+                                 step's four forward shapes: within 2 % of each other (16 is 8 % slower at K = 4096) although the launch
+                                 moves 7.3 GB for 1.7 GB of operands (profiles/r05_gemm_pk_pmc.txt): the re-fetches are Infinity-Cache hits */
 #endif
 // linear tile index (after the XCD remap) -> (M tile, N tile): row-major, or groups of PK_GROUP_M consecutive M tiles walked M
 // fastest - the 64 tiles resident on an XCD then cover 8 x 8 tiles instead of 4 x 16 and share twice as much per K step
