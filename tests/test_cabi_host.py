@@ -87,6 +87,21 @@ def test_host_side_validation_error_codes(lib):
     assert lib.lstc_clip_scale_multi(items, 2, None, 10.0, None) == -1 and lib.lstc_clip_scale_multi(items, 2, 16, 0.0, None) == -2
     assert lib.lstc_colsum_batched(None, 3, 8, 8, 8, 64, 16, 8, 16, None) == -1
     assert lib.lstc_colsum_batched(16, 0, 8, 8, 8, 64, 16, 8, 16, None) == -2 and lib.lstc_colsum_batched(16, 3, 8, 8, 4, 64, 16, 8, 16, None) == -2
+    # round-5 entry points: the packed CLS passes, row unpacking and the K-chunk finish validate before any launch
+    assert lib.lstc_cls_dot_pack(None, 16, 16, 16, 256, 49, 8, 2048, 1, 0.0, 0, None) == -1
+    assert lib.lstc_cls_dot_pack(16, 16, 16, 16, 256, 49, 16, 2048, 1, 0.0, 0, None) == -4        # H > 8
+    assert lib.lstc_cls_dot_pack(16, 16, 16, 16, 255, 49, 8, 2048, 1, 0.0, 0, None) == -4         # rows % 256
+    assert lib.lstc_cls_dot_pack(16, 16, 16, None, 256, 49, 8, 2048, 1, 0.0, 0, None) == -1       # softmax mode needs probs
+    assert lib.lstc_cls_wsum_pack(16, 16, 16, 256, 129, 8, 2048, None) == -5                      # S > 128
+    assert lib.lstc_cls_outer_pack(16, 16, 16, 16, 8, 16, 256, 49, 8, 2048, None) == -3           # add0 not 16-B aligned
+    assert lib.lstc_unpack1_rows(16, 256, 2048, 0, 49, 7, 16, 2048, None) == -2                   # rows past the end
+    assert lib.lstc_unpack1_rows(16, 256, 2044, 0, 1, 4, 16, 2044, None) == -3                    # K % 8
+    assert lib.lstc_splitk_finish(None, 4, 64, 8, 8, None, None, 0, None, 0, 16, 8, 0, 0.0, 0, 1, 0, 0, None) == -1
+    assert lib.lstc_splitk_finish(16, 4, 32, 8, 8, None, None, 0, None, 0, 16, 8, 0, 0.0, 0, 1, 0, 0, None) == -2       # part_stride < M * N
+    assert lib.lstc_splitk_finish(16, 4, 64, 8, 8, None, None, 0, None, 0, 16, 8, 1, 0.0, 0, 1, 0, 0, None) == -1       # BIAS without bias
+    assert lib.lstc_splitk_finish(16, 4, 64, 8, 8, None, None, 0, None, 0, 16, 8, 128, 0.0, 0, 1, 0, 0, None) == -4     # pack flags
+    assert lib.lstc_splitk_finish(16, 4, 64, 8, 8, 16, None, 0, None, 0, 16, 8, 1, 0.0, 0, 8, 256, 8, None) == -4       # groups: plain sums only
+    assert lib.lstc_splitk_finish(16, 4, 64, 8, 6, None, None, 0, None, 0, 16, 8, 0, 0.0, 0, 1, 0, 0, None) == -3       # N % 4
     d = GemmDesc()
     assert lib.lstc_gemm(C.byref(d), None) == -1                      # NULL operands
     d.A = d.B = d.C = 16
