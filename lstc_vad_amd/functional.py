@@ -427,7 +427,7 @@ def _head_k_chunks(w: torch.Tensor, H: int, dh: int, dm: int, s: int) -> torch.T
     key = (s, _wstamp(w), w._version, w.data_ptr())       # raw-pointer updates bump the stamp, torch's in-place ops the version
     c = w.__dict__.get("_lstc_kchunks")
     if c is None or c[0] != key or torch.cuda.is_current_stream_capturing():
-        c = (key, w.detach().view(H, dh, s, dm // s).permute(0, 2, 1, 3).contiguous())
+        c = (key, w.detach().contiguous().view(H, dh, s, dm // s).permute(0, 2, 1, 3).contiguous())
         w.__dict__["_lstc_kchunks"] = c
     return c[1]
 
