@@ -27,7 +27,7 @@ tools/tuning/%.o: $(CSRC)/%.hip $(CSRC)/lstc_common.h $(CSRC)/attention_common.h
 tools/tuning/liblstc_hip.so: $(TOBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(TOBJS)
 tools/tuning/gemm_check: tools/gemm_check.cpp tools/tuning/liblstc_hip.so
-	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -Iinclude $< -o $@ -Ltools/tuning -llstc_hip -Wl,-rpath,'$$ORIGIN'
+	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -DLSTC_TUNING -Iinclude $< -o $@ -Ltools/tuning -llstc_hip -Wl,-rpath,'$$ORIGIN'
 tuning: tools/tuning/gemm_check
 
 clean:

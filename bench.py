@@ -113,11 +113,13 @@ class SyntheticResidentPairs:
     of the GLOBAL batch (identical ``np.random`` consumption on every rank), and ``lstc_gather_rows`` forms this rank's
     shard ``[bs_local, pn*L, P, d]`` x2 out of the bank.  Pair order: a fresh permutation per epoch (``shuffle_keys``)."""
 
-    def __init__(self, cfg_name, bs_global, part_num, dev, rank, world, seed):
+    def __init__(self, cfg_name, bs_global, part_num, dev, rank, world, seed, max_clips=0):
         import numpy as np
         import torch
         from lstc_vad_amd.feed import ResidentBank
         mode, ekw, skw, _, (lo, hi) = CONFIGS[cfg_name]
+        if max_clips:
+            hi = max(min(hi, max_clips), lo)
         self.np, self.bs, self.pn, self.L = np, bs_global, part_num, skw["part_len"]
         self.rank, self.world = rank, world
         P, d = skw["n_patch"], ekw["d_model"]
@@ -194,6 +196,9 @@ def main():
     ap.add_argument("--batch_size", type=int, default=32, help="normal/abnormal pairs of the GLOBAL batch under --scaling strong "
                     "(B = 2*batch_size videos), per GPU under --scaling weak")
     ap.add_argument("--part_num", type=int, default=32)
+    ap.add_argument("--max_clips", type=int, default=0, help="cap the synthetic videos' clip counts (0 = the config's range; the UCF "
+                    "config draws up to 4000 clips per video = a 19-GB bank, which the shared-device functional checks - N ranks on ONE "
+                    "GPU, one bank each - cut down)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--feed", default="resident", choices=["resident", "static"],
                     help="resident (default): every step forms a fresh batch (host window sampler + lstc_gather_rows from the "
@@ -269,6 +274,8 @@ def main():
             dist.init_process_group(os.environ.get("LSTC_DIST_BACKEND", "gloo"), rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        from lstc_vad_amd.launch import mark_rank_ready
+        mark_rank_ready()
     if a.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     strong = a.scaling == "strong"
@@ -306,7 +313,7 @@ def main():
         feed = feed or a.feed
         if feed == "resident":
             src = SyntheticResidentPairs(cfg_name, bs_g, pn, dev, rank if strong else 0, world if strong else 1,
-                                         seed=1000 + 97 * seed_off + (0 if strong else rank))
+                                         seed=1000 + 97 * seed_off + (0 if strong else rank), max_clips=a.max_clips)
             nxt = src.next_batch
         else:
             gen = torch.Generator(device=dev).manual_seed(1000 + rank + 97 * seed_off)
@@ -574,6 +581,7 @@ def main():
         del ts, nxt, feeder
 
     rccl_ranks = 1
+    dist_backend = dist.get_backend() if dist.is_initialized() else None      # "nccl" = RCCL; "gloo" only in the shared-device functional checks
     if dist.is_initialized():
         # ranks that really joined the communicator: every rank contributes a 1 to a sum-all-reduce over RCCL
         one = torch.ones(1, device=dev, dtype=torch.float32)
@@ -624,7 +632,9 @@ def main():
                                       f"fresh weights and Adagrad state for the timed pass",
                           "feed": feed_txt, "global_videos": 2 * bs_global, "parallelism": f"dp{world}",
                           "per_rank_pairs": bs_local, "per_rank_sequences": nseq, "allreduce_MB": head_res["allreduce_MB"],
-                          "rccl_ranks": rccl_ranks,
+                          # rccl_ranks counts the ranks of the process group that answered a sum-all-reduce; whether that group IS
+                          # RCCL is dist_backend ("nccl" = RCCL over xGMI; "gloo" = the one-GPU functional check, never a measurement)
+                          "rccl_ranks": rccl_ranks, "dist_backend": dist_backend,
                           # N > 1: HIP events on the launch stream around backward and around reducer.finish() (max over ranks, mean
                           # over the timed steps): how much of the gradient all-reduce the backward did not hide
                           **(head_res["comm"] or {}),

@@ -101,10 +101,12 @@ typedef struct LstcGemmDesc {
                                        C + z*batch_stride_c instead (no atomics; the caller sums the partials) */
     int32_t variant;                /* 0 = library default tile (LSTC_F32: 128x128 tiles, one tile per workgroup, with the rows of a
                                        mostly empty last tile round on the 64x64 variant - bit-identical results; the default NEVER
-                                       selects the persistent kernel); 1..12 select a documented tile variant (tuning / tests;
-                                       12 = the persistent walk of the default loop, bit-identical, measured slower - in every
-                                       build); anything else -> LSTC_E_UNSUPPORTED.  Timing-only ablation variants (13-15) exist
-                                       only in -DLSTC_TUNING builds (tools/gemm_check), never in the production library */
+                                       selects the persistent kernel); LSTC_F32 in the production library: 4 = the default loop
+                                       without the row split, 8 = its fallback for unaligned operands (scalar epilogue: the
+                                       reference of the bitwise tests), 11 = the 64x64 tail tile, 12 = the persistent walk of the
+                                       default loop (bit-identical, measured slower); anything else -> LSTC_E_UNSUPPORTED.  The
+                                       other tile variants (1-3, 5-7, 9, 10) and the timing-only ablations (13-15) exist only in
+                                       -DLSTC_TUNING builds (`make tuning`, tools/tuning/gemm_check), never in the production library */
     int32_t batch;                  /* 0/1 = single problem; >1: `batch` independent problems of identical shape, problem z
                                        uses A + z*batch_stride_a etc. (elements).  Per-head products of the last layer's
                                        CLS attention (q_h W_k,h etc.).  Only alpha / ACCUM epilogues. */

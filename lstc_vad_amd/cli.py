@@ -182,7 +182,10 @@ def _launch_data_parallel(script: str, args: Namespace):
     folder = "Test" if script.startswith("evaluation") else "Train"
     child = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), folder, script + ".py")
     rc = launch_ranks(n_ranks, namespace_to_argv(script, args), script=child,
-                      rank_timeout_s=float(os.environ.get("LSTC_RANK_TIMEOUT_S", "0")), relay="all", devices=devs, tag=script)
+                      rank_timeout_s=float(os.environ.get("LSTC_RANK_TIMEOUT_S", "0")), relay="all", devices=devs, tag=script,
+                      # a rank hung in the rendezvous / RCCL communicator set-up would block the parent forever: 15 minutes to join
+                      # the process group (lstc_vad_amd.launch.mark_rank_ready), no limit on the training run itself
+                      init_timeout_s=float(os.environ.get("LSTC_INIT_TIMEOUT_S", "900")))
     if rc:
         raise SystemExit(rc)
     res = launch_ranks.last_result
@@ -204,6 +207,8 @@ def _init_ranks(torch):
         backend = os.environ.get("LSTC_DIST_BACKEND", "nccl")         # nccl = RCCL over xGMI
         if not dist.is_initialized():
             dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+        from .launch import mark_rank_ready
+        mark_rank_ready()
     return rank, world, dev
 
 
@@ -419,6 +424,11 @@ def train(script: str, argv=None, args=None):
         # temporal model's pseudo labels, score > --threshold else 0, to --temporal_pseudo_path (np.save appends .npy)
         from . import bump_weight_epoch
         from .pipeline import generate_pseudo_labels as gen
+        if world > 1:
+            # the paths may name checkpoints rank 0 wrote in THIS run (after the evaluation all-reduce, or --save_final): no rank
+            # may read them before rank 0's torch.save has returned - it would score with a partial file and the sum-all-reduce of
+            # the label scores would mix two sets of weights
+            dist.barrier()
         enc.load_state_dict(strip(torch.load(args.spatio_model_path, map_location="cpu")), False)
         head.load_state_dict(strip(torch.load(args.regression_model_path, map_location="cpu")), False)
         bump_weight_epoch()
@@ -618,7 +628,8 @@ def generate_pseudo_labels(script: str, argv=None, args=None):
             dist.barrier()
             dist.destroy_process_group()
         return out
-    # same seed -> same synthetic training videos (keys, lengths) as the Train/*.py loops on rank 0
+    # same seed -> same synthetic training videos (keys, lengths) as the Train/*.py loops on rank 0.  This branch is not sharded
+    # (a few synthetic videos): under a --data_parallel launch every rank scores them all, rank 0 ALONE writes the file and prints
     data = SyntheticVideos(args.synthetic_pairs or 8, 1, 1, part_len, args.n_patch, args.d_model, dev,
                            seed=int(getattr(args, "seed", 0)))
     out = {}
@@ -627,8 +638,13 @@ def generate_pseudo_labels(script: str, argv=None, args=None):
             s = score_video(enc, head, mode, feats, part_len)
             s = torch.where(s > args.threshold, s, torch.zeros_like(s))
             out[key] = s.reshape(-1, 1).cpu().numpy()
-    np.save(args.pseudo_labels_path, out)
-    print(f"{'temporal' if mode == 'LTN' else 'spatio'} pseudo label generation finished.")
+    if rank == 0:
+        np.save(args.pseudo_labels_path, out)
+        print(f"{'temporal' if mode == 'LTN' else 'spatio'} pseudo label generation finished.")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     return out
 
 

@@ -939,12 +939,13 @@ int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipS
     //   2, 6, 5 = 256x128 with 8 waves (PIPE 1 / 2 / 0)                           115-126, never the best
     //  13-15 = (-DLSTC_TUNING builds only) timing-only ablations of variant 8 (NT): no loads 142, no loads/LDS writes 146,
     //          +no barrier 146.5.  12 is the persistent kernel in EVERY build.
+    // The PRODUCTION library (`make all`) holds 0 = 4, 8 (the default's fallback), 11 and 12; variants 1-3, 5-7, 9, 10 are compiled into
+    // `make tuning` builds only (tools/tuning/liblstc_hip.so) and refused here otherwise.
     if (variant == 0) variant = 4;
     const int BM = (variant == 2 || variant == 5 || variant == 6 || variant == 9) ? 256 : variant == 11 ? 64 : 128, BN = variant == 11 ? 64 : 128;
     p.tilesM = (p.M + BM - 1) / BM;
     p.tilesN = (p.N + BN - 1) / BN;
     switch (variant) {
-        case 1: return launch_cfg<128, 128, 2, 2, 0, A_KC, B_KC>(p, va, vb, splits, st);
         case 11: return launch_cfg<64, 64, 2, 2, 0, A_KC, B_KC>(p, va, vb, splits, st);    // small tile: the tail rows of a row-split product
         //  12 = persistent PIPE 5 (gemm_f32_persist_kernel): next tile's first loads before the epilogue, float4 epilogue
         case 12: if (va && vb && p.a_bytes && p.b_bytes && splits == 1 && p.batch == 1 && p.K % BK == 0 && p.ktiles >= 4 && p.epi_f4)
@@ -954,18 +955,20 @@ int launch_layout(GemmParams& p, bool va, bool vb, int splits, int variant, hipS
                  }
                  if (va && vb && p.a_bytes && p.b_bytes) return launch_cfg<128, 128, 2, 2, 5, A_KC, B_KC>(p, true, true, splits, st);
                  return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);
+        case 8: return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // = the default's fallback for unaligned operands
+        case 4: if (va && vb && p.a_bytes && p.b_bytes) return launch_cfg<128, 128, 2, 2, 5, A_KC, B_KC>(p, true, true, splits, st);
+                return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // buffer path: aligned, < 4 GiB operands
+#ifdef LSTC_TUNING      // `make tuning` only (VERDICT r5 upkeep): the tile variants the product never selects - ~110 kernel instantiations,
+                        // half of the production library's size and build time - and the timing-only ablations (wrong products by construction)
+        case 1: return launch_cfg<128, 128, 2, 2, 0, A_KC, B_KC>(p, va, vb, splits, st);
         case 3: return launch_cfg<128, 128, 2, 2, 2, A_KC, B_KC>(p, va, vb, splits, st);
         case 6: return launch_cfg<256, 128, 4, 2, 2, A_KC, B_KC>(p, va, vb, splits, st);
         case 2: return launch_cfg<256, 128, 4, 2, 1, A_KC, B_KC>(p, va, vb, splits, st);
         case 5: return launch_cfg<256, 128, 4, 2, 0, A_KC, B_KC>(p, va, vb, splits, st);
         case 7: return launch_cfg<128, 128, 2, 2, 1, A_KC, B_KC>(p, va, vb, splits, st);
-        case 8: return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);
         case 9: return launch_cfg<256, 128, 4, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // 8 waves x (64x64), PIPE 3
-        case 4: if (va && vb && p.a_bytes && p.b_bytes) return launch_cfg<128, 128, 2, 2, 5, A_KC, B_KC>(p, true, true, splits, st);
-                return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // buffer path: aligned, < 4 GiB operands
         case 10: if (va && vb && p.K % BK == 0) return launch_cfg<128, 128, 2, 2, 4, A_KC, B_KC>(p, true, true, splits, st);
                  return launch_cfg<128, 128, 2, 2, 3, A_KC, B_KC>(p, va, vb, splits, st);   // LDS-DMA needs aligned rows, full K tiles
-#ifdef LSTC_TUNING      // timing-only ablations: products are WRONG by construction; never in the production library
         case 13: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 1, A_KC, B_KC>(p, va, vb, splits, st); return LSTC_E_UNSUPPORTED;
         case 14: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 3, A_KC, B_KC>(p, va, vb, splits, st); return LSTC_E_UNSUPPORTED;
         case 15: if constexpr (A_KC && B_KC) return launch_cfg<128, 128, 2, 2, 3 + 16 * 7, A_KC, B_KC>(p, va, vb, splits, st); return LSTC_E_UNSUPPORTED;
@@ -1005,7 +1008,7 @@ __attribute__((visibility("hidden"))) int lstc_gemm_f32_impl(const LstcGemmDesc*
 #else
     // the production library accepts the documented tile variants only: garbage in this public field must not select a
     // timing ablation or an undefined tile (LstcGemmDesc.variant, include/lstc_hip.h)
-    if (d->variant < 0 || d->variant > 12) return LSTC_E_UNSUPPORTED;
+    if (!(d->variant == 0 || d->variant == 4 || d->variant == 8 || d->variant == 11 || d->variant == 12)) return LSTC_E_UNSUPPORTED;
     p.debug = 0;
 #endif
     const size_t a_ext = ((size_t)((d->transA ? d->K : d->M) - 1) * d->lda + (d->transA ? d->M : d->K)) * sizeof(float) + p.batch_stride_a * sizeof(float) * (size_t)(p.batch - 1) * 0;

@@ -127,6 +127,10 @@ class ResidentBank:
         """``idx``: int64 numpy array of clip rows (any shape); returns ``bank[idx]`` with shape ``idx.shape + row`` plus the
         ``extras`` (small numpy arrays, e.g. labels) as device tensors.  ``lazy`` (``idx`` of shape [2, bs, rows]): the two
         halves come back as ``LazyRows`` - the indices are on the device, the rows are gathered by whoever consumes them."""
+        # the fused gather reads bank[(idx * P + patch) ...] with no bound of its own (lstc_cls_concat_gather_fwd, lstc_gather_rows):
+        # a stale or negative clip index would be a silent out-of-bounds read of HBM - reject it here, on a few hundred integers
+        if idx.size and (int(idx.min()) < 0 or int(idx.max()) >= int(self.bank.shape[0])):
+            raise IndexError(f"clip index out of range for a bank of {int(self.bank.shape[0])} clips: [{int(idx.min())}, {int(idx.max())}]")
         dev = self._stage([idx.reshape(-1)] + list(extras))
         if lazy:
             if idx.ndim != 3 or idx.shape[0] != 2:

@@ -30,29 +30,66 @@ def _splitmix64(x: np.ndarray) -> np.ndarray:
     return z
 
 
+_CHUNK = 1 << 24        # counters per pass: bounds the uint64 / float64 temporaries of the headline-size batches (805 MB each) to ~1 GB
+
+
+def _stream_base(seed: int, stream: int) -> np.uint64:
+    with np.errstate(over="ignore"):
+        return _splitmix64(np.array([(seed * 0x1000003 + stream * 0x10001 + 0x5bd1e995) & 0xFFFFFFFFFFFFFFFF],
+                                    dtype=np.uint64))[0]
+
+
+def _uniform_at(lo: int, hi: int, base) -> np.ndarray:
+    """float64 uniforms of the counters lo .. hi-1 of a stream (24 random bits each)."""
+    with np.errstate(over="ignore"):
+        ctr = (np.arange(lo, hi, dtype=np.uint64) * np.uint64(0x2545F4914F6CDD1D) + base) & _MASK64
+    bits = _splitmix64(ctr) >> np.uint64(40)            # top 24 bits
+    return bits.astype(np.float64) * (1.0 / 16777216.0)
+
+
 def uniform(shape, seed: int, stream: int = 0) -> np.ndarray:
     """float32 uniforms in [0, 1) with 24 random bits each; exact and portable."""
     n = int(np.prod(shape)) if len(tuple(shape)) else 1
-    with np.errstate(over="ignore"):
-        base = _splitmix64(np.array([(seed * 0x1000003 + stream * 0x10001 + 0x5bd1e995) & 0xFFFFFFFFFFFFFFFF],
-                                    dtype=np.uint64))[0]
-        ctr = (np.arange(n, dtype=np.uint64) * np.uint64(0x2545F4914F6CDD1D) + base) & _MASK64
-    bits = _splitmix64(ctr) >> np.uint64(40)            # top 24 bits
-    return (bits.astype(np.float64) * (1.0 / 16777216.0)).astype(np.float32).reshape(shape)
+    base = _stream_base(seed, stream)
+    out = np.empty(n, np.float32)
+    for lo in range(0, n, _CHUNK):
+        hi = min(n, lo + _CHUNK)
+        out[lo:hi] = _uniform_at(lo, hi, base).astype(np.float32)
+    return out.reshape(shape)
+
+
+def normal_range(n: int, lo: int, hi: int, seed: int, stream: int = 0) -> np.ndarray:
+    """Elements lo .. hi-1 of ``normal((n,), seed, stream)`` without forming the rest (a rank's shard of a global batch):
+    element i adds the uniforms of the counters i, n + i, 2 n + i, 3 n + i."""
+    base = _stream_base(seed, stream)
+    out = np.empty(hi - lo, np.float32)
+    for a in range(lo, hi, _CHUNK):
+        b = min(hi, a + _CHUNK)
+        # the float32 rounding of each uniform is part of the definition (uniform() returns float32)
+        u = [_uniform_at(j * n + a, j * n + b, base).astype(np.float32).astype(np.float64) for j in range(4)]
+        s = (u[0] + u[1]) + (u[2] + u[3])
+        out[a - lo:b - lo] = ((s - 2.0) * 1.7320508075688772).astype(np.float32)
+    return out
 
 
 def normal(shape, seed: int, stream: int = 0) -> np.ndarray:
     """Approximately N(0,1) float32 (sum of 4 uniforms, centred, scaled by sqrt(3))."""
     n = int(np.prod(shape)) if len(tuple(shape)) else 1
-    u = uniform((4, n), seed, stream).astype(np.float64)
-    s = (u[0] + u[1]) + (u[2] + u[3])
-    return ((s - 2.0) * 1.7320508075688772).astype(np.float32).reshape(shape)
+    return normal_range(n, 0, n, seed, stream).reshape(shape)
 
 
 def features(shape, seed: int, stream: int = 0) -> np.ndarray:
     """I3D-like snippet features: post-ReLU, non-negative, ``0.5*relu(N(0,1))``."""
     x = normal(shape, seed, stream)
     return (0.5 * np.maximum(x, 0.0)).astype(np.float32)
+
+
+def features_rows(shape, lo: int, hi: int, seed: int, stream: int = 0) -> np.ndarray:
+    """Rows lo .. hi-1 (first axis) of ``features(shape, seed, stream)``: what one rank of a data-parallel job holds of the batch."""
+    shape = tuple(shape)
+    row = int(np.prod(shape[1:]))
+    x = normal_range(shape[0] * row, lo * row, hi * row, seed, stream)
+    return (0.5 * np.maximum(x, 0.0)).astype(np.float32).reshape((hi - lo,) + shape[1:])
 
 
 def pseudo_labels(shape, seed: int, threshold: float, stream: int = 0) -> np.ndarray:

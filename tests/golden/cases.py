@@ -79,6 +79,20 @@ PACKED_CASES = {
                                           FFN_layerNorm=True, relative_pe=True, window_size=4, window_depth=5),
                               dict(batch_size=8, part_num=16, part_len=5, n_patch=16), 36),   # 256 sequences, S = 81, 20736 tokens
 }
+# The step bench.py's ``value`` times, held by the reference itself (missing #2): B = 64 videos (--batch_size 32),
+# T = 32 parts, P = 16 patches, d = 2048 - LTN at part_len 3 (2048 sequences of S = 49, 100 352 tokens,
+# Train/temporal_transformer_shanghaitech.py:99-144) and the literal [64, 32, 16, 2048] STN input (2048 sequences of S = 17,
+# Train/spatio_transformer_shanghaitech.py:90-101).  One reference step is 58 / 17 TFLOP and ~35 / 12 GB of autograd state on the
+# CPU: ~7 + 2 minutes of the build container's 8 cores, so tests/test_golden_recipes.py regenerates these two only when
+# LSTC_GOLDEN_HEADLINE=1 (the log of this round's regeneration: profiles/r06_headline_golden_regen.log); same recipe, same
+# sampled fixture format as FULL_CASES.
+HEADLINE_CASES = {
+    "ltn_headline": ("LTN", dict(d_model=2048, n_head=8, d_k=256, d_v=256, d_inner=4096, MHA_layerNorm=True,
+                                 FFN_layerNorm=True, relative_pe=True, window_size=4, window_depth=3),
+                     dict(batch_size=32, part_num=32, part_len=3, n_patch=16), 41),   # 2048 sequences, S = 49, 100352 tokens
+    "stn_headline": ("STN", dict(d_model=2048, n_head=8, d_k=256, d_v=256, d_inner=3027, FFN_layerNorm=True),
+                     dict(batch_size=32, part_num=32, part_len=1, n_patch=16), 42),   # 2048 sequences, S = 17, 34816 tokens
+}
 N_SAMPLE = 256
 
 

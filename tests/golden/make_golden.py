@@ -58,7 +58,7 @@ torch.set_num_threads(4)
 OUT_DIR = HERE      # ``--out DIR`` writes elsewhere (tests/test_golden_recipes.py regenerates into a temp dir and diffs)
 
 
-from cases import CASES, FULL_CASES, PACKED_CASES, fill_params, sample_index   # noqa: E402
+from cases import CASES, FULL_CASES, PACKED_CASES, HEADLINE_CASES, fill_params, sample_index   # noqa: E402
 
 
 def make_args(enc_kw, st_kw):
@@ -336,3 +336,7 @@ if __name__ == "__main__":
                 # the 256-sequence cases sum two to four times as many tokens into every gradient: a wider band of recorded
                 # ReLU-edge units (the summation-order noise of a pre-activation grows with the operand magnitudes it adds up)
                 run_full_case(name, mode, ekw, skw, seed, relu_edge=3 * RELU_EDGE if name in PACKED_CASES else None)
+    # the headline-size steps (minutes of CPU, tens of GB): only when named
+    for name, (mode, ekw, skw, seed) in HEADLINE_CASES.items():
+        if only is not None and name in only:
+            run_full_case(name, mode, ekw, skw, seed, relu_edge=3 * RELU_EDGE)

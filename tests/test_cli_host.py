@@ -223,8 +223,8 @@ def test_data_parallel_flag_starts_one_rank_per_listed_gpu(monkeypatch, tmp_path
     from lstc_vad_amd import cli, launch
     calls = []
 
-    def fake(n, argv, script=None, rank_timeout_s=0.0, relay="json", devices=None, tag="", extra_env=None):
-        calls.append(dict(n=n, argv=list(argv), script=script, relay=relay, devices=devices))
+    def fake(n, argv, script=None, rank_timeout_s=0.0, relay="json", devices=None, tag="", extra_env=None, init_timeout_s=0.0):
+        calls.append(dict(n=n, argv=list(argv), script=script, relay=relay, devices=devices, init_timeout_s=init_timeout_s))
         fake.last_result = "0.75"
         return 0
     fake.last_result = None
@@ -234,6 +234,7 @@ def test_data_parallel_flag_starts_one_rank_per_listed_gpu(monkeypatch, tmp_path
     assert got == 0.75 and len(calls) == 1
     c = calls[0]
     assert c["n"] == 4 and c["devices"] == ["0", "1", "2", "3"] and c["relay"] == "all"
+    assert c["init_timeout_s"] == 900.0         # the CLI path bounds the rendezvous (not the run) by default
     assert c["script"].endswith(os.path.join("Train", "temporal_transformer_shanghaitech.py")) and os.path.exists(c["script"])
     back = cli.complete_args("temporal_transformer_shanghaitech", argv=c["argv"])
     assert back.data_parallel and back.gpu == "0,1,2,3" and back.batch_size == 8 and back.epochs == 3
@@ -267,3 +268,39 @@ def test_data_parallel_flag_starts_one_rank_per_listed_gpu(monkeypatch, tmp_path
     bad = tmp_path / "rank_bad.py"
     bad.write_text("import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(3)\ntime.sleep(30)\n")
     assert launch.launch_ranks(2, [], script=str(bad), relay="all", tag="t", rank_timeout_s=60) == 1
+    # several complete lines written in ONE pipe chunk are all relayed when they arrive (a buffered readline() per
+    # selector wake-up kept the later ones back until the next write); the children run unbuffered
+    burst = tmp_path / "rank_burst.py"
+    burst.write_text("import os, sys, time\n"
+                     "assert os.environ.get('PYTHONUNBUFFERED') == '1'\n"
+                     "if os.environ['RANK'] == '0':\n"
+                     "    os.write(1, b'a1\\na2\\na3\\n')\n"
+                     "    time.sleep(3.0)\n"
+                     "    os.write(1, b'tail without newline')\n")
+    import threading
+    import time as _t
+    seen = []
+
+    class Tap(io.StringIO):
+        def write(self, x):
+            seen.append((_t.monotonic(), x))
+            return super().write(x)
+    tap = Tap()
+    t0 = _t.monotonic()
+    with contextlib.redirect_stdout(tap):
+        assert launch.launch_ranks(2, [], script=str(burst), relay="all", tag="t", rank_timeout_s=60) == 0
+    lines = [(t, x) for t, x in seen if x.strip()]
+    assert [x.strip() for _, x in lines] == ["a1", "a2", "a3", "tail without newline"]
+    assert lines[2][0] - lines[0][0] < 1.0 and lines[3][0] - lines[2][0] > 1.5        # the burst came through at once, the tail at EOF
+    # the init watchdog: a rank that never joins the process group (never calls mark_rank_ready) stops the job after init_timeout_s,
+    # a job whose ranks all did runs on past it
+    hang = tmp_path / "rank_hang.py"
+    hang.write_text("import os, sys, time\nsys.path.insert(0, %r)\nfrom lstc_vad_amd.launch import mark_rank_ready\n"
+                    "if os.environ['RANK'] == '0': mark_rank_ready()\ntime.sleep(60)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    t0 = _t.monotonic()
+    assert launch.launch_ranks(2, [], script=str(hang), relay="all", tag="t", rank_timeout_s=0, init_timeout_s=3.0) == 1
+    assert _t.monotonic() - t0 < 30
+    fine = tmp_path / "rank_fine.py"
+    fine.write_text("import os, sys, time\nsys.path.insert(0, %r)\nfrom lstc_vad_amd.launch import mark_rank_ready\n"
+                    "mark_rank_ready()\ntime.sleep(5)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert launch.launch_ranks(2, [], script=str(fine), relay="all", tag="t", rank_timeout_s=0, init_timeout_s=3.0) == 0

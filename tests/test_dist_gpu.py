@@ -214,13 +214,13 @@ def test_two_rank_mixed_step_over_gloo_matches_both_reference_goldens():
             assert float((diff > 5e-5).float().mean()) <= 1e-3 and float(diff.max()) <= 4e-4 + 1e-6, (name, k, float(diff.max()))
 
 
-def _bench_line(extra_args, env_extra=None):
+def _bench_line(extra_args, env_extra=None, timeout=600):
     import json
     import subprocess
     env = dict(os.environ, PYTHONPATH=ROOT, HIP_VISIBLE_DEVICES="0")
     env.update(env_extra or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch_size", "2", "--part_num", "8",
-                        "--no-extras", "--no-h2d", "--no-cpu-baseline"] + extra_args, env=env, capture_output=True, text=True, timeout=600)
+                        "--no-extras", "--no-h2d", "--no-cpu-baseline"] + extra_args, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-2500:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines                                   # ONE JSON line on stdout, nothing else (RCCL's banner goes to stderr)
@@ -243,7 +243,7 @@ def test_bench_line_contract_and_the_forced_rccl_bucket_path():
     assert abs(o["value"] - 2 * 2 * 8 * 3 / (o["ms_per_step"] * 1e-3)) < 0.02 * o["value"]                # snippets per step / step time
     rf = o["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert "comm_exposed_ms_per_step" not in o["config"] and o["config"]["rccl_ranks"] == 1
+    assert "comm_exposed_ms_per_step" not in o["config"] and o["config"]["rccl_ranks"] == 1 and o["config"]["dist_backend"] is None
     port = _free_port()
     f = _bench_line(["--buckets", "2", "--nccl_algo", "Ring", "--nccl_proto", "Simple"],
                     {"LSTC_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
@@ -251,6 +251,7 @@ def test_bench_line_contract_and_the_forced_rccl_bucket_path():
     assert c["allreduce_buckets"] == [2] and len(c["bucket_MB"][0]) == 2 and abs(sum(c["bucket_MB"][0]) - c["allreduce_MB"]) < 0.5
     assert c["backward_ms_per_step"] > 0 and 0 <= c["comm_exposed_ms_per_step"] < c["backward_ms_per_step"]
     assert c["nccl_env"].get("NCCL_ALGO") == "Ring" and c["nccl_env"].get("NCCL_PROTO") == "Simple" and c["rccl_ranks"] == 1
+    assert c["dist_backend"] == "nccl"           # the forced one-rank communicator IS RCCL
     assert abs(f["loss_first_timed_step"] - o["loss_first_timed_step"]) < 1e-6 and abs(f["loss_last_timed_step"] - o["loss_last_timed_step"]) < 1e-6
 
 
@@ -266,6 +267,58 @@ def test_bench_two_ranks_start_themselves_and_report_one_line(dtype):
                     {"LSTC_SHARE_DEVICE": "1", "LSTC_DIST_BACKEND": "gloo", "MASTER_PORT": str(_free_port())})
     c = o["config"]
     assert o["n_gpus"] == 2 and c["parallelism"] == "dp2" and c["rccl_ranks"] == 2 and o["scaling"] == "strong"
+    assert c["dist_backend"] == "gloo"           # rccl_ranks counts the group's ranks; THIS says the group is not RCCL (a functional check)
     assert c["per_rank_pairs"] == 2 and c["allreduce_MB"] > 400 and len(c["allreduce_buckets"]) == 1
     assert abs(o["value"] - 2 * 4 * 8 * 3 / (o["ms_per_step"] * 1e-3)) < 0.02 * o["value"]          # global snippets per step / step time
     assert 0 < o["loss_last_timed_step"] < 3 and 0 < o["loss_first_timed_step"] < 3
+
+
+@pytest.mark.timeout(2400)
+@pytest.mark.parametrize("config,dtype", [("ltn_sht", "bf16"), ("ltn_ucf", "fp32"), ("ltn_ucf", "bf16"), ("mixed_ubn_sht", "fp32"),
+                                          ("mixed_ubn_sht", "bf16")])
+def test_bench_eight_ranks_split_the_batch_of_one_rank(config, dtype):
+    """``python bench.py --gpus 8`` in WORLD_SIZE 8 on the one-GPU box (LSTC_SHARE_DEVICE=1, gloo): BASELINE configs 2 / 4 / 5 at 4
+    pairs per rank (config 5: 2 UBnormal + 2 SHT pairs per rank, two model pairs) - the 8-way pair split of the feed, the bag exchange
+    of 2 x 32 maxima, 7 buckets (x 2 models) x 8 ranks, the max-over-ranks timing, ONE JSON line with n_gpus 8 - and the SAME global
+    batch on one rank: with dropout off the loss of the timed steps must agree (the ranks' contributions add up to the single-process
+    loss, and the weights after the warm-up + timed steps followed the same trajectory: the summed gradients were the batch's)."""
+    common = ["--config", config, "--dtype", dtype, "--batch_size", "32", "--no-dropout", "--max_clips", "200", "--steps", "2"]
+    one = _bench_line(common, timeout=900)
+    o = _bench_line(common + ["--gpus", "8"], {"LSTC_SHARE_DEVICE": "1", "LSTC_DIST_BACKEND": "gloo", "MASTER_PORT": str(_free_port())},
+                    timeout=2000)
+    c = o["config"]
+    mixed = config == "mixed_ubn_sht"
+    assert o["n_gpus"] == 8 and c["parallelism"] == "dp8" and c["rccl_ranks"] == 8 and c["dist_backend"] == "gloo"
+    assert c["per_rank_pairs"] == 4 and c["global_videos"] == 64 and o["scaling"] == "strong" and o["steps"] == 2
+    assert c["allreduce_buckets"] == ([7, 7] if mixed else [7]) and c["allreduce_MB"] > (600 if mixed else 400)
+    assert one["n_gpus"] == 1 and one["config"]["global_videos"] == 64
+    tol = 2e-5 if dtype == "fp32" else 2e-2
+    for k in ("loss_first_timed_step", "loss_last_timed_step"):
+        assert 0 < o[k] < 3 and abs(o[k] - one[k]) < tol, (k, o[k], one[k])
+    snippets = {"ltn_sht": 64 * 8 * 3, "ltn_ucf": 64 * 8 * 2, "mixed_ubn_sht": 32 * 8 * (5 + 3)}[config]      # videos x parts x part_len
+    assert abs(o["value"] - snippets / (o["ms_per_step"] * 1e-3)) < 0.02 * o["value"]
+
+
+@pytest.mark.timeout(2400)
+def test_the_drivers_eight_gpu_command_runs_in_world_size_eight():
+    """The command the driver issues on an 8-GPU node, verbatim - ``python -m torch.distributed.run --nnodes=1 --nproc-per-node 8
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 --steps K --warmup W`` - at the DEFAULT workload (LTN-SHT, 32 pairs x
+    32 parts, fp32, reference dropout rates): eight ranks of 4 + 4 videos = 12 544 tokens each on the box's one GPU over gloo.  One
+    JSON line, n_gpus 8, the whole model's gradients in 7 buckets, value = the global batch's snippets over the slowest rank's time."""
+    import json
+    import subprocess
+    env = dict(os.environ, PYTHONPATH=ROOT, HIP_VISIBLE_DEVICES="0", LSTC_SHARE_DEVICE="1", LSTC_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=2000, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    o = json.loads(lines[0])
+    c = o["config"]
+    assert o["n_gpus"] == 8 and o["steps"] == 2 and o["warmup"] == 1 and c["parallelism"] == "dp8" and c["rccl_ranks"] == 8
+    assert c["per_rank_pairs"] == 4 and c["per_rank_sequences"] == 256 and c["global_videos"] == 64 and c["allreduce_buckets"] == [7]
+    assert o["metric"].startswith("snippets/sec training step") and o["unit"] == "snippets/s" and o["dtype"] == "f32"
+    assert abs(o["value"] - 64 * 32 * 3 / (o["ms_per_step"] * 1e-3)) < 0.02 * o["value"]
+    assert o["roofline"]["bound"] == "mfma" and 0 < o["loss_last_timed_step"] < 3
+    assert "cpu_baseline" not in o and "bf16" not in o           # N = 1 extras only

@@ -1,0 +1,268 @@
+"""The step ``bench.py``'s ``value`` times, against the REFERENCE's own run of that step (GPU only; VERDICT r5 missing #2).
+
+``tests/golden/ltn_headline.npz`` / ``stn_headline.npz`` hold what the unmodified reference produced for B = 64 videos
+(--batch_size 32), T = 32 parts, P = 16 patches, d = 2048 - LTN at part_len 3 (2048 sequences of S = 49, 100 352 tokens:
+Train/temporal_transformer_shanghaitech.py:99-144) and the literal [64, 32, 16, 2048] STN input (2048 sequences of S = 17:
+Train/spatio_transformer_shanghaitech.py:90-101) - made by tests/golden/make_golden.py (``cases.HEADLINE_CASES``; one step is
+58 / 17 TFLOP and 35 / 11 GB of CPU autograd state, so tests/test_golden_recipes.py regenerates them under LSTC_GOLDEN_HEADLINE=1).
+
+Three layers of checks, all through the C ABI:
+  1. the plain model step in both passes of the full-width scheme (un-aligned fraction, then ReLU-edge aligned) in fp32 and
+     f32x3 (``test_hip_parity._full_width_golden_check``);
+  2. ``engine.TrainStep`` EXACTLY as bench.py builds it - ``cls_only=True``, ``fuse_qkv="auto"``, the batch served as clip
+     indices from an HBM-resident bank and gathered inside the CLS concat - two optimisation steps at the reference's Adagrad
+     rates: scores 1e-4, scalars, every sampled gradient entry, weights after two steps; bf16 at its own bars;
+  3. the same global batch as an EIGHT-rank data-parallel job (8 processes sharing the box's one GPU over gloo: 4 pairs per
+     rank, bag exchange, 7 gradient buckets x 8 ranks), whose summed gradients and weights are compared with the same fixture.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from util import GOLDEN, max_abs_diff
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADLINE = ["ltn_headline", "stn_headline"]
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("dtype", ["fp32", "f32x3"])
+@pytest.mark.parametrize("name", HEADLINE)
+def test_headline_step_matches_reference_golden(name, dtype):
+    """The plain model step (``Encoder.forward_cls`` + head + loss + backward + Adagrad) at the headline batch against the
+    reference's run of it: un-aligned pass (forward at the strict bars, >= 99.5 % of the sampled gradient entries within the
+    strict bar), then the ReLU-edge-aligned pass at the strict bars and the weights after two steps."""
+    from test_hip_parity import _full_width_golden_check
+    _full_width_golden_check(name, True, dtype)
+
+
+def _resident_batch(nf, af, al, dev):
+    """The batch as bench.py's feed hands it to the step: one HBM-resident bank [clips, P, d] (normal videos first) and the
+    clip indices of every (pair, window row) - ``feed.ResidentBank.gather(lazy=True)`` -> LazyRows, gathered inside the CLS concat."""
+    from lstc_vad_amd.feed import ResidentBank
+    bs, rows, P, d = nf.shape
+    bank = torch.cat([torch.from_numpy(nf).reshape(bs * rows, P, d), torch.from_numpy(af).reshape(bs * rows, P, d)], 0).to(dev)
+    idx = np.arange(2 * bs * rows, dtype=np.int64).reshape(2, bs, rows)
+    feed = ResidentBank(bank)
+    out, labs = feed.gather(idx, np.ascontiguousarray(al), lazy=True)
+    return feed, out[0], out[1], labs
+
+
+def _headline_trainstep(name, dtype):
+    from cases import HEADLINE_CASES, fill_params, sample_index
+    from lstc_vad_amd import functional as Fn
+    from lstc_vad_amd import synthetic as syn
+    from lstc_vad_amd.engine import TrainStep
+    from lstc_vad_amd.feed import LazyRows
+    from test_hip_parity import _args, _models, _mil_max_moves
+    mode, ekw, skw, seed = HEADLINE_CASES[name]
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    assert int(z["seed"]) == seed
+    d = ekw["d_model"]
+    enc, head = _models(mode, dict(ekw), d)
+    fill_params(enc, seed)
+    fill_params(head, seed + 1)
+    enc, head = enc.to(DEV).train(), head.to(DEV).train()
+    nf, _, af, al = syn.training_batch(skw["batch_size"], skw["part_num"], skw["part_len"], skw["n_patch"], d, seed=seed,
+                                       with_pseudo=True, threshold=0.6)
+    args = _args(mode, skw)
+    Fn.set_compute_dtype(dtype)
+    try:
+        ts = TrainStep(args, mode, enc, head, lr_encoder=1e-4, lr_head=1e-2, weight_decay=1e-3, cls_only=True, fuse_qkv="auto")
+        feed, nfl, afl, labs = _resident_batch(nf, af, al, torch.device(DEV))
+        del nf, af
+        assert isinstance(nfl, LazyRows) and nfl.pairs_with(afl)            # the fused gather + CLS concat path of the bench step
+        with torch.no_grad():
+            _, _, outputs = ts.forward_loss(nfl, afl, labs)
+        sc0 = ts.step(nfl, afl, labs).clone()
+        grads = {(pre, k): p.grad.detach().clone() for pre, mod in (("enc", enc), ("head", head)) for k, p in mod.named_parameters()
+                 if p.grad is not None}
+        sc1 = ts.step(nfl, afl, labs).clone()
+        torch.cuda.synchronize()
+    finally:
+        Fn.set_compute_dtype("fp32")
+    tight = dtype != "bf16"
+    sbar, lbar = (1e-4, 2e-5) if tight else (2e-2, 2e-2)
+    assert max_abs_diff(outputs.reshape(z["outputs"].shape), z["outputs"]) < sbar           # north_star: scores within 1e-4 (fp32)
+    assert np.max(np.abs(sc0.cpu().double().numpy() - z["scalars"])) < lbar
+    # the second step runs on weights one Adagrad step (at the REFERENCE's rates: lr * sign(g) on the first step) away
+    assert np.max(np.abs(sc1.cpu().double().numpy() - z["scalars_step2"])) < (1e-4 if tight else 3e-2)
+    moves = 0 if tight else _mil_max_moves(outputs, z["outputs"], args.part_num)
+    n_tok = (2 * skw["batch_size"] * skw["part_num"] * (1 if mode == "LTN" else skw["part_len"]) *
+             (1 + skw["n_patch"] * (skw["part_len"] if mode == "LTN" else 1)))
+    gbar = 2e-4 * max(1.0, (n_tok / 6272.0) ** 0.5)            # the strict entry bar of the full-width tests, sqrt(tokens)-scaled
+    beyond = total = 0
+    worst = 0.0
+    for (pre, k), g in grads.items():
+        gmax, gnorm = float(z[f"{pre}_gmax.{k}"]), float(z[f"{pre}_gnorm.{k}"])
+        gs = torch.from_numpy(z[f"{pre}_gs.{k}"]).double()
+        got = g.reshape(-1)[torch.from_numpy(sample_index(g.numel())).to(DEV)].cpu().double()
+        if tight:
+            # un-aligned step (nothing edited): every sampled entry within 5e-3 of its tensor's maximum, every norm within 1e-3, and
+            # (below) >= 99.5 % of all sampled entries already within the strict bar
+            err = float((got - gs).abs().max())
+            assert err < 5e-3 * gmax + 1e-7, (pre, k, err, gmax)
+            assert abs(float(g.double().norm()) - gnorm) < 1e-3 * gnorm + 1e-9, (pre, k)
+            beyond += int(((got - gs).abs() >= gbar * gmax + 1e-7).sum())
+            total += int(gs.numel())
+            worst = max(worst, err / gmax if gmax > 0 else 0.0)
+        elif pre == "enc" and g.numel() >= 4096 and gnorm > 0:
+            cos = float((got * gs).sum() / (got.norm() * gs.norm() + 1e-30))
+            assert cos > (0.90 if moves else 0.95 if k.endswith(("pos_ffn.w_1.weight", "pos_ffn.w_1.bias")) else 0.98), (k, cos, moves)
+            assert abs(float(g.double().norm()) / gnorm - 1.0) < 0.05, k
+    if tight:
+        frac = 1.0 - beyond / max(total, 1)
+        print(f"\n[headline TrainStep {name} {dtype}] worst sampled gradient entry {worst:.2e} of its tensor's maximum; "
+              f"{100 * frac:.2f} % of {total} sampled entries within the strict bar ({gbar:.1e})")
+        assert total > 5000 and frac >= 0.995, (beyond, total)
+        # weights after the two steps (Adagrad inside TrainStep, lstc_adagrad_multi): an entry moves by at most lr per step
+        for pre, mod in (("enc", enc), ("head", head)):
+            lr = 1e-4 if pre == "enc" else 1e-2
+            for k, p in mod.named_parameters():
+                w = p.detach().reshape(-1)
+                diff = (w[torch.from_numpy(sample_index(w.numel())).to(DEV)].cpu() - torch.from_numpy(z[f"{pre}_w2s.{k}"])).abs()
+                assert float(diff.max()) <= 4 * lr + 1e-6, (pre, k, float(diff.max()))
+                assert float((diff > 5e-5).float().mean()) <= (1e-2 if pre == "head" else 4e-3), (pre, k, float(diff.max()))
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("name,dtype", [("ltn_headline", "fp32"), ("stn_headline", "fp32"), ("ltn_headline", "f32x3"),
+                                        ("ltn_headline", "bf16"), ("stn_headline", "bf16")])
+def test_headline_trainstep_on_the_resident_feed_matches_reference_golden(name, dtype):
+    """engine.TrainStep as bench.py builds it (cls_only, auto Q|K|V fusion, clip indices into the resident bank, the gather fused into
+    the CLS concat), two steps at the reference's learning rates, against the reference's two steps on the same 64-video batch."""
+    _headline_trainstep(name, dtype)
+
+
+# ------------------------------------------------------------------------------------------------ the same batch on 8 ranks
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank8(rank, world, port, name, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=1500))
+    try:
+        from cases import HEADLINE_CASES, fill_params, sample_index
+        from lstc_vad_amd import synthetic as syn
+        from lstc_vad_amd.engine import TrainStep
+        from test_hip_parity import _args, _models
+        dev = torch.device("cuda", 0)
+        mode, ekw, skw, seed = HEADLINE_CASES[name]
+        d, bs, pn, L, P = ekw["d_model"], skw["batch_size"], skw["part_num"], skw["part_len"], skw["n_patch"]
+        h = bs // world
+        enc, head = _models(mode, dict(ekw), d)
+        fill_params(enc, seed)
+        fill_params(head, seed + 1)
+        enc, head = enc.to(dev).train(), head.to(dev).train()
+        args = _args(mode, dict(skw, batch_size=h))
+        ts = TrainStep(args, mode, enc, head, lr_encoder=1e-4, lr_head=1e-2, weight_decay=1e-3, cls_only=True, fuse_qkv="auto")
+        assert ts.reducer is not None and ts.reducer.active and ts.world == world
+        # rank r owns pairs [r*bs/N, (r+1)*bs/N) of the global batch: only those rows are generated here
+        T = pn * L
+        lo, hi = rank * h, (rank + 1) * h
+        nf = torch.from_numpy(syn.features_rows((bs, T, P, d), lo, hi, seed, stream=1)).to(dev)
+        af = torch.from_numpy(syn.features_rows((bs, T, P, d), lo, hi, seed, stream=2)).to(dev)
+        al = torch.from_numpy(syn.pseudo_labels((bs, T, 1), seed, 0.6, stream=3)[lo:hi].copy()).to(dev)
+        out = {"buckets": len(ts.reducer.buckets)}
+        for step in range(2):
+            sc = ts.step(nf, af, al).clone()
+            dist.all_reduce(sc)                                   # rank-local contributions -> the global scalars
+            out[f"scalars{step}"] = sc.cpu().double().numpy()
+            if step == 0 and rank == 0:
+                # .grad = views of the buckets holding the all-reduced (summed over the 8 ranks) gradients of step 0
+                out["gs"] = {}
+                out["gnorm"] = {}
+                for pre, mod in (("enc", enc), ("head", head)):
+                    for k, p in mod.named_parameters():
+                        if p.grad is not None:
+                            g = p.grad.detach().reshape(-1)
+                            out["gs"][f"{pre}.{k}"] = g[torch.from_numpy(sample_index(g.numel())).to(dev)].cpu().numpy().copy()
+                            out["gnorm"][f"{pre}.{k}"] = float(g.double().norm())
+        torch.cuda.synchronize()
+        flat = torch.cat([p.detach().reshape(-1)[::97] for m in (enc, head) for p in m.parameters()])
+        every = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(every, flat)
+        out["replicas_identical"] = all(torch.equal(every[0], e) for e in every[1:])
+        if rank == 0:
+            out["w2s"] = {}
+            for pre, mod in (("enc", enc), ("head", head)):
+                for k, p in mod.named_parameters():
+                    w = p.detach().reshape(-1)
+                    out["w2s"][f"{pre}.{k}"] = w[torch.from_numpy(sample_index(w.numel())).to(dev)].cpu().numpy().copy()
+            q.put(out)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(2400)
+def test_eight_rank_step_at_the_headline_batch_matches_reference_golden():
+    """BASELINE's 8-GPU split of the headline step, functionally: EIGHT rank processes (all on the box's one GPU, collectives over
+    gloo - RCCL refuses several ranks per device), each owning 4 + 4 videos of the reference's 64-video batch: bag exchange of the
+    64 maxima, 7 gradient buckets all-reduced over 8 ranks as the backward produces them, Adagrad on every replica.  The SUM of
+    the ranks' gradients and the weights after two steps are compared with what the reference's single process computed for the
+    whole batch (Train/temporal_transformer_shanghaitech.py:76-78,99-144) - data parallelism reproduces the single-process step."""
+    import queue as _queue
+    import torch.multiprocessing as mp
+    name, world = "ltn_headline", 8
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank8, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = None
+    try:
+        res = q.get(timeout=2000)
+    except _queue.Empty:
+        pass
+    finally:
+        for p in procs:
+            p.join(60 if res is not None else 1)
+            if p.is_alive():
+                p.terminate()
+                p.join(10)
+    assert res is not None, [p.exitcode for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert res["replicas_identical"] and res["buckets"] == 7
+    assert np.max(np.abs(res["scalars0"] - z["scalars"])) < 2e-5
+    assert np.max(np.abs(res["scalars1"] - z["scalars_step2"])) < 1e-4
+    beyond = total = 0
+    gbar = 2e-4 * (100352 / 6272.0) ** 0.5
+    for key, got in res["gs"].items():
+        pre, k = key.split(".", 1)
+        gmax, gnorm = float(z[f"{pre}_gmax.{k}"]), float(z[f"{pre}_gnorm.{k}"])
+        dlt = np.abs(got.astype(np.float64) - z[f"{pre}_gs.{k}"].astype(np.float64))
+        assert float(dlt.max()) < 5e-3 * gmax + 1e-7, (key, float(dlt.max()), gmax)
+        assert abs(res["gnorm"][key] - gnorm) < 1e-3 * gnorm + 1e-9, key
+        beyond += int((dlt >= gbar * gmax + 1e-7).sum())
+        total += dlt.size
+    assert {f"{p}_gs.{k.split('.', 1)[1]}" for p in ("enc", "head") for k in res["gs"] if k.startswith(p + ".")} == \
+        {k for k in z.files if k.startswith(("enc_gs.", "head_gs."))}
+    print(f"\n[8 ranks, headline batch] {100 * (1 - beyond / total):.2f} % of {total} sampled entries of the summed gradients within "
+          f"the strict bar ({gbar:.1e} of the tensor's maximum)")
+    assert total > 5000 and 1.0 - beyond / total >= 0.995
+    for key, got in res["w2s"].items():
+        pre, k = key.split(".", 1)
+        lr = 1e-4 if pre == "enc" else 1e-2
+        diff = np.abs(got - z[f"{pre}_w2s.{k}"])
+        assert float(diff.max()) <= 4 * lr + 1e-6, (key, float(diff.max()))
+        assert float((diff > 5e-5).mean()) <= (1e-2 if pre == "head" else 4e-3), (key, float(diff.max()))

@@ -1057,8 +1057,8 @@ def test_f32x3_scale_edge_cases(f32x3_everywhere):
 
 def _full_width_models(name):
     """Build-side models at BASELINE width with the portable-generator weights the full-width fixture was made from."""
-    from cases import FULL_CASES, PACKED_CASES, fill_params
-    mode, ekw, skw, seed = {**FULL_CASES, **PACKED_CASES}[name]
+    from cases import FULL_CASES, HEADLINE_CASES, PACKED_CASES, fill_params
+    mode, ekw, skw, seed = {**FULL_CASES, **PACKED_CASES, **HEADLINE_CASES}[name]
     z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     assert int(z["seed"]) == seed
     d = ekw["d_model"]

@@ -420,6 +420,96 @@ def test_data_parallel_command_line_starts_ranks_and_shards_evaluation_and_label
     _check_pseudo(b, "pl/t_sht/", 0.45)
 
 
+def _wide_sht_world(root):
+    """A larger SHT-dialect set than the golden-pinned world (which has 4 abnormal training videos): 18 normal + 17 abnormal training
+    videos and 9 test videos, P = 16, d = 32 - enough for a global batch of 16 pairs = 8 ranks x 2 pairs and for an 8-way sharded
+    evaluation (video i on rank i % 8).  Not a fixture of the reference: the 8-rank run is compared with the single-process run."""
+    from lstc_vad_amd.archive import write_archive
+    os.makedirs(root, exist_ok=True)
+    train = [(f"{1 + i % 9:02d}_{100 + i:04d}" if i % 2 else f"{1 + i % 9:02d}_{100 + i:03d}", i % 2, 9 + (7 * i) % 31) for i in range(35)]
+    test = [(f"{1 + i % 5:02d}_{500 + i:04d}" if i % 2 else f"{1 + i % 5:02d}_{500 + i:03d}", i % 2, 5 + (5 * i) % 17) for i in range(9)]
+    arrays = {n + ".npy": pw._feats(c, 16, 32, 700 + i) for i, (n, _, c) in enumerate(train + test)}
+    W = {"feats": write_archive(os.path.join(root, "wide_feats.npz"), arrays)}
+    W["train"] = os.path.join(root, "wide_train.txt")
+    open(W["train"], "w").write("".join(f"{n},{l}\n" for n, l, _ in train))
+    W["test"] = os.path.join(root, "wide_test.txt")
+    open(W["test"], "w").write("".join(f"{n},{l},{-1 if l else c * pw.SEG + 3}\n" for n, l, c in test))
+    W["masks"] = os.path.join(root, "wide_masks") + os.sep
+    os.makedirs(W["masks"], exist_ok=True)
+    for i, (n, l, c) in enumerate(test + train):
+        if l:
+            np.save(os.path.join(W["masks"], n + ".npy"), pw._mask(c * pw.SEG + 5, 800 + i))
+    return W
+
+
+@pytest.mark.timeout(2400)
+def test_data_parallel_command_line_with_eight_ranks(world, tmp_path):
+    """``python Train/temporal_transformer_shanghaitech.py --data_parallel --gpu 0,0,0,0,0,0,0,0`` (LSTC_SHARE_DEVICE=1, gloo): the
+    script starts EIGHT ranks itself; a global batch of 16 pairs = 2 pairs per rank; evaluation, train-AUC and (second command) the
+    pseudo-label generator sharded ``i % 8`` over the ranks.  (a) with both learning rates 0: AUC lines, save decisions and
+    checkpoint names equal the single-process run character for character, label file bit for bit; (b) with the reference's
+    learning rates: every logged step's loss terms agree with the single-process run's to 1e-4 (the 8 ranks' gradients summed to
+    the batch gradient, step after step) and the AUCs after training to 1e-4."""
+    W = _wide_sht_world(str(tmp_path / "wide"))
+
+    def cmd(save, log, extra):
+        return ["--dataset_path", W["feats"], "--training_txt", W["train"], "--testing_txt", W["test"],
+                "--test_mask_dir", W["masks"], "--model_save_dir", save, "--batch_size", "16", "--part_num", "3",
+                "--n_patch", "16", "--n_head", "2", "--d_model", "32", "--d_k", "16", "--d_v", "16", "--FFN_layerNorm",
+                "--load_model", "--epochs", "3", "--inter_epoch", "1", "--seed", "3", "--save_threshold", "0.05",
+                "--log_dir", log, "--part_len", "3", "--n_hidden", "64", "--MHA_layerNorm", "--relative_position_encoding",
+                "--load_temporal_model_path", world["ltn_sht_enc.ckpt"], "--load_classifier_model_path", world["ltn_sht_cls.ckpt"],
+                "--MHA_attn_dropout", "0", "--MHA_fc_dropout", "0", "--FFN_dropout", "0", "--classifier_dropout", "0",
+                "--saved_prefix", "pre_"] + extra
+    env8 = dict(os.environ, PYTHONPATH=ROOT, LSTC_SHARE_DEVICE="1", LSTC_DIST_BACKEND="gloo", LSTC_RANK_TIMEOUT_S="1500")
+    env8.pop("HIP_VISIBLE_DEVICES", None)
+    eight = ["--data_parallel", "--gpu", "0,0,0,0,0,0,0,0"]
+
+    def auc_lines(err):
+        return [l.split(": ", 1)[1] for l in err.splitlines() if "_AUC" in l and ": " in l]
+
+    def numbers(line):
+        import re
+        return [float(x) for x in re.findall(r"[-+]?\d+\.\d+(?:e[-+]?\d+)?", line)]
+    for tag, lrs in (("frozen", ["--lr_encoder", "0", "--lr_classifier", "0"]), ("training", [])):
+        save1, save8 = str(tmp_path / f"{tag}_ck1") + os.sep, str(tmp_path / f"{tag}_ck8") + os.sep
+        r1 = _run("Train", "temporal_transformer_shanghaitech.py", cmd(save1, str(tmp_path / f"{tag}_log1"), lrs))
+        assert r1.returncode == 0, r1.stderr[-2500:]
+        r8 = subprocess.run([sys.executable, "temporal_transformer_shanghaitech.py"] + cmd(save8, str(tmp_path / f"{tag}_log8"), lrs + eight),
+                            cwd=os.path.join(ROOT, "Train"), env=env8, capture_output=True, text=True, timeout=2000)
+        assert r8.returncode == 0, r8.stderr[-2500:]
+        assert "--data_parallel: 8 rank(s)" in r8.stderr
+        a1, a8 = auc_lines(r1.stderr), auc_lines(r8.stderr)
+        assert a1 and len(a1) == len(a8)
+        if tag == "frozen":
+            assert a1 == a8, (a1, a8)
+            assert sorted(os.listdir(save1)) == sorted(os.listdir(save8)) and len(os.listdir(save1)) >= 2
+            assert r8.stderr.count("saving model......") == r1.stderr.count("saving model......")
+        else:
+            for x, y in zip(a1, a8):
+                nx, ny = numbers(x), numbers(y)
+                assert len(nx) == len(ny) and nx and max(abs(p - q) for p, q in zip(nx, ny)) < 2e-4, (x, y)     # 4-decimal log format
+            # the per-step log lines (loss terms of every optimisation step, rank 0): same count, same numbers to 1e-4
+            s1 = [l for l in r1.stderr.splitlines() if "loss" in l.lower() and "_AUC" not in l]
+            s8 = [l for l in r8.stderr.splitlines() if "loss" in l.lower() and "_AUC" not in l and "rank" not in l.lower()]
+            assert s1 and len(s1) == len(s8), (len(s1), len(s8))
+            for x, y in zip(s1, s8):
+                nx, ny = numbers(x), numbers(y)
+                assert len(nx) == len(ny) and max(abs(p - q) for p, q in zip(nx, ny)) < 2e-4, (x, y)
+    gen = ["--d_model", "32", "--n_head", "2", "--d_k", "16", "--d_v", "16", "--n_hidden", "64", "--MHA_layerNorm", "--FFN_layerNorm",
+           "--relative_position_encoding", "--part_len", "3", "--dataset", "SHT", "--dataset_path", W["feats"],
+           "--training_txt", W["train"], "--temporal_model_path", world["ltn_sht_enc.ckpt"], "--classifier_model_path",
+           world["ltn_sht_cls.ckpt"], "--threshold", "0.45"]
+    p1, p8 = str(tmp_path / "pl1.npy"), str(tmp_path / "pl8.npy")
+    g1 = _run("Train", "pseudo_labels_generator_temporal.py", gen + ["--pseudo_labels_path", p1])
+    assert g1.returncode == 0, g1.stderr[-2000:]
+    g8 = subprocess.run([sys.executable, "pseudo_labels_generator_temporal.py"] + gen + ["--pseudo_labels_path", p8] + eight,
+                        cwd=os.path.join(ROOT, "Train"), env=env8, capture_output=True, text=True, timeout=2000)
+    assert g8.returncode == 0, g8.stderr[-2500:]
+    a, b = np.load(p1, allow_pickle=True).tolist(), np.load(p8, allow_pickle=True).tolist()
+    assert len(a) == 35 and list(a) == list(b) and all(np.array_equal(a[k], b[k]) for k in a)
+
+
 def test_sharded_evaluation_is_bitwise_the_single_rank_evaluation(world):
     """pipeline.evaluate_auc / evaluate_train_auc / generate_pseudo_labels with two emulated ranks on the HIP model (fp32): every
     frame score, label, AUC and label row equals the single-rank pass BIT FOR BIT - a sequence's score does not depend on what

@@ -31,7 +31,7 @@ static float bf16_round(float x) {   // RNE to bfloat16, back to float (host mod
 
 static int check(const Case& c) {
     const int M = c.M, N = c.N, K = c.K;
-    const bool pad = (c.variant % 2 == 0) && c.variant != 4;     // padded lds exercise the scalar-load path
+    const bool pad = (c.variant % 2 == 0) && c.variant != 4 && !(c.dtype == 0 && c.variant == 12 && c.alignc);     // padded lds exercise the scalar-load path
     const int lda = (c.tA ? M : K) + (pad ? 3 : 0);
     const int ldb = (c.tB ? K : N) + (pad ? 1 : 0);
     const int ldc = c.alignc ? N + 4 : N + 2, ldr = c.alignc ? N + 8 : N + 1, ldm = N;
@@ -194,7 +194,13 @@ int main(int argc, char** argv) {
     int fails = 0;
     if (!time_only) {
         const int ALL = LSTC_EPI_BIAS | LSTC_EPI_RELU | LSTC_EPI_RESIDUAL | LSTC_EPI_RELU_MASK | LSTC_EPI_ACCUM;
-        for (int variant : {0, 2, 4}) {   // 4 -> default tile with padded lds (scalar-load path)
+        // production library: 0 (default; padded lds -> the PIPE 3 scalar-load fallback), 8 (PIPE 3 itself), 4 (PIPE 5, aligned), 12 (persistent;
+        // padded lds -> its fallback); `make tuning` builds also hold 2 / 6 (256x128 tiles) and 10 (LDS-DMA staging)
+#ifdef LSTC_TUNING
+        for (int variant : {0, 8, 4, 12, 2, 6, 10}) {
+#else
+        for (int variant : {0, 8, 4, 12}) {
+#endif
             fails += check({300, 200, 100, 0, 1, 0, variant, 1});
             fails += check({257, 131, 67, 0, 1, ALL, variant, 1});
             fails += check({300, 200, 100, 0, 0, LSTC_EPI_RELU_MASK, variant, 1});
@@ -202,11 +208,18 @@ int main(int argc, char** argv) {
             fails += check({130, 260, 515, 1, 0, 0, variant, 3});
             fails += check({64, 1, 32, 0, 1, LSTC_EPI_BIAS, variant, 1});
         }
-        // aligned (vector-path) variants: variant id odd -> no ld padding in check(); use 5.. mapped to default tile
-        fails += check({256, 256, 128, 0, 1, 0, 1, 1});
-        fails += check({256, 256, 128, 0, 0, 0, 1, 1});
-        fails += check({256, 256, 128, 1, 0, 0, 1, 1});
-        fails += check({384, 132, 260, 1, 0, 0, 1, 2});
+#ifdef LSTC_TUNING
+        // aligned (vector-path) tuning variants: variant id odd -> no ld padding in check()
+        for (int variant : {1, 3, 5, 7, 9}) {
+            fails += check({256, 256, 128, 0, 1, 0, variant, 1});
+            fails += check({256, 256, 128, 0, 0, 0, variant, 1});
+            fails += check({256, 256, 128, 1, 0, 0, variant, 1});
+            fails += check({384, 132, 260, 1, 0, 0, variant, 2});
+        }
+#endif
+        // the persistent walk on aligned operands (alignc: 16-B epilogue path - what variant 12 needs to run its own kernel)
+        fails += check({1024, 512, 256, 0, 1, LSTC_EPI_BIAS | LSTC_EPI_RELU, 12, 1, 0, 1});
+        fails += check({1024, 512, 256, 0, 0, LSTC_EPI_RESIDUAL, 12, 1, 0, 1});
         // LDS-DMA variant (10): aligned leading dims (odd variant id would pad; 10 is even -> use sizes whose padded lds
         // stay multiples of 4 is impossible, so these go through variant 11 = same kernel, no padding)
         for (int tb : {1, 0}) {
@@ -284,7 +297,11 @@ int main(int argc, char** argv) {
     // LTN headline shapes: tokens M = 2048*49 = 100352, d = 2048, Hd = 2048, F = 4096.  A smaller M (25088)
     // is timed first to keep the table quick; TFLOP/s is what matters.
     const int Mtok = 100352;
+#ifdef LSTC_TUNING
     for (int variant : {0, 1, 2, 5}) {
+#else
+    for (int variant : {0, 12}) {
+#endif
         timeit(Mtok, 2048, 2048, 0, 1, variant, 1, 0, 6);
         timeit(Mtok, 4096, 2048, 0, 1, variant, 1, LSTC_EPI_BIAS | LSTC_EPI_RELU, 5);
         timeit(Mtok, 2048, 4096, 0, 1, variant, 1, LSTC_EPI_BIAS | LSTC_EPI_DROPOUT | LSTC_EPI_RESIDUAL, 5);
