@@ -370,6 +370,11 @@ def train(script: str, argv=None, args=None):
     for epoch in range(epochs):
         for norm_feats, norm_labs, abnorm_feats, abnorm_labs in data:
             sc = ts.step(norm_feats, abnorm_feats, abnorm_labs)
+            if world > 1:
+                # a rank's five scalars are its CONTRIBUTIONS to the global loss terms (local sums over global counts): the log line
+                # shows the batch's loss like a single-process run does - one 20-byte sum-all-reduce on the launch stream, no host sync
+                sc = sc.clone()
+                dist.all_reduce(sc)
             if late is not None:
                 late.push(it, epoch, sc)          # the PREVIOUS step's line is written now: no sync on the step just queued
             it += 1

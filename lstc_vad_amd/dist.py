@@ -55,6 +55,9 @@ class GradAllReducer:
         self._accum_from: List[int] = []           # per bucket: first element of the autograd-accumulated (zero-filled) tail
         self._direct: List[torch.nn.Parameter] = []       # parameters with a gradient sink, and which of them delivered this step
         self._delivered = set()
+        self._ready_ev = {}                        # bucket -> event on the launch stream where its all-reduce was issued (per-bucket steps)
+        self._side = self._land = None             # streams of finish(on_bucket=...)
+        self.landed = None                         # event: the LAST bucket's reduction has landed (exposed-communication measurement)
         direct_ids = {id(p) for p in direct}
         for bi, params in enumerate(param_groups):
             params = [p for p in params if p.requires_grad]
@@ -133,6 +136,11 @@ class GradAllReducer:
             return            # somebody else owns .grad now (the model is being used without this reducer): not our step
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
+            if self.buckets[bi].is_cuda:
+                ev = self._ready_ev.get(bi)
+                if ev is None:
+                    ev = self._ready_ev[bi] = torch.cuda.Event()
+                ev.record()                        # everything the backward has issued so far, on the launch stream
             self._handles.append(self._launch(bi, True))
         elif self._pending[bi] < 0:
             # a parameter reported twice in one backward (a weight used by two Functions): a direct gradient would have been
@@ -140,10 +148,61 @@ class GradAllReducer:
             raise RuntimeError("GradAllReducer: a parameter delivered its gradient twice in one backward pass (shared weights are "
                                "not supported by the bucket path; call zero_grad() before every backward)")
 
-    def finish(self):
-        """Call after ``backward()`` and before the optimizer step."""
+    def finish(self, on_bucket=None, backward_end=None):
+        """Call after ``backward()`` and before the optimizer step.
+
+        ``on_bucket(bi, params)`` (engine.TrainStep passes its per-bucket Adagrad + weight repack when
+        ``--clip_grad`` is off): instead of waiting for ALL buckets and then stepping everything, bucket k is stepped as soon as
+        ITS reduction has landed - on a side stream, beside the backward of the layers below it.  Order on the side stream =
+        the order the buckets became ready (head, then layers last to first).  Bucket k's weights may still be read by the
+        backward kernels issued before bucket k + 1 became ready (a Function delivers a weight gradient before it has issued
+        every product that reads the weight), so the side stream waits for the launch-stream event recorded when the NEXT bucket's
+        all-reduce was issued (the end of the backward for the last one) before it touches bucket k's weights.  The launch stream
+        waits for the side stream at the end: the next forward sees every weight updated.  Weights are bit-identical to the
+        all-buckets-then-one-step order (the update is elementwise)."""
         self._check_direct()
+        self.landed = None
         if not self.active:
+            if on_bucket is not None:
+                for bi in range(len(self.buckets)):
+                    on_bucket(bi, [p for p, _ in self._views[bi]])
+            return
+        if on_bucket is not None and self.overlap:
+            if any(n != 0 for n in self._pending):
+                missing = [bi for bi, n in enumerate(self._pending) if n]
+                raise RuntimeError(f"GradAllReducer: buckets {missing} did not receive all gradients this step")
+            if not self.buckets[0].is_cuda:                      # host tensors (gloo tests): no streams to play with
+                for bi, h in self._handles:
+                    h.wait()
+                    self._widen(bi)
+                    on_bucket(bi, [p for p, _ in self._views[bi]])
+                self._handles = []
+                return
+            dev = self.buckets[0].device
+            main = torch.cuda.current_stream(dev)
+            if self._side is None:
+                self._side, self._land = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+            end = backward_end                                   # MixedStep: this model's backward ended before the next model's began
+            if end is None:
+                end = torch.cuda.Event()
+                end.record(main)
+            order = [bi for bi, _ in self._handles]
+            for j, (bi, h) in enumerate(self._handles):
+                gate = self._ready_ev[order[j + 1]] if j + 1 < len(order) else end
+                self._side.wait_event(gate)
+                with torch.cuda.stream(self._side):
+                    h.wait()                                     # the side stream waits for this bucket's reduction only
+                    self._widen(bi)
+                    on_bucket(bi, [p for p, _ in self._views[bi]])
+            if self._handles:
+                # when did the LAST reduction land?  (its own stream: the side stream may still be stepping earlier buckets)
+                with torch.cuda.stream(self._land):
+                    self._handles[-1][1].wait()
+                    self.landed = torch.cuda.Event(enable_timing=True)
+                    self.landed.record()
+            main.wait_stream(self._side)
+            main.wait_stream(self._land)
+            self._handles = []
             return
         if not self.overlap:
             for bi in range(len(self.buckets)):

@@ -47,6 +47,8 @@ class TrainStep:
         # measurement hook (bench.py at N > 1): a list to receive (before backward, after backward, after reducer.finish()) HIP events
         # of every step on the launch stream - backward time and the part of the gradient all-reduce that the backward did not hide
         self.comm_events = None
+        # LSTC_BUCKET_STEPS=0 restores the all-buckets-then-one-optimizer-step order (A/B runs; bit-identical weights)
+        self.bucket_steps = os.environ.get("LSTC_BUCKET_STEPS", "1") != "0"
         # default bucketing: head, then per layer (last to first) its FFN half and its attention half - 2 x layers + 1 buckets of
         # <= 67 MB at the LTN widths.  Only the LAST bucket's reduction (layer 0's attention weights, ready when the backward ends)
         # cannot hide under the backward; halving it halves what is exposed, and 67 MB is still far above the size at which
@@ -124,6 +126,16 @@ class TrainStep:
         loss.backward()
         if ev is not None:
             marks[1].record()
+        if self.reducer is not None and self.bucket_steps and not getattr(self.args, "clip_grad", False):
+            # per-bucket optimizer: Adagrad + the bf16 weight repack of bucket k run on a side stream as soon as
+            # bucket k's reduction has landed, beside the backward of the layers below - not behind the LAST bucket's reduction.
+            # (--clip_grad needs the norm of ALL gradients first: it keeps the one-step order below.)
+            self.reducer.finish(on_bucket=lambda bi, params: self.optimizer.step(only=params))
+            if ev is not None:
+                # exposed communication keeps its meaning: end of the backward -> the LAST bucket's reduction has landed
+                marks[2] = self.reducer.landed if self.reducer.landed is not None else marks[1]
+                ev.append(marks)
+            return scalars
         if self.reducer is not None:
             self.reducer.finish()
         if ev is not None:
@@ -259,18 +271,44 @@ class MixedStep:
 
     def step(self, batches):
         """``batches``: one ``(norm_feats, abnorm_feats, abnorm_labs)`` per TrainStep.  Returns the per-model scalar tensors."""
-        scalars = []
+        scalars, ends = [], []
         for ts, (nf, af, al) in zip(self.steps, batches):
             loss, sc, _ = ts.forward_loss(nf, af, al)
             if ts.reducer is not None:
                 ts.reducer.zero_grad()
             else:
                 ts.optimizer.zero_grad(set_to_none=True)
+            ev = getattr(ts, "comm_events", None)
+            if ev is not None:
+                marks = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                marks[0].record()
             loss.backward()
+            if ev is not None:
+                marks[1].record()
+                ev.append(marks)                     # marks[2] is set below, when this model's reductions have been waited for
             scalars.append(sc)
-        for ts in self.steps:
+            ends.append(None)
+            if ts.reducer is not None and ts.reducer.active and loss.is_cuda:
+                ends[-1] = torch.cuda.Event()
+                ends[-1].record()                    # this model's backward is issued: its last bucket's weights are free from here on
+        if any(getattr(ts, "comm_events", None) for ts in self.steps):
+            all_done = torch.cuda.Event(enable_timing=True)
+            all_done.record()                        # every model's backward is issued: exposed communication counts from here
+            for ts in self.steps:
+                if getattr(ts, "comm_events", None):
+                    ts.comm_events[-1].append(all_done)
+        for ts, end in zip(self.steps, ends):
+            if ts.reducer is not None and getattr(ts, "bucket_steps", False) and not getattr(ts.args, "clip_grad", False):
+                # per-bucket Adagrad + repack on a side stream as each reduction lands (TrainStep.step has the same arm)
+                ts.reducer.finish(on_bucket=lambda bi, params, ts=ts: ts.optimizer.step(only=params), backward_end=end)
+                if ts.comm_events:
+                    m = ts.comm_events[-1]
+                    m[2] = ts.reducer.landed if ts.reducer.landed is not None else m[1]
+                continue
             if ts.reducer is not None:
                 ts.reducer.finish()
+            if getattr(ts, "comm_events", None):
+                ts.comm_events[-1][2].record()
             if getattr(ts.args, "clip_grad", False):
                 clip_grad_norm_(ts.encoder.parameters(), 10)
                 clip_grad_norm_(ts.head.parameters(), 10)

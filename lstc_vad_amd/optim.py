@@ -27,14 +27,18 @@ class Adagrad(torch.optim.Optimizer):
                 self.state[p]["step"] = 0
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scales=None):
-        """``grad_scales``: optional {group index: device-or-host scale} from ``clip_grad_norm_`` below."""
+    def step(self, closure=None, grad_scales=None, only=None):
+        """``grad_scales``: optional {group index: device-or-host scale} from ``clip_grad_norm_`` below.  ``only``: step just these
+        parameters (one gradient bucket of a data-parallel job whose all-reduce has landed - engine.TrainStep steps bucket k while
+        the backward of the layers below it is still running); the element arithmetic does not depend on how the parameters are
+        grouped into launches, so any partition into ``only`` sets gives the weights of ONE whole step bit for bit."""
         lib = _lib.load()
         items, keep, updated = [], [], []
+        sel = None if only is None else {id(p) for p in only}
         for gi, group in enumerate(self.param_groups):
             gs = 1.0 if not grad_scales else float(grad_scales.get(gi, 1.0))
             for p in group["params"]:
-                if p.grad is None:
+                if p.grad is None or (sel is not None and id(p) not in sel):
                     continue
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 state = self.state[p]

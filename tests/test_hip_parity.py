@@ -441,7 +441,7 @@ def test_rccl_gradient_bucket_path_single_rank(name, dtype, fuse):
     args = _args(mode, skw)
     nf, af, al = (torch.from_numpy(z[k]).to(DEV) for k in ("norm_feats", "abnorm_feats", "abnorm_labs"))
 
-    def run(forced):
+    def run(forced, bucket_steps=True):
         enc, head = _models(mode, ekw, d)
         enc.load_state_dict(sub(z, "enc_init."), strict=True)
         head.load_state_dict(sub(z, "head_init."), strict=True)
@@ -449,6 +449,7 @@ def test_rccl_gradient_bucket_path_single_rank(name, dtype, fuse):
         os.environ["LSTC_FORCE_DIST"] = "1" if forced else "0"
         ts = TrainStep(args, mode, enc, head, 1e-4, 1e-2, 1e-3, fuse_qkv=fuse)
         assert (ts.reducer is not None) == forced
+        ts.bucket_steps = bucket_steps
         if forced:
             sunk = [p for p in list(enc.parameters()) + list(head.parameters()) if Fn.grad_sink(p) is not None]
             assert len(sunk) == 3 * 6 + 1                          # 4 projections + 2 FFN matrices per layer, the head's first Linear
@@ -458,6 +459,8 @@ def test_rccl_gradient_bucket_path_single_rank(name, dtype, fuse):
             sc = ts.step(nf, af, al)
         if forced:
             assert all(torch.isfinite(b).all() for b in ts.reducer.buckets)
+            # round 6: per-bucket optimizer steps on a side stream as each reduction lands (the default) vs all buckets, then one step
+            assert (ts.reducer.landed is not None) == bucket_steps
         return sc.cpu(), {k: v.detach().cpu().clone() for k, v in list(enc.state_dict().items()) + list(head.state_dict().items())}
 
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -469,6 +472,7 @@ def test_rccl_gradient_bucket_path_single_rank(name, dtype, fuse):
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         try:
             sc1, w1 = run(True)
+            sc2, w2 = run(True, bucket_steps=False)
         finally:
             dist.destroy_process_group()
             os.environ["LSTC_FORCE_DIST"] = "0"
@@ -476,9 +480,9 @@ def test_rccl_gradient_bucket_path_single_rank(name, dtype, fuse):
     finally:
         Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
     # (the two paths differ only in where the gradients live - flat buckets vs per-parameter tensors)
-    assert torch.equal(sc0, sc1), (sc0, sc1)
+    assert torch.equal(sc0, sc1) and torch.equal(sc0, sc2), (sc0, sc1, sc2)
     for k in w0:
-        assert torch.equal(w0[k], w1[k]), k
+        assert torch.equal(w0[k], w1[k]) and torch.equal(w0[k], w2[k]), k
     if dtype == "fp32":
         assert abs(float(sc0[0]) - float(z["scalars_step2"][0])) < 1e-4
 
@@ -1091,10 +1095,14 @@ class _align_relu_edges:
     bodies look up at call time) and edits the f32 result of the ReLU-epilogue products - the three FFN hiddens in layer order,
     then the head's - before their consumer is launched."""
 
-    def __init__(self, z, n_seq, S, n_layers=3):
+    def __init__(self, z, n_seq, S, n_layers=3, only=None):
+        """``only``: the sites whose recorded decisions are imposed (default: all four); the others are visited and counted
+        (``changed_at``) but left as the HIP step decided them."""
         self.z, self.n_seq, self.S = z, n_seq, S
         self.changed = self.listed = 0
         self.sites = [str(i) for i in range(n_layers)] + ["head"]
+        self.only = None if only is None else set(only)
+        self.changed_at = {s_: 0 for s_ in self.sites}
         self.calls = 0
 
     def _apply(self, site, h):
@@ -1118,9 +1126,12 @@ class _align_relu_edges:
         want = pre.clamp_min(0.0)
         got = h[rows, cols]
         assert float((got - want).abs().max()) < 2 * band               # same values up to f32 rounding of the product
-        self.changed += int(((got > 0) != (want > 0)).sum())
+        n_ch = int(((got > 0) != (want > 0)).sum())
+        self.changed += n_ch
+        self.changed_at[site] += n_ch
         self.listed += int(pre.numel())
-        h[rows, cols] = want
+        if self.only is None or site in self.only:
+            h[rows, cols] = want
 
     def __enter__(self):
         from lstc_vad_amd import functional as Fn
@@ -1268,6 +1279,26 @@ def _full_width_golden_body(name, cls_only):
     beyond, beyond5 = beyond
     frac_ok, frac5_ok = 1.0 - beyond / max(total, 1), 1.0 - beyond5 / max(total, 1)
     del enc_out, outputs, loss
+    # (1b) round 6 - no case is exempted BY NAME any more.  Where the un-aligned fraction misses the bar, the cause must be the one
+    # the exemption used to assert in prose: a hidden unit of the HEAD (Linear(d, 512) + ReLU, models/Classifier.py:8-10 /
+    # models/Regressor.py:7-9) whose reference pre-activation lies within f32 rounding of zero decided differently - every
+    # encoder gradient flows through the head, and under the MIL loss through the few rows that hold a video's maximum.  Then the
+    # same step with ONLY the head's recorded units taken from the reference (the three FFNs as the product decides them) must
+    # meet the fraction bar, and the head must really have decided a recorded unit differently.
+    head_only = None
+    if frac_ok < UNALIGNED_FRACTION_BAR or frac5_ok < 0.999:
+        with _align_relu_edges(z, n_seq_all, S_all, only=("head",)) as he:
+            enc_out, outputs, loss, sc_h = _step(enc, head, mode, args, nf, af, al, d, cls_only)
+        opt.zero_grad()
+        loss.backward()
+        clip()
+        _, _, (b1, b5), tot = _compare_full_width_step0(z, enc, head, enc_out, outputs, sc_h, cls_only, UNALIGNED_GRAD_BAR, UNALIGNED_NORM_BAR,
+                                                         strict=gbar)
+        head_only = (1.0 - b1 / max(tot, 1), 1.0 - b5 / max(tot, 1), he.changed_at["head"])
+        print(f"\n[head-aligned only] {name}: {he.changed_at['head']} recorded head unit(s) decided differently; with the reference's decision "
+              f"there (FFN units untouched) {100.0 * head_only[0]:.2f} % of the sampled entries within the strict bar, {100.0 * head_only[1]:.2f} % within 5x")
+        assert he.changed_at["head"] >= 1 and head_only[0] >= UNALIGNED_FRACTION_BAR and head_only[1] >= 0.999, (name, head_only)
+        del enc_out, outputs, loss
 
     for step in range(2):
         if step == 0:
@@ -1290,8 +1321,12 @@ def _full_width_golden_body(name, cls_only):
             # one - ltn_ubnormal_full_256, 96.5 %: ONE hidden unit of the HEAD (reference pre-activation -6e-8) lands on the other side
             # of zero there and shifts every gradient of the encoder, since all of them flow through the head - and >= 99.99 % within
             # five times the strict bar everywhere
-            assert total > 5000 and frac5_ok >= 0.999 and frac_ok >= (0.95 if name == "ltn_ubnormal_full_256" else UNALIGNED_FRACTION_BAR), \
-                (name, cls_only, beyond, beyond5, total)
+            # (round 6: the exemption of that case by name is gone - a miss must be explained by pass (1b) above, and even then the
+            # un-aligned step keeps 85 % within the strict bar and 99.5 % within five times it)
+            if head_only is None:
+                assert total > 5000 and frac5_ok >= 0.999 and frac_ok >= UNALIGNED_FRACTION_BAR, (name, cls_only, beyond, beyond5, total)
+            else:
+                assert total > 5000 and frac5_ok >= 0.995 and frac_ok >= 0.85, (name, cls_only, beyond, beyond5, total, head_only)
         else:
             enc_out, outputs, loss, sc = _step(enc, head, mode, args, nf, af, al, d, cls_only)
         opt.zero_grad()
