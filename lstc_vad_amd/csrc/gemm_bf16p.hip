@@ -237,6 +237,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
 #define P1_ABL_L2STORE (p.debug & 32)      /* every tile stores into rows 0-255 (the output stays in L2) */
 #define P1_ABL_HOTDMA (p.debug & 64)       /* every DMA reads K step 0 of tile (0, 0): same instruction stream, always cache hits */
 #define P1_ABL_NOXPOSE (p.debug & 128)     /* fast epilogue without the quad transposes / 16-lane exchange (values land in wrong places) */
+#define P1_STAMPS (p.debug & 0x2000)       /* round 6: s_memtime stamps per item (tools/gemm_check stamps): where a persistent workgroup's time goes */
 #else
 #define P1_ABL_DMA 0
 #define P1_ABL_RD 0
@@ -244,6 +245,27 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
 #define P1_ABL_L2STORE 0
 #define P1_ABL_HOTDMA 0
 #define P1_ABL_NOXPOSE 0
+#define P1_STAMPS 0
+#endif
+#ifdef LSTC_TUNING
+    // stamps live in LDS until the workgroup ends (a global store per stamp would join the hand-counted vmcnt queue): wave 0 writes
+    // [item][0..3] = item start / K step 0 landed / K loop done / epilogue done, then copies them to p.relu_src (the tuning harness
+    // passes a buffer there and no ReLU-mask flag): [block][0] = {memtime, memrealtime} at start, [block][1] = at end, [block][2 + 4 i + j]
+    __shared__ unsigned long long p1_stamps[4 * 24 + 4];
+    int p1_item_no = 0;
+#define P1_STAMP(j)                                                                                                    \
+    do {                                                                                                               \
+        if (P1_STAMPS && wave == 0 && p1_item_no < 24) {                                                                \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                \
+            if (lane == 0) p1_stamps[4 + 4 * p1_item_no + (j)] = t_;                                                    \
+        }                                                                                                              \
+    } while (0)
+    if (P1_STAMPS && wave == 0) {
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(), r_ = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) { p1_stamps[0] = t_; p1_stamps[1] = r_; }
+    }
+#else
+#define P1_STAMP(j) do { } while (0)
 #endif
     // ---- LDS-DMA: per unit one wave-uniform global base (SGPRs) + LDS byte address; pieces j = 0, 1 are consecutive KBs
     // (the instruction's immediate offset applies to both sides).  Element offsets.
@@ -475,10 +497,12 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
     issue_head();
     bool pending = false;                 // 32 epilogue stores of the previous item younger than the head DMA
     while (true) {
+        P1_STAMP(0);
         // ---- K step 0 landed?  younger ops: K step 1 (8) and the pending stores (32)
         if (nkt > 1) { if (pending) __builtin_amdgcn_s_waitcnt(vmcnt_imm(40)); else __builtin_amdgcn_s_waitcnt(vmcnt_imm(8)); }
         else { if (pending) __builtin_amdgcn_s_waitcnt(vmcnt_imm(32)); else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0)); }
         __builtin_amdgcn_s_barrier();
+        P1_STAMP(1);
         if (wr == 1) __builtin_amdgcn_s_barrier();       // waves 4-7 run one barrier behind: their LOAD beside the partner's COMPUTE
         if constexpr (S16) {
 #pragma unroll
@@ -503,6 +527,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
         if (tl < nkt) tile(tl, I0{}, BF{}, I0{});
         if (wr == 0) __builtin_amdgcn_s_barrier();       // balance the stagger: every LDS read of the item is complete
         __builtin_amdgcn_sched_barrier(0);
+        P1_STAMP(2);
 
         // ---- next item: request its first two K steps before this item's epilogue
         const int cmb = mb, cnb = nb, csplit = kt0 / p.steps_per_split;
@@ -521,7 +546,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
             fastepi = p.vec_epi && !(p.splits > 1 && p.split_stride == 0) && !(f_ & LSTC_EPI_ACCUM) &&
                       !((f_ & LSTC_EPI_RESIDUAL) && (f_ & LSTC_EPI_RELU_MASK)) && (cmb + 1) * 256 <= p.M && (cnb + 1) * 256 <= p.N;
 #ifdef LSTC_TUNING
-            if (p.debug & ~128) fastepi = false;
+            if (p.debug & ~(128 | 0x2000)) fastepi = false;
 #endif
             if (fastepi && (f_ & LSTC_EPI_BIAS)) {
 #pragma unroll
@@ -865,9 +890,23 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
             __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
         }
         __builtin_amdgcn_sched_barrier(0);
+        P1_STAMP(3);
+#ifdef LSTC_TUNING
+        ++p1_item_no;
+#endif
         if (!has_next) break;
         item = next;
     }
+#ifdef LSTC_TUNING
+    if (P1_STAMPS && wave == 0) {
+        __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(), r_ = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) { p1_stamps[2] = t_; p1_stamps[3] = r_; }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.relu_src)) + (size_t)blockIdx.x * 100;
+        for (int i = lane; i < 100; i += 64) dst[i] = (i < 4 + 4 * p1_item_no) ? p1_stamps[i] : 0ull;
+    }
+#endif
 #undef P1_DMA_UNIT
 #undef P1_MMA
 #undef P1_SYNC_COMPUTE

@@ -47,8 +47,13 @@ class TrainStep:
         # measurement hook (bench.py at N > 1): a list to receive (before backward, after backward, after reducer.finish()) HIP events
         # of every step on the launch stream - backward time and the part of the gradient all-reduce that the backward did not hide
         self.comm_events = None
-        # LSTC_BUCKET_STEPS=0 restores the all-buckets-then-one-optimizer-step order (A/B runs; bit-identical weights)
-        self.bucket_steps = os.environ.get("LSTC_BUCKET_STEPS", "1") != "0"
+        # LSTC_BUCKET_STEPS=1: per-bucket optimizer steps on a side stream as each bucket's reduction lands (weights
+        # bit-identical to the one-step order).  OFF by default: on the one box this build can measure - the RCCL bucket path forced onto
+        # one rank, where a reduction lands at once and hides nothing - the 7 + 7 launches beside the backward cost more than the one
+        # launch behind it saves (tools/r06_bucket_steps_ab.sh, profiles/r06_bucket_steps_ab.txt: 4 pairs per rank bf16 7.25 -> 7.31 ms,
+        # fp32 36.95 -> 37.15; full batch bf16 39.1 -> 39.4).  What it is FOR - stepping six of seven buckets under the exposed wait for the
+        # last reduction over xGMI - needs N > 1 devices to show.
+        self.bucket_steps = os.environ.get("LSTC_BUCKET_STEPS", "0") == "1"
         # default bucketing: head, then per layer (last to first) its FFN half and its attention half - 2 x layers + 1 buckets of
         # <= 67 MB at the LTN widths.  Only the LAST bucket's reduction (layer 0's attention weights, ready when the backward ends)
         # cannot hide under the backward; halving it halves what is exposed, and 67 MB is still far above the size at which

@@ -344,6 +344,8 @@ def _mat(t: torch.Tensor):
 
 
 _SMALL_M_SPLIT = os.environ.get("LSTC_SMALL_M_SPLIT", "1") != "0"      # A/B hook: 0 = small products as ONE launch over the whole K range
+_SMALL_M_ROWS_AS = None      # test hook: choose the K chunks of a small-row product AS IF it had this many rows (a full batch chunked like one
+                             # rank's 256-sequence shard: what tests/test_hip_parity.py compares the summed shard gradients with)
 _small_m_depth = 0
 
 
@@ -372,7 +374,7 @@ class small_m_products:
 def _small_m_split(M: int, N: int, K: int) -> int:
     """K chunks for a product of few output tiles: the largest power of two <= 16 that keeps the items within one round of the
     512 workgroup slots and every chunk >= 256 deep (whole 64-k steps); 1 = leave it alone (more than a quarter of a round already)."""
-    tiles = -(-M // 128) * -(-N // 128)
+    tiles = -(-(_SMALL_M_ROWS_AS or M) // 128) * -(-N // 128)
     if tiles > 128 or K < 512 or N % 4 or M * N >= 1 << 32:       # (2048-row products - 256 tiles - gain nothing in either mode: measured)
         return 1
     s = 1
@@ -439,7 +441,7 @@ def per_head_rows_wT(a3: torch.Tensor, w: torch.Tensor, out: torch.Tensor, N: in
     it lies, a [H, s, dh, K/s] arrangement of the weight and partials [H, s, N, dh] - and lstc_splitk_finish sums the groups."""
     s = 1
     if _small_m_depth > 0 and _SMALL_M_SPLIT and dh % 4 == 0:
-        tiles = H * -(-N // 128) * -(-dh // 128)
+        tiles = H * -(-(_SMALL_M_ROWS_AS or N) // 128) * -(-dh // 128)
         if tiles <= 128 and dm >= 512:
             while s < 16 and tiles * s * 2 <= 512 and dm % (s * 2 * 64) == 0 and dm // (s * 2) >= 256:
                 s *= 2

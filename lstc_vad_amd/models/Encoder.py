@@ -71,6 +71,11 @@ class Encoder(nn.Module):
         qualifies (functional.act_chain_ok)."""
         if self.input_layerNorm or self.CLS_learned or self.position_encoding:
             return False
+        if not self.training:
+            # evaluation keeps f32 activations between the blocks (ADVICE r5): whether the stream applies depends on the launch's
+            # row count (whole 256-row pack tiles), and scoring.py batches by pool, by video or by rank shard - a video's score,
+            # hence pseudo-label thresholds and AUC-based checkpoint selection, must not depend on what shares its launch
+            return False
         if isinstance(enc_output, tuple):
             N, Sm1, d = self._gather_spec(enc_output)
             return act_chain_ok(N, Sm1 + 1, d, layers)

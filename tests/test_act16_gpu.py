@@ -188,8 +188,9 @@ def test_cls_passes_over_a_packed_input_match_the_f32_kernels_on_the_packed_valu
         Fn.set_compute_dtype("fp32")
 
 
-def _run_step(name, act, dropout=0.0, steps=1, lrs=(1e-6, 1e-6, 1e-3)):
-    """One or more optimisation steps of a production-width case in bf16 mode with the given activation dtype."""
+def _run_step(name, act, dropout=0.0, steps=1, lrs=(1e-6, 1e-6, 1e-3), mil_like=None):
+    """One or more optimisation steps of a production-width case in bf16 mode with the given activation dtype.  ``mil_like``: outputs
+    of another run whose MIL arg-max parts this run's loss is made to follow (test_hip_parity._align_mil_max)."""
     hp = _hp()
     from lstc_vad_amd import functional as Fn
     from lstc_vad_amd.engine import TrainStep
@@ -221,10 +222,12 @@ def _run_step(name, act, dropout=0.0, steps=1, lrs=(1e-6, 1e-6, 1e-3)):
     try:
         ts = TrainStep(args, mode, enc, head, *lrs, fuse_qkv="on")
         out = []
+        import contextlib
         for _ in range(steps):
-            loss, sc, outputs = ts.forward_loss(nf, af, al)
-            ts.optimizer.zero_grad(set_to_none=True)
-            loss.backward()
+            with (hp._align_mil_max(mil_like, args.part_num) if mil_like is not None else contextlib.nullcontext()):
+                loss, sc, outputs = ts.forward_loss(nf, af, al)
+                ts.optimizer.zero_grad(set_to_none=True)
+                loss.backward()
             out.append((outputs.detach().clone(), sc.detach().clone(),
                         {k: p.grad.detach().clone() for k, p in enc.named_parameters() if p.grad is not None}))
             ts.optimizer.step()
@@ -258,16 +261,26 @@ def test_bf16_activation_stream_step_tracks_the_f32_activation_step_and_the_refe
     # the direction bars then are 0.90 (measured 0.937)
     flips = _hp()._mil_max_moves(o16, o32, _run_step.part_num)
     assert flips <= 1
-    worst = (1.0, "")
-    for k in g32:
-        if g32[k].numel() < 4096 or float(g32[k].norm()) == 0.0:
-            continue
-        a, b = g16[k].double().reshape(-1), g32[k].double().reshape(-1)
-        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
-        worst = min(worst, (cos, k))
-        bar = 0.90 if flips else (0.96 if k.endswith(("pos_ffn.w_1.weight", "pos_ffn.w_1.bias")) else 0.985)
-        assert cos > bar, (k, cos, flips)
-        assert abs(float(a.norm() / b.norm()) - 1.0) < 0.03, k
+
+    def directions(g16, strict):
+        worst = (1.0, "")
+        for k in g32:
+            if g32[k].numel() < 4096 or float(g32[k].norm()) == 0.0:
+                continue
+            a, b = g16[k].double().reshape(-1), g32[k].double().reshape(-1)
+            cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+            worst = min(worst, (cos, k))
+            bar = (0.96 if k.endswith(("pos_ffn.w_1.weight", "pos_ffn.w_1.bias")) else 0.985) if strict else 0.90
+            assert cos > bar, (k, cos, flips, strict)
+            assert abs(float(a.norm() / b.norm()) - 1.0) < 0.03, k
+        return worst
+    worst = directions(g16, strict=not flips)
+    if flips:
+        # round 6: the 0.90 arm is the UN-ALIGNED statement only - with the f32-activation run's arg-max part for the moved video
+        # (test_hip_parity._align_mil_max, nothing else touched) the stream's gradients are held to the strict bars
+        _, b16, _, _, _ = _run_step(name, "bf16", mil_like=o32)
+        worst_al = directions(b16[0][2], strict=True)
+        print(f"\n[act16 {name}] MIL arg-max aligned: worst gradient cosine {worst_al[0]:.4f} ({worst_al[1]})")
     print(f"\n[act16 {name}] scores vs f32-activation step {max_abs_diff(o16, o32):.2e}, vs reference "
           f"{max_abs_diff(o16.reshape(z['outputs'].shape), z['outputs']):.2e}; worst gradient cosine {worst[0]:.4f} ({worst[1]}); "
           f"videos whose MIL maximum moved to another part: {flips}; peak memory {peak16 / 2**30:.2f} vs {peak32 / 2**30:.2f} GiB")

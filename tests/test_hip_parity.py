@@ -1279,27 +1279,28 @@ def _full_width_golden_body(name, cls_only):
     beyond, beyond5 = beyond
     frac_ok, frac5_ok = 1.0 - beyond / max(total, 1), 1.0 - beyond5 / max(total, 1)
     del enc_out, outputs, loss
-    # (1b) round 6 - no case is exempted BY NAME any more.  Where the un-aligned fraction misses the bar, the cause must be the one
-    # the exemption used to assert in prose: a hidden unit of the HEAD (Linear(d, 512) + ReLU, models/Classifier.py:8-10 /
-    # models/Regressor.py:7-9) whose reference pre-activation lies within f32 rounding of zero decided differently - every
-    # encoder gradient flows through the head, and under the MIL loss through the few rows that hold a video's maximum.  Then the
-    # same step with ONLY the head's recorded units taken from the reference (the three FFNs as the product decides them) must
-    # meet the fraction bar, and the head must really have decided a recorded unit differently.
-    head_only = None
+    # (1b) round 6 - no case is exempted BY NAME any more.  Where the un-aligned fraction misses the bar, the test measures WHICH
+    # recorded ReLU-edge site explains it: the same step with the reference's decision imposed at ONE site at a time (layer 0 / 1 / 2
+    # FFN hidden, the head's hidden; everything else as the product decides).  Printed for the record (DESIGN 4 quotes it); asserted:
+    # at least one site really decided a recorded unit differently, and the fully aligned pass (2) below meets the strict bars - i.e.
+    # the recorded edge units, and nothing else, separate this step from the reference's.
+    site_table = None
     if frac_ok < UNALIGNED_FRACTION_BAR or frac5_ok < 0.999:
-        with _align_relu_edges(z, n_seq_all, S_all, only=("head",)) as he:
-            enc_out, outputs, loss, sc_h = _step(enc, head, mode, args, nf, af, al, d, cls_only)
-        opt.zero_grad()
-        loss.backward()
-        clip()
-        _, _, (b1, b5), tot = _compare_full_width_step0(z, enc, head, enc_out, outputs, sc_h, cls_only, UNALIGNED_GRAD_BAR, UNALIGNED_NORM_BAR,
-                                                         strict=gbar)
-        head_only = (1.0 - b1 / max(tot, 1), 1.0 - b5 / max(tot, 1), he.changed_at["head"])
-        print(f"\n[head-aligned only] {name}: {he.changed_at['head']} recorded head unit(s) decided differently; with the reference's decision "
-              f"there (FFN units untouched) {100.0 * head_only[0]:.2f} % of the sampled entries within the strict bar, {100.0 * head_only[1]:.2f} % within 5x")
-        assert he.changed_at["head"] >= 1 and head_only[0] >= UNALIGNED_FRACTION_BAR and head_only[1] >= 0.999, (name, head_only)
-        del enc_out, outputs, loss
-
+        site_table = {}
+        for site in ("0", "1", "2", "head"):
+            with _align_relu_edges(z, n_seq_all, S_all, only=(site,)) as he:
+                enc_out, outputs, loss, sc_h = _step(enc, head, mode, args, nf, af, al, d, cls_only)
+            opt.zero_grad()
+            loss.backward()
+            clip()
+            _, _, (b1, b5), tot = _compare_full_width_step0(z, enc, head, enc_out, outputs, sc_h, cls_only, UNALIGNED_GRAD_BAR,
+                                                             UNALIGNED_NORM_BAR, strict=gbar)
+            site_table[site] = (he.changed_at[site], 1.0 - b1 / max(tot, 1), 1.0 - b5 / max(tot, 1))
+            del enc_out, outputs, loss
+        print(f"\n[one site aligned] {name}: un-aligned {100.0 * frac_ok:.2f} % within the strict bar; with the reference's decisions at ONE site: " +
+              "; ".join(f"{'head' if k == 'head' else 'FFN ' + k}: {v[0]} unit(s) differed -> {100.0 * v[1]:.2f} % ({100.0 * v[2]:.2f} % within 5x)"
+                        for k, v in site_table.items()))
+        assert sum(v[0] for v in site_table.values()) >= 1, site_table
     for step in range(2):
         if step == 0:
             # (2) the same step with the reference's decision at the recorded edge units: every gradient at the strict bars
@@ -1321,12 +1322,13 @@ def _full_width_golden_body(name, cls_only):
             # one - ltn_ubnormal_full_256, 96.5 %: ONE hidden unit of the HEAD (reference pre-activation -6e-8) lands on the other side
             # of zero there and shifts every gradient of the encoder, since all of them flow through the head - and >= 99.99 % within
             # five times the strict bar everywhere
-            # (round 6: the exemption of that case by name is gone - a miss must be explained by pass (1b) above, and even then the
-            # un-aligned step keeps 85 % within the strict bar and 99.5 % within five times it)
-            if head_only is None:
+            # (round 6: the exemption of that case by name is gone - a miss is analysed site by site in pass (1b) above, the aligned pass
+            # below must then meet the strict bars, and even so the un-aligned step keeps 85 % within the strict bar and 99.5 % within
+            # five times it.  Measured misses: ltn_ubnormal_full_256 96.5 %, stn_headline 87.8 % in exact f32 - 100 % in f32x3)
+            if site_table is None:
                 assert total > 5000 and frac5_ok >= 0.999 and frac_ok >= UNALIGNED_FRACTION_BAR, (name, cls_only, beyond, beyond5, total)
             else:
-                assert total > 5000 and frac5_ok >= 0.995 and frac_ok >= 0.85, (name, cls_only, beyond, beyond5, total, head_only)
+                assert total > 5000 and frac5_ok >= 0.995 and frac_ok >= 0.85, (name, cls_only, beyond, beyond5, total, site_table)
         else:
             enc_out, outputs, loss, sc = _step(enc, head, mode, args, nf, af, al, d, cls_only)
         opt.zero_grad()
@@ -1537,17 +1539,21 @@ def test_headline_size_backward_is_the_sum_of_its_shards_and_bit_reproducible():
         return training_loss(args_for(hi - lo), "LTN", out, al[lo:hi], distributed=distributed, exchange=exchange)
 
     # ---- linearity over the 8-GPU split (dropout off: a shard draws other masks than the batch)
-    def linearity(k_chunks):
+    def linearity(k_chunks, batch_rows_as=None):
         """Worst relative difference between the summed shard gradients and the batch gradient.  ``k_chunks``: the product's own
         routing (functional.small_m_products: a shard's 256-sequence products of the CLS-only layer and the head run as K chunks,
-        the batch's 2048-sequence ones as one launch) or every product as one launch."""
+        the batch's 2048-sequence ones as one launch) or every product as one launch.  ``batch_rows_as`` = 256: the BATCH's small-row
+        products are chunked exactly like a shard's (functional._SMALL_M_ROWS_AS), so every output row is summed in the same k order
+        on both sides and what is left is the token split of the weight-gradient sums alone."""
         Fn._SMALL_M_SPLIT = k_chunks
+        Fn._SMALL_M_ROWS_AS = batch_rows_as
         enc, head = build((0.0, 0.0, 0.0, 0.0))
         params = [(k, p) for k, p in list(enc.named_parameters()) + list(head.named_parameters())]
         loss, sc_full = run(enc, head, 0, bs)
         loss.backward()
         full = {k: p.grad.detach().clone() for k, p in params if p.grad is not None}
         sc_full = sc_full.detach().clone()
+        Fn._SMALL_M_ROWS_AS = None                              # the shards run as the product runs them
         for _, p in params:
             p.grad = None
         h = bs // R
@@ -1586,8 +1592,10 @@ def test_headline_size_backward_is_the_sum_of_its_shards_and_bit_reproducible():
     try:
         worst, tab = linearity(False)
         worst_k, tab_k = linearity(True)
+        worst_s, tab_s = linearity(True, batch_rows_as=bs // R * 2 * pn)           # 256: a shard's row count
     finally:
         Fn._SMALL_M_SPLIT = True
+        Fn._SMALL_M_ROWS_AS = None
     print(f"\n[headline backward] sum of {R} shard gradients vs the batch gradient: worst relative difference {worst[0]:.2e} ({worst[1]}), "
           f"bias tables {tab[0]:.2e}; with the shards' small products as K chunks {worst_k[0]:.2e} ({worst_k[1]}), bias tables {tab_k[0]:.2e}")
     # f32 sums over 100 352 tokens split 8 ways vs at once (measured 6.1e-6, layer 1's dW2)
@@ -1598,6 +1606,12 @@ def test_headline_size_backward_is_the_sum_of_its_shards_and_bit_reproducible():
     # cancelling sums, their norms ~1e-2 of the other weights' - carry it amplified (measured 2.5e-4 / 4.0e-4 of the tensor's norm);
     # bar 1e-3 / 2e-3
     assert worst_k[0] < 1e-3 and tab_k[0] < 2e-3, (worst_k, tab_k)
+    # round 6: the statement "DP reproduces the single-process step" at the bar of the equal-routing arm - the
+    # batch's few-row products chunked exactly like a shard's (same k order per output row on both sides): what remains is the token
+    # split of the weight-gradient sums, as in the first arm.  The 2.5e-4 above is therefore the re-association of the BATCH-side
+    # one-launch products against the chunked ones, not a property of the data-parallel composition
+    print(f"[headline backward] K-chunked shards vs the batch chunked the same way: worst {worst_s[0]:.2e} ({worst_s[1]}), bias tables {tab_s[0]:.2e}")
+    assert worst_s[0] < 2e-5 and tab_s[0] < 2e-5, (worst_s, tab_s)
     # ---- bit reproducibility at the headline size, reference dropout rates on
     enc, head = build((0.2, 0.2, 0.1, 0.6))
     outs = []
@@ -1780,6 +1794,43 @@ def _mil_max_moves(outputs, ref_outputs, part_num):
     return len(moved)
 
 
+class _align_mil_max:
+    """``with _align_mil_max(ref_outputs, part_num) as st:`` - the MIL ranking term reads ONE part per video, the maximum of column 1
+    over its parts (losses.get_MIL_loss, Train/temporal_transformer_shanghaitech.py:25-36).  Inside the context the loss sees, for
+    every video whose maximum sits on another part than in ``ref_outputs``, the reference's part lifted just above the current
+    maximum (a constant added to that one score: at most the gap between the top two parts, which ``_mil_max_moves`` has shown to be
+    smaller than the score tolerance) - so the ranking gradient travels through the part the reference's run chose.  The same
+    device as ``_align_relu_edges``: an arg-max over nearly tied scores is decided by rounding, and the comparison of everything else
+    should not inherit that coin flip.  Nothing in the product knows about this: the context wraps ``training_loss`` as the TEST
+    and ``engine`` look it up.  ``st.moved`` = videos re-routed."""
+
+    def __init__(self, ref_outputs, part_num):
+        self.ref, self.pn, self.moved = torch.as_tensor(ref_outputs).detach().float().cpu(), int(part_num), 0
+
+    def __enter__(self):
+        from lstc_vad_amd import engine, losses
+        self.losses, self.engine, self.real = losses, engine, losses.training_loss
+        st = self
+
+        def training_loss(args, mode, outputs, *a, **kw):
+            if st.ref.dim() == 2 and st.ref.shape[1] == 2:
+                r = st.ref.to(outputs.device).reshape(outputs.shape)
+                cur, rr = outputs.detach()[:, 1].reshape(-1, st.pn), r[:, 1].reshape(-1, st.pn)
+                want, have = rr.argmax(1), cur.argmax(1)
+                delta = torch.zeros_like(outputs)
+                for v in (want != have).nonzero().reshape(-1).tolist():
+                    delta[v * st.pn + int(want[v]), 1] = float(cur[v].max() - cur[v, want[v]]) + 1e-6
+                    st.moved += 1
+                outputs = outputs + delta
+            return st.real(args, mode, outputs, *a, **kw)
+        losses.training_loss = engine.training_loss = training_loss
+        return self
+
+    def __exit__(self, *exc):
+        self.losses.training_loss = self.engine.training_loss = self.real
+        return False
+
+
 @pytest.mark.parametrize("name,fused", [(n, False) for n in FULL_NAMES] + [("stn_full", True), ("stn_mil_ce_full", True), ("ltn_ucf_full", True),
                                         ("ltn_full_256", True), ("ltn_ubnormal_full_256", True)])
 def test_full_width_bf16_step_tracks_reference(name, fused):
@@ -1824,18 +1875,40 @@ def test_full_width_bf16_step_tracks_reference(name, fused):
     assert moves <= 1
     if moves:
         print(f"\n[bf16 {name}] {moves} video's MIL maximum sits on another part than in the reference's run")
-    for k, p in enc.named_parameters():
-        if p.grad is None or p.numel() < 4096 or float(z[f"enc_gnorm.{k}"]) == 0.0:
-            continue
-        gs = torch.from_numpy(z[f"enc_gs.{k}"]).double()
-        got = p.grad.detach().reshape(-1)[torch.from_numpy(sample_index(p.numel())).to(DEV)].cpu().double()
-        cos = float((got * gs).sum() / (got.norm() * gs.norm() + 1e-30))
-        # 256 sampled entries per tensor: > 0.98 everywhere except the first FFN weight, whose gradient dh^T x inherits the
-        # ReLU decisions of the ~0.5 % of hidden units whose pre-activation lies within bf16 product rounding of zero (a
-        # flipped unit rewrites its whole row of dW1; ltn_ucf_full layer 1: 0.968 on the sample at a norm ratio of 1.0006)
-        # (the same holds for that layer's bias gradient db1 = column sums of the hidden's gradient: 0.976 on ltn_clip_full layer 1)
-        assert cos > (0.90 if moves else 0.95 if k.endswith(("pos_ffn.w_1.weight", "pos_ffn.w_1.bias")) else 0.98), (k, cos, moves)
-        assert abs(float(p.grad.double().norm()) / float(z[f"enc_gnorm.{k}"]) - 1.0) < 0.05, k
+    def check(strict):
+        for k, p in enc.named_parameters():
+            if p.grad is None or p.numel() < 4096 or float(z[f"enc_gnorm.{k}"]) == 0.0:
+                continue
+            gs = torch.from_numpy(z[f"enc_gs.{k}"]).double()
+            got = p.grad.detach().reshape(-1)[torch.from_numpy(sample_index(p.numel())).to(DEV)].cpu().double()
+            cos = float((got * gs).sum() / (got.norm() * gs.norm() + 1e-30))
+            # 256 sampled entries per tensor: > 0.98 everywhere except the first FFN weight, whose gradient dh^T x inherits the
+            # ReLU decisions of the ~0.5 % of hidden units whose pre-activation lies within bf16 product rounding of zero (a
+            # flipped unit rewrites its whole row of dW1; ltn_ucf_full layer 1: 0.968 on the sample at a norm ratio of 1.0006)
+            # (the same holds for that layer's bias gradient db1 = column sums of the hidden's gradient: 0.976 on ltn_clip_full layer 1)
+            assert cos > ((0.95 if k.endswith(("pos_ffn.w_1.weight", "pos_ffn.w_1.bias")) else 0.98) if strict else 0.90), (k, cos, moves, strict)
+            assert abs(float(p.grad.double().norm()) / float(z[f"enc_gnorm.{k}"]) - 1.0) < 0.05, k
+    check(strict=not moves)
+    if moves:
+        # round 6: the 0.90 arm above documents the UN-ALIGNED step only.  The same step with the reference's
+        # arg-max part for the moved video (``_align_mil_max``; nothing else touched) is held to the bars of every other case
+        for p in list(enc.parameters()) + list(head.parameters()):
+            p.grad = None
+        Fn.set_compute_dtype("bf16")
+        try:
+            with _align_mil_max(z["outputs"], args.part_num) as st:
+                enc_out, outputs, loss, sc = _step(enc, head, mode, args, nf, af, al, d, cls_only=True)
+                loss.backward()
+            if args.clip_grad:
+                from lstc_vad_amd.optim import clip_grad_norm_
+                clip_grad_norm_(enc.parameters(), 10)
+                clip_grad_norm_(head.parameters(), 10)
+            torch.cuda.synchronize()
+        finally:
+            Fn.set_compute_dtype("fp32")
+        assert st.moved == moves
+        check(strict=True)
+        print(f"[bf16 {name}] with the reference's arg-max part for that video: every gradient direction at the strict bars")
 
 
 def test_mixed_step_bf16_vs_fp32_auc_on_the_mixed_pair():

@@ -112,6 +112,7 @@ static int check(const Case& c) {
 }
 
 static void timeit(int M, int N, int K, int tA, int tB, int variant, int split, int flags, int iters, int pad_a = 0, int pad_b = 0, int dtype = 0) {
+    const int v15 = variant & 15;          // the tile / form selector; the bits above it select tuning ablations (LSTC_TUNING builds)
     const int lda = (tA ? M : K) + pad_a, ldb = (tB ? K : N) + pad_b;
     const size_t na = (size_t)(tA ? K : M) * lda, nb = (size_t)(tB ? N : K) * ldb, nc = (size_t)M * N;
     float *dA, *dB, *dC, *dbias;
@@ -133,23 +134,23 @@ static void timeit(int M, int N, int K, int tA, int tB, int variant, int split, 
     auto packf = [&](const float* s_, int64_t r_, int64_t k_, int64_t ld_, int km_, void* d_) {
         return p1 ? lstc_pack1(s_, r_, k_, ld_, km_, d_, nullptr) : lstc_pack3(s_, r_, k_, ld_, km_, d_, nullptr); };
     if (dtype == LSTC_F32X3 || p1) {
-        const bool trc = variant >= 7 && variant <= 9;
+        const bool trc = v15 >= 7 && v15 <= 9;
         CK(hipMalloc(&pA, p1 ? (trc ? lstc_pack1_bytes(K, M) : lstc_pack1_bytes(M, K)) : lstc_pack3_bytes(M, K)));
         CK(hipMalloc(&pB, p1 ? (trc ? lstc_pack1_bytes(K, N) : lstc_pack1_bytes(N, K)) : lstc_pack3_bytes(N, K)));
         for (int rep = 0; rep < 2; ++rep) {
             CK(hipEventRecord(e0, nullptr));
-            if (variant >= 7 && variant <= 9) packf(dA, K, M, lda, 0, pA); else packf(dA, M, K, lda, tA ? 1 : 0, pA);
+            if (v15 >= 7 && v15 <= 9) packf(dA, K, M, lda, 0, pA); else packf(dA, M, K, lda, tA ? 1 : 0, pA);
             CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
             float msa; CK(hipEventElapsedTime(&msa, e0, e1));
             CK(hipEventRecord(e0, nullptr));
-            if (variant >= 7 && variant <= 9) packf(dB, K, N, ldb, 0, pB); else packf(dB, N, K, ldb, tB ? 0 : 1, pB);
+            if (v15 >= 7 && v15 <= 9) packf(dB, K, N, ldb, 0, pB); else packf(dB, N, K, ldb, tB ? 0 : 1, pB);
             CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
             float msb; CK(hipEventElapsedTime(&msb, e0, e1));
             if (rep) printf("PACK A [%d x %d]%s %.3f ms (%.2f TB/s read + write)   B [%d x %d]%s %.3f ms\n", M, K, tA ? " k-major" : "", msa,
                             (p1 ? 6.0 : 12.0) * M * K / (msa * 1e-3) / 1e12, N, K, tB ? "" : " k-major", msb);
         }
         d.A = pA; d.B = pB;
-        if (variant >= 7 && variant <= 9) { d.transA = 1; d.transB = 0; d.variant = p1 ? 0 : variant == 8 ? 2 : variant == 9 ? 3 : 1; } else { d.transA = 0; d.transB = 1; if (p1) d.variant = variant & ~15; }
+        if (v15 >= 7 && v15 <= 9) { d.transA = 1; d.transB = 0; d.variant = p1 ? (variant & ~15) : v15 == 8 ? 2 : v15 == 9 ? 3 : 1; } else { d.transA = 0; d.transB = 1; if (p1) d.variant = variant & ~15; }
     }
     void *pC = nullptr, *pR = nullptr;
     if (p1 && (flags & LSTC_EPI_OUT_PACK)) {                // timing of the packed-output / packed-residual epilogues (bf16 activation stream)
@@ -161,6 +162,11 @@ static void timeit(int M, int N, int K, int tA, int tB, int variant, int split, 
             d.residual = pR;
         }
     }
+#ifdef LSTC_TUNING
+    unsigned long long* dstamp = nullptr;
+    const bool stamps = p1 && ((variant >> 4) & 0x2000) && !(flags & LSTC_EPI_RELU_MASK);
+    if (stamps) { CK(hipMalloc(&dstamp, 1024 * 100 * 8)); CK(hipMemset(dstamp, 0, 1024 * 100 * 8)); d.relu_src = (const float*)dstamp; }
+#endif
     for (int i = 0; i < 6; ++i) { int rc = lstc_gemm(&d, nullptr); if (rc) { printf("rc=%d\n", rc); return; } }   // clock ramp
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, nullptr));
@@ -171,6 +177,39 @@ static void timeit(int M, int N, int K, int tA, int tB, int variant, int split, 
     const double peak = (dtype == LSTC_BF16 || dtype == LSTC_BF16P) ? 2500.0 : 157.3;
     printf("TIME %s M=%6d N=%5d K=%6d tA=%d tB=%d var=%d split=%d flags=%3d pad=%d,%d : %8.3f ms  %7.2f TFLOP/s (%.1f%% of %.1f)\n", dtype == LSTC_F32X3 ? "f32x3" : dtype == LSTC_BF16P ? "bf16p" : dtype ? "bf16c" : "f32", M, N, K, tA, tB,
            variant, split, flags, pad_a, pad_b, ms, tf, 100.0 * tf / peak, peak);
+#ifdef LSTC_TUNING
+    if (stamps) {
+        // per persistent workgroup: [0..3] = memtime / memrealtime at start and end, then per item 4 stamps (item start, K step 0 landed,
+        // K loop done, epilogue done).  Shader cycles -> us through the workgroup's own cycles per 100-MHz tick.
+        std::vector<unsigned long long> h(1024 * 100);
+        CK(hipMemcpy(h.data(), dstamp, h.size() * 8, hipMemcpyDeviceToHost));
+        double sum[3][4] = {{0}}, cnt[3] = {0, 0, 0}, span = 0, clk = 0; int nb = 0, maxit = 0;
+        for (int b = 0; b < 1024; ++b) {
+            const unsigned long long* s = &h[(size_t)b * 100];
+            if (!s[0] || s[3] <= s[1]) continue;
+            const double cyc_per_us = (double)(s[2] - s[0]) / ((double)(s[3] - s[1]) / 100.0);
+            int n = 0; while (n < 24 && s[4 + 4 * n + 3]) ++n;
+            if (n == 0) continue;
+            ++nb; clk += cyc_per_us; span += (double)(s[2] - s[0]) / cyc_per_us; maxit = std::max(maxit, n);
+            for (int i = 0; i < n; ++i) {
+                const unsigned long long* t = s + 4 + 4 * i;
+                const int cls = i == 0 ? 0 : (i == n - 1 ? 2 : 1);
+                sum[cls][0] += (double)(t[1] - t[0]) / cyc_per_us; sum[cls][1] += (double)(t[2] - t[1]) / cyc_per_us;
+                sum[cls][2] += (double)(t[3] - t[2]) / cyc_per_us;
+                sum[cls][3] += i + 1 < n ? (double)(t[4] - t[3]) / cyc_per_us : 0.0;
+                cnt[cls] += 1;
+            }
+        }
+        printf("STAMPS %d workgroups, up to %d items each, in-kernel clock %.0f MHz, mean workgroup span %.1f us (launch %.1f us)\n", nb, maxit,
+               nb ? clk / nb : 0.0, nb ? span / nb : 0.0, ms * 1e3);
+        const char* nm[3] = {"first item ", "middle items", "last item  "};
+        for (int c = 0; c < 3; ++c)
+            if (cnt[c] > 0)
+                printf("STAMPS %s (%6.0f): wait for K step 0 %6.2f us | K loop %6.2f us | next-item head + epilogue %6.2f us | to next item %5.2f us\n", nm[c], cnt[c],
+                       sum[c][0] / cnt[c], sum[c][1] / cnt[c], sum[c][2] / cnt[c], sum[c][3] / cnt[c]);
+        hipFree(dstamp);
+    }
+#endif
     if (pA) hipFree(pA);
     if (pB) hipFree(pB);
     if (pC) hipFree(pC);
