@@ -251,7 +251,8 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
     // stamps live in LDS until the workgroup ends (a global store per stamp would join the hand-counted vmcnt queue): wave 0 writes
     // [item][0..3] = item start / K step 0 landed / K loop done / epilogue done, then copies them to p.relu_src (the tuning harness
     // passes a buffer there and no ReLU-mask flag): [block][0] = {memtime, memrealtime} at start, [block][1] = at end, [block][2 + 4 i + j]
-    __shared__ unsigned long long p1_stamps[4 * 24 + 4];
+    // (behind the two operand buffers of the dynamic allocation - the LDS-DMA addresses are absolute, a static array would sit at 0)
+    unsigned long long* const p1_stamps = reinterpret_cast<unsigned long long*>(smem_p1 + 2 * P1_BUF);
     int p1_item_no = 0;
 #define P1_STAMP(j)                                                                                                    \
     do {                                                                                                               \
@@ -374,7 +375,8 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                 _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                        \
                     _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                    \
                         a4[4 * (ih) + rt][2 * (jj) + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
-                            fa[2 * kk + (rt >> 1)][rt & 1], fb[rs][2 * kk + ct], a4[4 * (ih) + rt][2 * (jj) + ct], 0, 0, 0); \
+                            OPK ? fb[rs][2 * kk + ct] : fa[2 * kk + (rt >> 1)][rt & 1],                                 \
+                            OPK ? fa[2 * kk + (rt >> 1)][rt & 1] : fb[rs][2 * kk + ct], a4[4 * (ih) + rt][2 * (jj) + ct], 0, 0, 0); \
                 if (kk == 0) { __builtin_amdgcn_sched_barrier(0); __VA_ARGS__; __builtin_amdgcn_sched_barrier(0); }     \
             }                                                                                                          \
         } else {                                                                                                       \
@@ -485,7 +487,10 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
-    typedef std::integral_constant<int, 32> I32;
+    // stores of an item's hand-counted epilogue that may still be outstanding when the next item's K step 0 is waited for: 32 per wave
+    // (8-B / 16-B stores of 4 outputs), 16 in the packed-output kernels (16-B stores of 8 outputs, round 6)
+    constexpr int PENDN = OPK ? 16 : 32;
+    typedef std::integral_constant<int, PENDN> I32;
     typedef std::integral_constant<bool, true> BT;
     typedef std::integral_constant<bool, false> BF;
 
@@ -499,8 +504,8 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
     while (true) {
         P1_STAMP(0);
         // ---- K step 0 landed?  younger ops: K step 1 (8) and the pending stores (32)
-        if (nkt > 1) { if (pending) __builtin_amdgcn_s_waitcnt(vmcnt_imm(40)); else __builtin_amdgcn_s_waitcnt(vmcnt_imm(8)); }
-        else { if (pending) __builtin_amdgcn_s_waitcnt(vmcnt_imm(32)); else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0)); }
+        if (nkt > 1) { if (pending) __builtin_amdgcn_s_waitcnt(vmcnt_imm(8 + PENDN)); else __builtin_amdgcn_s_waitcnt(vmcnt_imm(8)); }
+        else { if (pending) __builtin_amdgcn_s_waitcnt(vmcnt_imm(PENDN)); else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0)); }
         __builtin_amdgcn_s_barrier();
         P1_STAMP(1);
         if (wr == 1) __builtin_amdgcn_s_barrier();       // waves 4-7 run one barrier behind: their LOAD beside the partner's COMPUTE
@@ -541,7 +546,27 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
         // 100352 x 2048 x 2048 with a residual 770 TFLOP/s against 1055 without).
         bool fastepi = false;
         floatx4v fbias[2] = {floatx4v{0.f, 0.f, 0.f, 0.f}, floatx4v{0.f, 0.f, 0.f, 0.f}};
-        if constexpr (S16) {
+        // OPK (packed output, round 6): the products ran with the MFMA operands SWAPPED (B fragment first), so a 16 x 16 accumulator holds,
+        // per lane, ONE output row (l15) and four consecutive columns (4 c16 + r) - no quad transposes.  One v_permlane16_swap per
+        // register between the two column tiles of a 32-column pack tile leaves every lane with EIGHT consecutive columns = one 16-B
+        // chunk of the pack: a wave's 128 x 64 outputs leave as 16 global_store_dwordx4 (was 32 global_store_dwordx2; the epilogue is
+        // store-ISSUE bound: tools/r06_bf16p_stamps.sh, 11.4 us per item whatever the flags), operands arrive as 16-B loads of the same
+        // shape, ALL issued before the first group is computed (no wait ever covers a store).
+        // lane rows c16 = 0 .. 3 of an accumulator end up with the chunks 0, 2, 1, 3 of the 32-column tile:
+        const int pk_chunk = (0xD8 >> (2 * c16)) & 3;
+        floatx4v pbias[2][2] = {{floatx4v{0.f, 0.f, 0.f, 0.f}, floatx4v{0.f, 0.f, 0.f, 0.f}}, {floatx4v{0.f, 0.f, 0.f, 0.f}, floatx4v{0.f, 0.f, 0.f, 0.f}}};
+        if constexpr (OPK) {
+            if (p.flags & LSTC_EPI_BIAS) {
+#pragma unroll
+                for (int cp = 0; cp < 2; ++cp) {
+                    const float* bp = p.bias + (cnb * 256 + wc * 64 + 32 * cp);                        // wave-uniform
+                    const uint32_t bo = (uint32_t)pk_chunk * 32u;
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pbias[cp][0]) : "v"(bo), "s"(bp) : "memory");
+                    asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(pbias[cp][1]) : "v"(bo), "s"(bp) : "memory");
+                }
+            }
+        }
+        if constexpr (S16 && !OPK) {
             const int f_ = p.flags;
             fastepi = p.vec_epi && !(p.splits > 1 && p.split_stride == 0) && !(f_ & LSTC_EPI_ACCUM) &&
                       !((f_ & LSTC_EPI_RESIDUAL) && (f_ & LSTC_EPI_RELU_MASK)) && (cmb + 1) * 256 <= p.M && (cnb + 1) * 256 <= p.N;
@@ -587,7 +612,154 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
         const bool atomic = p.splits > 1 && p.split_stride == 0;
         float* const Cz = p.C + (size_t)csplit * p.split_stride;
         const float alpha = p.alpha;
-        if constexpr (S16) {
+        if constexpr (OPK) {
+            if (!done) {
+                typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+                typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+                typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+                const bool f_res = (flags & LSTC_EPI_RESIDUAL) != 0, f_mask = (flags & LSTC_EPI_RELU_MASK) != 0;
+                const int hdma = has_next ? (nkt > 1 ? 16 : 8) : 0;                              // LDS-DMA of the next item in flight
+                const int nbias = (flags & LSTC_EPI_BIAS) ? 4 : 0;
+                // byte offset of the lane's 16-B chunk inside a 16-row x 32-column sub-tile of a pack (64-B rows, chunk XOR (row >> 2) & 3)
+                const uint32_t offP = (uint32_t)(l15 * 32 + ((pk_chunk ^ ((l15 >> 2) & 3)) << 3)) * 2u;
+                const int urow0 = cmb * 256 + wr * 128, ucol0 = cnb * 256 + wc * 64;
+                const uint32_t idx0 = (uint32_t)(urow0 + l15) * (uint32_t)p.N + (uint32_t)(ucol0 + 8 * pk_chunk);
+                // f32 operand (residual or ReLU-mask source kept in f32: the f32-activation configuration): row-major, the lane's 8 columns
+                const float* aux = f_res ? p.res : f_mask ? p.relu_src : nullptr;
+                const int ldx = f_res ? p.ldr : p.ld_relu;
+                const uint32_t offX = ((uint32_t)l15 * (uint32_t)ldx + 8u * (uint32_t)pk_chunk) * 4u;
+                auto tile_elems = [&](int kbp, int cp, int rt) -> size_t {
+                    return ((size_t)(2 * cmb + wr) * kbp + cnb * 8 + wc * 2 + cp) * P1_TILE + rt * 512;
+                };
+                // one unit u = 8 rt' + ... : (cp = u >> 3, rt = u & 7): the two 16-column accumulators a4[rt][2 cp], a4[rt][2 cp + 1]
+                auto unit = [&](int rt, int cp, const uint4v& opk, const floatx4v& o0, const floatx4v& o1) {
+                    float e0 = a4[S16 ? rt : 0][S16 ? 2 * cp : 0][0], e1 = a4[S16 ? rt : 0][S16 ? 2 * cp : 0][1];
+                    float e2 = a4[S16 ? rt : 0][S16 ? 2 * cp : 0][2], e3 = a4[S16 ? rt : 0][S16 ? 2 * cp : 0][3];
+                    float o_0 = a4[S16 ? rt : 0][S16 ? 2 * cp + 1 : 0][0], o_1 = a4[S16 ? rt : 0][S16 ? 2 * cp + 1 : 0][1];
+                    float o_2 = a4[S16 ? rt : 0][S16 ? 2 * cp + 1 : 0][2], o_3 = a4[S16 ? rt : 0][S16 ? 2 * cp + 1 : 0][3];
+#define P1_SWAP(x, y)                                                                                                    \
+                    do {                                                                                                 \
+                        const uint2v r_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false); \
+                        x = __uint_as_float(r_[0]); y = __uint_as_float(r_[1]);                                           \
+                    } while (0)
+                    P1_SWAP(e0, o_0); P1_SWAP(e1, o_1); P1_SWAP(e2, o_2); P1_SWAP(e3, o_3);
+#undef P1_SWAP
+                    float v[8] = {e0, e1, e2, e3, o_0, o_1, o_2, o_3};
+                    const float bvv[8] = {pbias[cp][0][0], pbias[cp][0][1], pbias[cp][0][2], pbias[cp][0][3],
+                                          pbias[cp][1][0], pbias[cp][1][1], pbias[cp][1][2], pbias[cp][1][3]};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] * alpha + bvv[e];
+                    if (flags & LSTC_EPI_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (flags & LSTC_EPI_DROPOUT) {
+                        const uint32_t idx = idx0 + (uint32_t)(rt * 16) * (uint32_t)p.N + 32u * (uint32_t)cp;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = drop_keep(idx + e, dkn) ? v[e] * dkn.scale : 0.f;
+                    }
+                    if constexpr (RPK) {             // bf16 -> f32 is a 16-bit shift: exact
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] += __uint_as_float(opk[e] << 16);
+                            v[2 * e + 1] += __uint_as_float(opk[e] & 0xffff0000u);
+                        }
+                    } else if (f_res) {
+                        const float xx[8] = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += xx[e];
+                    }
+                    if constexpr (MPK) {             // bf16 > 0 <=> the element's 16 bits, as the upper half of an int32, are > 0
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] = (int)(opk[e] << 16) > 0 ? v[2 * e] : 0.f;
+                            v[2 * e + 1] = (int)(opk[e] & 0xffff0000u) > 0 ? v[2 * e + 1] : 0.f;
+                        }
+                    } else if (f_mask) {
+                        const float xx[8] = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = xx[e] > 0.f ? v[e] : 0.f;
+                    }
+                    uint4v h_;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        bf16x2 t2; t2[0] = (bf16_t)v[2 * e]; t2[1] = (bf16_t)v[2 * e + 1];
+                        h_[e] = __builtin_bit_cast(unsigned, t2);
+                    }
+                    bf16_t* ob_ = reinterpret_cast<bf16_t*>(p.C) + tile_elems(p.out_kbp, cp, rt);
+                    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(offP), "v"(h_), "s"(ob_) : "memory");
+                };
+                if constexpr (RPK || MPK) {
+                    // 16 packed-operand loads (16 B each), ALL issued first: queue = [bias 4] [head DMA] L0 .. L15 S0 S1 ...; before unit u
+                    // the ops younger than L(u) are 15 - u loads and u stores = 15, a constant - and no wait ever covers a store
+                    uint4v opk[16];
+                    const bf16_t* src = reinterpret_cast<const bf16_t*>(RPK ? p.res : p.relu_src);
+                    const int kbp = RPK ? p.res_kbp : p.mask_kbp;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const bf16_t* rb_ = src + tile_elems(kbp, u >> 3, u & 7);
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(opk[u]) : "v"(offP), "s"(rb_) : "memory");
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        __builtin_amdgcn_s_waitcnt(vmcnt_imm(15));
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("" : "+v"(opk[u]));          // nothing computed from the load may move above its wait
+                        if (u == 0) { asm volatile("" : "+v"(pbias[0][0]), "+v"(pbias[0][1]), "+v"(pbias[1][0]), "+v"(pbias[1][1])); }
+                        unit(u & 7, u >> 3, opk[u], floatx4v{0.f, 0.f, 0.f, 0.f}, floatx4v{0.f, 0.f, 0.f, 0.f});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if (aux) {
+                    // f32 operand rows: two 16-B loads per unit, one 32-column half (8 units, 16 loads) at a time
+                    floatx4v ox[8][2];
+#pragma unroll
+                    for (int cp = 0; cp < 2; ++cp) {
+#pragma unroll
+                        for (int rt = 0; rt < 8; ++rt) {
+                            const float* ab_ = aux + (size_t)(urow0 + rt * 16) * ldx + (ucol0 + 32 * cp);
+                            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ox[rt][0]) : "v"(offX), "s"(ab_) : "memory");
+                            asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(ox[rt][1]) : "v"(offX), "s"(ab_) : "memory");
+                        }
+#pragma unroll
+                        for (int rt = 0; rt < 8; ++rt) {
+                            // younger than this unit's two loads: 2 (7 - rt) loads and rt stores
+                            switch (rt) {
+                                case 0: __builtin_amdgcn_s_waitcnt(vmcnt_imm(14)); break;
+                                case 1: __builtin_amdgcn_s_waitcnt(vmcnt_imm(13)); break;
+                                case 2: __builtin_amdgcn_s_waitcnt(vmcnt_imm(12)); break;
+                                case 3: __builtin_amdgcn_s_waitcnt(vmcnt_imm(11)); break;
+                                case 4: __builtin_amdgcn_s_waitcnt(vmcnt_imm(10)); break;
+                                case 5: __builtin_amdgcn_s_waitcnt(vmcnt_imm(9)); break;
+                                case 6: __builtin_amdgcn_s_waitcnt(vmcnt_imm(8)); break;
+                                default: __builtin_amdgcn_s_waitcnt(vmcnt_imm(7)); break;
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            asm volatile("" : "+v"(ox[rt][0]), "+v"(ox[rt][1]));
+                            if (cp == 0 && rt == 0) { asm volatile("" : "+v"(pbias[0][0]), "+v"(pbias[0][1]), "+v"(pbias[1][0]), "+v"(pbias[1][1])); }
+                            unit(rt, cp, uint4v{0u, 0u, 0u, 0u}, ox[rt][0], ox[rt][1]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                } else {
+                    if (nbias) {                                  // the bias (issued before the head DMA) has landed; the DMA stays in flight
+                        if (hdma == 16) __builtin_amdgcn_s_waitcnt(vmcnt_imm(16));
+                        else if (hdma == 8) __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));
+                        else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("" : "+v"(pbias[0][0]), "+v"(pbias[0][1]), "+v"(pbias[1][0]), "+v"(pbias[1][1]));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        unit(u & 7, u >> 3, uint4v{0u, 0u, 0u, 0u}, floatx4v{0.f, 0.f, 0.f, 0.f}, floatx4v{0.f, 0.f, 0.f, 0.f});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                done = true;
+                if (has_next) pending = true;
+                else { pending = false; __builtin_amdgcn_s_waitcnt(vmcnt_imm(0)); }
+            }
+        }
+        if constexpr (S16 && !OPK) {
             if (!done && fastepi) {
                 // operation order per wave: [bias 2] [head DMA 16] L0 L1 | wait L0 | S0 L2 | wait L1 | S1 L3 | ... (Lb / Sb = the 4
                 // operand loads / 4 stores of batch b = column pair b >> 2, row tiles 2 (b & 3), 2 (b & 3) + 1)
@@ -946,9 +1118,16 @@ __attribute__((visibility("hidden"))) int lstc_gemm_bf16p_impl(const LstcGemmDes
     if (p.res_kbp && (!(d->flags & LSTC_EPI_RESIDUAL) || !p.out_kbp || (d->flags & LSTC_EPI_RELU_MASK))) return LSTC_E_UNSUPPORTED;
     if (p.out_kbp || p.mask_kbp) {
         // packed outputs / mask operands exist on the pipelined epilogue only: NT form on whole 256 x 256 tiles, no K split
-        if (tr || splits > 1 || !P1_NT_S16 || d->M % 256 || d->N % 256 || (d->flags & LSTC_EPI_ACCUM) || d->variant != 0 ||
+#ifdef LSTC_TUNING
+        const int tile_variant = d->variant & 15;          // the bits above select timing ablations / stamps
+#else
+        const int tile_variant = d->variant;
+#endif
+        if (tr || splits > 1 || !P1_NT_S16 || d->M % 256 || d->N % 256 || (d->flags & LSTC_EPI_ACCUM) || tile_variant != 0 ||
             (p.mask_kbp && (!(d->flags & LSTC_EPI_RELU_MASK) || (d->flags & LSTC_EPI_RESIDUAL)))) return LSTC_E_UNSUPPORTED;
         if (p.out_kbp && !aligned16(d->C)) return LSTC_E_ALIGN;
+        // one per-element operand stream per epilogue (the hand-counted loads): residual OR ReLU mask, never both
+        if (p.out_kbp && (d->flags & LSTC_EPI_RESIDUAL) && (d->flags & LSTC_EPI_RELU_MASK)) return LSTC_E_UNSUPPORTED;
     }
     p.dk = make_drop_key(d->dropout_p, d->dropout_seed);
 #ifdef LSTC_TUNING
@@ -975,7 +1154,11 @@ __attribute__((visibility("hidden"))) int lstc_gemm_bf16p_impl(const LstcGemmDes
     p.tilesN = (d->N + 255) / 256;
     p.splits = eff_splits;
     p.total_items = tilesM * p.tilesN * eff_splits;
+#ifdef LSTC_TUNING
+    constexpr size_t lds = (size_t)2 * P1_BUF * sizeof(bf16_t) + 1024;       // + the stamp array of the tuning build
+#else
     constexpr size_t lds = (size_t)2 * P1_BUF * sizeof(bf16_t);
+#endif
     // per device: the CU count sizes the persistent grid and the 128-KB dynamic-LDS opt-in is a per-device kernel attribute
     static std::atomic<int> n_cu_dev[64];
     static LstcDevOnce setup;

@@ -184,6 +184,9 @@ static void timeit(int M, int N, int K, int tA, int tB, int variant, int split, 
         std::vector<unsigned long long> h(1024 * 100);
         CK(hipMemcpy(h.data(), dstamp, h.size() * 8, hipMemcpyDeviceToHost));
         double sum[3][4] = {{0}}, cnt[3] = {0, 0, 0}, span = 0, clk = 0; int nb = 0, maxit = 0;
+        double xspan[8] = {0}, xclk[8] = {0}, xend[8] = {0}, xstart[8] = {0}; int xn[8] = {0};
+        double smin = 1e30, smax = 0, s13 = 0, s12 = 0; int n13 = 0, n12 = 0;
+        unsigned long long r0 = ~0ull, r1 = 0;
         for (int b = 0; b < 1024; ++b) {
             const unsigned long long* s = &h[(size_t)b * 100];
             if (!s[0] || s[3] <= s[1]) continue;
@@ -191,6 +194,15 @@ static void timeit(int M, int N, int K, int tA, int tB, int variant, int split, 
             int n = 0; while (n < 24 && s[4 + 4 * n + 3]) ++n;
             if (n == 0) continue;
             ++nb; clk += cyc_per_us; span += (double)(s[2] - s[0]) / cyc_per_us; maxit = std::max(maxit, n);
+            {   // by XCD (blockIdx % 8 share one under round-robin placement) and by item count; realtime (100 MHz) brackets of the launch
+                const double sp = (double)(s[2] - s[0]) / cyc_per_us;
+                const int x = b & 7;
+                xspan[x] += sp; xclk[x] += cyc_per_us; ++xn[x];
+                smin = std::min(smin, sp); smax = std::max(smax, sp);
+                if (n >= 13) { s13 += sp; ++n13; } else { s12 += sp; ++n12; }
+                r0 = std::min(r0, s[1]); r1 = std::max(r1, s[3]);
+                xstart[x] += (double)s[1]; xend[x] += (double)s[3];
+            }
             for (int i = 0; i < n; ++i) {
                 const unsigned long long* t = s + 4 + 4 * i;
                 const int cls = i == 0 ? 0 : (i == n - 1 ? 2 : 1);
@@ -202,6 +214,11 @@ static void timeit(int M, int N, int K, int tA, int tB, int variant, int split, 
         }
         printf("STAMPS %d workgroups, up to %d items each, in-kernel clock %.0f MHz, mean workgroup span %.1f us (launch %.1f us)\n", nb, maxit,
                nb ? clk / nb : 0.0, nb ? span / nb : 0.0, ms * 1e3);
+        printf("STAMPS workgroup spans: min %.1f max %.1f us; %d workgroups with >= 13 items mean %.1f us, %d with fewer mean %.1f us; first start -> last end %.1f us\n",
+               smin, smax, n13, n13 ? s13 / n13 : 0.0, n12, n12 ? s12 / n12 : 0.0, (double)(r1 - r0) / 100.0);
+        printf("STAMPS by blockIdx %% 8 (one XCD each): ");
+        for (int x = 0; x < 8; ++x) if (xn[x]) printf("[%d: %.0f MHz, span %.1f us, ends +%.1f us] ", x, xclk[x] / xn[x], xspan[x] / xn[x], (xend[x] / xn[x] - (double)r0) / 100.0);
+        printf("\n");
         const char* nm[3] = {"first item ", "middle items", "last item  "};
         for (int c = 0; c < 3; ++c)
             if (cnt[c] > 0)
