@@ -9,6 +9,7 @@ run() { echo "== $1"; shift; timeout 120 $G one "$@" | grep -E "TIME|STAMPS"; }
 # flags: 128 = OUT_PACK; 652 = OUT_PACK | RESIDUAL_PACK | RESIDUAL | DROPOUT; 131 = OUT_PACK | BIAS | RELU; 0 = f32 output
 run "N=2048 K=2048 packed output (flags 128)"            100352 2048 2048 0 1 $((S * 16)) 1 128 20 0 0 3
 run "N=2048 K=2048 packed residual + output (flags 652)" 100352 2048 2048 0 1 $((S * 16)) 1 652 20 0 0 3
+run "N=2048 K=2048 packed residual + output, no dropout (flags 648)" 100352 2048 2048 0 1 $((S * 16)) 1 648 20 0 0 3
 run "N=2048 K=4096 packed residual + output (flags 652)" 100352 2048 4096 0 1 $((S * 16)) 1 652 20 0 0 3
 run "N=2048 K=6144 packed residual + output (flags 652)" 100352 2048 6144 0 1 $((S * 16)) 1 652 20 0 0 3
 run "N=4096 K=2048 bias + ReLU, packed output (flags 131)" 100352 4096 2048 0 1 $((S * 16)) 1 131 20 0 0 3
