@@ -453,7 +453,7 @@ def train(script: str, argv=None, args=None):
 
 
 class _HostPairs:
-    """Batches of a lazy / ten-crop dataset: items collated on the host (``DataLoader(batch_size, drop_last=True,
+    """Fallback for a set that does not fit in HBM (or LSTC_HOST_FEED=1): items collated on the host (``DataLoader(batch_size, drop_last=True,
     num_workers=0)`` order), staged through pinned memory, copied to the device."""
 
     def __init__(self, dataset, batch_size, device, rank=0, world=1, streams=None):
@@ -510,8 +510,9 @@ def _real_data(script, args, mode, part_len, pseudo_path, dev, rank, world, enc,
     k = {"temporal_transformer_shanghaitech": 4, "temporal_transformer_UBnormal": 4, "temporal_transformer_UCF": 1}.get(
         script, int(getattr(args, "num_workers", 0) or 0))
     streams = lds.WorkerStreams(k, int(getattr(args, "seed", 0)))
-    # HBM-resident feed whenever the set fits (eager AND lazy single-crop datasets: upstream's per-item archive reads exist because
-    # host memory cannot hold UCF-Crime; 288 GB of HBM can); ten-crop datasets and sets beyond 60 % of the free HBM stay host-staged
+    # HBM-resident feed whenever the set fits (eager AND lazy datasets: upstream's per-item archive reads exist because host memory
+    # cannot hold UCF-Crime; 288 GB of HBM can; since round 6 the ten-crop classes too, all ten crops resident); only sets beyond
+    # 60 % of the free HBM - or LSTC_HOST_FEED=1 - stay host-staged
     import torch
     resident = lds.ResidentPairs.serves(ds) and os.environ.get("LSTC_HOST_FEED", "0") != "1" and \
         lds.ResidentPairs.bank_bytes(ds) < 0.6 * torch.cuda.mem_get_info(dev)[0]

@@ -323,27 +323,36 @@ class _WorkerScope:
         return False
 
 
-def shard_plan(ds, offsets, n_norm, b, bs, rank=0, world=1):
+def shard_plan(ds, offsets, n_norm, b, bs, rank=0, world=1, crops=1):
     """Window indices + labels of global batch ``b`` (``bs`` pairs) for rank ``rank`` of ``world``: pairs
     ``[rank*bs/world, (rank+1)*bs/world)``.  The sampler runs for EVERY pair (same ``np.random`` consumption on every rank
     as in the single-process run), so the ranks' shards are disjoint and their union is the single-process batch.  A video's
-    clip count is the length of its slice of the bank (``offsets``): lazy datasets hold only keys in ``norm_feats``."""
+    clip count is the length of its slice of the bank (``offsets``): lazy datasets hold only keys in ``norm_feats``.
+
+    ``crops`` = 10 (round 6): a ten-crop bank holds clip ``c``'s crop ``k`` in row ``10 c + k`` of the video's slice.  The crop is
+    drawn from Python's ``random`` exactly where the dataset's own item code draws it - ONE ``randint(0, 9)`` per item in front of
+    both videos' windows (``_PairSource.__getitem__``, utils/load_dataset.py:229-232), or one per video at fetch time (UCF's
+    ``crop_return``, :437-438) - on every rank, for every pair of the global batch."""
     rows = ds.part_num * ds.part_len
     bl = bs // world
     lo = rank * bl
     idx = np.empty((2, bl, rows), np.int64)
     labs = np.empty((2, bl, rows, 1), np.float32)
+    per_fetch = crops > 1 and not ds.ten_crop            # UCF crop_return: the crop is drawn inside _fetch, once per video
     for j in range(bs):
         item = b * bs + j
         ni, ai = ds.norm_iters[item], ds.abnorm_iters[item]
+        crop = random.randint(0, 9) if (crops > 1 and not per_fetch) else 0
         for kind, vid in ((0, ni), (1, ai)):
             slot = vid + (n_norm if kind else 0)
-            n_clips = int(offsets[slot + 1] - offsets[slot])
+            if per_fetch:
+                crop = random.randint(0, 9)
+            n_clips = int(offsets[slot + 1] - offsets[slot]) // crops
             keys = ds.norm_keys if kind == 0 else ds.abnorm_keys
             l = ds._labels_for(n_clips, ds._pseudo(keys[vid]), "Normal" if kind == 0 else "Abnormal")
             w = window_indices(n_clips, ds.part_num, ds.part_len, ds.sample)     # consumes np.random on every rank
             if lo <= j < lo + bl:
-                idx[kind, j - lo] = w + offsets[vid + (n_norm if kind else 0)]
+                idx[kind, j - lo] = w * crops + crop + offsets[slot]
                 labs[kind, j - lo] = np.asarray(l, np.float32).reshape(-1, 1)[w] if np.ndim(l) == 1 else l[w]
     return idx, labs
 
@@ -372,37 +381,52 @@ class ResidentPairs:
         shards are disjoint and their union IS the single-process batch."""
         from .feed import ResidentBank
         if not self.serves(dataset):
-            raise ValueError("ResidentPairs serves the single-crop datasets (SH / UBnormal / UCF without crop_return)")
+            raise ValueError("ResidentPairs serves _PairSource datasets")
         if batch_size % world:
             raise ValueError(f"--batch_size {batch_size} pairs do not split over {world} ranks")
         self.ds, self.bs, self.device, self.rank, self.world = dataset, batch_size, device, rank, world
         self.streams = streams or WorkerStreams(0, 0)
         P = dataset.n_patch
         entries = dataset.norm_feats + dataset.abnorm_feats           # arrays (eager) or archive keys (lazy)
-        cut = (lambda f: f) if P == 1 else (lambda f: f[:, :P, :])
+        crop_return = bool(getattr(dataset, "crop_return", False))
+        # round 6: the ten-crop datasets (utils/load_dataset.py:134-232, :631-729) and UCF's crop_return (:437-438) too - all ten crops
+        # of every clip are resident ([clips * 10, P, d]: ten times the single-crop bank) and the item's crop index, drawn on the host
+        # where the dataset draws it, is part of the gathered row index (shard_plan)
+        self.crops = 10 if (dataset.ten_crop or crop_return) else 1
+        if dataset.ten_crop:
+            cut = lambda f: f.reshape((-1,) + tuple(f.shape[2:]))                        # [n, 10, P, d] -> [10 n, P, d]; items keep every stored patch
+        else:
+            cut = (lambda f: f) if P == 1 else (lambda f: f[:, :P, :])
+
+        def rows_of(e):
+            """A video as the rows it contributes to the bank."""
+            if crop_return:
+                # the dataset's own _fetch draws a crop; here: the raw read, all ten crops, then the short-video repeat per clip
+                f = np.asarray(_PairSource._fetch(dataset, e)).reshape((-1, 10, dataset.n_patch, dataset.d_model))
+                if f.shape[0] <= dataset.part_len:
+                    f = np.repeat(f, 2, axis=0)
+                return f.reshape((-1, dataset.n_patch, dataset.d_model))
+            return dataset._fetch(e) if dataset.lazy else e
         self.n_norm = len(dataset.norm_feats)
         if dataset.lazy:
             # two passes over the archive: clip counts first (one allocation of the bank), then one upload per video; nothing but
             # the video in flight is held on the host
             keep_np, keep_py = np.random.get_state(), random.getstate()      # _fetch of a single-crop dataset draws nothing; be sure
-            lens = [int(dataset._fetch(e).shape[0]) for e in entries]
-        else:
-            lens = [int(v.shape[0]) for v in entries]
+        lens = [int(cut(rows_of(e)).shape[0]) for e in entries] if (dataset.lazy or dataset.ten_crop) else [int(v.shape[0]) for v in entries]
         self.offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-        first = dataset._fetch(entries[0]) if dataset.lazy else entries[0]
-        self.row_shape = tuple(cut(first).shape[1:])
+        self.row_shape = tuple(cut(rows_of(entries[0])).shape[1:])
         self.bank = torch.empty((int(self.offsets[-1]),) + self.row_shape, dtype=torch.float32, device=device)
         for o, e in zip(self.offsets[:-1], entries):         # one staged copy per video, then everything is resident
-            v = dataset._fetch(e) if dataset.lazy else e
-            self.bank[o:o + v.shape[0]].copy_(torch.from_numpy(np.ascontiguousarray(cut(v), dtype=np.float32)))
+            v = cut(rows_of(e))
+            self.bank[o:o + v.shape[0]].copy_(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)))
         if dataset.lazy:
             np.random.set_state(keep_np); random.setstate(keep_py)
         self.feed = ResidentBank(self.bank)
 
     @staticmethod
     def serves(dataset) -> bool:
-        """Single-crop datasets only: a ten-crop item picks its crop with ``random`` per item (it stays on the host path)."""
-        return not dataset.ten_crop and not getattr(dataset, "crop_return", False)
+        """Every ``_PairSource``: single-crop (rounds 2-5) and, since round 6, the ten-crop classes and UCF with ``crop_return``."""
+        return isinstance(dataset, _PairSource)
 
     @staticmethod
     def bank_bytes(dataset) -> int:
@@ -416,7 +440,8 @@ class ResidentPairs:
         with FeatureArchive(dataset.h5_path) as arc:
             for k in dataset.norm_feats + dataset.abnorm_feats:
                 shp = arc.shape(k)
-                tot += 4 * int(np.prod(shp)) * (2 if shp[0] <= dataset.part_len and hasattr(dataset, "frames_per_clip") else 1)
+                n_clips = int(np.prod(shp)) // (10 * dataset.n_patch * dataset.d_model) if getattr(dataset, "crop_return", False) else shp[0]
+                tot += 4 * int(np.prod(shp)) * (2 if n_clips <= dataset.part_len and hasattr(dataset, "frames_per_clip") else 1)
         return int(tot)
 
     def __len__(self):
@@ -425,7 +450,7 @@ class ResidentPairs:
     def plan(self, b):
         """Host side of batch ``b``: (clip rows into the bank ``[2, bs_local, pn*L]`` int64, labels ``[2, bs_local, pn*L, 1]``)
         of THIS rank's shard.  Draws the windows of every pair of the global batch, in the dataset's own order."""
-        return shard_plan(self.ds, self.offsets, self.n_norm, b, self.bs, self.rank, self.world)
+        return shard_plan(self.ds, self.offsets, self.n_norm, b, self.bs, self.rank, self.world, self.crops)
 
     def __iter__(self):
         self.streams.begin_epoch()                       # upstream re-forks (re-seeds) the loader's workers every epoch

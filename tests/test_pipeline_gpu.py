@@ -97,11 +97,13 @@ def test_gather_rows_is_an_exact_row_copy():
 
 
 @pytest.mark.parametrize("name", ["sh_uniform", "sh_random_pseudo", "ubn_uniform", "ubn_random", "sh_mutual_uniform_pseudo", "sh_mutual_random",
-                                  "ucf_uniform", "ucf_random_pseudo"])
+                                  "ucf_uniform", "ucf_random_pseudo", "sh_tencrop_uniform", "sh_tencrop_random", "ubn_tencrop", "ucf_crop_return",
+                                  "sh_npatch1"])
 def test_resident_pairs_serve_the_host_batches(world, name):
     """Batches gathered out of HBM == default-collated dataset items with the same seeds (which the CPU suite pins to the
     reference's classes) - round 5: also for the LAZY single-crop datasets (the co-teaching stage's MutualTraining class and UCF,
-    whose items upstream re-reads from the archive one by one)."""
+    whose items upstream re-reads from the archive one by one); round 6: the TEN-CROP classes (utils/load_dataset.py:134-232,
+    :631-729) and UCF's ``crop_return`` (:437-438): all ten crops resident, the per-item / per-video crop draw part of the row index."""
     spec = DATASET_CASES[name]
     np.random.seed(spec["seed"]); random.seed(spec["seed"])
     host = build_dataset(ds_mod, spec, world)
