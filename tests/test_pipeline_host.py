@@ -309,19 +309,24 @@ def test_loader_worker_rng_streams_like_the_reference_dataloader(world, name):
     assert np.array_equal(np.concatenate(firsts), G[f"dlw/{name}/first"])
     assert np.array_equal(np.concatenate(labs), G[f"dlw/{name}/labs"])
     assert np.array_equal(np.array(crops, np.int64), G[f"dlw/{name}/crops"])
-    if not ds.lazy and not ds.ten_crop:
-        # the HBM-resident source plans the same clips: shard_plan under the same streams (ranks 0 and 1 of 2 when bs splits)
+    if not ds.lazy:
+        # the HBM-resident source plans the same clips: shard_plan under the same streams (ranks 0 and 1 of 2 when bs splits).
+        # Round 6: the ten-crop classes too - the bank holds clip c's crop k in row 10 c + k and the per-item crop draw (Python's
+        # ``random``, in the worker's stream) is part of the planned row
         np.random.seed(seed); random.seed(seed)
         ds2 = build_dataset(ds_mod, spec, world)
         st2 = ds_mod.WorkerStreams(k, seed)
-        offs = np.concatenate([[0], np.cumsum([v.shape[0] for v in ds2.norm_feats + ds2.abnorm_feats])]).astype(np.int64)
-        bank = np.concatenate([v[:, :ds2.n_patch] if ds2.n_patch != 1 else v for v in ds2.norm_feats + ds2.abnorm_feats], 0)
+        crops = 10 if ds2.ten_crop else 1
+        vids = [v.reshape((-1,) + v.shape[2:]) if ds2.ten_crop else (v[:, :ds2.n_patch] if ds2.n_patch != 1 else v)
+                for v in ds2.norm_feats + ds2.abnorm_feats]
+        offs = np.concatenate([[0], np.cumsum([v.shape[0] for v in vids])]).astype(np.int64)
+        bank = np.concatenate(vids, 0)
         got = []
         for epoch in range(2):
             st2.begin_epoch()
             for b in range(len(ds2) // bs):
                 with st2.batch(b):
-                    idx, _ = ds_mod.shard_plan(ds2, offs, len(ds2.norm_feats), b, bs)
+                    idx, _ = ds_mod.shard_plan(ds2, offs, len(ds2.norm_feats), b, bs, crops=crops)
                 for kind in (0, 1):
                     a = bank[idx[kind].reshape(-1)]
                     got.append(a.reshape(a.shape[0], -1)[:, 0].copy())
