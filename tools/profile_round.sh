@@ -22,6 +22,8 @@ GRAFT_REPO_ROOT=$R bash tools/pmc_gemm.sh $OUT/${TAG}_gemm_bf16p_pmc.txt gemm_bf
 GRAFT_REPO_ROOT=$R bash tools/pmc_gemm.sh $OUT/${TAG}_gemm_bf16p_tr_pmc.txt gemm_bf16p 2048 2048 100352 1 0 0 4 0 3 0 0 3 > /dev/null 2>&1
 # round 5: the same NT launch as the bf16 activation stream runs it - packed output + packed residual (flags 8 + 128 + 512)
 GRAFT_REPO_ROOT=$R bash tools/pmc_gemm.sh $OUT/${TAG}_gemm_bf16p_act_pmc.txt gemm_bf16p 100352 2048 2048 0 1 0 1 648 3 0 0 3 > /dev/null 2>&1
+# round 6: the launch WITHOUT a per-element operand (packed output only, flags 128): where the 16-byte epilogue shows
+GRAFT_REPO_ROOT=$R bash tools/pmc_gemm.sh $OUT/${TAG}_gemm_bf16p_out_pmc.txt gemm_bf16p 100352 2048 2048 0 1 0 1 128 3 0 0 3 > /dev/null 2>&1
 bash tools/pmc_attn.sh $OUT/${TAG}_attn_pmc_fp32.txt fp32 49 3 2048 256 > /dev/null 2>&1
 bash tools/pmc_attn.sh $OUT/${TAG}_attn_pmc_bf16.txt bf16 49 3 2048 256 packed > /dev/null 2>&1
 ls -la $OUT

@@ -20,3 +20,7 @@ run "N=2048 K=2048 no epilogue, no DMA"                  100352 2048 2048 0 1 $(
 run "N=2048 K=6144 no epilogue"                          100352 2048 6144 0 1 $(((S + 1) * 16)) 1 0 20 0 0 3
 run "rank shape 12544 x 2048 x 2048 (flags 128)"         12544 2048 2048 0 1 $((S * 16)) 1 128 20 0 0 3
 run "weight gradient 2048 x 2048 x 100352, split 4"      2048 2048 100352 1 0 $((S * 16 + 7)) 4 0 20 0 0 3
+# (XCD-staggered starts - workgroups of XCD x sleeping 3.2 / 6.4 us x x before their first item, so that the eight XCDs' epilogues do
+# not coincide - were measured with a throw-away tuning bit on this script's shapes: profiles/r06_gemm_bf16p_stamps_stagger.txt.  No
+# effect on the epilogue length (9.2 us with and without) or on the launch (0.752 vs 0.744 / 0.745 ms, 0.816 vs 0.815): the epilogue is
+# not an HBM burst.  The code was removed again.)
