@@ -37,6 +37,12 @@ typedef float floatx4v __attribute__((ext_vector_type(4)));
 #ifndef P1_NT_S16
 #define P1_NT_S16 1                      // NT form on v_mfma_f32_16x16x32_bf16 (0: 32x32x16, A/B builds)
 #endif
+#ifndef P1_TR_S16
+#define P1_TR_S16 0                      // 1: the TR (weight-gradient) form on v_mfma_f32_16x16x32_bf16 too (A/B builds).  Measured, round 6:
+                                         // correct (tools/gemm_check check: ALL PASS) but the register allocator no longer fits the loop into
+                                         // 256 VGPRs (40 - 58 spills, scratch reloads inside the LOAD segments drain the LDS-DMA queue):
+                                         // 2048 x 2048 x 100352 924 TFLOP/s against 1122 on 32x32x16, 6144 x 2048 954 against 1254 - stays off
+#endif
 #ifndef P1_SPLIT_MAJOR
 #define P1_SPLIT_MAJOR 1                 // item order, see set_item (0 / 0: the round-3 order, A/B builds)
 #endif
@@ -184,7 +190,8 @@ constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >>
 template <bool TR, bool S16, int EPK = 0>
 __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
     const DropKey dkn = drop_key_now(p.dk);      // graph replays: seed + device offset (lstc_dropout_seed_device)
-    static_assert(!(TR && S16), "the transposed-read form keeps the 32x32x16 shape");
+    // (rounds 2-5 kept the transposed-read form on 32x32x16; round 6: its fragments are read for the 16x16x32 shape too - per 16-lane
+    // group one 4-token x 16-feature block per ds_read_b64_tr_b16, group g = the k group 8 g .. 8 g + 7 of the instruction's 32)
     static_assert(EPK == 0 || S16, "packed outputs / masks exist on the pipelined epilogue of the S16 form only");
     constexpr bool OPK = EPK == 1 || EPK == 2 || EPK == 4, MPK = EPK == 2 || EPK == 3, RPK = EPK == 4;
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_p1[];
@@ -340,12 +347,34 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
     // measured SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE.
     const int l15 = lane & 15, c16 = lane >> 4;
     const int s16_off = l15 * 32 + ((((0x9C >> (2 * c16)) & 3) ^ ((l15 >> 2) & 3)) * 8);      // 0x9C: 2-bit entries 0, 3, 1, 2 for lane groups 0..3
+    // S16 + TR: a TR slot holds 64 tokens x 32 features (64-B token rows, chunk XOR (token >> 2) & 3).  The 16x16x32 operand wants, per
+    // lane, feature l15 and the tokens 8 c16 .. 8 c16 + 7 of a 32-token half: two ds_read_b64_tr_b16, group c16 reading the 4-token x
+    // 16-feature blocks at tokens 8 c16 (+4); lane 4 q + p of a group supplies token row q, features 4 p .. 4 p + 3 of the block.
+    // fh = which 16 features of the slot's 32 (it flips bit 1 of the chunk index under the XOR: four per-lane offsets in all)
+    const int tq16 = (lane >> 2) & 3, tp16 = lane & 3;
+    auto s16tr_at = [&](int fh, int second) -> int {
+        const int r = 8 * c16 + tq16 + 4 * second, c = 2 * fh + (tp16 >> 1);
+        return r * 32 + ((c ^ ((r >> 2) & 3)) * 8) + (tp16 & 1) * 4;
+    };
+    const int s16tr_off[2][2] = {{s16tr_at(0, 0), s16tr_at(0, 1)}, {s16tr_at(1, 0), s16tr_at(1, 1)}};
+    auto rd_tr16 = [&](const bf16_t* slot, int kk, int fh) -> bf16x8 {           // tokens 32 kk .. +31, features 16 fh .. +15 of the slot
+        typedef short short4v __attribute__((ext_vector_type(4)));
+        typedef short short8v __attribute__((ext_vector_type(8)));
+        typedef short4v __attribute__((address_space(3))) * lds_ptr;
+        const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(slot + kk * 1024 + s16tr_off[fh][0]));
+        const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(slot + kk * 1024 + s16tr_off[fh][1]));
+        short8v f;
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        return __builtin_bit_cast(bf16x8, f);
+    };
     auto rd_a16 = [&](const bf16_t* buf, int i2, int rt, int kk) -> bf16x8 {     // rows 64 i2 + 16 rt .. +15 of the wave's 128, k tile kk
         if (P1_ABL_RD) return bf16x8{};
+        if (TR) return rd_tr16(buf + (4 * wr + 2 * i2 + (rt >> 1)) * P1_SLOT, kk, rt & 1);
         return *reinterpret_cast<const bf16x8*>(buf + (2 * (2 * wr + i2) + kk) * P1_SLOT + rt * 512 + s16_off);
     };
     auto rd_b16 = [&](const bf16_t* buf, int ct4, int kk) -> bf16x8 {            // columns 16 ct4 .. +15 of the wave's 64, k tile kk
         if (P1_ABL_RD) return bf16x8{};
+        if (TR) return rd_tr16(buf + (8 + 2 * wc + (ct4 >> 1)) * P1_SLOT, kk, ct4 & 1);
         return *reinterpret_cast<const bf16x8*>(buf + (8 + 2 * wc + kk) * P1_SLOT + ct4 * 512 + s16_off);
     };
     // A: [k16 step][row tile of the current half] (S16: [2 kk + (rt >> 1)][rt & 1]); B: [column half][k16 step] (S16: [jj][2 kk + ct])
@@ -566,7 +595,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                 }
             }
         }
-        if constexpr (S16 && !OPK) {
+        if constexpr (S16 && !OPK && !TR) {      // (the TR form writes one tile per workgroup: no pipelined epilogue)
             const int f_ = p.flags;
             fastepi = p.vec_epi && !(p.splits > 1 && p.split_stride == 0) && !(f_ & LSTC_EPI_ACCUM) &&
                       !((f_ & LSTC_EPI_RESIDUAL) && (f_ & LSTC_EPI_RELU_MASK)) && (cmb + 1) * 256 <= p.M && (cnb + 1) * 256 <= p.N;
@@ -759,7 +788,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                 else { pending = false; __builtin_amdgcn_s_waitcnt(vmcnt_imm(0)); }
             }
         }
-        if constexpr (S16 && !OPK) {
+        if constexpr (S16 && !OPK && !TR) {      // (the TR form writes one tile per workgroup: no pipelined epilogue)
             if (!done && fastepi) {
                 // operation order per wave: [bias 2] [head DMA 16] L0 L1 | wait L0 | S0 L2 | wait L1 | S1 L3 | ... (Lb / Sb = the 4
                 // operand loads / 4 stores of batch b = column pair b >> 2, row tiles 2 (b & 3), 2 (b & 3) + 1)
@@ -1172,7 +1201,7 @@ __attribute__((visibility("hidden"))) int lstc_gemm_bf16p_impl(const LstcGemmDes
         n_cu_dev[dev_ & 63].store(n > 0 ? n : 256, std::memory_order_relaxed);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<true, P1_TR_S16 != 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1185,7 +1214,7 @@ __attribute__((visibility("hidden"))) int lstc_gemm_bf16p_impl(const LstcGemmDes
     // lose: 0.732 -> 0.774 ms at K = 2048, 1.303 -> 1.350 at K = 4096, step 38.3 -> 39.2 ms.  The chip is not power-limited at this
     // granularity: idle CUs buy the busy ones nothing.)
     const int grid = p.total_items < n_cu ? p.total_items : n_cu;
-    if (tr) hipLaunchKernelGGL((gemm_bf16p_kernel<true, false>), dim3(grid), dim3(NT8), lds, st, p);
+    if (tr) hipLaunchKernelGGL((gemm_bf16p_kernel<true, P1_TR_S16 != 0>), dim3(grid), dim3(NT8), lds, st, p);
     else if (P1_NT_S16) {
         const int epk = p.res_kbp ? 4 : p.out_kbp ? (p.mask_kbp ? 2 : 1) : (p.mask_kbp ? 3 : 0);
         if (epk == 0) hipLaunchKernelGGL((gemm_bf16p_kernel<false, true, 0>), dim3(grid), dim3(NT8), lds, st, p);
