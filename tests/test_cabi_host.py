@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib):
     raw = C.CDLL(_lib.LIB_PATH)
     for s in declared:
         assert hasattr(raw, s), s
-    assert lib.lstc_version() == 110        # 0.1.1: INTEGRATION.md, "ABI history"
+    assert lib.lstc_version() == 111        # 0.1.1 patch 1 (round 6): INTEGRATION.md, "ABI history"
 
 
 def test_descriptor_layouts_match_header(lib, tmp_path):
