@@ -2316,6 +2316,14 @@ def test_packed_output_and_packed_relu_mask_of_the_bf16_gemm(M, N, K):
             assert torch.equal(d_f32, d_msk)
             d_pk = Fn.gemm(dy, w, trans_b=True, relu_mask=h_pk, out_pack=True)
             assert torch.equal(d_pk.buf[:tiles], Fn.pack3(d_f32, False).buf[:tiles])
+            # round 6: the 16-byte packed-output epilogue with an F32 per-element operand (two 16-B loads per group of 8 outputs) -
+            # the f32 ReLU-mask source, and bias + dropout + an f32 residual - against the f32-output launch of the same flags
+            d_pk2 = Fn.gemm(dy, w, trans_b=True, relu_mask=h_f32, out_pack=True)
+            assert torch.equal(d_pk2.buf[:tiles], d_pk.buf[:tiles])
+            res = torch.randn(M, N, device=DEV, generator=g)
+            r_f32 = Fn.gemm(x, w, trans_b=True, bias=b, dropout=(0.2, 1234), residual=res)
+            r_pk = Fn.gemm(x, w, trans_b=True, bias=b, dropout=(0.2, 1234), residual=res, out_pack=True)
+            assert torch.equal(r_pk.buf[:tiles], Fn.pack3(r_f32, False).buf[:tiles])
             cs = Fn.colsum_pack(d_pk)
         torch.cuda.synchronize()
     finally:
