@@ -405,14 +405,15 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
                     _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                    \
                         a4[4 * (ih) + rt][2 * (jj) + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
                             OPK ? fb[rs][2 * kk + ct] : fa[2 * kk + (rt >> 1)][rt & 1],                                 \
-                            OPK ? fa[2 * kk + (rt >> 1)][rt & 1] : fb[rs][2 * kk + ct], a4[4 * (ih) + rt][2 * (jj) + ct], 0, 0, 0); \
+                            OPK ? fa[2 * kk + (rt >> 1)][rt & 1] : fb[rs][2 * kk + ct],                                 \
+                            (HEAD && kk == 0) ? floatx4v{0.f, 0.f, 0.f, 0.f} : a4[4 * (ih) + rt][2 * (jj) + ct], 0, 0, 0); \
                 if (kk == 0) { __builtin_amdgcn_sched_barrier(0); __VA_ARGS__; __builtin_amdgcn_sched_barrier(0); }     \
             }                                                                                                          \
         } else {                                                                                                       \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                             \
                 _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                        \
                     acc[S16 ? 0 : 2 * (ih) + ii][S16 ? 0 : jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                 \
-                        fa[q][ii], fb[rs][q], acc[S16 ? 0 : 2 * (ih) + ii][S16 ? 0 : jj], 0, 0, 0);                       \
+                        fa[q][ii], fb[rs][q], (HEAD && q == 0) ? floatx16{} : acc[S16 ? 0 : 2 * (ih) + ii][S16 ? 0 : jj], 0, 0, 0); \
                 if (q == 1) { __builtin_amdgcn_sched_barrier(0); __VA_ARGS__; __builtin_amdgcn_sched_barrier(0); }      \
             }                                                                                                          \
         }                                                                                                              \
@@ -538,19 +539,8 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
         __builtin_amdgcn_s_barrier();
         P1_STAMP(1);
         if (wr == 1) __builtin_amdgcn_s_barrier();       // waves 4-7 run one barrier behind: their LOAD beside the partner's COMPUTE
-        if constexpr (S16) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) a4[i][j] = floatx4v{0.f, 0.f, 0.f, 0.f};
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[S16 ? 0 : i][S16 ? 0 : j][r] = 0.f;
-        }
+        // (no zeroing pass: in an item's HEAD K step the first MFMA of every accumulator takes the constant 0 as its C operand - round 6,
+        // 128 v_mov per wave and item less)
         if (pending) tile(0, I0{}, BT{}, I32{}); else tile(0, I0{}, BT{}, I0{});
         int tl = 1;
         if (tl < nkt) { tile(tl, I1{}, BF{}, I0{}); ++tl; }
