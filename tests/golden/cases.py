@@ -92,6 +92,11 @@ HEADLINE_CASES = {
                      dict(batch_size=32, part_num=32, part_len=3, n_patch=16), 41),   # 2048 sequences, S = 49, 100352 tokens
     "stn_headline": ("STN", dict(d_model=2048, n_head=8, d_k=256, d_v=256, d_inner=3027, FFN_layerNorm=True),
                      dict(batch_size=32, part_num=32, part_len=1, n_patch=16), 42),   # 2048 sequences, S = 17, 34816 tokens
+    # BASELINE config 4 (the 8-GPU config: UCF-Crime, n_patch = 9, part_num = 32, part_len = 2) at the same global batch of 64 videos:
+    # 2048 sequences of S = 19, the [32, 32] relative-position index read through [:18, :18]
+    "ltn_ucf_headline": ("LTN", dict(d_model=2048, n_head=8, d_k=256, d_v=256, d_inner=4096, MHA_layerNorm=True,
+                                     FFN_layerNorm=True, relative_pe=True, window_size=4, window_depth=2),
+                         dict(batch_size=32, part_num=32, part_len=2, n_patch=9), 43),    # 2048 sequences, S = 19, 38912 tokens
 }
 N_SAMPLE = 256
 
