@@ -292,11 +292,31 @@ def main():
     from lstc_vad_amd.engine import MixedStep, TrainStep
     from lstc_vad_amd.models import Classifier, Encoder, Regressor
     Fn.set_act_dtype(a.act_dtype)
+    if os.environ.get("LSTC_POISON_EMPTY") == "1":
+        # diagnostic (tools/uninit_probe.sh): every torch.empty() - the step's workspaces, partial sums, packs - comes back filled with
+        # NaN / 0xFF instead of whatever the allocator's block held: a kernel that reads an element nobody wrote shows up as a NaN loss
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        torch.utils.deterministic.fill_uninitialized_memory = True
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def reduce_report(t, op=None):
+        """All-reduce of a few REPORTING scalars (timings, the loss of the timed steps).  Over RCCL: on the device.  Over gloo (the
+        shared-device functional checks: N processes on one GPU) the tensor goes through the host explicitly - twice in 26 such runs
+        the 2 x 5 loss vector came back ~0.5 % off while twelve identical runs and every model state agreed: gloo's own
+        staging of device tensors is kept out of what the line reports."""
+        op = op or dist.ReduceOp.SUM
+        if dist.get_backend() == "gloo":
+            torch.cuda.synchronize()
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
+        return t
 
     def make(cfg_name, bs_l, bs_g, seed_off=0, feed=None):
         """Fresh model + optimizer state (identical replica on every rank) and the batch source of one config."""
@@ -392,7 +412,7 @@ def main():
             ex = sum(max(exposed(ev_[i]) for ev_ in evs) for i in range(min(len(ev_) for ev_ in evs))) / steps
             cm = torch.tensor([bw, ex], device=dev, dtype=torch.float64)
             if world > 1:
-                dist.all_reduce(cm, op=dist.ReduceOp.MAX)
+                reduce_report(cm, dist.ReduceOp.MAX)
             comm = {"backward_ms_per_step": round(float(cm[0]), 3), "comm_exposed_ms_per_step": round(float(cm[1]), 3),
                     "allreduce_buckets": [len(t.reducer.buckets) for t in tss if t.reducer is not None],
                     "bucket_MB": [[round(b.numel() * 4 / 1e6, 1) for b in t.reducer.buckets] for t in tss if t.reducer is not None]}
@@ -412,15 +432,15 @@ def main():
         Fn.set_compute_dtype("fp32")
         if world > 1:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            reduce_report(tt, dist.ReduceOp.MAX)
             dt = float(tt.item())
         first, last = torch.stack([scs[0], scs[-1]]).clone()
         if world > 1:                      # scalars are rank-local contributions: their sum is the global loss
-            both = torch.stack([first, last]); dist.all_reduce(both); first, last = both
+            both = torch.stack([first, last]); reduce_report(both); first, last = both
         med = step_ms[steps // 2] if steps % 2 else 0.5 * (step_ms[steps // 2 - 1] + step_ms[steps // 2])
         if world > 1:
             tm = torch.tensor([med], device=dev, dtype=torch.float64)
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            reduce_report(tm, dist.ReduceOp.MAX)
             med = float(tm.item())
         res = {"dt": dt, "steps": steps, "step_ms_median": med, "step_ms_min": step_ms[0], "step_ms_max": step_ms[-1], "prof": prof, "pprof": pprof, "prof_steps": prof_steps, "events_inline": inline_events, "loss_first": float(first[0]), "loss_last": float(last[0]),
                "hbm": torch.cuda.max_memory_allocated(dev), "comm": comm,
@@ -592,7 +612,7 @@ def main():
     if dist.is_initialized():
         # ranks that really joined the communicator: every rank contributes a 1 to a sum-all-reduce over RCCL
         one = torch.ones(1, device=dev, dtype=torch.float32)
-        dist.all_reduce(one)
+        reduce_report(one)
         rccl_ranks = int(round(float(one.item())))
     if rank == 0:
         mixed = a.config == "mixed_ubn_sht"
