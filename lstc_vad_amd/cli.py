@@ -374,7 +374,8 @@ def train(script: str, argv=None, args=None):
                 # a rank's five scalars are its CONTRIBUTIONS to the global loss terms (local sums over global counts): the log line
                 # shows the batch's loss like a single-process run does - one 20-byte sum-all-reduce on the launch stream, no host sync
                 sc = sc.clone()
-                dist.all_reduce(sc)
+                from .dist import all_reduce_sum
+                all_reduce_sum(sc)
             if late is not None:
                 late.push(it, epoch, sc)          # the PREVIOUS step's line is written now: no sync on the step just queued
             it += 1

@@ -24,6 +24,31 @@ import torch
 import torch.distributed as dist
 
 
+class _Done:
+    """Handle of a collective that has already completed (host-staged gloo path)."""
+
+    def wait(self):
+        return True
+
+
+def all_reduce_sum(t: torch.Tensor, group=None, async_op: bool = False):
+    """SUM all-reduce of a device (or host) tensor.  Over RCCL (backend "nccl"): ``dist.all_reduce`` on the device, asynchronous if
+    asked.  Over gloo with a DEVICE tensor - the functional checks that put several ranks on one GPU (LSTC_SHARE_DEVICE), never a
+    measured configuration - the tensor is staged through the host HERE, synchronously: torch's own gloo path (pinned staging
+    copies on side streams, reduction on worker threads) returned wrong sums in roughly one of six 8-rank runs with eight
+    processes time-slicing one MI355X (round 6: tools/r06_flake_probe8.sh), with every stream dependency of this
+    repository's side in place.  ``LSTC_GLOO_DEVICE_TENSORS=1`` restores torch's path.  Returns a handle with ``wait()``."""
+    import os
+    if t.is_cuda and dist.get_backend(group) == "gloo" and os.environ.get("LSTC_GLOO_DEVICE_TENSORS", "0") != "1":
+        torch.cuda.current_stream(t.device).synchronize()
+        h = t.detach().to("cpu")
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return _Done()
+    h = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return h if async_op else _Done()
+
+
 class GradAllReducer:
     def __init__(self, param_groups: Sequence[Iterable[torch.nn.Parameter]], group=None, overlap: bool = True,
                  force: bool = False, reduce_dtype: str = "fp32", direct: Iterable[torch.nn.Parameter] = ()):
@@ -227,7 +252,7 @@ class GradAllReducer:
             _lib.check(_lib.load().lstc_cast_f32_bf16(_lib.dev_ptr(flat), _lib.dev_ptr(half), flat.numel(), _lib.stream_ptr()),
                        "lstc_cast_f32_bf16")
             flat = half
-        h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        h = all_reduce_sum(flat, self.group, async_op=async_op)
         return (bi, h)
 
     def _widen(self, bi):

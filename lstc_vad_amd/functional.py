@@ -1993,8 +1993,8 @@ class VadLossFunction(torch.autograd.Function):
             if exchange is not None:
                 exchange(bag)
             else:
-                import torch.distributed as dist
-                dist.all_reduce(bag, group=group)
+                from .dist import all_reduce_sum
+                all_reduce_sum(bag, group)
             d.phase = 1
             check(lib.lstc_vad_loss(C.byref(d), stream_ptr()), "lstc_vad_loss")
         ctx.save_for_backward(dout)
