@@ -84,6 +84,8 @@ enum {
     LSTC_EPI_OUT_PACK = 128, LSTC_EPI_RELU_MASK_PACK = 256, LSTC_EPI_RESIDUAL_PACK = 512
 };
 
+#define LSTC_VARIANT_NO_QTAIL (1 << 30)
+
 typedef struct LstcGemmDesc {
     int32_t M, N, K;
     int32_t lda, ldb, ldc;
@@ -106,7 +108,10 @@ typedef struct LstcGemmDesc {
                                        reference of the bitwise tests), 11 = the 64x64 tail tile, 12 = the persistent walk of the
                                        default loop (bit-identical, measured slower); anything else -> LSTC_E_UNSUPPORTED.  The
                                        other tile variants (1-3, 5-7, 9, 10) and the timing-only ablations (13-15) exist only in
-                                       -DLSTC_TUNING builds (`make tuning`, tools/tuning/gemm_check), never in the production library */
+                                       -DLSTC_TUNING builds (`make tuning`, tools/tuning/gemm_check), never in the production library.
+                                       LSTC_BF16P: 0, or LSTC_VARIANT_NO_QTAIL = the product as ONE persistent launch of 256 x 256 tiles,
+                                       without the quarter-tile kernel that otherwise takes the tiles behind the last whole round of
+                                       workgroups (bit-identical results: the reference of the bitwise tests) */
     int32_t batch;                  /* 0/1 = single problem; >1: `batch` independent problems of identical shape, problem z
                                        uses A + z*batch_stride_a etc. (elements).  Per-head products of the last layer's
                                        CLS attention (q_h W_k,h etc.).  Only alpha / ACCUM epilogues. */

@@ -25,6 +25,7 @@
 //   U0 = A rows/features of every wave's FIRST 64 (read in phase 0), U1 = B first 32 (phase 0), U2 = B second 32 (phase 1),
 //   U3 = A second 64 (phase 2).  Issue at (tile t, phase p): p0 U2(t+1), p1 U3(t+1), p2 U0(t+2), p3 U1(t+2) - each region was
 //   last read >= 2 phases earlier (WAR), each unit lands >= 5 phases before its first read (RAW: vmcnt(4) at p3 + barrier).
+#include <cstdlib>
 #include <type_traits>
 #include "lstc_common.h"
 
@@ -1103,6 +1104,304 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
 #undef P1_SYNC_COMPUTE
 }
 
+// ---- QUARTER tiles for the tail round (round 6, second session).  The persistent kernel above pays a launch's last, partly filled
+// round of 256 workgroups in full: 3136 tiles of the N = 2048 products are 12.25 rounds paid as 13, the 64 tiles of a 2048 x 2048
+// product keep 64 of 256 CUs busy.  The launcher therefore hands the tiles behind the last WHOLE round (tile index >= tile0, same
+// tile order as set_item above) to this kernel as four 128 x 128 quarter items each, one workgroup per item: 64 tail tiles = 256
+// workgroups of a quarter of the work.
+//   * Every output element sees the same K order and the same MFMA chain as in the 256 x 256 tile (one v_mfma_f32_16x16x32_bf16 per
+//     16 x 16 block and 32-k tile, kk = 0 before kk = 1, operand order as in the main kernel): results are bit-identical to the
+//     one-kernel product (tests/test_act16_gpu.py::test_quarter_tail_*, against d->variant = 16 = "no quarter tail").
+//   * Producer / consumer waves: a 128 x 128 item has MFMA work for four waves of 64 x 64 (16 ds_read_b128 per 32 MFMAs and K step;
+//     eight waves of 64 x 32 would read 12 per 16: LDS-bound).  Waves 0-3 (one per SIMD) compute; waves 4-7 own the LDS-DMA
+//     stream and its vmcnt - so the consumers' epilogue can use ordinary loads and stores, nothing hand-counted.
+//   * A K step of 64 is FOUR whole pack tiles (A and B, k tiles 2 s and 2 s + 1 of the item's 128-row blocks): 8 KB contiguous
+//     each, copied verbatim - one producer wave per tile, 8 x 1 KB.  Four stages of 32 KB; the DMA of step s + 3 is issued when
+//     step s - 1's stage falls free, fragment registers are double-buffered (reads of step s + 1 beside the MFMAs of step s),
+//     ONE s_barrier per K step.
+#ifndef P1_QTAIL_ROUNDS
+#define P1_QTAIL_ROUNDS 2                 // rounds of quarter items a launch's tail may take (LSTC_P1_QTAIL overrides at run time; 0 = off)
+#endif
+constexpr int Q_NS = 4;                   // stages (32 KB each)
+constexpr int Q_STAGE = 4 * P1_TILE;      // A k0 | A k1 | B k0 | B k1
+template <int EPK>
+__global__ void __launch_bounds__(NT8, 2) gemm_bf16p_q_kernel(const P1Params p, const int tile0) {
+    const DropKey dkn = drop_key_now(p.dk);
+    constexpr bool OPK = EPK == 1 || EPK == 2 || EPK == 4, MPK = EPK == 2, RPK = EPK == 4;
+    static_assert(EPK == 0 || EPK == 1 || EPK == 2 || EPK == 4, "quarter items: f32 output, packed output, + packed mask, + packed residual");
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem_p1[];
+    bf16_t* const smem = smem_p1;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool producer = wave >= 4;
+    const int pw = wave & 3;
+    // items sharing a tile (and tiles sharing a panel) sit on one XCD: blockIdx % 8 -> a contiguous run of items
+    const int nblk = gridDim.x;
+    const int item = (nblk & 7) ? (int)blockIdx.x : ((int)(blockIdx.x & 7) * (nblk >> 3) + (int)(blockIdx.x >> 3));
+    const int tile = tile0 + (item >> 2), qr = (item >> 1) & 1, qc = item & 1;
+    int mb, nb;
+#if P1_GROUP_M
+    {
+        const int per_group = P1_GROUP_M * p.tilesN;
+        const int gid = tile / per_group, first_m = gid * P1_GROUP_M;
+        const int gsz = min(p.tilesM - first_m, P1_GROUP_M);
+        const int loc = tile - gid * per_group;
+        mb = first_m + loc % gsz;
+        nb = loc / gsz;
+    }
+#else
+    mb = tile / p.tilesN; nb = tile - mb * p.tilesN;
+#endif
+    const int nkt = p.nsteps;
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    // producer wave pw copies pack tile pw of a stage: 0 / 1 = A (row block 2 mb + qr), k tiles 2 s / 2 s + 1; 2 / 3 = B (2 nb + qc)
+    const bf16_t* const src0 = (pw >= 2 ? p.B + (size_t)(2 * nb + qc) * p.KBb * P1_TILE : p.A + (size_t)(2 * mb + qr) * p.KBa * P1_TILE) +
+                               (size_t)(pw & 1) * P1_TILE;
+    auto q_issue = [&](int s) {
+        const bf16_t* g_ = src0 + (size_t)(2 * s) * P1_TILE;
+        const uint32_t l_ = (uint32_t)(((s & (Q_NS - 1)) * Q_STAGE + pw * P1_TILE) * 2);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
+                     :: "v"(lane_off), "s"(g_), "s"(l_) : "memory");
+        const bf16_t* g2_ = g_ + 2048;
+        const uint32_t l2_ = l_ + 4096u;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
+                     :: "v"(lane_off), "s"(g2_), "s"(l2_) : "memory");
+    };
+    // consumer wave pw = (w2r, w2c): rows 64 w2r .. +63, columns 64 w2c .. +63 of the item; fragments as in the main kernel (s16_off)
+    const int w2r = pw >> 1, w2c = pw & 1;
+    const int l15 = lane & 15, c16 = lane >> 4;
+    const int s16_off = l15 * 32 + ((((0x9C >> (2 * c16)) & 3) ^ ((l15 >> 2) & 3)) * 8);
+    const int a_off = (64 * w2r) * 32 + s16_off, b_off = 2 * P1_TILE + (64 * w2c) * 32 + s16_off;
+    bf16x8 fa0[2][4], fb0[2][4], fa1[2][4], fb1[2][4];
+    floatx4v qa[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) qa[i][j] = floatx4v{0.f, 0.f, 0.f, 0.f};
+    auto q_read = [&](int s, bf16x8 (&fa_)[2][4], bf16x8 (&fb_)[2][4]) {
+        const bf16_t* stg = smem + (s & (Q_NS - 1)) * Q_STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) fa_[kk][rt] = *reinterpret_cast<const bf16x8*>(stg + kk * P1_TILE + a_off + rt * 512);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) fb_[kk][ct] = *reinterpret_cast<const bf16x8*>(stg + kk * P1_TILE + b_off + ct * 512);
+        }
+    };
+    auto q_mma = [&](const bf16x8 (&fa_)[2][4], const bf16x8 (&fb_)[2][4]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    qa[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(OPK ? fb_[kk][ct] : fa_[kk][rt], OPK ? fa_[kk][rt] : fb_[kk][ct],
+                                                                         qa[rt][ct], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // K step s, as the two kinds of wave see it: the producers' DMA of step s + 1 has landed (younger: step s + 2), everyone meets (ONE
+    // s_barrier per step, the same count on both sides), then the producers refill the stage step s - 1 left (every consumer's reads
+    // of it completed before its MFMAs of step s - 1) and the consumers read step s + 1 beside the MFMAs of step s.  Two separate
+    // loops: with one loop and a branch inside, every fragment register is a phi of "unchanged" and "new" at the join and the
+    // allocator spills around the copies (481 spilled registers).
+#define Q_BARRIER()                                                                                                     \
+    do {                                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        asm volatile("" ::: "memory");                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+    } while (0)
+    if (producer) {
+        q_issue(0);
+        if (nkt > 1) q_issue(1);
+        if (nkt > 2) q_issue(2);
+        if (nkt > 2) __builtin_amdgcn_s_waitcnt(vmcnt_imm(16));
+        else if (nkt > 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));
+        else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+        Q_BARRIER();
+        for (int s = 0; s < nkt; ++s) {
+            if (s + 2 < nkt) __builtin_amdgcn_s_waitcnt(vmcnt_imm(8)); else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+            Q_BARRIER();
+            if (s + 3 < nkt) q_issue(s + 3);
+        }
+        return;       // (the item is the workgroup's only one: no barrier follows)
+    }
+    Q_BARRIER();
+    q_read(0, fa0, fb0);
+    {
+        // (reads behind the last step are unconditional: a stage nobody writes, values nobody uses)
+        int s = 0;
+        for (; s + 1 < nkt; s += 2) {
+            Q_BARRIER();
+            q_read(s + 1, fa1, fb1);
+            q_mma(fa0, fb0);
+            Q_BARRIER();
+            q_read(s + 2, fa0, fb0);
+            q_mma(fa1, fb1);
+        }
+        if (s < nkt) {
+            Q_BARRIER();
+            q_mma(fa0, fb0);
+        }
+    }
+#undef Q_BARRIER
+
+    // ---- epilogue of the item: rows urow0 .. +63, columns ucol0 .. +63 per consumer wave (semantics and operation order of the main kernel)
+    const int flags = p.flags;
+    const float alpha = p.alpha;
+    const int urow0 = mb * 256 + qr * 128 + w2r * 64, ucol0 = nb * 256 + qc * 128 + w2c * 64;
+    typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+    if constexpr (OPK) {
+        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+        typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+        const bool f_res = (flags & LSTC_EPI_RESIDUAL) != 0, f_mask = (flags & LSTC_EPI_RELU_MASK) != 0;
+        // swapped operands: a lane holds ONE row (l15) and, after the 16-lane exchange, eight consecutive columns = chunk pk_chunk
+        const int pk_chunk = (0xD8 >> (2 * c16)) & 3;
+        const uint32_t offP = (uint32_t)(l15 * 32 + ((pk_chunk ^ ((l15 >> 2) & 3)) << 3)) * 2u;
+        const uint32_t idx0 = (uint32_t)(urow0 + l15) * (uint32_t)p.N + (uint32_t)(ucol0 + 8 * pk_chunk);
+        const float* aux = f_res ? p.res : f_mask ? p.relu_src : nullptr;
+        const int ldx = f_res ? p.ldr : p.ld_relu;
+        auto tile_elems = [&](int kbp, int cp, int rt) -> size_t {
+            return ((size_t)(2 * mb + qr) * kbp + nb * 8 + qc * 4 + w2c * 2 + cp) * P1_TILE + (w2r * 4 + rt) * 512;
+        };
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            floatx4v b0 = floatx4v{0.f, 0.f, 0.f, 0.f}, b1 = b0;
+            if (flags & LSTC_EPI_BIAS) {
+                const float* bp = p.bias + (ucol0 + 32 * cp + 8 * pk_chunk);
+                b0 = *reinterpret_cast<const floatx4v*>(bp);
+                b1 = *reinterpret_cast<const floatx4v*>(bp + 4);
+            }
+            const float bvv[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                float e0 = qa[rt][2 * cp][0], e1 = qa[rt][2 * cp][1], e2 = qa[rt][2 * cp][2], e3 = qa[rt][2 * cp][3];
+                float o_0 = qa[rt][2 * cp + 1][0], o_1 = qa[rt][2 * cp + 1][1], o_2 = qa[rt][2 * cp + 1][2], o_3 = qa[rt][2 * cp + 1][3];
+#define P1_SWAP(x, y)                                                                                                    \
+                do {                                                                                                     \
+                    const uint2v r_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false); \
+                    x = __uint_as_float(r_[0]); y = __uint_as_float(r_[1]);                                               \
+                } while (0)
+                P1_SWAP(e0, o_0); P1_SWAP(e1, o_1); P1_SWAP(e2, o_2); P1_SWAP(e3, o_3);
+#undef P1_SWAP
+                float v[8] = {e0, e1, e2, e3, o_0, o_1, o_2, o_3};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * alpha + bvv[e];
+                if (flags & LSTC_EPI_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (flags & LSTC_EPI_DROPOUT) {
+                    const uint32_t idx = idx0 + (uint32_t)(rt * 16) * (uint32_t)p.N + 32u * (uint32_t)cp;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = drop_keep(idx + e, dkn) ? v[e] * dkn.scale : 0.f;
+                }
+                uint4v opk = uint4v{0u, 0u, 0u, 0u};
+                if constexpr (RPK || MPK) {
+                    const bf16_t* src = reinterpret_cast<const bf16_t*>(RPK ? p.res : p.relu_src) + tile_elems(RPK ? p.res_kbp : p.mask_kbp, cp, rt);
+                    opk = *reinterpret_cast<const uint4v*>(reinterpret_cast<const char*>(src) + offP);
+                }
+                float xx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if ((!RPK && f_res) || (!MPK && !f_res && f_mask)) {      // the f32 per-element operand (never the packed one's pointer)
+                    const float* ab_ = aux + (size_t)(urow0 + rt * 16 + l15) * ldx + (ucol0 + 32 * cp + 8 * pk_chunk);
+                    const floatx4v o0 = *reinterpret_cast<const floatx4v*>(ab_), o1 = *reinterpret_cast<const floatx4v*>(ab_ + 4);
+                    xx[0] = o0[0]; xx[1] = o0[1]; xx[2] = o0[2]; xx[3] = o0[3]; xx[4] = o1[0]; xx[5] = o1[1]; xx[6] = o1[2]; xx[7] = o1[3];
+                }
+                if constexpr (RPK) {             // bf16 -> f32 is a 16-bit shift: exact
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] += __uint_as_float(opk[e] << 16);
+                        v[2 * e + 1] += __uint_as_float(opk[e] & 0xffff0000u);
+                    }
+                } else if (f_res) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += xx[e];
+                }
+                if constexpr (MPK) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] = (int)(opk[e] << 16) > 0 ? v[2 * e] : 0.f;
+                        v[2 * e + 1] = (int)(opk[e] & 0xffff0000u) > 0 ? v[2 * e + 1] : 0.f;
+                    }
+                } else if (f_mask) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = xx[e] > 0.f ? v[e] : 0.f;
+                }
+                uint4v h_;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bf16x2 t2; t2[0] = (bf16_t)v[2 * e]; t2[1] = (bf16_t)v[2 * e + 1];
+                    h_[e] = __builtin_bit_cast(unsigned, t2);
+                }
+                bf16_t* ob_ = reinterpret_cast<bf16_t*>(p.C) + tile_elems(p.out_kbp, cp, rt);
+                *reinterpret_cast<uint4v*>(reinterpret_cast<char*>(ob_) + offP) = h_;
+            }
+        }
+    } else {
+        // f32 output: quad transposes + the half-wave exchange of the main kernel's wide epilogue - a lane stores 4 consecutive columns
+        const int c4 = lane & 3;
+        auto xpose = [&](float& v0, float& v1, float& v2, float& v3) {
+            const bool b1 = (c4 & 2) != 0, b0 = (c4 & 1) != 0;
+            int s0 = __float_as_int(b1 ? v0 : v2), s1 = __float_as_int(b1 ? v1 : v3);
+            float r0 = __int_as_float(__builtin_amdgcn_mov_dpp(s0, 0x4E, 0xF, 0xF, true));
+            float r1 = __int_as_float(__builtin_amdgcn_mov_dpp(s1, 0x4E, 0xF, 0xF, true));
+            if (b1) { v0 = r0; v1 = r1; } else { v2 = r0; v3 = r1; }
+            s0 = __float_as_int(b0 ? v0 : v1); s1 = __float_as_int(b0 ? v2 : v3);
+            r0 = __int_as_float(__builtin_amdgcn_mov_dpp(s0, 0xB1, 0xF, 0xF, true));
+            r1 = __int_as_float(__builtin_amdgcn_mov_dpp(s1, 0xB1, 0xF, 0xF, true));
+            if (b0) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
+        };
+        auto store4 = [&](float v0, float v1, float v2, float v3, int row, int col, const float4& bv) {
+            if (col >= p.N || row >= p.M) return;
+            float4 v = make_float4(v0 * alpha + bv.x, v1 * alpha + bv.y, v2 * alpha + bv.z, v3 * alpha + bv.w);
+            if (flags & LSTC_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (flags & LSTC_EPI_DROPOUT) {
+                const uint32_t idx = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+                v.x = drop_keep(idx, dkn) ? v.x * dkn.scale : 0.f;
+                v.y = drop_keep(idx + 1, dkn) ? v.y * dkn.scale : 0.f;
+                v.z = drop_keep(idx + 2, dkn) ? v.z * dkn.scale : 0.f;
+                v.w = drop_keep(idx + 3, dkn) ? v.w * dkn.scale : 0.f;
+            }
+            if (flags & LSTC_EPI_RESIDUAL) {
+                const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)row * p.ldr + col);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            if (flags & LSTC_EPI_RELU_MASK) {
+                const float4 m = *reinterpret_cast<const float4*>(p.relu_src + (size_t)row * p.ld_relu + col);
+                v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+            }
+            float* cp = p.C + (size_t)row * p.ldc + col;
+            if (flags & LSTC_EPI_ACCUM) { const float4 o = *reinterpret_cast<const float4*>(cp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *reinterpret_cast<float4*>(cp) = v;
+        };
+#pragma unroll
+        for (int cp2 = 0; cp2 < 2; ++cp2) {
+            const int col = ucol0 + (2 * cp2 + (c16 >> 1)) * 16 + 4 * (l15 >> 2);
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((flags & LSTC_EPI_BIAS) && col < p.N) bv = *reinterpret_cast<const float4*>(p.bias + col);
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                float x0 = qa[rt][2 * cp2][0], x1 = qa[rt][2 * cp2][1], x2 = qa[rt][2 * cp2][2], x3 = qa[rt][2 * cp2][3];
+                float y0 = qa[rt][2 * cp2 + 1][0], y1 = qa[rt][2 * cp2 + 1][1], y2 = qa[rt][2 * cp2 + 1][2], y3 = qa[rt][2 * cp2 + 1][3];
+                xpose(x0, x1, x2, x3);
+                xpose(y0, y1, y2, y3);
+#define P1_SWAP(x, y)                                                                                                    \
+                do {                                                                                                     \
+                    const uint2v r_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false); \
+                    x = __uint_as_float(r_[0]); y = __uint_as_float(r_[1]);                                               \
+                } while (0)
+                P1_SWAP(x0, y0); P1_SWAP(x1, y1); P1_SWAP(x2, y2); P1_SWAP(x3, y3);
+#undef P1_SWAP
+                const int row = urow0 + rt * 16 + 4 * (c16 & 1) + c4;
+                store4(x0, x1, x2, x3, row, col, bv);
+                store4(y0, y1, y2, y3, row + 8, col, bv);
+            }
+        }
+    }
+}
+
 inline int64_t p1_rbp(int64_t rows) { const int64_t rb = (rows + 127) / 128; return rb + (rb & 1); }
 inline int64_t p1_kbp(int64_t K) { const int64_t kb = (K + 31) / 32; return kb + (kb & 1); }
 
@@ -1140,7 +1439,7 @@ __attribute__((visibility("hidden"))) int lstc_gemm_bf16p_impl(const LstcGemmDes
 #ifdef LSTC_TUNING
         const int tile_variant = d->variant & 15;          // the bits above select timing ablations / stamps
 #else
-        const int tile_variant = d->variant;
+        const int tile_variant = d->variant & ~LSTC_VARIANT_NO_QTAIL;
 #endif
         if (tr || splits > 1 || !P1_NT_S16 || d->M % 256 || d->N % 256 || (d->flags & LSTC_EPI_ACCUM) || tile_variant != 0 ||
             (p.mask_kbp && (!(d->flags & LSTC_EPI_RELU_MASK) || (d->flags & LSTC_EPI_RESIDUAL)))) return LSTC_E_UNSUPPORTED;
@@ -1149,11 +1448,15 @@ __attribute__((visibility("hidden"))) int lstc_gemm_bf16p_impl(const LstcGemmDes
         if (p.out_kbp && (d->flags & LSTC_EPI_RESIDUAL) && (d->flags & LSTC_EPI_RELU_MASK)) return LSTC_E_UNSUPPORTED;
     }
     p.dk = make_drop_key(d->dropout_p, d->dropout_seed);
+    // d->variant: 0 = default; LSTC_VARIANT_NO_QTAIL = the same product without the quarter-tile tail kernel (one persistent launch: the
+    // reference of the bitwise tests).  Tuning builds: bits 0-3 tile variant, bits 4.. timing ablations / stamps
+    const bool no_qtail = (d->variant & LSTC_VARIANT_NO_QTAIL) != 0;
+    const int variant_ = d->variant & ~LSTC_VARIANT_NO_QTAIL;
 #ifdef LSTC_TUNING
-    p.debug = d->variant >> 4;
+    p.debug = variant_ >> 4;
 #else
     p.debug = 0;
-    if (d->variant != 0) return LSTC_E_UNSUPPORTED;
+    if (variant_ != 0) return LSTC_E_UNSUPPORTED;
 #endif
     p.vec_epi = (d->N % 4 == 0) && (d->ldc % 4 == 0) && aligned16(d->C) && (p.split_stride % 4 == 0) &&
                 (!(d->flags & LSTC_EPI_BIAS) || aligned16(d->bias)) &&
@@ -1178,6 +1481,7 @@ __attribute__((visibility("hidden"))) int lstc_gemm_bf16p_impl(const LstcGemmDes
 #else
     constexpr size_t lds = (size_t)2 * P1_BUF * sizeof(bf16_t);
 #endif
+    constexpr size_t q_lds = (size_t)Q_NS * Q_STAGE * sizeof(bf16_t);
     // per device: the CU count sizes the persistent grid and the 128-KB dynamic-LDS opt-in is a per-device kernel attribute
     static std::atomic<int> n_cu_dev[64];
     static LstcDevOnce setup;
@@ -1196,6 +1500,10 @@ __attribute__((visibility("hidden"))) int lstc_gemm_bf16p_impl(const LstcGemmDes
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel<false, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_q_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)q_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_q_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)q_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_q_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)q_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_q_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)q_lds);
         setup.end(dev_);
     }
     const int n_cu = n_cu_dev[cur & 63].load(std::memory_order_relaxed);
@@ -1203,7 +1511,38 @@ __attribute__((visibility("hidden"))) int lstc_gemm_bf16p_impl(const LstcGemmDes
     // N = 2048 products are 12.25 rounds of 256 but exactly 14 of 224.  A round takes the same 55 - 56 us either way, so 14 of them
     // lose: 0.732 -> 0.774 ms at K = 2048, 1.303 -> 1.350 at K = 4096, step 38.3 -> 39.2 ms.  The chip is not power-limited at this
     // granularity: idle CUs buy the busy ones nothing.)
+    // Quarter-tile tail (gemm_bf16p_q_kernel): the tiles behind the last whole round of n_cu workgroups run as four 128 x 128 items
+    // each when that fills the chip better - at most P1_QTAIL_ROUNDS rounds of quarter items (a quarter item takes ~0.35 of a tile's
+    // time: two rounds of them still beat one round of tiles, three do not).  NT form on 16x16x32, no K split, 16-B epilogue accesses.
+    const int epk_ = p.res_kbp ? 4 : p.out_kbp ? (p.mask_kbp ? 2 : 1) : (p.mask_kbp ? 3 : 0);
+    int q_tiles = 0;
+    if (!tr && P1_NT_S16 && eff_splits == 1 && p.vec_epi && epk_ != 3 && !no_qtail && variant_ == 0 && n_cu > 0) {
+        static const int q_rounds = [] {
+            const char* e = getenv("LSTC_P1_QTAIL");            // 0 = off (A/B runs), 1 .. 3 = rounds of quarter items allowed
+            const int v = e ? atoi(e) : P1_QTAIL_ROUNDS;
+            return v < 0 ? 0 : v > 3 ? 3 : v;
+        }();
+        const int tail = p.total_items % n_cu;
+        if (tail > 0 && 4 * tail <= q_rounds * n_cu) { q_tiles = tail; p.total_items -= tail; }
+    }
     const int grid = p.total_items < n_cu ? p.total_items : n_cu;
+    if (q_tiles) {
+        const int tile0 = p.total_items;
+        if (grid > 0) {
+            const int epk = epk_;
+            if (epk == 0) hipLaunchKernelGGL((gemm_bf16p_kernel<false, true, 0>), dim3(grid), dim3(NT8), lds, st, p);
+            else if (epk == 1) hipLaunchKernelGGL((gemm_bf16p_kernel<false, true, 1>), dim3(grid), dim3(NT8), lds, st, p);
+            else if (epk == 2) hipLaunchKernelGGL((gemm_bf16p_kernel<false, true, 2>), dim3(grid), dim3(NT8), lds, st, p);
+            else hipLaunchKernelGGL((gemm_bf16p_kernel<false, true, 4>), dim3(grid), dim3(NT8), lds, st, p);
+            const int rc = lstc_launch_status();
+            if (rc) return rc;
+        }
+        if (epk_ == 0) hipLaunchKernelGGL((gemm_bf16p_q_kernel<0>), dim3(4 * q_tiles), dim3(NT8), q_lds, st, p, tile0);
+        else if (epk_ == 1) hipLaunchKernelGGL((gemm_bf16p_q_kernel<1>), dim3(4 * q_tiles), dim3(NT8), q_lds, st, p, tile0);
+        else if (epk_ == 2) hipLaunchKernelGGL((gemm_bf16p_q_kernel<2>), dim3(4 * q_tiles), dim3(NT8), q_lds, st, p, tile0);
+        else hipLaunchKernelGGL((gemm_bf16p_q_kernel<4>), dim3(4 * q_tiles), dim3(NT8), q_lds, st, p, tile0);
+        return lstc_launch_status();
+    }
     if (tr) hipLaunchKernelGGL((gemm_bf16p_kernel<true, P1_TR_S16 != 0>), dim3(grid), dim3(NT8), lds, st, p);
     else if (P1_NT_S16) {
         const int epk = p.res_kbp ? 4 : p.out_kbp ? (p.mask_kbp ? 2 : 1) : (p.mask_kbp ? 3 : 0);

@@ -62,6 +62,84 @@ def test_packed_residual_epilogue_is_bitwise_the_f32_residual_epilogue(M, N, K):
         Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
 
 
+NO_QTAIL = 1 << 30          # LSTC_VARIANT_NO_QTAIL (include/lstc_hip.h)
+
+
+@pytest.mark.parametrize("M,N,K", [(8448, 2048, 512),      # 264 tiles: one whole round of 256 + 8 tail tiles = 32 quarter items
+                                   (2048, 2048, 320),      # 64 tiles, no whole round: 256 quarter items; 5 K steps (odd)
+                                   (12544, 4096, 128),     # BASELINE config 2's rank shape at 8 GPUs: 784 tiles = 3 rounds + 16; 2 K steps
+                                   (512, 256, 64),         # 2 tiles, ONE K step
+                                   (1024, 768, 192),       # 12 tiles, 3 K steps
+                                   (33024, 2048, 64)])     # 1032 tiles = 4 rounds + 8
+def test_quarter_tail_is_bitwise_the_one_launch_product(M, N, K):
+    """csrc/gemm_bf16p.hip, gemm_bf16p_q_kernel: the tiles behind the last whole round of 256 persistent workgroups run as four
+    128 x 128 quarter items each (producer / consumer waves, four LDS stages).  Same K order and MFMA chain per output element,
+    same epilogue arithmetic: every epilogue the training step uses - f32 output (plain; bias + ReLU; bias + dropout + residual;
+    ReLU mask; accumulate) and packed output (plain; bias + ReLU; bias + dropout + f32 residual; f32 mask; packed mask; packed
+    residual + dropout) - must equal the product computed as ONE persistent launch (variant LSTC_VARIANT_NO_QTAIL) bit for bit."""
+    from lstc_vad_amd import functional as Fn
+    g = torch.Generator(device=DEV).manual_seed(77)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = torch.randn(N, K, device=DEV, generator=g) * 0.1
+    b = torch.randn(N, device=DEV, generator=g)
+    r = _bf16(torch.randn(M, N, device=DEV, generator=g))
+    m = torch.randn(M, N, device=DEV, generator=g)
+    Fn.set_compute_dtype("bf16"); Fn.set_x3_threshold(0, 0, 0)
+    try:
+        with Fn.pack_memo():
+            rp, mp = Fn.pack3(r, False), Fn.pack3(m, False)
+            tiles = M * N * 2
+            f32_cases = (dict(), dict(bias=b, relu=True), dict(bias=b, dropout=(0.2, 0x1234567), residual=r), dict(relu_mask=m, alpha=0.5))
+            for kw in f32_cases:
+                got = Fn.gemm(x, w, trans_b=True, **kw)
+                ref = Fn.gemm(x, w, trans_b=True, variant=NO_QTAIL, **kw)
+                assert torch.equal(got, ref), (kw.keys(), int((got != ref).sum()))
+                if not kw:
+                    plain = got
+            acc0 = torch.randn(M, N, device=DEV, generator=g)
+            a1, a2 = acc0.clone(), acc0.clone()
+            Fn.gemm(x, w, trans_b=True, out=a1, accumulate=True)
+            Fn.gemm(x, w, trans_b=True, out=a2, accumulate=True, variant=NO_QTAIL)
+            assert torch.equal(a1, a2)
+            pk_cases = (dict(), dict(bias=b, relu=True), dict(bias=b, dropout=(0.2, 0x1234567), residual=r), dict(relu_mask=m),
+                        dict(relu_mask=mp), dict(bias=b, dropout=(0.1, 99), residual=rp), dict(residual=rp))
+            for kw in pk_cases:
+                got = Fn.gemm(x, w, trans_b=True, out_pack=True, **kw)
+                ref = Fn.gemm(x, w, trans_b=True, out_pack=True, variant=NO_QTAIL, **kw)
+                assert torch.equal(got.buf[:tiles], ref.buf[:tiles]), (kw.keys(), int((got.buf[:tiles] != ref.buf[:tiles]).sum()))
+        torch.cuda.synchronize()
+    finally:
+        Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
+    want = _bf16(x).double() @ _bf16(w).double().T
+    assert max_abs_diff(plain.double(), want) < 2e-5 * (K ** 0.5)
+
+
+@pytest.mark.parametrize("M,N,K", [(2000, 1028, 200), (300, 520, 1000), (4000, 2048, 96)])
+def test_quarter_tail_on_ragged_f32_outputs(M, N, K):
+    """Quarter items on products off the 256-tile grid (f32 output, N a multiple of 4: the 16-B epilogue): rows / columns outside the
+    matrix are never written, the result equals the one-launch product bit for bit and f64 on the rounded operands to f32 rounding."""
+    from lstc_vad_amd import functional as Fn
+    g = torch.Generator(device=DEV).manual_seed(78)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = torch.randn(N, K, device=DEV, generator=g) * 0.1
+    b = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g)
+    Fn.set_compute_dtype("bf16"); Fn.set_x3_threshold(0, 0, 0)
+    try:
+        with Fn.pack_memo():
+            big = torch.full((M + 3, N + 8), 7.0, device=DEV)
+            out = big[:M, :N]
+            Fn.gemm(x, w, trans_b=True, bias=b, residual=res, out=out)
+            ref = Fn.gemm(x, w, trans_b=True, bias=b, residual=res, variant=NO_QTAIL)
+        torch.cuda.synchronize()
+    finally:
+        Fn.set_compute_dtype("fp32"); Fn.set_x3_threshold()
+    assert torch.equal(out, ref)
+    assert bool((big[M:] == 7.0).all()) and bool((big[:, N:] == 7.0).all())
+    want = _bf16(x).double() @ _bf16(w).double().T + b.double() + res.double()
+    assert max_abs_diff(ref.double(), want) < 2e-5 * (K ** 0.5)
+
+
 @pytest.mark.parametrize("rows,d,p", [(512, 2048, 0.2), (768, 1024, 0.1), (256, 2048, 0.0)])
 def test_layernorm_on_packs_matches_f64_on_the_packed_values(rows, d, p):
     """lstc_layernorm_fwd_act / lstc_layernorm_bwd_act: inputs as packs (and as f32), outputs as packs (and f32); against f64
