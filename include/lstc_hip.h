@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LSTC_VERSION 111            /* 0.1.1 patch 1: see INTEGRATION.md, "ABI history" */
+#define LSTC_VERSION 112            /* 0.1.1 patch 2: see INTEGRATION.md, "ABI history" */
 
 enum {
     LSTC_OK = 0,

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib):
     raw = C.CDLL(_lib.LIB_PATH)
     for s in declared:
         assert hasattr(raw, s), s
-    assert lib.lstc_version() == 111        # 0.1.1 patch 1 (round 6): INTEGRATION.md, "ABI history"
+    assert lib.lstc_version() == 112        # 0.1.1 patch 2 (round 6): INTEGRATION.md, "ABI history"
 
 
 def test_descriptor_layouts_match_header(lib, tmp_path):
@@ -69,7 +69,7 @@ def test_production_library_refuses_tuning_variants(lib):
     d.transB = 1
     # f32: the production library holds 0 = 4 (default), 8 (its fallback), 11 (64x64 tail tile), 12 (persistent); the other tile variants
     # (1-3, 5-7, 9, 10) live in `make tuning` builds only since round 6
-    for dtype, bad in ((0, (1, 2, 3, 5, 6, 7, 9, 10, 13, 14, 15, 16, 4 + 16, 1 << 20, -1)), (3, (1, 16, 32))):
+    for dtype, bad in ((0, (1, 2, 3, 5, 6, 7, 9, 10, 13, 14, 15, 16, 4 + 16, 1 << 20, -1)), (3, (1, 16, 32, (1 << 30) | 1))):      # LSTC_BF16P: 0 or LSTC_VARIANT_NO_QTAIL (1 << 30) alone
         d.dtype = dtype
         for v in bad:
             d.variant = v
