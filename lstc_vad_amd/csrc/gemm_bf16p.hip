@@ -1116,13 +1116,19 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
 //     eight waves of 64 x 32 would read 12 per 16: LDS-bound).  Waves 0-3 (one per SIMD) compute; waves 4-7 own the LDS-DMA
 //     stream and its vmcnt - so the consumers' epilogue can use ordinary loads and stores, nothing hand-counted.
 //   * A K step of 64 is FOUR whole pack tiles (A and B, k tiles 2 s and 2 s + 1 of the item's 128-row blocks): 8 KB contiguous
-//     each, copied verbatim - one producer wave per tile, 8 x 1 KB.  Four stages of 32 KB; the DMA of step s + 3 is issued when
+//     each, copied verbatim - one producer wave per tile, 8 x 1 KB.  Q_NS stages of 32 KB; the DMA of step s + Q_NS - 1 is issued when
 //     step s - 1's stage falls free, fragment registers are double-buffered (reads of step s + 1 beside the MFMAs of step s),
 //     ONE s_barrier per K step.
 #ifndef P1_QTAIL_ROUNDS
 #define P1_QTAIL_ROUNDS 2                 // rounds of quarter items a launch's tail may take (LSTC_P1_QTAIL overrides at run time; 0 = off)
 #endif
-constexpr int Q_NS = 4;                   // stages (32 KB each)
+#ifndef P1_Q_NS
+#define P1_Q_NS 4                         // 5 (all 160 KB of the CU, one more K step to land) measured: no change - 2048 x 2048 x 2048 0.024 ms, K = 4096
+#endif                                    // 0.046 either way.  The item is not latency-bound: a 16-tile product (64 workgroups, 192 CUs idle) takes the
+                                          // same 0.66 us per K step as a 64-tile one - 32 KB per step and CU = 48 GB/s per CU, the rate the 256 x 256
+                                          // loop's 64 KB per 1.33 us comes to as well: the CU's LDS-DMA intake (profiles/r06_qtail5_ab.txt)
+constexpr int Q_NS = P1_Q_NS;             // stages (32 KB each); the DMA of a K step has Q_NS - 2 steps to land
+static_assert(Q_NS == 4 || Q_NS == 5, "quarter items: four or five stages");
 constexpr int Q_STAGE = 4 * P1_TILE;      // A k0 | A k1 | B k0 | B k1
 template <int EPK>
 __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_q_kernel(const P1Params p, const int tile0) {
@@ -1158,7 +1164,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_q_kernel(const P1Params p, 
                                (size_t)(pw & 1) * P1_TILE;
     auto q_issue = [&](int s) {
         const bf16_t* g_ = src0 + (size_t)(2 * s) * P1_TILE;
-        const uint32_t l_ = (uint32_t)(((s & (Q_NS - 1)) * Q_STAGE + pw * P1_TILE) * 2);
+        const uint32_t l_ = (uint32_t)(((s % Q_NS) * Q_STAGE + pw * P1_TILE) * 2);
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
                      "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
                      :: "v"(lane_off), "s"(g_), "s"(l_) : "memory");
@@ -1180,7 +1186,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_q_kernel(const P1Params p, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) qa[i][j] = floatx4v{0.f, 0.f, 0.f, 0.f};
     auto q_read = [&](int s, bf16x8 (&fa_)[2][4], bf16x8 (&fb_)[2][4]) {
-        const bf16_t* stg = smem + (s & (Q_NS - 1)) * Q_STAGE;
+        const bf16_t* stg = smem + (s % Q_NS) * Q_STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -1214,17 +1220,26 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_q_kernel(const P1Params p, 
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     } while (0)
     if (producer) {
-        q_issue(0);
-        if (nkt > 1) q_issue(1);
-        if (nkt > 2) q_issue(2);
-        if (nkt > 2) __builtin_amdgcn_s_waitcnt(vmcnt_imm(16));
-        else if (nkt > 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));
-        else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+        // Q_NS - 1 steps in flight: the DMA of step s + Q_NS - 1 is issued when step s - 1's stage falls free and has Q_NS - 2 steps to land
+#pragma unroll
+        for (int s0 = 0; s0 < Q_NS - 1; ++s0)
+            if (s0 < nkt) q_issue(s0);
+        {   // step 0 landed: younger = min(Q_NS - 2, nkt - 1) steps of 8 pieces
+            const int y = min(Q_NS - 2, nkt - 1);
+            if (y >= 3) __builtin_amdgcn_s_waitcnt(vmcnt_imm(24));
+            else if (y == 2) __builtin_amdgcn_s_waitcnt(vmcnt_imm(16));
+            else if (y == 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));
+            else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+        }
         Q_BARRIER();
         for (int s = 0; s < nkt; ++s) {
-            if (s + 2 < nkt) __builtin_amdgcn_s_waitcnt(vmcnt_imm(8)); else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+            // step s + 1 landed: younger = the steps s + 2 .. s + Q_NS - 2 that exist
+            const int y = min(Q_NS - 3, nkt - 2 - s);
+            if (y >= 2) __builtin_amdgcn_s_waitcnt(vmcnt_imm(16));
+            else if (y == 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));
+            else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
             Q_BARRIER();
-            if (s + 3 < nkt) q_issue(s + 3);
+            if (s + Q_NS - 1 < nkt) q_issue(s + Q_NS - 1);
         }
         return;       // (the item is the workgroup's only one: no barrier follows)
     }
