@@ -70,8 +70,9 @@ def _headline_trainstep(name, dtype):
     fill_params(enc, seed)
     fill_params(head, seed + 1)
     enc, head = enc.to(DEV).train(), head.to(DEV).train()
-    nf, _, af, al = syn.training_batch(skw["batch_size"], skw["part_num"], skw["part_len"], skw["n_patch"], d, seed=seed,
-                                       with_pseudo=True, threshold=0.6)
+    from util import cached_training_batch
+    nf, _, af, al = cached_training_batch(skw["batch_size"], skw["part_num"], skw["part_len"], skw["n_patch"], d, seed=seed,
+                                          with_pseudo=True, threshold=0.6)
     args = _args(mode, skw)
     Fn.set_compute_dtype(dtype)
     try:

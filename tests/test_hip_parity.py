@@ -1069,9 +1069,9 @@ def _full_width_models(name):
     enc, head = _models(mode, dict(ekw), d)
     fill_params(enc, seed)
     fill_params(head, seed + 1)
-    from lstc_vad_amd import synthetic as syn
-    nf, _, af, al = syn.training_batch(skw["batch_size"], skw["part_num"], skw["part_len"], skw["n_patch"], d, seed=seed,
-                                       with_pseudo=True, threshold=0.6)
+    from util import cached_training_batch
+    nf, _, af, al = cached_training_batch(skw["batch_size"], skw["part_num"], skw["part_len"], skw["n_patch"], d, seed=seed,
+                                          with_pseudo=True, threshold=0.6)
     return z, mode, skw, d, enc, head, nf, af, al
 
 

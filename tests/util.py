@@ -59,3 +59,20 @@ def host_dropout_keep(i, p, seed):
     h = (h * u(0xC2B2AE3D)) & lo
     h ^= h >> u(16)
     return h >= u(thr)
+
+
+_BATCH_CACHE = {}
+
+
+def cached_training_batch(*args, **kw):
+    """``synthetic.training_batch`` with the last three results kept: the headline-size batches (2 x 403 MB from the portable
+    generator, several seconds each) are asked for by five tests in a row.  Returns copies: a test may write into its arrays."""
+    from lstc_vad_amd import synthetic as syn
+    key = (args, tuple(sorted(kw.items())))
+    hit = _BATCH_CACHE.get(key)
+    if hit is None:
+        hit = syn.training_batch(*args, **kw)
+        while len(_BATCH_CACHE) >= 3:
+            _BATCH_CACHE.pop(next(iter(_BATCH_CACHE)))
+        _BATCH_CACHE[key] = hit
+    return tuple(a.copy() for a in hit)
