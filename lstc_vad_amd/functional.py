@@ -192,6 +192,7 @@ _pack_prof = None          # list of (bytes_in, start_event, end_event) while be
 _wepoch = 0
 _memo_stack = []           # activation packs made inside one autograd-node body are shared by the GEMMs of that body
 _x3_min = (256, 256, 1 << 30)   # min(M, N), K, M*N*K from which a product goes to the packed kernel
+_BF16P_MIN_MNK = int(os.environ.get("LSTC_BF16P_MIN_MNK", str(1 << 28)))      # the M*N*K bound of the packed bf16 kernel (A/B: 1073741824 = rounds 2 - 5)
 _CLS_PACK = os.environ.get("LSTC_CLS_PACK", "1") != "0"             # A/B hook: 0 = the CLS-only layer reads f32 rows (round 5's first form)
 _ATTN_F32 = os.environ.get("LSTC_ATTN_F32", "0") == "1"          # bf16 mode: keep the attention products on the exact-f32 MFMA
 _ATTN_VARIANT = int(os.environ.get("LSTC_ATTN_VARIANT", "0"))     # 1: first-generation attention kernels (A/B measurements)
@@ -511,7 +512,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a=False, trans_b=False, out:
     if pkind is not None:
         # small products (heads of 512 / 32 columns, the CLS-only last layer) stay on the exact-f32 kernel (f32x3 mode) or on
         # the convert-while-staging bf16 kernel (bf16 mode)
-        if isinstance(a, Packed) or isinstance(b, Packed) or (min(M, N) >= _x3_min[0] and K >= _x3_min[1] and M * N * K >= _x3_min[2]):
+        # (bf16 mode: a quarter of the size suffices since round 6 - products of a few 256 x 256 tiles run as 128 x 128 quarter items
+        # on the packed kernel (csrc/gemm_bf16p.hip, gemm_bf16p_q_kernel): the head's 256 x 512 x 2048 product of one rank of the 8-GPU
+        # split 0.084 ms on the convert-while-staging kernel, four workgroups walking K alone)
+        min_mnk = min(_x3_min[2], _BF16P_MIN_MNK) if pkind == _lib.BF16P else _x3_min[2]
+        if isinstance(a, Packed) or isinstance(b, Packed) or (min(M, N) >= _x3_min[0] and K >= _x3_min[1] and M * N * K >= min_mnk):
             a = _packed_operand(a, trans_a)
             b = _packed_operand(b, not trans_b)
             pa, pb = dev_ptr(a.buf), dev_ptr(b.buf)
