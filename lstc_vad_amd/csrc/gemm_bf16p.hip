@@ -1111,9 +1111,9 @@ __global__ void __launch_bounds__(NT8, 2) gemm_bf16p_kernel(const P1Params p) {
 // workgroups of a quarter of the work.
 //   * Every output element sees the same K order and the same MFMA chain as in the 256 x 256 tile (one v_mfma_f32_16x16x32_bf16 per
 //     16 x 16 block and 32-k tile, kk = 0 before kk = 1, operand order as in the main kernel): results are bit-identical to the
-//     one-kernel product (tests/test_act16_gpu.py::test_quarter_tail_*, against d->variant = 16 = "no quarter tail").
+//     one-kernel product (tests/test_act16_gpu.py::test_quarter_tail_*, against d->variant = LSTC_VARIANT_NO_QTAIL).
 //   * Producer / consumer waves: a 128 x 128 item has MFMA work for four waves of 64 x 64 (16 ds_read_b128 per 32 MFMAs and K step;
-//     eight waves of 64 x 32 would read 12 per 16: LDS-bound).  Waves 0-3 (one per SIMD) compute; waves 4-7 own the LDS-DMA
+//     eight waves of 64 x 32 would read 12 per 16).  Waves 0-3 (one per SIMD) compute; waves 4-7 own the LDS-DMA
 //     stream and its vmcnt - so the consumers' epilogue can use ordinary loads and stores, nothing hand-counted.
 //   * A K step of 64 is FOUR whole pack tiles (A and B, k tiles 2 s and 2 s + 1 of the item's 128-row blocks): 8 KB contiguous
 //     each, copied verbatim - one producer wave per tile, 8 x 1 KB.  Q_NS stages of 32 KB; the DMA of step s + Q_NS - 1 is issued when
