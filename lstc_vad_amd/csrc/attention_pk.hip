@@ -35,9 +35,13 @@ typedef uint32_t a3_u4 __attribute__((ext_vector_type(4)));
 typedef float a3_f4 __attribute__((ext_vector_type(4)));
 typedef a3_s4 __attribute__((address_space(3))) * a3_lds4;
 
+#ifndef A3_DMA_MOD
+#define A3_DMA_MOD ""                    // cache-policy modifier of the ring's LDS-DMA.  " nt" (once-read operands) measured, round 6: bf16 step
+                                         // 36.58 / 36.58 / 36.57 vs 36.54 / 36.61 / 36.63 ms - nothing (profiles/r06_attn_nt_ab.txt)
+#endif
 __device__ __forceinline__ void a3_dma(const __bf16* tile, uint32_t voff, uint32_t lds_bytes) {
     const uint32_t lb = __builtin_amdgcn_readfirstlane(lds_bytes);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(tile), "s"(lb) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" A3_DMA_MOD :: "v"(voff), "s"(tile), "s"(lb) : "memory");
 }
 // byte offset, inside tile column 0 of a pack with `kb` tiles per row block, of this lane's 16-B piece of global row g
 __device__ __forceinline__ uint32_t a3_row_off(uint32_t g, uint32_t kb, uint32_t lane) {
