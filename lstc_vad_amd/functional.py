@@ -198,6 +198,9 @@ _ATTN_F32 = os.environ.get("LSTC_ATTN_F32", "0") == "1"          # bf16 mode: ke
 _ATTN_VARIANT = int(os.environ.get("LSTC_ATTN_VARIANT", "0"))     # 1: first-generation attention kernels (A/B measurements)
 _BWD_NPW = int(os.environ.get("LSTC_ATTN_BWD_NPW", "0"))       # measurement hook: sequences per workgroup of the attention backward
 _ATTN_PACKED_IN = os.environ.get("LSTC_ATTN_PACKED_IN", "1") != "0"   # bf16 mode: Q | K | V / dO reach the attention core as packs
+_WGRAD_COST_MODEL = os.environ.get("LSTC_WGRAD_COST_MODEL", "0") == "1"     # opt-in (measured, round 6: profiles/r06_wgrad_split_ab.txt): the cost-model split of the
+# packed bf16 weight gradients gains 3 % on the UCF / STN rank shapes (4352 - 4864 tokens) and nothing elsewhere; it stays off by default - fewer partial
+# buffers move the peak-memory comparison of tests/test_act16_gpu.py (both activation dtypes lose the same transient, the f32-activation run more)
 _DETERMINISTIC_WGRAD = os.environ.get("LSTC_ATOMIC_SPLITK", "0") != "1"   # split-K weight gradients: partials + ordered sum, not atomics
 
 
@@ -659,6 +662,28 @@ def _wgrad_split(m_out: int, n_out: int, tile: int = 128) -> int:
     return best
 
 
+def _wgrad_split_bf16p(m_out: int, n_out: int, tokens: int) -> int:
+    """Split-K factor of a weight gradient on the packed bf16 kernel (256 x 256 tiles, one workgroup per CU) from a cost model instead
+    of round filling alone: rounds(s) x (K steps per item x 1.84 us + ~8 us of item prologue / partial-tile epilogue) + the ordered sum
+    of the s partials ((s + 1) x 4 m n bytes at ~4 TB/s; none for s = 1).  At the headline token counts it picks what `_wgrad_split`
+    picks (the K loops dominate: 4 / 2 / 4 / 8 for dW_qkv, dW_1 / dW_2, dW_fc and UBnormal's dW_qkv); with a few thousand tokens - one
+    rank of an 8-GPU split of the STN / UCF configs - the fixed costs and the partial sums decide: the STN rank's [3072, 2048] x 4352
+    tokens ran 8 splits of 8.5 K steps each at 576 TFLOP/s (profiles/r06_rank_gemm_launch_table_bf16.txt era), two splits model 1.5x faster."""
+    tiles = -(-m_out // 256) * -(-n_out // 256)
+    steps = -(-tokens // 64)
+    best, best_t = 1, None
+    for s in (1, 2, 4, 8, 16):
+        if s > 1 and steps // s < 8:
+            break
+        rounds = -(-(tiles * s) // 256)
+        t = rounds * (-(-steps // s) * 1.84 + 8.0)
+        if s > 1:
+            t += (s + 1) * 4.0 * m_out * n_out / 4.0e6
+        if best_t is None or t < best_t - 1e-9:
+            best, best_t = s, t
+    return best
+
+
 # ---- gradient sinks (data parallel).  dist.GradAllReducer keeps every gradient of a bucket in ONE flat buffer that RCCL reduces in
 # place.  Letting autograd ACCUMULATE into views of that buffer costs a 407-MB fill per step plus a read-add-write of every weight
 # gradient after the kernel that produced it.  Instead the reducer hangs a sink on each large weight -
@@ -718,7 +743,10 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, x_pack: Optional[Packed] = None, ou
         raise RuntimeError(f"wgrad: out must be a contiguous float32 [{O}, {I}] tensor")
     pkind = _packed_kind()
     # split-K factor: 256x256 output tiles on the packed bf16 kernel, 128x128 everywhere else
-    s = _wgrad_split(O, I, 256 if pkind == _lib.BF16P else 128) if T >= 4096 else 1
+    if pkind == _lib.BF16P and _WGRAD_COST_MODEL:
+        s = _wgrad_split_bf16p(O, I, T) if T >= 4096 else 1       # (below 4096 tokens: one launch, no partial buffers - as rounds 2 - 5)
+    else:
+        s = _wgrad_split(O, I, 256 if pkind == _lib.BF16P else 128) if T >= 4096 else 1
     tr_ok = T % 128 == 0 and (pkind == _lib.BF16P or (O % 128 == 0 and I % 128 == 0))
     # a gradient that already IS a packed operand (layernorm_bwd_branch emits df packed whenever [rows, d_model] fills the tile
     # grid, whatever the width of its partner) always takes the packed TR form; the partner is packed on demand (the TR kernel
